@@ -1,0 +1,161 @@
+/* sdqn.h — C ABI of libsdqn_hip.so: the MI355X (gfx950) DQN training-step hot path.
+ *
+ * The reference (tambetm/simple_dqn) has no FFI of its own: its boundary for this
+ * path is the duck-typed Python API of two classes.  Each entry point below names
+ * the reference interface (file:line under /root/reference) that it replaces; the
+ * ctypes binding that turns them back into those classes is
+ * simple_dqn_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative sdqn_status on failure;
+ *     sdqn_last_error() returns a thread-local message for the last failure.
+ *     No exception crosses the boundary.
+ *   - handles are opaque, owned by the library, single-owner (not thread-safe),
+ *     matching the reference's single-threaded caller (src/agent.py:96-116).
+ *   - every device operation is enqueued on ONE library stream per process and is
+ *     asynchronous unless the call returns host data (then it synchronises).
+ *   - host pointers passed in are borrowed for the duration of the call only;
+ *     pointers handed out (sdqn_replay_host_ptrs) live as long as the handle.
+ *   - there is NO CPU fallback: without a gfx950 device every device entry point
+ *     fails with SDQN_ERR_HIP.
+ */
+#ifndef SDQN_H
+#define SDQN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  SDQN_OK = 0,
+  SDQN_ERR_ARG = -1,     /* precondition / shape violation: the reference raises AssertionError */
+  SDQN_ERR_HIP = -2,     /* HIP runtime failure (incl. "no device") */
+  SDQN_ERR_RCCL = -3,    /* RCCL failure */
+  SDQN_ERR_STATE = -4    /* call not valid in the handle's current state */
+} sdqn_status;
+
+typedef struct sdqn_replay_s* sdqn_replay_t;
+typedef struct sdqn_net_s* sdqn_net_t;
+
+#define SDQN_MT_WORDS 625          /* CPython random.getstate()[1]: 624 state words + position */
+
+/* ---- misc ---------------------------------------------------------------- */
+const char* sdqn_last_error(void);
+int sdqn_version(void);
+int sdqn_device_count(int* n);
+int sdqn_set_device(int dev);                 /* replaces --device_id, src/main.py:52, deepqnetwork.py:32 */
+int sdqn_device_sync(void);
+
+/* ---- index sampler: pure host, no device needed ---------------------------
+ * replaces the rejection sampler in ReplayMemory.getMinibatch, src/replay_memory.py:54-68,
+ * bit-exact against CPython 3.10's random.randint stream (Lib/random.py randint ->
+ * _randbelow_with_getrandbits; Modules/_randommodule.c genrand_uint32).               */
+int sdqn_mt_seed(uint32_t mt[SDQN_MT_WORDS], uint64_t seed);            /* random.seed(int), src/main.py:89-90 */
+int sdqn_mt_randint(uint32_t mt[SDQN_MT_WORDS], int64_t a, int64_t b, int64_t* out);
+int sdqn_sample_indices(uint32_t mt[SDQN_MT_WORDS], const uint8_t* terminals, int64_t count,
+                        int64_t current, int history_length, int batch,
+                        int64_t* idx_out /*[batch]*/, int64_t* draws_out /*nullable*/);
+
+/* ---- replay memory: src/replay_memory.py ---------------------------------- */
+#define SDQN_REPLAY_HBM_MIRROR 1   /* ring master in pinned host DRAM + mirror in HBM (default) */
+#define SDQN_REPLAY_ZERO_COPY  2   /* no mirror: kernels read the pinned ring over PCIe */
+
+/* ReplayMemory.__init__, replay_memory.py:7-24 */
+int sdqn_replay_create(sdqn_replay_t* h, int64_t size, int screen_height, int screen_width,
+                       int history_length, int batch_size, int flags);
+int sdqn_replay_destroy(sdqn_replay_t h);
+/* the numpy attributes screens/actions/rewards/terminals (replay_memory.py:10-13) are views of these */
+int sdqn_replay_host_ptrs(sdqn_replay_t h, uint8_t** screens, uint8_t** actions, int64_t** rewards,
+                          uint8_t** terminals);
+/* preallocated minibatch outputs prestates/poststates (replay_memory.py:21-22) + a/r/t, pinned host */
+int sdqn_replay_minibatch_ptrs(sdqn_replay_t h, uint8_t** pre, uint8_t** post, uint8_t** actions,
+                               int64_t** rewards, uint8_t** terminals);
+/* ReplayMemory.add, replay_memory.py:26-34 (also enqueues the 7 KB H2D into the mirror) */
+int sdqn_replay_add(sdqn_replay_t h, int action, int64_t reward, const uint8_t* screen, int terminal);
+int sdqn_replay_get_state(sdqn_replay_t h, int64_t* count, int64_t* current);
+int sdqn_replay_set_state(sdqn_replay_t h, int64_t count, int64_t current);
+/* after writing the host views directly (bulk fill): copy slots [first, first+n) into the mirror */
+int sdqn_replay_upload(sdqn_replay_t h, int64_t first, int64_t n);
+/* replay_memory.py:54-68 on this ring (terminals/count/current of the handle) */
+int sdqn_replay_sample(sdqn_replay_t h, uint32_t mt[SDQN_MT_WORDS], int64_t* idx_out, int64_t* draws_out);
+/* replay_memory.py:71-78: HIP gather of (s, a, r, s', terminal) by index into device HBM (async) */
+int sdqn_replay_gather(sdqn_replay_t h, const int64_t* idx_host /*[batch]*/);
+/* replay_memory.py:79: the device minibatch copied into the buffers of sdqn_replay_minibatch_ptrs (sync) */
+int sdqn_replay_minibatch_to_host(sdqn_replay_t h);
+/* device-side timing of the last n gather launches, for bench.py (HIP events on the library stream) */
+int sdqn_replay_bench_gather(sdqn_replay_t h, const int64_t* idx_host, int iters, float* ms_per_launch);
+
+/* ---- Q-network: src/deepqnetwork.py ---------------------------------------- */
+typedef struct {
+  int batch_size;          /* args.batch_size      deepqnetwork.py:19 */
+  int history_length;      /* args.history_length  :21 (must be 4) */
+  int screen_height;       /* :22 (must be 84) */
+  int screen_width;        /* :22 (must be 84) */
+  int num_actions;         /* :18 */
+  int target_enabled;      /* bool(args.target_steps) :64 */
+  int reserved0[2];
+  /* Python floats (doubles) exactly as argparse hands them over; the library rounds to fp32
+   * where Neon's fp32 backend would (lr, decay, epsilon, clip) and keeps doubles where the
+   * reference does host-side float math (discount, reward clip: deepqnetwork.py:136-143).  */
+  double discount_rate;    /* :20 */
+  double clip_error;       /* :23 (0 disables clipping, :158) */
+  double min_reward;       /* :24 */
+  double max_reward;       /* :25 */
+  double learning_rate;    /* :51 */
+  double decay_rate;       /* :52 */
+  double epsilon;          /* Neon RMSProp default 1e-6 */
+  double reserved1[4];
+} sdqn_net_cfg;
+
+/* DeepQNetwork.__init__, deepqnetwork.py:16-75 (weights start at zero: inject with set_weights) */
+int sdqn_net_create(sdqn_net_t* h, const sdqn_net_cfg* cfg);
+int sdqn_net_destroy(sdqn_net_t h);
+/* which: 0 online theta, 1 target theta-, 2 RMSProp state, 3 last gradient sum (get only).
+ * layer: 0..4 = conv1, conv2, conv3, fc4, fc5.  Data in Neon layout:
+ * conv (C*R*S, K) rows c*R*S+r*S+s; fc4 (512, 3136) nin in (K,P,Q) order; fc5 (A, 512).  */
+int sdqn_net_layer_size(sdqn_net_t h, int layer, int64_t* n);
+int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const float* w, int64_t n);
+int sdqn_net_get_weights(sdqn_net_t h, int which, int layer, float* w, int64_t n);   /* sync */
+/* DeepQNetwork.predict, deepqnetwork.py:174-186: states u8[B,4,84,84] -> q float[B,A] (sync) */
+int sdqn_net_predict(sdqn_net_t h, const uint8_t* states, float* q_out);
+/* DeepQNetwork.train, deepqnetwork.py:107-172, minibatch given as host arrays.
+ * cost_out nullable: NULL -> no synchronisation. */
+int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8_t* actions, const int64_t* rewards,
+                        const uint8_t* post, const uint8_t* terminals, float* cost_out);
+/* same step with the minibatch gathered on the device straight from the replay ring:
+ * fuses replay_memory.py:71-78 with deepqnetwork.py:94-100 (no u8 minibatch is materialised) */
+int sdqn_net_train_replay(sdqn_net_t h, sdqn_replay_t r, const int64_t* idx_host, float* cost_out);
+/* n_steps x { sample (replay_memory.py:54-68) ; train } without returning to Python:
+ * the loop body of Agent.train, src/agent.py:108-114 */
+int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t mt[SDQN_MT_WORDS], int n_steps,
+                        float* mean_cost /*nullable*/);
+/* DeepQNetwork.update_target_network, deepqnetwork.py:102-105 */
+int sdqn_net_update_target(sdqn_net_t h);
+int sdqn_net_sync(sdqn_net_t h);
+/* q-values of the last train step: preq float[B,A] (online, prestates), maxpostq float[B] (sync) */
+int sdqn_net_last_q(sdqn_net_t h, float* preq, float* maxpostq);
+int sdqn_net_train_iterations(sdqn_net_t h, int64_t* n);     /* deepqnetwork.py:168 */
+
+/* test hook: raw read-back of an internal device buffer ("a1","a2","a3","a4","d4","d3p","d2p","d1","q",
+ * "dq","g","theta","cost_terms"; internal layouts documented in simple_dqn_amd/csrc/problems.h) */
+int sdqn_net_debug_read(sdqn_net_t h, const char* name, float* out, int64_t n);
+
+/* per-kernel device timing (HIP events on the library stream), for bench.py's roofline leg.
+ * kernel < 0 brackets every kernel of the step, otherwise only that kernel id. */
+int sdqn_net_profile(sdqn_net_t h, int enable, int kernel);
+int sdqn_net_profile_count(int* n_kernels);
+int sdqn_net_profile_read(sdqn_net_t h, int kernel, const char** name, double* total_ms, int64_t* launches);
+int sdqn_net_profile_reset(sdqn_net_t h);
+
+/* ---- data parallel: one learner per GPU, one RCCL all-reduce of the flat gradient per step ---
+ * (no reference counterpart: deepqnetwork.py:46-48 disables Neon's DP) */
+int sdqn_dp_unique_id(const char* rccl_path, char id[128]);
+int sdqn_dp_init(sdqn_net_t h, const char* rccl_path, const char id[128], int rank, int nranks);
+int sdqn_dp_shutdown(sdqn_net_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDQN_H */

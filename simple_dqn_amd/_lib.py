@@ -1,0 +1,133 @@
+"""ctypes binding of include/sdqn.h — the only caller of libsdqn_hip.so.
+
+Status codes are mapped the way the reference behaves: precondition / shape violations
+(SDQN_ERR_ARG) become AssertionError like the reference's asserts (deepqnetwork.py:110-116,
+replay_memory.py:27,38,52); HIP / RCCL failures become RuntimeError (SdqnError).
+"""
+import ctypes as C
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MT_WORDS = 625
+
+
+class SdqnError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libsdqn_hip.so")
+
+
+class NetCfg(C.Structure):
+    _fields_ = [("batch_size", C.c_int), ("history_length", C.c_int), ("screen_height", C.c_int),
+                ("screen_width", C.c_int), ("num_actions", C.c_int), ("target_enabled", C.c_int),
+                ("reserved0", C.c_int * 2),
+                ("discount_rate", C.c_double), ("clip_error", C.c_double), ("min_reward", C.c_double),
+                ("max_reward", C.c_double), ("learning_rate", C.c_double), ("decay_rate", C.c_double),
+                ("epsilon", C.c_double), ("reserved1", C.c_double * 4)]
+
+
+_u8p, _i64p, _f32p, _u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/sdqn.h declares
+SIGNATURES = {
+    "sdqn_last_error": (C.c_char_p, []),
+    "sdqn_version": (C.c_int, []),
+    "sdqn_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sdqn_set_device": (C.c_int, [C.c_int]),
+    "sdqn_device_sync": (C.c_int, []),
+    "sdqn_mt_seed": (C.c_int, [_u32p, C.c_uint64]),
+    "sdqn_mt_randint": (C.c_int, [_u32p, C.c_int64, C.c_int64, _i64p]),
+    "sdqn_sample_indices": (C.c_int, [_u32p, _u8p, C.c_int64, C.c_int64, C.c_int, C.c_int, _i64p, _i64p]),
+    "sdqn_replay_create": (C.c_int, [C.POINTER(_vp), C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sdqn_replay_destroy": (C.c_int, [_vp]),
+    "sdqn_replay_host_ptrs": (C.c_int, [_vp, C.POINTER(_u8p), C.POINTER(_u8p), C.POINTER(_i64p), C.POINTER(_u8p)]),
+    "sdqn_replay_minibatch_ptrs": (C.c_int, [_vp, C.POINTER(_u8p), C.POINTER(_u8p), C.POINTER(_u8p),
+                                             C.POINTER(_i64p), C.POINTER(_u8p)]),
+    "sdqn_replay_add": (C.c_int, [_vp, C.c_int, C.c_int64, _u8p, C.c_int]),
+    "sdqn_replay_get_state": (C.c_int, [_vp, _i64p, _i64p]),
+    "sdqn_replay_set_state": (C.c_int, [_vp, C.c_int64, C.c_int64]),
+    "sdqn_replay_upload": (C.c_int, [_vp, C.c_int64, C.c_int64]),
+    "sdqn_replay_sample": (C.c_int, [_vp, _u32p, _i64p, _i64p]),
+    "sdqn_replay_gather": (C.c_int, [_vp, _i64p]),
+    "sdqn_replay_minibatch_to_host": (C.c_int, [_vp]),
+    "sdqn_replay_bench_gather": (C.c_int, [_vp, _i64p, C.c_int, _f32p]),
+    "sdqn_net_create": (C.c_int, [C.POINTER(_vp), C.POINTER(NetCfg)]),
+    "sdqn_net_destroy": (C.c_int, [_vp]),
+    "sdqn_net_layer_size": (C.c_int, [_vp, C.c_int, _i64p]),
+    "sdqn_net_set_weights": (C.c_int, [_vp, C.c_int, C.c_int, _f32p, C.c_int64]),
+    "sdqn_net_get_weights": (C.c_int, [_vp, C.c_int, C.c_int, _f32p, C.c_int64]),
+    "sdqn_net_predict": (C.c_int, [_vp, _u8p, _f32p]),
+    "sdqn_net_train_host": (C.c_int, [_vp, _u8p, _u8p, _i64p, _u8p, _u8p, _f32p]),
+    "sdqn_net_train_replay": (C.c_int, [_vp, _vp, _i64p, _f32p]),
+    "sdqn_net_train_many": (C.c_int, [_vp, _vp, _u32p, C.c_int, _f32p]),
+    "sdqn_net_update_target": (C.c_int, [_vp]),
+    "sdqn_net_sync": (C.c_int, [_vp]),
+    "sdqn_net_last_q": (C.c_int, [_vp, _f32p, _f32p]),
+    "sdqn_net_train_iterations": (C.c_int, [_vp, _i64p]),
+    "sdqn_net_debug_read": (C.c_int, [_vp, C.c_char_p, _f32p, C.c_int64]),
+    "sdqn_net_profile": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "sdqn_net_profile_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sdqn_net_profile_read": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), _i64p]),
+    "sdqn_net_profile_reset": (C.c_int, [_vp]),
+    "sdqn_dp_unique_id": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "sdqn_dp_init": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
+    "sdqn_dp_shutdown": (C.c_int, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libsdqn_hip.so (built in-tree by __graft_entry__.build()).  No fallback: a missing
+    library is an error, never a silent CPU path.
+
+    HIP runtime note: the library needs libamdhip64.so.7.  If torch was imported first its
+    bundled runtime (same soname) is already mapped and is reused; otherwise /opt/rocm's is
+    loaded.  Never import torch AFTER this library in the same process (two HIP runtimes)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SdqnError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    lib = C.CDLL(path, mode=os.RTLD_NOW | os.RTLD_LOCAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here == header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = (load().sdqn_last_error() or b"").decode("utf-8", "replace")
+    if rc == -1:
+        raise AssertionError(msg)
+    raise SdqnError("libsdqn_hip status %d: %s" % (rc, msg))
+
+
+def ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def rccl_path():
+    """The RCCL this process already has mapped (torch's bundled one, if torch is loaded), else ROCm's."""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "librccl" in line:
+                    return line.split()[-1]
+    except OSError:
+        pass
+    if "torch" in sys.modules:
+        import torch
+        p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(p):
+            return p
+    return "/opt/rocm/lib/librccl.so.1"

@@ -1,0 +1,64 @@
+// kernels.h — launch interface between the host orchestration (sdqn_api.hip) and the device
+// code (sdqn_kernels.hip).  Kernel ids double as the profiler's slots.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "problems.h"
+
+namespace sdqn {
+
+enum KernelId {
+  K_CONV1_FWD = 0, K_CONV2_FWD, K_CONV3_FWD, K_FC4_FWD, K_HEAD,
+  K_FC4_DGRAD, K_FC4_WGRAD, K_CONV3_DGRAD, K_CONV3_WGRAD, K_CONV2_DGRAD, K_CONV2_WGRAD,
+  K_CONV1_WGRAD, K_UPDATE, K_ALLREDUCE, K_GATHER, K_COUNT
+};
+const char* kernel_name(int id);
+
+struct HeadArgs {
+  const MetaRec* meta;          // ring metadata mirror (from_ring)
+  const uint8_t* st_actions;    // staged host minibatch (else)
+  const int64_t* st_rewards;
+  const uint8_t* st_terminals;
+  float* q;                     // [2][B][A] q-values of both nets
+  float* maxq;                  // [B]
+  float* dq;                    // [B][A] clipped deltas
+  float* cost_terms;            // [B]  0.5 * delta^2 (pre-clip)
+  double discount, min_reward, max_reward;
+  float clip_error;
+  int train;                    // 0: predict only (z = 0)
+};
+
+struct UpdateArgs {
+  float* theta;                 // online parameters (flat, internal layout)
+  float* state;                 // RMSProp state
+  float* g;                     // flat gradient sum
+  const float* slab[3];
+  int ns[3];
+  const float* dq;              // [B][A]
+  const float* a4;              // online a4 [B][512]
+  const float* cost_terms;
+  float* cost_out;              // [1]
+  double* cost_accum;           // running sum over steps
+  int B, A;
+  int mode;                     // 0 fused reduce+apply, 1 reduce only (-> g), 2 apply only (g already reduced)
+  float bsz;                    // divisor of A9 (B, or R*B under data parallel)
+  float rho, one_minus_rho, lr, eps;
+};
+
+struct GatherArgs {
+  const uint8_t* ring;          // [size][84][84]
+  const MetaRec* meta;
+  const int64_t* idx;           // [B]
+  uint8_t* pre;                 // [B][4][84][84]
+  uint8_t* post;
+  uint8_t* actions;             // [B]
+  int64_t* rewards;
+  uint8_t* terminals;
+  int B;
+};
+
+hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s);     // the GEMM-shaped stages
+hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s);
+hipError_t launch_update(const UpdateArgs& u, hipStream_t s);
+hipError_t launch_gather(const GatherArgs& g, hipStream_t s);
+
+}  // namespace sdqn

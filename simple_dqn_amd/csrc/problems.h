@@ -1,0 +1,356 @@
+// problems.h — every GEMM-shaped stage of the DQN train step expressed as
+//   C(m, n) = sum_k A(m, k) * B(k, n)      A(m,k) = srcA[a_row(m) + a_col(k)]
+//                                            B(k,n) = srcB[b_row(k) + b_col(n)]
+// i.e. im2col is never materialised: it is a separable gather the tile loader
+// performs while staging LDS tiles (gemm_engine.h).  The functions are
+// __host__ __device__ so tests/emul can execute the very same index math on the CPU.
+//
+// Reference: the layer stack of src/deepqnetwork.py:83-91 and Neon's
+// fprop/bprop/update semantics.
+//
+// Internal layouts (ours, chosen for coalesced loads; Neon layouts only at the C ABI):
+//   activations / deltas : NHWC  [z][n][y][x][c]            (row-major GEMM outputs)
+//   W1i [(c,r,s)=256][32]   == Neon (CRS, K)
+//   W2i [(r,s,c)=512][64]   rows permuted from Neon's (c,r,s)
+//   W3i [(r,s,c)=576][64]   rows permuted from Neon's (c,r,s)
+//   W4i [(pix,f)=3136][512] == transpose of Neon (512, 3136[(f,pix)])
+//   W5i [A][512]            == Neon
+//   d3p [n][11][11][64]  conv3-output delta, zero-padded by 2 (full correlation for dgrad)
+//   d2p [n][11][11][64]  conv2-output delta, zero-padded by 1 (stride-2 parity decomposition)
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define SDQN_HD __host__ __device__ inline
+#else
+#define SDQN_HD inline
+#endif
+
+namespace sdqn {
+
+constexpr int H0 = 84, W0 = 84, C0 = 4;
+constexpr int FRAME = H0 * W0;          // 7056 B
+constexpr int STATE = C0 * FRAME;       // 28224 B
+constexpr int ST1 = 4, P1 = 20, Q1 = 20, K1 = 32;   // conv 8x8 s4   deepqnetwork.py:83
+constexpr int ST2 = 2, P2 = 9, Q2 = 9, K2 = 64;     // conv 4x4 s2   :85
+constexpr int P3 = 7, Q3 = 7, K3 = 64;              // conv 3x3 s1   :87
+constexpr int PIX1 = P1 * Q1, PIX2 = P2 * Q2, PIX3 = P3 * Q3;
+constexpr int CRS1 = 256, CRS2 = 512, CRS3 = 576;
+constexpr int NFC = 512, NIN4 = PIX3 * K3;          // Affine 512    :89
+constexpr int PD3 = 11, PD2 = 11;                   // padded delta planes
+constexpr int NW1 = CRS1 * K1, NW2 = CRS2 * K2, NW3 = CRS3 * K3, NW4 = NIN4 * NFC;
+constexpr int OFF1 = 0, OFF2 = OFF1 + NW1, OFF3 = OFF2 + NW2, OFF4 = OFF3 + NW3, OFF5 = OFF4 + NW4;
+constexpr int MAX_ACTIONS = 18;
+
+struct MetaRec {            // device mirror of (rewards, actions, terminals) of one ring slot
+  int64_t reward;
+  uint8_t action;
+  uint8_t terminal;
+  uint8_t pad[6];
+};
+
+struct StepArgs {
+  const uint8_t* src;       // ring mirror (from_ring) or staging states [2][B][STATE]
+  const int64_t* idx;       // sampled indexes [B] (from_ring)
+  int from_ring;
+  int B, A, nz;
+  const float* theta[2];    // flat parameter buffers: [0] online, [1] target
+  float* a1;                // [2][B*400][32]
+  float* a2;                // [2][B*81][64]
+  float* a3;                // [2][B*49][64]
+  float* slab4;             // fc4 fwd split-K slabs [S4][2][B][512]
+  float* a4;                // [2][B][512]
+  float* d4;                // [B][512]
+  float* d3p;               // [B][11][11][64]
+  float* d2p;               // [B][11][11][64]
+  float* d1;                // [B][20][20][32]
+  float* g;                 // flat gradient sum (internal layout)
+  float* slab1;             // conv wgrad split-K slabs [ns][NWx]
+  float* slab2;
+  float* slab3;
+  int S4;                   // fc4 fwd K-splits
+  int tps1, tps2, tps3;     // K-tiles (of 32) per wgrad split
+};
+
+SDQN_HD int64_t sbase(const StepArgs& a, int z, int n) {
+  // replay_memory.py:71-72: prestate = screens[i-4:i], poststate = screens[i-3:i+1]
+  return a.from_ring ? (a.idx[n] - C0 + z) * (int64_t)FRAME : ((int64_t)z * a.B + n) * (int64_t)STATE;
+}
+SDQN_HD float norm_u8(uint8_t v) { return (float)v / 255.0f; }   // deepqnetwork.py:100 be.divide(input, 255)
+
+SDQN_HD int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- im2col index helpers -------------------------------------------------------------
+SDQN_HD int64_t row1(const StepArgs& a, int z, int m) {      // conv1 patch origin in the byte source
+  int n = m / PIX1, pix = m - n * PIX1, p = pix / Q1, q = pix - p * Q1;
+  return sbase(a, z, n) + (int64_t)(p * ST1) * W0 + q * ST1;
+}
+SDQN_HD int col1(int k) { int c = k >> 6, r = (k >> 3) & 7, s = k & 7; return c * FRAME + r * W0 + s; }
+SDQN_HD int row2(const StepArgs& a, int z, int m) {          // conv2 patch origin in a1 (NHWC)
+  int n = m / PIX2, pix = m - n * PIX2, p = pix / Q2, q = pix - p * Q2;
+  return (((z * a.B + n) * P1 + p * ST2) * Q1 + q * ST2) * K1;
+}
+SDQN_HD int col2(int k) { int r = k >> 7, s = (k >> 5) & 3, c = k & 31; return (r * Q1 + s) * K1 + c; }
+SDQN_HD int row3(const StepArgs& a, int z, int m) {          // conv3 patch origin in a2 (NHWC)
+  int n = m / PIX3, pix = m - n * PIX3, p = pix / Q3, q = pix - p * Q3;
+  return (((z * a.B + n) * P2 + p) * Q2 + q) * K2;
+}
+SDQN_HD int col3(int k) { int rs = k >> 6, c = k & 63, r = rs / 3, s = rs - r * 3; return (r * Q2 + s) * K2 + c; }
+SDQN_HD int prow3(int m) {                                   // (n,p,q) of conv3 output -> d3p (pad 2)
+  int n = m / PIX3, pix = m - n * PIX3, p = pix / Q3, q = pix - p * Q3;
+  return ((n * PD3 + p + 2) * PD3 + q + 2) * K3;
+}
+SDQN_HD int prow2(int m) {                                   // (n,p,q) of conv2 output -> d2p (pad 1)
+  int n = m / PIX2, pix = m - n * PIX2, p = pix / Q2, q = pix - p * Q2;
+  return ((n * PD2 + p + 1) * PD2 + q + 1) * K2;
+}
+
+// =========================== forward =====================================================
+struct Conv1Fwd {   // fused gather + normalise + conv1 + ReLU: replay_memory.py:71-72 + deepqnetwork.py:94-100,83
+  static constexpr int WM = 2, WN = 1, WK = 2; static constexpr bool A_K = false, B_K = false;
+  typedef int64_t aoff_t;
+  SDQN_HD static int M(const StepArgs& a) { return a.B * PIX1; }
+  SDQN_HD static int N(const StepArgs&) { return K1; }
+  SDQN_HD static int nbz(const StepArgs& a) { return a.nz; }
+  SDQN_HD static void ksplit(const StepArgs&, int bz, int& z, int& ks, int& kb, int& ke) { z = bz; ks = 0; kb = 0; ke = CRS1; }
+  SDQN_HD static aoff_t a_row(const StepArgs& a, int z, int m) { return row1(a, z, m); }
+  SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) { return col1(k); }
+  SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return norm_u8(a.src[o]); }
+  SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * K1; }
+  SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
+  SDQN_HD static float b_load(const StepArgs& a, int z, int o) { return a.theta[z][OFF1 + o]; }
+  SDQN_HD static void store(const StepArgs& a, int z, int, int m, int n, float v) {
+    a.a1[((int64_t)z * M(a) + m) * K1 + n] = fmaxf(v, 0.0f);
+  }
+};
+
+struct Conv2Fwd {   // deepqnetwork.py:85
+  static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = false;
+  typedef int aoff_t;
+  SDQN_HD static int M(const StepArgs& a) { return a.B * PIX2; }
+  SDQN_HD static int N(const StepArgs&) { return K2; }
+  SDQN_HD static int nbz(const StepArgs& a) { return a.nz; }
+  SDQN_HD static void ksplit(const StepArgs&, int bz, int& z, int& ks, int& kb, int& ke) { z = bz; ks = 0; kb = 0; ke = CRS2; }
+  SDQN_HD static aoff_t a_row(const StepArgs& a, int z, int m) { return row2(a, z, m); }
+  SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) { return col2(k); }
+  SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a1[o]; }
+  SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * K2; }
+  SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
+  SDQN_HD static float b_load(const StepArgs& a, int z, int o) { return a.theta[z][OFF2 + o]; }
+  SDQN_HD static void store(const StepArgs& a, int z, int, int m, int n, float v) {
+    a.a2[((int64_t)z * M(a) + m) * K2 + n] = fmaxf(v, 0.0f);
+  }
+};
+
+struct Conv3Fwd {   // deepqnetwork.py:87
+  static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = false;
+  typedef int aoff_t;
+  SDQN_HD static int M(const StepArgs& a) { return a.B * PIX3; }
+  SDQN_HD static int N(const StepArgs&) { return K3; }
+  SDQN_HD static int nbz(const StepArgs& a) { return a.nz; }
+  SDQN_HD static void ksplit(const StepArgs&, int bz, int& z, int& ks, int& kb, int& ke) { z = bz; ks = 0; kb = 0; ke = CRS3; }
+  SDQN_HD static aoff_t a_row(const StepArgs& a, int z, int m) { return row3(a, z, m); }
+  SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) { return col3(k); }
+  SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a2[o]; }
+  SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * K3; }
+  SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
+  SDQN_HD static float b_load(const StepArgs& a, int z, int o) { return a.theta[z][OFF3 + o]; }
+  SDQN_HD static void store(const StepArgs& a, int z, int, int m, int n, float v) {
+    a.a3[((int64_t)z * M(a) + m) * K3 + n] = fmaxf(v, 0.0f);
+  }
+};
+
+struct Fc4Fwd {     // deepqnetwork.py:89, split-K over S4 slabs; bias-free, ReLU applied by the head kernel
+  static constexpr int WM = 1, WN = 2, WK = 2; static constexpr bool A_K = true, B_K = false;
+  typedef int aoff_t;
+  SDQN_HD static int M(const StepArgs& a) { return a.B; }
+  SDQN_HD static int N(const StepArgs&) { return NFC; }
+  SDQN_HD static int nbz(const StepArgs& a) { return a.nz * a.S4; }
+  SDQN_HD static void ksplit(const StepArgs& a, int bz, int& z, int& ks, int& kb, int& ke) {
+    z = bz / a.S4; ks = bz - z * a.S4;
+    int per = ceil_div(NIN4 / 32, a.S4) * 32;
+    kb = ks * per; ke = kb + per; if (ke > NIN4) ke = NIN4; if (kb > NIN4) kb = NIN4;
+  }
+  SDQN_HD static aoff_t a_row(const StepArgs& a, int z, int m) { return (z * a.B + m) * NIN4; }
+  SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) { return k; }
+  SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a3[o]; }
+  SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * NFC; }
+  SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
+  SDQN_HD static float b_load(const StepArgs& a, int z, int o) { return a.theta[z][OFF4 + o]; }
+  SDQN_HD static void store(const StepArgs& a, int z, int ks, int m, int n, float v) {
+    a.slab4[(((int64_t)ks * 2 + z) * a.B + m) * NFC + n] = v;
+  }
+};
+
+// =========================== backward (online net, z = 0) ===================================
+struct Fc4Dgrad {   // delta3 = (W4^T delta4) * 1[a3 > 0]  (A5, A8), written straight into the padded d3p
+  static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
+  typedef int aoff_t;
+  SDQN_HD static int M(const StepArgs& a) { return a.B; }
+  SDQN_HD static int N(const StepArgs&) { return NIN4; }
+  SDQN_HD static int nbz(const StepArgs&) { return 1; }
+  SDQN_HD static void ksplit(const StepArgs&, int, int& z, int& ks, int& kb, int& ke) { z = 0; ks = 0; kb = 0; ke = NFC; }
+  SDQN_HD static aoff_t a_row(const StepArgs&, int, int m) { return m * NFC; }
+  SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) { return k; }
+  SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.d4[o]; }
+  SDQN_HD static int b_row(const StepArgs&, int, int k) { return k; }
+  SDQN_HD static int b_col(const StepArgs&, int, int n) { return n * NFC; }
+  SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.theta[0][OFF4 + o]; }
+  SDQN_HD static void store(const StepArgs& a, int, int, int m, int n, float v) {
+    int pix = n >> 6, f = n & 63, p = pix / Q3, q = pix - p * Q3;
+    bool on = a.a3[(int64_t)m * NIN4 + n] > 0.0f;
+    a.d3p[((m * PD3 + p + 2) * PD3 + q + 2) * K3 + f] = on ? v : 0.0f;
+  }
+};
+
+struct Fc4Wgrad {   // gW4 = delta4 . a3^T (sum over batch, A8) in the W4i layout; no split (K = B)
+  static constexpr int WM = 2, WN = 2, WK = 1; static constexpr bool A_K = false, B_K = false;
+  typedef int aoff_t;
+  SDQN_HD static int M(const StepArgs&) { return NIN4; }
+  SDQN_HD static int N(const StepArgs&) { return NFC; }
+  SDQN_HD static int nbz(const StepArgs&) { return 1; }
+  SDQN_HD static void ksplit(const StepArgs& a, int, int& z, int& ks, int& kb, int& ke) { z = 0; ks = 0; kb = 0; ke = a.B; }
+  SDQN_HD static aoff_t a_row(const StepArgs&, int, int m) { return m; }
+  SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) { return k * NIN4; }
+  SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a3[o]; }
+  SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * NFC; }
+  SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
+  SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.d4[o]; }
+  SDQN_HD static void store(const StepArgs& a, int, int, int m, int n, float v) { a.g[OFF4 + (int64_t)m * NFC + n] = v; }
+};
+
+struct Conv3Dgrad { // delta2 = full-correlation(d3p, W3) * 1[a2 > 0], written into the padded d2p
+  static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
+  typedef int aoff_t;
+  SDQN_HD static int M(const StepArgs& a) { return a.B * PIX2; }
+  SDQN_HD static int N(const StepArgs&) { return K2; }
+  SDQN_HD static int nbz(const StepArgs&) { return 1; }
+  SDQN_HD static void ksplit(const StepArgs&, int, int& z, int& ks, int& kb, int& ke) { z = 0; ks = 0; kb = 0; ke = CRS3; }
+  SDQN_HD static aoff_t a_row(const StepArgs&, int, int m) {
+    int n = m / PIX2, pix = m - n * PIX2, y = pix / Q2, x = pix - y * Q2;
+    return ((n * PD3 + y + 2) * PD3 + x + 2) * K3;
+  }
+  SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) {
+    int rs = k >> 6, f = k & 63, r = rs / 3, s = rs - r * 3;
+    return -(r * PD3 + s) * K3 + f;
+  }
+  SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.d3p[o]; }
+  SDQN_HD static int b_row(const StepArgs&, int, int k) { return (k >> 6) * (K2 * K3) + (k & 63); }
+  SDQN_HD static int b_col(const StepArgs&, int, int c) { return c * K3; }
+  SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.theta[0][OFF3 + o]; }
+  SDQN_HD static void store(const StepArgs& a, int, int, int m, int c, float v) {
+    bool on = a.a2[(int64_t)m * K2 + c] > 0.0f;
+    a.d2p[prow2(m) + c] = on ? v : 0.0f;
+  }
+};
+
+struct Conv3Wgrad { // gW3[(r,s,c)][f] = sum_(n,p,q) a2 patch * delta3   (Neon update_conv), split-K slabs
+  static constexpr int WM = 2, WN = 2, WK = 1; static constexpr bool A_K = false, B_K = false;
+  typedef int aoff_t;
+  SDQN_HD static int Kt(const StepArgs& a) { return a.B * PIX3; }
+  SDQN_HD static int M(const StepArgs&) { return CRS3; }
+  SDQN_HD static int N(const StepArgs&) { return K3; }
+  SDQN_HD static int nbz(const StepArgs& a) { return ceil_div(ceil_div(Kt(a), 32), a.tps3); }
+  SDQN_HD static void ksplit(const StepArgs& a, int bz, int& z, int& ks, int& kb, int& ke) {
+    z = 0; ks = bz; kb = bz * a.tps3 * 32; ke = kb + a.tps3 * 32; if (ke > Kt(a)) ke = Kt(a);
+  }
+  SDQN_HD static aoff_t a_row(const StepArgs&, int, int m) { return col3(m); }
+  SDQN_HD static aoff_t a_col(const StepArgs& a, int, int k) { return row3(a, 0, k); }
+  SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a2[o]; }
+  SDQN_HD static int b_row(const StepArgs&, int, int k) { return prow3(k); }
+  SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
+  SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.d3p[o]; }
+  SDQN_HD static void store(const StepArgs& a, int, int ks, int m, int n, float v) { a.slab3[(int64_t)ks * NW3 + m * K3 + n] = v; }
+};
+
+struct Conv2Dgrad { // stride-2 dgrad as 4 parity classes (z = py*2+px), each a dense 2x2 correlation over d2p
+  static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
+  typedef int aoff_t;
+  SDQN_HD static int M(const StepArgs& a) { return a.B * 100; }
+  SDQN_HD static int N(const StepArgs&) { return K1; }
+  SDQN_HD static int nbz(const StepArgs&) { return 4; }
+  SDQN_HD static void ksplit(const StepArgs&, int bz, int& z, int& ks, int& kb, int& ke) { z = bz; ks = 0; kb = 0; ke = 256; }
+  SDQN_HD static aoff_t a_row(const StepArgs&, int, int m) {
+    int n = m / 100, pix = m - n * 100, i = pix / 10, j = pix - i * 10;
+    return ((n * PD2 + i + 1) * PD2 + j + 1) * K2;
+  }
+  SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) {
+    int ab = k >> 6, f = k & 63, aa = ab >> 1, bb = ab & 1;
+    return -(aa * PD2 + bb) * K2 + f;
+  }
+  SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.d2p[o]; }
+  SDQN_HD static int b_row(const StepArgs&, int z, int k) {
+    int py = z >> 1, px = z & 1, ab = k >> 6, f = k & 63, aa = ab >> 1, bb = ab & 1;
+    return ((py + 2 * aa) * 4 + (px + 2 * bb)) * (K1 * K2) + f;
+  }
+  SDQN_HD static int b_col(const StepArgs&, int, int c) { return c * K2; }
+  SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.theta[0][OFF2 + o]; }
+  SDQN_HD static void store(const StepArgs& a, int z, int, int m, int c, float v) {
+    int py = z >> 1, px = z & 1;
+    int n = m / 100, pix = m - n * 100, i = pix / 10, j = pix - i * 10;
+    int o = ((n * P1 + 2 * i + py) * Q1 + 2 * j + px) * K1 + c;
+    a.d1[o] = a.a1[o] > 0.0f ? v : 0.0f;
+  }
+};
+
+struct Conv2Wgrad {
+  static constexpr int WM = 2, WN = 2, WK = 1; static constexpr bool A_K = false, B_K = false;
+  typedef int aoff_t;
+  SDQN_HD static int Kt(const StepArgs& a) { return a.B * PIX2; }
+  SDQN_HD static int M(const StepArgs&) { return CRS2; }
+  SDQN_HD static int N(const StepArgs&) { return K2; }
+  SDQN_HD static int nbz(const StepArgs& a) { return ceil_div(ceil_div(Kt(a), 32), a.tps2); }
+  SDQN_HD static void ksplit(const StepArgs& a, int bz, int& z, int& ks, int& kb, int& ke) {
+    z = 0; ks = bz; kb = bz * a.tps2 * 32; ke = kb + a.tps2 * 32; if (ke > Kt(a)) ke = Kt(a);
+  }
+  SDQN_HD static aoff_t a_row(const StepArgs&, int, int m) { return col2(m); }
+  SDQN_HD static aoff_t a_col(const StepArgs& a, int, int k) { return row2(a, 0, k); }
+  SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a1[o]; }
+  SDQN_HD static int b_row(const StepArgs&, int, int k) { return prow2(k); }
+  SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
+  SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.d2p[o]; }
+  SDQN_HD static void store(const StepArgs& a, int, int ks, int m, int n, float v) { a.slab2[(int64_t)ks * NW2 + m * K2 + n] = v; }
+};
+
+struct Conv1Wgrad { // re-gathers the normalised u8 patches from the ring (no fp32 input copy is ever stored)
+  static constexpr int WM = 2, WN = 1, WK = 2; static constexpr bool A_K = false, B_K = false;
+  typedef int64_t aoff_t;
+  SDQN_HD static int Kt(const StepArgs& a) { return a.B * PIX1; }
+  SDQN_HD static int M(const StepArgs&) { return CRS1; }
+  SDQN_HD static int N(const StepArgs&) { return K1; }
+  SDQN_HD static int nbz(const StepArgs& a) { return ceil_div(ceil_div(Kt(a), 32), a.tps1); }
+  SDQN_HD static void ksplit(const StepArgs& a, int bz, int& z, int& ks, int& kb, int& ke) {
+    z = 0; ks = bz; kb = bz * a.tps1 * 32; ke = kb + a.tps1 * 32; if (ke > Kt(a)) ke = Kt(a);
+  }
+  SDQN_HD static aoff_t a_row(const StepArgs&, int, int m) { return col1(m); }
+  SDQN_HD static aoff_t a_col(const StepArgs& a, int, int k) { return row1(a, 0, k); }
+  SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return norm_u8(a.src[o]); }
+  SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * K1; }
+  SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
+  SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.d1[o]; }
+  SDQN_HD static void store(const StepArgs& a, int, int ks, int m, int n, float v) { a.slab1[(int64_t)ks * NW1 + m * K1 + n] = v; }
+};
+
+// ---- Neon <-> internal parameter layouts (host side; C ABI boundary) ---------------------------
+// returns the internal flat index (relative to the layer's OFFx) of Neon element (row, col)
+inline int64_t neon_to_internal(int layer, int64_t row, int64_t col) {
+  switch (layer) {
+    case 0: return row * K1 + col;                                               // identical
+    case 1: { int c = (int)(row / 16), rs = (int)(row % 16); return ((int64_t)rs * 32 + c) * K2 + col; }
+    case 2: { int c = (int)(row / 9), rs = (int)(row % 9); return ((int64_t)rs * 64 + c) * K3 + col; }
+    case 3: { int f = (int)(col / PIX3), pix = (int)(col % PIX3); return ((int64_t)pix * K3 + f) * NFC + row; }
+    default: return row * NFC + col;                                             // fc5 identical
+  }
+}
+inline void layer_dims(int layer, int A, int64_t& rows, int64_t& cols, int64_t& off) {
+  switch (layer) {
+    case 0: rows = CRS1; cols = K1; off = OFF1; break;
+    case 1: rows = CRS2; cols = K2; off = OFF2; break;
+    case 2: rows = CRS3; cols = K3; off = OFF3; break;
+    case 3: rows = NFC; cols = NIN4; off = OFF4; break;
+    default: rows = A; cols = NFC; off = OFF5; break;
+  }
+}
+
+}  // namespace sdqn

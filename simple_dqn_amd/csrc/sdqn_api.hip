@@ -1,0 +1,624 @@
+// sdqn_api.hip — host side of libsdqn_hip.so: handles, memory, step orchestration, C ABI (include/sdqn.h).
+// No CPU fallback lives here: every device entry point needs a HIP device and fails loudly without one.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/sdqn.h"
+#include "kernels.h"
+#include "sampler.h"
+
+using namespace sdqn;
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_err = buf;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return SDQN_ERR_HIP; } } while (0)
+#define ARGCHK(c, ...) do { if (!(c)) { set_error(__VA_ARGS__); return SDQN_ERR_ARG; } } while (0)
+
+static hipStream_t g_stream = nullptr;
+static int ensure_stream() {
+  if (g_stream) return SDQN_OK;
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n));
+  if (n <= 0) { set_error("no HIP device visible (libsdqn_hip has no CPU path)"); return SDQN_ERR_HIP; }
+  HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  return SDQN_OK;
+}
+#define STREAMCHK() do { int r_ = ensure_stream(); if (r_) return r_; } while (0)
+
+extern "C" const char* sdqn_last_error(void) { return g_err.c_str(); }
+extern "C" int sdqn_version(void) { return 100; }
+extern "C" int sdqn_device_count(int* n) { ARGCHK(n, "n is NULL"); HIPCHK(hipGetDeviceCount(n)); return SDQN_OK; }
+extern "C" int sdqn_set_device(int dev) {
+  if (g_stream) { set_error("sdqn_set_device must precede any other device call"); return SDQN_ERR_STATE; }
+  HIPCHK(hipSetDevice(dev));
+  return SDQN_OK;
+}
+extern "C" int sdqn_device_sync(void) { STREAMCHK(); HIPCHK(hipStreamSynchronize(g_stream)); return SDQN_OK; }
+
+// ---- sampler (pure host) -------------------------------------------------------------------------
+extern "C" int sdqn_mt_seed(uint32_t* mt, uint64_t seed) { ARGCHK(mt, "mt is NULL"); MT::seed(mt, seed); return SDQN_OK; }
+extern "C" int sdqn_mt_randint(uint32_t* mt, int64_t a, int64_t b, int64_t* out) {
+  ARGCHK(mt && out && b >= a, "bad randint arguments");
+  ARGCHK(mt[624] <= 624, "corrupt MT state (position %u)", mt[624]);
+  MT m(mt); *out = m.randint(a, b); return SDQN_OK;
+}
+static int sample_checked(uint32_t* mt, const uint8_t* terminals, int64_t count, int64_t current, int hist,
+                          int batch, int64_t* idx_out, int64_t* draws_out) {
+  ARGCHK(mt && terminals && idx_out, "NULL argument");
+  ARGCHK(mt[624] <= 624, "corrupt MT state (position %u)", mt[624]);
+  ARGCHK(count > hist, "replay memory must hold more than history_length frames (count=%lld)", (long long)count);  // :52
+  ARGCHK(batch > 0 && hist > 0 && current >= 0, "bad sampler arguments");
+  // guard against a ring with no admissible index (the reference would spin forever)
+  bool any_ok = false;
+  for (int64_t i = hist; i < count && !any_ok; ++i) {
+    if (i >= current && i - hist < current) continue;
+    bool t = false;
+    for (int64_t k = i - hist; k < i; ++k) t |= terminals[k] != 0;
+    any_ok = !t;
+  }
+  ARGCHK(any_ok, "no admissible index in the ring (every window straddles the write pointer or a terminal)");
+  int64_t d = sample_indices(mt, terminals, count, current, hist, batch, idx_out);
+  if (draws_out) *draws_out = d;
+  return SDQN_OK;
+}
+extern "C" int sdqn_sample_indices(uint32_t* mt, const uint8_t* terminals, int64_t count, int64_t current,
+                                   int hist, int batch, int64_t* idx_out, int64_t* draws_out) {
+  return sample_checked(mt, terminals, count, current, hist, batch, idx_out, draws_out);
+}
+
+// ---- replay -----------------------------------------------------------------------------------------
+static const int NSLOT = 64;     // pinned index slots: kernels read the sampled indexes zero-copy
+struct sdqn_replay_s {
+  int64_t size = 0; int H = 0, W = 0, hist = 0, B = 0, flags = 0;
+  int64_t count = 0, current = 0;
+  uint8_t* screens = nullptr; uint8_t* actions = nullptr; int64_t* rewards = nullptr; uint8_t* terminals = nullptr;  // pinned master
+  MetaRec* h_meta = nullptr;                       // pinned packed metadata (source of the per-add H2D)
+  uint8_t* d_ring = nullptr; MetaRec* d_meta = nullptr;
+  uint8_t *d_pre = nullptr, *d_post = nullptr, *d_act = nullptr, *d_term = nullptr; int64_t* d_rew = nullptr;
+  uint8_t *h_pre = nullptr, *h_post = nullptr, *h_act = nullptr, *h_term = nullptr; int64_t* h_rew = nullptr;
+  int64_t* h_idx = nullptr; int64_t* d_idx_view = nullptr;      // [NSLOT][B] pinned + its device alias
+  hipEvent_t slot_ev[NSLOT]; bool slot_busy[NSLOT]; int next_slot = 0;
+};
+
+static int replay_free(sdqn_replay_s* r) {
+  if (!r) return SDQN_OK;
+  if (g_stream) hipStreamSynchronize(g_stream);
+  if (!(r->flags & SDQN_REPLAY_ZERO_COPY)) { hipFree(r->d_ring); hipFree(r->d_meta); }
+  hipFree(r->d_pre); hipFree(r->d_post); hipFree(r->d_act); hipFree(r->d_term); hipFree(r->d_rew);
+  hipHostFree(r->screens); hipHostFree(r->actions); hipHostFree(r->rewards); hipHostFree(r->terminals);
+  hipHostFree(r->h_meta); hipHostFree(r->h_pre); hipHostFree(r->h_post); hipHostFree(r->h_act);
+  hipHostFree(r->h_term); hipHostFree(r->h_rew); hipHostFree(r->h_idx);
+  for (int i = 0; i < NSLOT; ++i) if (r->slot_ev[i]) hipEventDestroy(r->slot_ev[i]);
+  delete r;
+  return SDQN_OK;
+}
+
+extern "C" int sdqn_replay_create(sdqn_replay_t* out, int64_t size, int H, int W, int hist, int batch, int flags) {
+  ARGCHK(out, "handle pointer is NULL");
+  ARGCHK(size > hist && batch > 0, "bad replay geometry (size=%lld, batch=%d)", (long long)size, batch);
+  ARGCHK(H == H0 && W == W0 && hist == C0, "this build supports 84x84 screens with history_length 4 (got %dx%d, %d)", H, W, hist);
+  if (!flags) flags = SDQN_REPLAY_HBM_MIRROR;
+  STREAMCHK();
+  sdqn_replay_s* r = new sdqn_replay_s();
+  memset(r->slot_ev, 0, sizeof r->slot_ev); memset(r->slot_busy, 0, sizeof r->slot_busy);
+  r->size = size; r->H = H; r->W = W; r->hist = hist; r->B = batch; r->flags = flags;
+  const unsigned hf = hipHostMallocMapped | hipHostMallocPortable;
+#define RCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s -> %s", #x, hipGetErrorString(e_)); replay_free(r); return SDQN_ERR_HIP; } } while (0)
+  RCHK(hipHostMalloc((void**)&r->screens, (size_t)size * FRAME, hf));
+  RCHK(hipHostMalloc((void**)&r->actions, (size_t)size, hf));
+  RCHK(hipHostMalloc((void**)&r->rewards, (size_t)size * 8, hf));
+  RCHK(hipHostMalloc((void**)&r->terminals, (size_t)size, hf));
+  RCHK(hipHostMalloc((void**)&r->h_meta, (size_t)size * sizeof(MetaRec), hf));
+  memset(r->h_meta, 0, (size_t)size * sizeof(MetaRec));
+  if (flags & SDQN_REPLAY_ZERO_COPY) {
+    RCHK(hipHostGetDevicePointer((void**)&r->d_ring, r->screens, 0));
+    RCHK(hipHostGetDevicePointer((void**)&r->d_meta, r->h_meta, 0));
+  } else {
+    RCHK(hipMalloc((void**)&r->d_ring, (size_t)size * FRAME));
+    RCHK(hipMalloc((void**)&r->d_meta, (size_t)size * sizeof(MetaRec)));
+    RCHK(hipMemsetAsync(r->d_meta, 0, (size_t)size * sizeof(MetaRec), g_stream));
+  }
+  const size_t sb = (size_t)batch * STATE;
+  RCHK(hipMalloc((void**)&r->d_pre, sb)); RCHK(hipMalloc((void**)&r->d_post, sb));
+  RCHK(hipMalloc((void**)&r->d_act, batch)); RCHK(hipMalloc((void**)&r->d_term, batch));
+  RCHK(hipMalloc((void**)&r->d_rew, (size_t)batch * 8));
+  RCHK(hipHostMalloc((void**)&r->h_pre, sb, hf)); RCHK(hipHostMalloc((void**)&r->h_post, sb, hf));
+  RCHK(hipHostMalloc((void**)&r->h_act, batch, hf)); RCHK(hipHostMalloc((void**)&r->h_term, batch, hf));
+  RCHK(hipHostMalloc((void**)&r->h_rew, (size_t)batch * 8, hf));
+  RCHK(hipHostMalloc((void**)&r->h_idx, (size_t)NSLOT * batch * 8, hf));
+  RCHK(hipHostGetDevicePointer((void**)&r->d_idx_view, r->h_idx, 0));
+  for (int i = 0; i < NSLOT; ++i) RCHK(hipEventCreateWithFlags(&r->slot_ev[i], hipEventDisableTiming));
+#undef RCHK
+  *out = r;
+  return SDQN_OK;
+}
+extern "C" int sdqn_replay_destroy(sdqn_replay_t r) { return replay_free(r); }
+
+extern "C" int sdqn_replay_host_ptrs(sdqn_replay_t r, uint8_t** screens, uint8_t** actions, int64_t** rewards, uint8_t** terminals) {
+  ARGCHK(r, "NULL handle");
+  if (screens) *screens = r->screens; if (actions) *actions = r->actions;
+  if (rewards) *rewards = r->rewards; if (terminals) *terminals = r->terminals;
+  return SDQN_OK;
+}
+extern "C" int sdqn_replay_minibatch_ptrs(sdqn_replay_t r, uint8_t** pre, uint8_t** post, uint8_t** actions, int64_t** rewards, uint8_t** terminals) {
+  ARGCHK(r, "NULL handle");
+  if (pre) *pre = r->h_pre; if (post) *post = r->h_post; if (actions) *actions = r->h_act;
+  if (rewards) *rewards = r->h_rew; if (terminals) *terminals = r->h_term;
+  return SDQN_OK;
+}
+
+extern "C" int sdqn_replay_add(sdqn_replay_t r, int action, int64_t reward, const uint8_t* screen, int terminal) {
+  ARGCHK(r && screen, "NULL argument");
+  const int64_t c = r->current;                                   // replay_memory.py:29-32
+  r->actions[c] = (uint8_t)action; r->rewards[c] = reward; r->terminals[c] = terminal ? 1 : 0;
+  memcpy(r->screens + c * FRAME, screen, FRAME);
+  MetaRec& m = r->h_meta[c];
+  m.reward = reward; m.action = (uint8_t)action; m.terminal = terminal ? 1 : 0;
+  if (!(r->flags & SDQN_REPLAY_ZERO_COPY)) {
+    HIPCHK(hipMemcpyAsync(r->d_ring + c * FRAME, r->screens + c * FRAME, FRAME, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(r->d_meta + c, &m, sizeof(MetaRec), hipMemcpyHostToDevice, g_stream));
+  }
+  if (c + 1 > r->count) r->count = c + 1;                         // :33
+  r->current = (c + 1) % r->size;                                 // :34
+  return SDQN_OK;
+}
+extern "C" int sdqn_replay_get_state(sdqn_replay_t r, int64_t* count, int64_t* current) {
+  ARGCHK(r, "NULL handle"); if (count) *count = r->count; if (current) *current = r->current; return SDQN_OK;
+}
+extern "C" int sdqn_replay_set_state(sdqn_replay_t r, int64_t count, int64_t current) {
+  ARGCHK(r && count >= 0 && count <= r->size && current >= 0 && current < r->size, "bad count/current");
+  r->count = count; r->current = current; return SDQN_OK;
+}
+extern "C" int sdqn_replay_upload(sdqn_replay_t r, int64_t first, int64_t n) {
+  ARGCHK(r && first >= 0 && n >= 0 && first + n <= r->size, "bad upload range");
+  for (int64_t i = first; i < first + n; ++i) {
+    MetaRec& m = r->h_meta[i];
+    m.reward = r->rewards[i]; m.action = r->actions[i]; m.terminal = r->terminals[i] ? 1 : 0;
+  }
+  if (!(r->flags & SDQN_REPLAY_ZERO_COPY) && n > 0) {
+    HIPCHK(hipMemcpyAsync(r->d_ring + first * FRAME, r->screens + first * FRAME, (size_t)n * FRAME, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(r->d_meta + first, r->h_meta + first, (size_t)n * sizeof(MetaRec), hipMemcpyHostToDevice, g_stream));
+  }
+  HIPCHK(hipStreamSynchronize(g_stream));
+  return SDQN_OK;
+}
+extern "C" int sdqn_replay_sample(sdqn_replay_t r, uint32_t* mt, int64_t* idx_out, int64_t* draws_out) {
+  ARGCHK(r, "NULL handle");
+  return sample_checked(mt, r->terminals, r->count, r->current, r->hist, r->B, idx_out, draws_out);
+}
+
+// take the next pinned index slot (waiting for its previous consumer), fill it, return its device alias
+static int replay_push_idx(sdqn_replay_s* r, const int64_t* idx, int* slot_out, const int64_t** dev) {
+  const int s = r->next_slot; r->next_slot = (s + 1) % NSLOT;
+  if (r->slot_busy[s]) { HIPCHK(hipEventSynchronize(r->slot_ev[s])); r->slot_busy[s] = false; }
+  int64_t* dst = r->h_idx + (size_t)s * r->B;
+  for (int i = 0; i < r->B; ++i) {
+    ARGCHK(idx[i] >= r->hist && idx[i] < r->size, "index %lld out of range", (long long)idx[i]);
+    dst[i] = idx[i];
+  }
+  *slot_out = s; *dev = r->d_idx_view + (size_t)s * r->B;
+  return SDQN_OK;
+}
+static int replay_release_idx(sdqn_replay_s* r, int slot) {
+  HIPCHK(hipEventRecord(r->slot_ev[slot], g_stream)); r->slot_busy[slot] = true; return SDQN_OK;
+}
+
+static GatherArgs gather_args(sdqn_replay_s* r, const int64_t* didx) {
+  GatherArgs g; g.ring = r->d_ring; g.meta = r->d_meta; g.idx = didx; g.pre = r->d_pre; g.post = r->d_post;
+  g.actions = r->d_act; g.rewards = r->d_rew; g.terminals = r->d_term; g.B = r->B; return g;
+}
+extern "C" int sdqn_replay_gather(sdqn_replay_t r, const int64_t* idx_host) {
+  ARGCHK(r && idx_host, "NULL argument");
+  int slot; const int64_t* didx; int rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
+  HIPCHK(launch_gather(gather_args(r, didx), g_stream));
+  return replay_release_idx(r, slot);
+}
+extern "C" int sdqn_replay_minibatch_to_host(sdqn_replay_t r) {
+  ARGCHK(r, "NULL handle");
+  const size_t sb = (size_t)r->B * STATE;
+  HIPCHK(hipMemcpyAsync(r->h_pre, r->d_pre, sb, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpyAsync(r->h_post, r->d_post, sb, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpyAsync(r->h_act, r->d_act, r->B, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpyAsync(r->h_rew, r->d_rew, (size_t)r->B * 8, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpyAsync(r->h_term, r->d_term, r->B, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  return SDQN_OK;
+}
+extern "C" int sdqn_replay_bench_gather(sdqn_replay_t r, const int64_t* idx_host, int iters, float* ms_per_launch) {
+  ARGCHK(r && idx_host && iters > 0 && ms_per_launch, "bad arguments");
+  int slot; const int64_t* didx; int rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  GatherArgs g = gather_args(r, didx);
+  HIPCHK(launch_gather(g, g_stream));                                        // warm
+  HIPCHK(hipEventRecord(e0, g_stream));
+  for (int i = 0; i < iters; ++i) HIPCHK(launch_gather(g, g_stream));
+  HIPCHK(hipEventRecord(e1, g_stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_per_launch = ms / iters;
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return replay_release_idx(r, slot);
+}
+
+// ---- RCCL (resolved at run time from the library the process already uses) ------------------------------
+struct Id128 { char b[128]; };   // ncclUniqueId is passed BY VALUE to ncclCommInitRank
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+static Rccl g_rccl;
+static int rccl_load(const char* path) {
+  if (g_rccl.lib) return SDQN_OK;
+  const char* p = (path && *path) ? path : "librccl.so.1";
+  void* lib = dlopen(p, RTLD_NOW | RTLD_LOCAL);
+  if (!lib) { set_error("dlopen(%s) failed: %s", p, dlerror()); return SDQN_ERR_RCCL; }
+  g_rccl.GetUniqueId = (int (*)(void*))dlsym(lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(lib, "ncclCommInitRank");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
+  g_rccl.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+    set_error("%s lacks the nccl* entry points", p); dlclose(lib); return SDQN_ERR_RCCL;
+  }
+  g_rccl.lib = lib;
+  return SDQN_OK;
+}
+#define NCCLCHK(x) do { int e_ = (x); if (e_ != 0) { set_error("%s -> %s", #x, g_rccl.GetErrorString ? g_rccl.GetErrorString(e_) : "rccl error"); return SDQN_ERR_RCCL; } } while (0)
+
+// ---- network -------------------------------------------------------------------------------------------
+struct ProfPair { int id; hipEvent_t a, b; };
+struct sdqn_net_s {
+  sdqn_net_cfg cfg; int B = 0, A = 0; int64_t NP = 0;
+  float *theta = nullptr, *theta_t = nullptr, *state = nullptr, *g = nullptr;
+  float *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *slab4 = nullptr, *a4 = nullptr, *d4 = nullptr;
+  float *d3p = nullptr, *d2p = nullptr, *d1 = nullptr, *slab1 = nullptr, *slab2 = nullptr, *slab3 = nullptr;
+  float *q = nullptr, *maxq = nullptr, *dq = nullptr, *cost_terms = nullptr, *cost_out = nullptr; double* cost_accum = nullptr;
+  uint8_t *st_states = nullptr, *st_act = nullptr, *st_term = nullptr; int64_t* st_rew = nullptr;
+  float* h_f = nullptr;                    // pinned scratch for small read-backs
+  int S4 = 14, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
+  int64_t train_iterations = 0;
+  // profiler
+  bool prof_on = false; int prof_filter = -1;
+  std::vector<ProfPair> prof_pending; std::vector<hipEvent_t> prof_free;
+  double prof_ms[K_COUNT]; int64_t prof_n[K_COUNT];
+  // data parallel
+  void* comm = nullptr; int rank = 0, nranks = 1;
+  std::vector<void*> allocs;
+};
+
+static int dalloc(sdqn_net_s* h, void** p, size_t bytes, bool zero = true) {
+  HIPCHK(hipMalloc(p, bytes)); h->allocs.push_back(*p);
+  if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, g_stream));
+  return SDQN_OK;
+}
+static int net_free(sdqn_net_s* h) {
+  if (!h) return SDQN_OK;
+  if (g_stream) hipStreamSynchronize(g_stream);
+  if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  for (void* p : h->allocs) hipFree(p);
+  hipHostFree(h->h_f);
+  for (auto& pp : h->prof_pending) { hipEventDestroy(pp.a); hipEventDestroy(pp.b); }
+  for (auto e : h->prof_free) hipEventDestroy(e);
+  delete h;
+  return SDQN_OK;
+}
+
+extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
+  ARGCHK(out && c, "NULL argument");
+  ARGCHK(c->batch_size > 0 && c->batch_size <= 4096, "bad batch_size %d", c->batch_size);
+  ARGCHK(c->num_actions > 0 && c->num_actions <= MAX_ACTIONS, "num_actions must be in 1..%d (got %d)", MAX_ACTIONS, c->num_actions);
+  ARGCHK(c->screen_height == H0 && c->screen_width == W0 && c->history_length == C0,
+         "this build supports 84x84 screens with history_length 4 (got %dx%d, %d)", c->screen_height, c->screen_width, c->history_length);
+  STREAMCHK();
+  sdqn_net_s* h = new sdqn_net_s();
+  h->cfg = *c; h->B = c->batch_size; h->A = c->num_actions; h->NP = OFF5 + (int64_t)h->A * NFC;
+  memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n);
+  const int B = h->B;
+  auto pick = [](int T, int target) { int t = (T + target - 1) / target; return t < 1 ? 1 : t; };
+  const int big = B >= 128 ? 2 : 1;
+  const int T1 = ceil_div(B * PIX1, 32), T2 = ceil_div(B * PIX2, 32), T3 = ceil_div(B * PIX3, 32);
+  h->tps1 = pick(T1, 100 * big); h->tps2 = pick(T2, 27 * big); h->tps3 = pick(T3, 25 * big);
+  h->ns1 = ceil_div(T1, h->tps1); h->ns2 = ceil_div(T2, h->tps2); h->ns3 = ceil_div(T3, h->tps3);
+  h->S4 = 14;
+#define NCHK(x) do { int r_ = (x); if (r_) { net_free(h); return r_; } } while (0)
+  NCHK(dalloc(h, (void**)&h->theta, h->NP * 4));
+  if (c->target_enabled) NCHK(dalloc(h, (void**)&h->theta_t, h->NP * 4)); else h->theta_t = h->theta;   // deepqnetwork.py:64-73
+  NCHK(dalloc(h, (void**)&h->state, h->NP * 4));
+  NCHK(dalloc(h, (void**)&h->g, h->NP * 4));
+  NCHK(dalloc(h, (void**)&h->a1, (size_t)2 * B * PIX1 * K1 * 4));
+  NCHK(dalloc(h, (void**)&h->a2, (size_t)2 * B * PIX2 * K2 * 4));
+  NCHK(dalloc(h, (void**)&h->a3, (size_t)2 * B * PIX3 * K3 * 4));
+  NCHK(dalloc(h, (void**)&h->slab4, (size_t)h->S4 * 2 * B * NFC * 4));
+  NCHK(dalloc(h, (void**)&h->a4, (size_t)2 * B * NFC * 4));
+  NCHK(dalloc(h, (void**)&h->d4, (size_t)B * NFC * 4));
+  NCHK(dalloc(h, (void**)&h->d3p, (size_t)B * PD3 * PD3 * K3 * 4));    // borders stay zero for ever
+  NCHK(dalloc(h, (void**)&h->d2p, (size_t)B * PD2 * PD2 * K2 * 4));
+  NCHK(dalloc(h, (void**)&h->d1, (size_t)B * PIX1 * K1 * 4));
+  NCHK(dalloc(h, (void**)&h->slab1, (size_t)h->ns1 * NW1 * 4));
+  NCHK(dalloc(h, (void**)&h->slab2, (size_t)h->ns2 * NW2 * 4));
+  NCHK(dalloc(h, (void**)&h->slab3, (size_t)h->ns3 * NW3 * 4));
+  NCHK(dalloc(h, (void**)&h->q, (size_t)2 * B * h->A * 4));
+  NCHK(dalloc(h, (void**)&h->maxq, (size_t)B * 4));
+  NCHK(dalloc(h, (void**)&h->dq, (size_t)B * h->A * 4));
+  NCHK(dalloc(h, (void**)&h->cost_terms, (size_t)B * 4));
+  NCHK(dalloc(h, (void**)&h->cost_out, 16));
+  NCHK(dalloc(h, (void**)&h->cost_accum, 16));
+  NCHK(dalloc(h, (void**)&h->st_states, (size_t)2 * B * STATE));
+  NCHK(dalloc(h, (void**)&h->st_act, B)); NCHK(dalloc(h, (void**)&h->st_term, B));
+  NCHK(dalloc(h, (void**)&h->st_rew, (size_t)B * 8));
+  { hipError_t e = hipHostMalloc((void**)&h->h_f, (size_t)(2 * B * MAX_ACTIONS + B + 64) * 8, hipHostMallocMapped);
+    if (e != hipSuccess) { set_error("hipHostMalloc -> %s", hipGetErrorString(e)); net_free(h); return SDQN_ERR_HIP; } }
+#undef NCHK
+  HIPCHK(hipStreamSynchronize(g_stream));
+  *out = h;
+  return SDQN_OK;
+}
+extern "C" int sdqn_net_destroy(sdqn_net_t h) { return net_free(h); }
+
+extern "C" int sdqn_net_layer_size(sdqn_net_t h, int layer, int64_t* n) {
+  ARGCHK(h && n && layer >= 0 && layer < 5, "bad arguments");
+  int64_t r, c, o; layer_dims(layer, h->A, r, c, o); *n = r * c; return SDQN_OK;
+}
+static float* which_buf(sdqn_net_s* h, int which) {
+  switch (which) { case 0: return h->theta; case 1: return h->theta_t; case 2: return h->state; case 3: return h->g; default: return nullptr; }
+}
+extern "C" int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const float* w, int64_t n) {
+  ARGCHK(h && w && layer >= 0 && layer < 5 && which >= 0 && which <= 2, "bad arguments");
+  int64_t rows, cols, off; layer_dims(layer, h->A, rows, cols, off);
+  ARGCHK(n == rows * cols, "layer %d holds %lld values, got %lld", layer, (long long)(rows * cols), (long long)n);
+  std::vector<float> tmp((size_t)n);
+  for (int64_t r = 0; r < rows; ++r) for (int64_t c = 0; c < cols; ++c) tmp[(size_t)neon_to_internal(layer, r, c)] = w[r * cols + c];
+  HIPCHK(hipStreamSynchronize(g_stream));
+  HIPCHK(hipMemcpy(which_buf(h, which) + off, tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  return SDQN_OK;
+}
+extern "C" int sdqn_net_get_weights(sdqn_net_t h, int which, int layer, float* w, int64_t n) {
+  ARGCHK(h && w && layer >= 0 && layer < 5 && which >= 0 && which <= 3, "bad arguments");
+  int64_t rows, cols, off; layer_dims(layer, h->A, rows, cols, off);
+  ARGCHK(n == rows * cols, "layer %d holds %lld values, got %lld", layer, (long long)(rows * cols), (long long)n);
+  std::vector<float> tmp((size_t)n);
+  HIPCHK(hipStreamSynchronize(g_stream));
+  HIPCHK(hipMemcpy(tmp.data(), which_buf(h, which) + off, (size_t)n * 4, hipMemcpyDeviceToHost));
+  for (int64_t r = 0; r < rows; ++r) for (int64_t c = 0; c < cols; ++c) w[r * cols + c] = tmp[(size_t)neon_to_internal(layer, r, c)];
+  return SDQN_OK;
+}
+
+// ---- profiler -------------------------------------------------------------------------------------------
+static int prof_collect(sdqn_net_s* h) {
+  if (h->prof_pending.empty()) return SDQN_OK;
+  HIPCHK(hipStreamSynchronize(g_stream));
+  for (auto& p : h->prof_pending) {
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
+    h->prof_ms[p.id] += ms; h->prof_n[p.id] += 1;
+    h->prof_free.push_back(p.a); h->prof_free.push_back(p.b);
+  }
+  h->prof_pending.clear();
+  return SDQN_OK;
+}
+static int prof_event(sdqn_net_s* h, hipEvent_t* e) {
+  if (!h->prof_free.empty()) { *e = h->prof_free.back(); h->prof_free.pop_back(); return SDQN_OK; }
+  HIPCHK(hipEventCreate(e)); return SDQN_OK;
+}
+#define LAUNCH(KID, expr) do { \
+  const bool pf_ = h->prof_on && (h->prof_filter < 0 || h->prof_filter == (KID)); ProfPair pp_; \
+  if (pf_) { pp_.id = (KID); int r1_ = prof_event(h, &pp_.a); if (r1_) return r1_; r1_ = prof_event(h, &pp_.b); if (r1_) return r1_; \
+             HIPCHK(hipEventRecord(pp_.a, g_stream)); } \
+  hipError_t le_ = (expr); \
+  if (le_ != hipSuccess) { set_error("launch %s -> %s", kernel_name(KID), hipGetErrorString(le_)); return SDQN_ERR_HIP; } \
+  if (pf_) { HIPCHK(hipEventRecord(pp_.b, g_stream)); h->prof_pending.push_back(pp_); \
+             if (h->prof_pending.size() > 16384) { int r2_ = prof_collect(h); if (r2_) return r2_; } } \
+} while (0)
+
+extern "C" int sdqn_net_profile(sdqn_net_t h, int enable, int kernel) {
+  ARGCHK(h && kernel < K_COUNT, "bad arguments"); h->prof_on = enable != 0; h->prof_filter = kernel; return SDQN_OK;
+}
+extern "C" int sdqn_net_profile_count(int* n) { ARGCHK(n, "NULL"); *n = K_COUNT; return SDQN_OK; }
+extern "C" int sdqn_net_profile_read(sdqn_net_t h, int kernel, const char** name, double* total_ms, int64_t* launches) {
+  ARGCHK(h && kernel >= 0 && kernel < K_COUNT, "bad arguments");
+  int rc = prof_collect(h); if (rc) return rc;
+  if (name) *name = kernel_name(kernel); if (total_ms) *total_ms = h->prof_ms[kernel]; if (launches) *launches = h->prof_n[kernel];
+  return SDQN_OK;
+}
+extern "C" int sdqn_net_profile_reset(sdqn_net_t h) {
+  ARGCHK(h, "NULL handle"); int rc = prof_collect(h); if (rc) return rc;
+  memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n); return SDQN_OK;
+}
+
+// ---- the step ---------------------------------------------------------------------------------------------
+static StepArgs step_args(sdqn_net_s* h) {
+  StepArgs a; memset(&a, 0, sizeof a);
+  a.B = h->B; a.A = h->A; a.nz = 2; a.theta[0] = h->theta; a.theta[1] = h->theta_t;
+  a.a1 = h->a1; a.a2 = h->a2; a.a3 = h->a3; a.slab4 = h->slab4; a.a4 = h->a4; a.d4 = h->d4; a.d3p = h->d3p; a.d2p = h->d2p;
+  a.d1 = h->d1; a.g = h->g; a.slab1 = h->slab1; a.slab2 = h->slab2; a.slab3 = h->slab3;
+  a.S4 = h->S4; a.tps1 = h->tps1; a.tps2 = h->tps2; a.tps3 = h->tps3;
+  return a;
+}
+static HeadArgs head_args(sdqn_net_s* h, int train) {
+  HeadArgs hd; memset(&hd, 0, sizeof hd);
+  hd.st_actions = h->st_act; hd.st_rewards = h->st_rew; hd.st_terminals = h->st_term;
+  hd.q = h->q; hd.maxq = h->maxq; hd.dq = h->dq; hd.cost_terms = h->cost_terms;
+  hd.discount = h->cfg.discount_rate; hd.min_reward = h->cfg.min_reward; hd.max_reward = h->cfg.max_reward;
+  hd.clip_error = (float)h->cfg.clip_error; hd.train = train;
+  return hd;
+}
+static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
+  LAUNCH(K_CONV1_FWD, launch_kernel(K_CONV1_FWD, a, g_stream));
+  LAUNCH(K_CONV2_FWD, launch_kernel(K_CONV2_FWD, a, g_stream));
+  LAUNCH(K_CONV3_FWD, launch_kernel(K_CONV3_FWD, a, g_stream));
+  LAUNCH(K_FC4_FWD, launch_kernel(K_FC4_FWD, a, g_stream));
+  LAUNCH(K_HEAD, launch_head(a, hd, g_stream));
+  return SDQN_OK;
+}
+static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
+  int rc = run_forward(h, a, hd); if (rc) return rc;
+  LAUNCH(K_FC4_DGRAD, launch_kernel(K_FC4_DGRAD, a, g_stream));
+  LAUNCH(K_FC4_WGRAD, launch_kernel(K_FC4_WGRAD, a, g_stream));
+  LAUNCH(K_CONV3_DGRAD, launch_kernel(K_CONV3_DGRAD, a, g_stream));
+  LAUNCH(K_CONV3_WGRAD, launch_kernel(K_CONV3_WGRAD, a, g_stream));
+  LAUNCH(K_CONV2_DGRAD, launch_kernel(K_CONV2_DGRAD, a, g_stream));
+  LAUNCH(K_CONV2_WGRAD, launch_kernel(K_CONV2_WGRAD, a, g_stream));
+  LAUNCH(K_CONV1_WGRAD, launch_kernel(K_CONV1_WGRAD, a, g_stream));
+  UpdateArgs u; memset(&u, 0, sizeof u);
+  u.theta = h->theta; u.state = h->state; u.g = h->g;
+  u.slab[0] = h->slab1; u.slab[1] = h->slab2; u.slab[2] = h->slab3; u.ns[0] = h->ns1; u.ns[1] = h->ns2; u.ns[2] = h->ns3;
+  u.dq = h->dq; u.a4 = h->a4; u.cost_terms = h->cost_terms; u.cost_out = h->cost_out; u.cost_accum = h->cost_accum;
+  u.B = h->B; u.A = h->A;
+  u.rho = (float)h->cfg.decay_rate; u.one_minus_rho = (float)(1.0 - h->cfg.decay_rate);
+  u.lr = (float)h->cfg.learning_rate; u.eps = (float)h->cfg.epsilon;
+  if (h->comm) {
+    // synchronous data parallel: local gradient sums -> one RCCL all-reduce of the flat buffer -> identical RMSProp
+    u.mode = 1; u.bsz = (float)h->B;
+    LAUNCH(K_UPDATE, launch_update(u, g_stream));
+    LAUNCH(K_ALLREDUCE, (g_rccl.AllReduce(h->g, h->g, (size_t)h->NP, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, g_stream) == 0
+                         ? hipSuccess : hipErrorUnknown));
+    u.mode = 2; u.bsz = (float)h->B * (float)h->nranks;
+    LAUNCH(K_UPDATE, launch_update(u, g_stream));
+  } else {
+    u.mode = 0; u.bsz = (float)h->B;
+    LAUNCH(K_UPDATE, launch_update(u, g_stream));
+  }
+  h->train_iterations += 1;                                                   // deepqnetwork.py:168
+  return SDQN_OK;
+}
+static int read_cost(sdqn_net_s* h, float* cost_out) {
+  HIPCHK(hipMemcpyAsync(h->h_f, h->cost_out, 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  *cost_out = h->h_f[0];
+  return SDQN_OK;
+}
+
+extern "C" int sdqn_net_predict(sdqn_net_t h, const uint8_t* states, float* q_out) {
+  ARGCHK(h && states && q_out, "NULL argument");
+  HIPCHK(hipMemcpyAsync(h->st_states, states, (size_t)h->B * STATE, hipMemcpyHostToDevice, g_stream));
+  StepArgs a = step_args(h); a.nz = 1; a.from_ring = 0; a.src = h->st_states;
+  HeadArgs hd = head_args(h, 0);
+  int rc = run_forward(h, a, hd); if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(h->h_f, h->q, (size_t)h->B * h->A * 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  memcpy(q_out, h->h_f, (size_t)h->B * h->A * 4);                             // (B, A): deepqnetwork.py:186 qvalues.T
+  return SDQN_OK;
+}
+
+extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8_t* actions, const int64_t* rewards,
+                                   const uint8_t* post, const uint8_t* terminals, float* cost_out) {
+  ARGCHK(h && pre && actions && rewards && post && terminals, "NULL argument");
+  for (int i = 0; i < h->B; ++i) ARGCHK(actions[i] < h->A, "action %d out of range at %d", (int)actions[i], i);
+  const size_t sb = (size_t)h->B * STATE;
+  HIPCHK(hipMemcpyAsync(h->st_states, pre, sb, hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipMemcpyAsync(h->st_states + sb, post, sb, hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipMemcpyAsync(h->st_act, actions, h->B, hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipMemcpyAsync(h->st_rew, rewards, (size_t)h->B * 8, hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipMemcpyAsync(h->st_term, terminals, h->B, hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));       // the caller's (pageable) arrays are free to change after return
+  StepArgs a = step_args(h); a.from_ring = 0; a.src = h->st_states;
+  HeadArgs hd = head_args(h, 1);
+  int rc = run_train(h, a, hd); if (rc) return rc;
+  if (cost_out) return read_cost(h, cost_out);
+  return SDQN_OK;
+}
+
+static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* didx) {
+  StepArgs a = step_args(h); a.from_ring = 1; a.src = r->d_ring; a.idx = didx;
+  HeadArgs hd = head_args(h, 1); hd.meta = r->d_meta;
+  return run_train(h, a, hd);
+}
+extern "C" int sdqn_net_train_replay(sdqn_net_t h, sdqn_replay_t r, const int64_t* idx_host, float* cost_out) {
+  ARGCHK(h && r && idx_host, "NULL argument");
+  ARGCHK(r->B == h->B, "replay batch_size %d != network batch_size %d", r->B, h->B);
+  int slot; const int64_t* didx; int rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
+  rc = train_replay_slot(h, r, didx); if (rc) return rc;
+  rc = replay_release_idx(r, slot); if (rc) return rc;
+  if (cost_out) return read_cost(h, cost_out);
+  return SDQN_OK;
+}
+extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, int n_steps, float* mean_cost) {
+  ARGCHK(h && r && mt && n_steps >= 0, "bad arguments");
+  ARGCHK(r->B == h->B, "replay batch_size %d != network batch_size %d", r->B, h->B);
+  std::vector<int64_t> idx((size_t)r->B);
+  HIPCHK(hipMemsetAsync(h->cost_accum, 0, 8, g_stream));
+  for (int i = 0; i < n_steps; ++i) {
+    int rc = sample_checked(mt, r->terminals, r->count, r->current, r->hist, r->B, idx.data(), nullptr); if (rc) return rc;
+    int slot; const int64_t* didx; rc = replay_push_idx(r, idx.data(), &slot, &didx); if (rc) return rc;
+    rc = train_replay_slot(h, r, didx); if (rc) return rc;
+    rc = replay_release_idx(r, slot); if (rc) return rc;
+  }
+  if (mean_cost) {
+    HIPCHK(hipMemcpyAsync(h->h_f, h->cost_accum, 8, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    *mean_cost = n_steps ? (float)(*(double*)h->h_f / n_steps) : 0.0f;
+  }
+  return SDQN_OK;
+}
+extern "C" int sdqn_net_update_target(sdqn_net_t h) {
+  ARGCHK(h, "NULL handle");
+  if (h->theta_t != h->theta)
+    HIPCHK(hipMemcpyAsync(h->theta_t, h->theta, (size_t)h->NP * 4, hipMemcpyDeviceToDevice, g_stream));   // deepqnetwork.py:102-105
+  return SDQN_OK;
+}
+extern "C" int sdqn_net_sync(sdqn_net_t h) { ARGCHK(h, "NULL handle"); HIPCHK(hipStreamSynchronize(g_stream)); return SDQN_OK; }
+extern "C" int sdqn_net_last_q(sdqn_net_t h, float* preq, float* maxpostq) {
+  ARGCHK(h, "NULL handle");
+  const size_t nq = (size_t)h->B * h->A;
+  HIPCHK(hipMemcpyAsync(h->h_f, h->q, nq * 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpyAsync(h->h_f + nq, h->maxq, (size_t)h->B * 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  if (preq) memcpy(preq, h->h_f, nq * 4);
+  if (maxpostq) memcpy(maxpostq, h->h_f + nq, (size_t)h->B * 4);
+  return SDQN_OK;
+}
+extern "C" int sdqn_net_train_iterations(sdqn_net_t h, int64_t* n) { ARGCHK(h && n, "NULL"); *n = h->train_iterations; return SDQN_OK; }
+
+// test hook: raw read of an internal device buffer (internal layouts, see problems.h)
+extern "C" int sdqn_net_debug_read(sdqn_net_t h, const char* name, float* out, int64_t n) {
+  ARGCHK(h && name && out, "NULL argument");
+  const int B = h->B;
+  struct { const char* n; float* p; int64_t len; } tab[] = {
+    {"a1", h->a1, (int64_t)2 * B * PIX1 * K1}, {"a2", h->a2, (int64_t)2 * B * PIX2 * K2}, {"a3", h->a3, (int64_t)2 * B * PIX3 * K3},
+    {"a4", h->a4, (int64_t)2 * B * NFC}, {"d4", h->d4, (int64_t)B * NFC}, {"d3p", h->d3p, (int64_t)B * PD3 * PD3 * K3},
+    {"d2p", h->d2p, (int64_t)B * PD2 * PD2 * K2}, {"d1", h->d1, (int64_t)B * PIX1 * K1}, {"q", h->q, (int64_t)2 * B * h->A},
+    {"dq", h->dq, (int64_t)B * h->A}, {"g", h->g, h->NP}, {"theta", h->theta, h->NP}, {"cost_terms", h->cost_terms, B}};
+  for (auto& e : tab) if (!strcmp(e.n, name)) {
+    ARGCHK(n <= e.len, "buffer %s holds %lld floats", name, (long long)e.len);
+    HIPCHK(hipStreamSynchronize(g_stream));
+    HIPCHK(hipMemcpy(out, e.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return SDQN_OK;
+  }
+  set_error("unknown buffer %s", name); return SDQN_ERR_ARG;
+}
+
+// ---- data parallel ---------------------------------------------------------------------------------------
+extern "C" int sdqn_dp_unique_id(const char* rccl_path, char id[128]) {
+  ARGCHK(id, "NULL id"); int rc = rccl_load(rccl_path); if (rc) return rc;
+  NCCLCHK(g_rccl.GetUniqueId(id));
+  return SDQN_OK;
+}
+extern "C" int sdqn_dp_init(sdqn_net_t h, const char* rccl_path, const char id[128], int rank, int nranks) {
+  ARGCHK(h && id && nranks >= 1 && rank >= 0 && rank < nranks, "bad arguments");
+  if (h->comm) { set_error("data parallel already initialised"); return SDQN_ERR_STATE; }
+  int rc = rccl_load(rccl_path); if (rc) return rc;
+  Id128 u; memcpy(u.b, id, 128);
+  NCCLCHK(g_rccl.CommInitRank(&h->comm, nranks, u, rank));
+  h->rank = rank; h->nranks = nranks;
+  return SDQN_OK;
+}
+extern "C" int sdqn_dp_shutdown(sdqn_net_t h) {
+  ARGCHK(h, "NULL handle");
+  if (h->comm) { HIPCHK(hipStreamSynchronize(g_stream)); NCCLCHK(g_rccl.CommDestroy(h->comm)); h->comm = nullptr; }
+  h->rank = 0; h->nranks = 1;
+  return SDQN_OK;
+}

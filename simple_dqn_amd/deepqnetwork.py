@@ -1,0 +1,220 @@
+"""DeepQNetwork — drop-in for /root/reference/src/deepqnetwork.py:15-192, no Neon.
+
+Same constructor (num_actions, args), methods (train / predict / update_target_network /
+load_weights / save_weights) and attributes (train_iterations, callback, batch_size, num_actions).
+The whole step — target forward, online forward, TD target, clipped error, backward, RMSProp —
+runs in libsdqn_hip.so on the device with zero host round trips (the reference does six, :119-171).
+"""
+import ctypes as C
+import logging
+
+import numpy as np
+
+from . import _lib
+
+logger = logging.getLogger(__name__)
+
+# (rows, cols) in Neon layout per layer for 84x84x4 inputs (deepqnetwork.py:83-91)
+def layer_shapes(num_actions):
+    return [(256, 32), (512, 64), (576, 64), (512, 3136), (num_actions, 512)]
+
+
+class DeepQNetwork:
+    def __init__(self, num_actions, args):
+        self._lib = _lib.load()
+        self.num_actions = num_actions
+        self.batch_size = args.batch_size
+        self.discount_rate = args.discount_rate
+        self.history_length = args.history_length
+        self.screen_dim = (args.screen_height, args.screen_width)
+        self.clip_error = args.clip_error
+        self.min_reward = args.min_reward
+        self.max_reward = args.max_reward
+        self.batch_norm = getattr(args, "batch_norm", False)
+        if self.batch_norm:
+            raise NotImplementedError("batch_norm=True is not on the MI355X hot path yet (SURVEY.md §8f)")
+        if getattr(args, "backend", "hip") == "cpu":
+            raise NotImplementedError("there is no CPU backend: libsdqn_hip is MI355X-only")
+        if str(getattr(args, "datatype", "float32")) not in ("float32", "<class 'numpy.float32'>"):
+            raise NotImplementedError("only float32 is implemented (fp16 activations: SURVEY.md config 5, next)")
+        optimizer = getattr(args, "optimizer", "rmsprop")
+        if optimizer != "rmsprop":
+            if optimizer in ("adam", "adadelta"):
+                raise NotImplementedError("optimizer %s is not implemented yet (SURVEY.md §8f)" % optimizer)
+            assert False, "Unknown optimizer"                      # deepqnetwork.py:61
+        dev = getattr(args, "device_id", None)
+        cfg = _lib.NetCfg()
+        cfg.batch_size, cfg.history_length = self.batch_size, self.history_length
+        cfg.screen_height, cfg.screen_width = self.screen_dim
+        cfg.num_actions = num_actions
+        cfg.target_enabled = 1 if getattr(args, "target_steps", 10000) else 0          # :64
+        cfg.discount_rate, cfg.clip_error = float(self.discount_rate), float(self.clip_error or 0)
+        cfg.min_reward, cfg.max_reward = float(self.min_reward), float(self.max_reward)
+        cfg.learning_rate = float(getattr(args, "learning_rate", 0.00025))
+        cfg.decay_rate = float(getattr(args, "decay_rate", 0.95))
+        cfg.epsilon = float(getattr(args, "rmsprop_epsilon", 1e-6))                    # Neon RMSProp default (A10)
+        self._dev = dev
+        h = C.c_void_p()
+        _lib.check(self._lib.sdqn_net_create(C.byref(h), C.byref(cfg)))
+        self._h = h
+        self.train_iterations = 0
+        self.callback = None
+        self.save_weights_prefix = getattr(args, "save_weights_prefix", None)
+        # Xavier init (A4): online layers first, then the target model's own draw (:65-70)
+        rng = np.random.RandomState(getattr(args, "random_seed", None) or None)
+        for which in ((0, 1) if cfg.target_enabled else (0,)):
+            for i, shp in enumerate(layer_shapes(num_actions)):
+                fan_in = shp[0] if i < 3 else shp[1]
+                k = np.sqrt(3.0 / fan_in)
+                self.set_layer(i, rng.uniform(-k, k, size=shp).astype(np.float32), which)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and self._lib is not None:
+            self._lib.sdqn_net_destroy(h)
+
+    # ---- weights at the boundary are ALWAYS in Neon layout --------------------------------------
+    def set_layer(self, layer, w, which=0):
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        assert w.shape == layer_shapes(self.num_actions)[layer], (w.shape, layer)
+        _lib.check(self._lib.sdqn_net_set_weights(self._h, which, layer, _lib.ptr(w, C.c_float), w.size))
+
+    def get_layer(self, layer, which=0):
+        w = np.empty(layer_shapes(self.num_actions)[layer], dtype=np.float32)
+        _lib.check(self._lib.sdqn_net_get_weights(self._h, which, layer, _lib.ptr(w, C.c_float), w.size))
+        return w
+
+    def set_weights(self, weights, which=0):
+        for i, w in enumerate(weights):
+            self.set_layer(i, w, which)
+
+    def get_weights(self, which=0):
+        return [self.get_layer(i, which) for i in range(5)]
+
+    # ---- reference API ----------------------------------------------------------------------------
+    def update_target_network(self):                               # :102-105
+        _lib.check(self._lib.sdqn_net_update_target(self._h))
+
+    def train(self, minibatch, epoch=0):                           # :107-172
+        prestates, actions, rewards, poststates, terminals = minibatch
+        assert len(prestates.shape) == 4
+        assert len(poststates.shape) == 4
+        assert len(actions.shape) == 1
+        assert len(rewards.shape) == 1
+        assert len(terminals.shape) == 1
+        assert prestates.shape == poststates.shape
+        assert prestates.shape[0] == actions.shape[0] == rewards.shape[0] == poststates.shape[0] == terminals.shape[0]
+        assert prestates.shape == (self.batch_size, self.history_length) + self.screen_dim
+        pre = np.ascontiguousarray(prestates, dtype=np.uint8)
+        post = np.ascontiguousarray(poststates, dtype=np.uint8)
+        act = np.ascontiguousarray(actions, dtype=np.uint8)
+        rew = np.ascontiguousarray(rewards, dtype=np.int64)
+        term = np.ascontiguousarray(terminals).astype(np.uint8)
+        cost = C.c_float()
+        want = self.callback is not None
+        _lib.check(self._lib.sdqn_net_train_host(self._h, _lib.ptr(pre, C.c_uint8), _lib.ptr(act, C.c_uint8),
+                                                 _lib.ptr(rew, C.c_int64), _lib.ptr(post, C.c_uint8),
+                                                 _lib.ptr(term, C.c_uint8), C.byref(cost) if want else None))
+        self.train_iterations += 1                                 # :168
+        if self.callback:
+            self.callback.on_train(cost.value)                     # :171-172
+
+    def predict(self, states):                                     # :174-186
+        assert states.shape == ((self.batch_size, self.history_length,) + self.screen_dim)
+        st = np.ascontiguousarray(states, dtype=np.uint8)
+        q = np.empty((self.batch_size, self.num_actions), dtype=np.float32)
+        _lib.check(self._lib.sdqn_net_predict(self._h, _lib.ptr(st, C.c_uint8), _lib.ptr(q, C.c_float)))
+        return q
+
+    def load_weights(self, load_path):                             # :188-189 (own .npz; Neon pickles: SURVEY.md §8f)
+        with np.load(load_path) as f:
+            for which, key in ((0, "W"), (1, "Wt"), (2, "S")):
+                for i in range(5):
+                    name = "%s%d" % (key, i)
+                    if name in f:
+                        self.set_layer(i, f[name], which)
+            if "train_iterations" in f:
+                self.train_iterations = int(f["train_iterations"])
+
+    def save_weights(self, save_path):                             # :191-192
+        d = {}
+        for which, key in ((0, "W"), (1, "Wt"), (2, "S")):
+            for i in range(5):
+                d["%s%d" % (key, i)] = self.get_layer(i, which)
+        d["train_iterations"] = np.int64(self.train_iterations)
+        with open(save_path, "wb") as f:
+            np.savez(f, **d)
+
+    # ---- additive fast paths (SURVEY.md §8b "new, additive") ------------------------------------------
+    def train_from_memory(self, mem, n_steps=1, use_global_random=True, mt_state=None, want_cost=None):
+        """n_steps x { sample ; fused gather+train } entirely inside the library (agent.py:108-114's
+        loop body).  Consumes Python's global random stream unless an explicit 625-word mt_state
+        (ctypes uint32 array) is given."""
+        import random
+        if mt_state is None:
+            st = random.getstate()
+            mt = (C.c_uint32 * _lib.MT_WORDS)(*st[1])
+        else:
+            mt = mt_state
+        want = (self.callback is not None) if want_cost is None else want_cost
+        cost = C.c_float()
+        _lib.check(self._lib.sdqn_net_train_many(self._h, mem._h, mt, int(n_steps), C.byref(cost) if want else None))
+        if mt_state is None:
+            random.setstate((st[0], tuple(mt), st[2]))
+        self.train_iterations += n_steps
+        if self.callback and n_steps:
+            self.callback.on_train(cost.value)
+        return cost.value if want else None
+
+    def train_indexes(self, mem, indexes, want_cost=False):
+        idx = np.ascontiguousarray(indexes, dtype=np.int64)
+        cost = C.c_float()
+        _lib.check(self._lib.sdqn_net_train_replay(self._h, mem._h, _lib.ptr(idx, C.c_int64), C.byref(cost) if want_cost else None))
+        self.train_iterations += 1
+        return cost.value if want_cost else None
+
+    def sync(self):
+        _lib.check(self._lib.sdqn_net_sync(self._h))
+
+    def last_q(self):
+        preq = np.empty((self.batch_size, self.num_actions), dtype=np.float32)
+        mq = np.empty((self.batch_size,), dtype=np.float32)
+        _lib.check(self._lib.sdqn_net_last_q(self._h, _lib.ptr(preq, C.c_float), _lib.ptr(mq, C.c_float)))
+        return preq, mq
+
+    def debug_read(self, name, n):
+        out = np.empty(int(n), dtype=np.float32)
+        _lib.check(self._lib.sdqn_net_debug_read(self._h, name.encode(), _lib.ptr(out, C.c_float), out.size))
+        return out
+
+    # ---- per-kernel device timing (bench.py roofline leg) -------------------------------------------
+    def profile(self, enable, kernel=-1):
+        _lib.check(self._lib.sdqn_net_profile(self._h, int(bool(enable)), int(kernel)))
+
+    def profile_reset(self):
+        _lib.check(self._lib.sdqn_net_profile_reset(self._h))
+
+    def profile_read(self):
+        n = C.c_int()
+        _lib.check(self._lib.sdqn_net_profile_count(C.byref(n)))
+        out = []
+        for k in range(n.value):
+            name, ms, cnt = C.c_char_p(), C.c_double(), C.c_int64()
+            _lib.check(self._lib.sdqn_net_profile_read(self._h, k, C.byref(name), C.byref(ms), C.byref(cnt)))
+            out.append(dict(id=k, name=name.value.decode(), total_ms=ms.value, launches=cnt.value))
+        return out
+
+    # ---- data parallel -----------------------------------------------------------------------------
+    def dp_init(self, unique_id, rank, nranks, rccl=None):
+        path = (rccl or _lib.rccl_path()).encode()
+        _lib.check(self._lib.sdqn_dp_init(self._h, path, unique_id, rank, nranks))
+
+    def dp_shutdown(self):
+        _lib.check(self._lib.sdqn_dp_shutdown(self._h))
+
+
+def dp_unique_id(rccl=None):
+    buf = C.create_string_buffer(128)
+    path = (rccl or _lib.rccl_path()).encode()
+    _lib.check(_lib.load().sdqn_dp_unique_id(path, buf))
+    return buf.raw

@@ -1,0 +1,121 @@
+"""ReplayMemory — drop-in for /root/reference/src/replay_memory.py:6-79.
+
+Same constructor, methods, attributes and return types as the reference class; the ring's master
+copy lives in pinned host DRAM (the numpy attributes are views of it) with a mirror in HBM, and
+getMinibatch() gathers (s, a, r, s', terminal) with a HIP kernel (sdqn_replay_gather).  Index
+sampling consumes Python's global `random` stream exactly like the reference (:59), natively.
+"""
+import ctypes as C
+import logging
+import random
+
+import numpy as np
+
+from . import _lib
+
+logger = logging.getLogger(__name__)
+HBM_MIRROR, ZERO_COPY = 1, 2
+
+
+class ReplayMemory:
+    def __init__(self, size, args, flags=HBM_MIRROR):
+        self._lib = _lib.load()
+        self.size = size
+        self.history_length = args.history_length
+        self.dims = (args.screen_height, args.screen_width)
+        self.batch_size = args.batch_size
+        h = C.c_void_p()
+        _lib.check(self._lib.sdqn_replay_create(C.byref(h), size, self.dims[0], self.dims[1],
+                                                self.history_length, self.batch_size, flags))
+        self._h = h
+        ps, pa, pr, pt = _lib._u8p(), _lib._u8p(), _lib._i64p(), _lib._u8p()
+        _lib.check(self._lib.sdqn_replay_host_ptrs(h, C.byref(ps), C.byref(pa), C.byref(pr), C.byref(pt)))
+        # replay_memory.py:10-13 — same dtypes (np.integer resolves to int64 on Linux)
+        self.actions = np.ctypeslib.as_array(pa, shape=(size,))
+        self.rewards = np.ctypeslib.as_array(pr, shape=(size,))
+        self.screens = np.ctypeslib.as_array(ps, shape=(size,) + self.dims)
+        self.terminals = np.ctypeslib.as_array(pt, shape=(size,)).view(np.bool_)
+        mp, mq, ma, mr, mt = _lib._u8p(), _lib._u8p(), _lib._u8p(), _lib._i64p(), _lib._u8p()
+        _lib.check(self._lib.sdqn_replay_minibatch_ptrs(h, C.byref(mp), C.byref(mq), C.byref(ma), C.byref(mr), C.byref(mt)))
+        shp = (self.batch_size, self.history_length) + self.dims
+        self.prestates = np.ctypeslib.as_array(mp, shape=shp)          # :21-22, reused every call (aliased, like the reference)
+        self.poststates = np.ctypeslib.as_array(mq, shape=shp)
+        self._mb_actions = np.ctypeslib.as_array(ma, shape=(self.batch_size,))
+        self._mb_rewards = np.ctypeslib.as_array(mr, shape=(self.batch_size,))
+        self._mb_terminals = np.ctypeslib.as_array(mt, shape=(self.batch_size,)).view(np.bool_)
+        self._idx = np.empty(self.batch_size, dtype=np.int64)
+        self._mt = (C.c_uint32 * _lib.MT_WORDS)()
+        self.last_indexes = None
+        logger.info("Replay memory size: %d" % self.size)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and self._lib is not None:
+            self._lib.sdqn_replay_destroy(h)
+
+    # count / current live in the native handle (add() updates them there)
+    def _state(self):
+        c, k = C.c_int64(), C.c_int64()
+        _lib.check(self._lib.sdqn_replay_get_state(self._h, C.byref(c), C.byref(k)))
+        return c.value, k.value
+
+    @property
+    def count(self):
+        return self._state()[0]
+
+    @count.setter
+    def count(self, v):
+        _lib.check(self._lib.sdqn_replay_set_state(self._h, int(v), self._state()[1]))
+
+    @property
+    def current(self):
+        return self._state()[1]
+
+    @current.setter
+    def current(self, v):
+        _lib.check(self._lib.sdqn_replay_set_state(self._h, self._state()[0], int(v)))
+
+    def add(self, action, reward, screen, terminal):               # :26-34
+        assert screen.shape == self.dims
+        scr = np.ascontiguousarray(screen, dtype=np.uint8)
+        _lib.check(self._lib.sdqn_replay_add(self._h, int(action), int(reward), _lib.ptr(scr, C.c_uint8), int(bool(terminal))))
+
+    def getState(self, index):                                     # :37-48 (host views; not on the train path)
+        count = self.count
+        assert count > 0, "replay memory is empy, use at least --random_steps 1"
+        index = index % count
+        if index >= self.history_length - 1:
+            return self.screens[(index - (self.history_length - 1)):(index + 1), ...]
+        indexes = [(index - i) % count for i in reversed(range(self.history_length))]
+        return self.screens[indexes, ...]
+
+    def sync_mirror(self, first=0, n=None):
+        """After writing the numpy views directly (bulk fills), copy slots into the HBM mirror."""
+        n = self.size - first if n is None else n
+        _lib.check(self._lib.sdqn_replay_upload(self._h, first, n))
+
+    def sample_indexes(self):
+        """replay_memory.py:54-68 on Python's GLOBAL random stream (shared with agent.py:32,50-51)."""
+        st = random.getstate()
+        self._mt[:] = st[1]
+        _lib.check(self._lib.sdqn_replay_sample(self._h, self._mt, _lib.ptr(self._idx, C.c_int64), None))
+        random.setstate((st[0], tuple(self._mt), st[2]))
+        return self._idx
+
+    def gather(self, indexes):
+        idx = np.ascontiguousarray(indexes, dtype=np.int64)
+        assert idx.shape == (self.batch_size,)
+        _lib.check(self._lib.sdqn_replay_gather(self._h, _lib.ptr(idx, C.c_int64)))
+        _lib.check(self._lib.sdqn_replay_minibatch_to_host(self._h))
+        self.last_indexes = idx.copy()
+        return self.prestates, self._mb_actions, self._mb_rewards, self.poststates, self._mb_terminals
+
+    def getMinibatch(self):                                        # :50-79
+        assert self.count > self.history_length
+        return self.gather(self.sample_indexes())
+
+    def bench_gather(self, indexes, iters=100):
+        idx = np.ascontiguousarray(indexes, dtype=np.int64)
+        ms = C.c_float()
+        _lib.check(self._lib.sdqn_replay_bench_gather(self._h, _lib.ptr(idx, C.c_int64), iters, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,101 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/sdqn.h declares,
+the native sampler is bit-exact against CPython's random stream and the reference KATs, and device
+entry points fail loudly (no CPU fallback) when no GPU is present."""
+import ctypes as C
+import json
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import simple_dqn_amd as sd
+from simple_dqn_amd import _lib
+from oracle.replay_numpy import ReplayOracle, synthetic_fill
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported_and_bound():
+    hdr = open(os.path.join(ROOT, "include", "sdqn.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sdqn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    lib = sd.load()
+    for name in declared:
+        assert hasattr(lib, name), "missing export " + name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.sdqn_version() >= 100
+
+
+def test_cfg_struct_layout():
+    assert C.sizeof(_lib.NetCfg) == 8 * 4 + 11 * 8
+
+
+def test_mt_seed_and_randint_bit_exact():
+    lib = sd.load()
+    mt = (C.c_uint32 * 625)()
+    out = C.c_int64()
+    for seed in (0, 42, 1234, 2**31 + 5, 2**40 + 17):
+        random.seed(seed)
+        _lib.check(lib.sdqn_mt_seed(mt, seed))
+        assert tuple(mt) == random.getstate()[1]
+        for n in (2, 7, 9996, 2**20 + 1, 2**32 - 5, 2**33 + 11):
+            for _ in range(40):
+                _lib.check(lib.sdqn_mt_randint(mt, 4, 3 + n, C.byref(out)))
+                assert out.value == random.randint(4, 3 + n)
+        assert tuple(mt) == random.getstate()[1]
+
+
+def test_native_sampler_matches_reference_kats(golden_dir):
+    lib = sd.load()
+    kats = json.load(open(os.path.join(golden_dir, "replay_kat.json")))["kats"]
+    for k in kats:
+        m = ReplayOracle(k["size"], batch_size=k["B"])
+        synthetic_fill(m, k["fill_seed"], count=k["count"], current=k["current"])
+        term = np.ascontiguousarray(m.terminals.view(np.uint8))
+        mt = (C.c_uint32 * 625)()
+        _lib.check(lib.sdqn_mt_seed(mt, k["seed"]))
+        idx = np.empty(k["B"], np.int64)
+        draws = C.c_int64()
+        for call in k["calls"]:
+            _lib.check(lib.sdqn_sample_indices(mt, _lib.ptr(term, C.c_uint8), k["count"], k["current"], 4, k["B"],
+                                               _lib.ptr(idx, C.c_int64), C.byref(draws)))
+            assert idx.tolist() == call["indexes"] and draws.value == call["draws"]
+
+
+def test_sampler_preconditions():
+    lib = sd.load()
+    mt = (C.c_uint32 * 625)()
+    lib.sdqn_mt_seed(mt, 1)
+    term = np.zeros(100, np.uint8)
+    idx = np.empty(8, np.int64)
+    with pytest.raises(AssertionError):        # replay_memory.py:52 assert count > history_length
+        _lib.check(lib.sdqn_sample_indices(mt, _lib.ptr(term, C.c_uint8), 4, 0, 4, 8, _lib.ptr(idx, C.c_int64), None))
+    term[:] = 1
+    with pytest.raises(AssertionError):        # no admissible index: the reference would spin forever
+        _lib.check(lib.sdqn_sample_indices(mt, _lib.ptr(term, C.c_uint8), 100, 0, 4, 8, _lib.ptr(idx, C.c_int64), None))
+
+
+def test_no_cpu_fallback():
+    lib = sd.load()
+    n = C.c_int(0)
+    rc = lib.sdqn_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    from util import make_args
+    with pytest.raises(sd.SdqnError):
+        sd.ReplayMemory(100, make_args())
+    with pytest.raises(sd.SdqnError):
+        sd.DeepQNetwork(4, make_args())
+
+
+def test_product_never_imports_oracle():
+    pk = os.path.join(ROOT, "simple_dqn_amd")
+    for dp, _, fs in os.walk(pk):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("oracle/", "ORACLE_DIR").lower() or "import oracle" not in src, f
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f

