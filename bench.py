@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""bench.py — train_steps/sec of the DQN training step (sample -> gather -> target fwd -> online fwd ->
+clipped TD error -> bwd -> RMSProp) on MI355X, BASELINE.json's metric.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload at every N: BASELINE.json configs[1] — "Breakout, 1xMI355X, batch_size=32, replay_size=1M,
+HIP Q-net + device replay gather", A=4, one learner (own ring + sampler stream) per GPU; for N > 1 the
+learners average gradients with ONE RCCL all-reduce of the flat fp32 gradient per step (weak scaling:
+per-GPU work fixed).  One "step" = one minibatch step of one learner; value = N*K / max-over-ranks time.
+Inputs are synthetic (seeded uniform uint8 frames tiled into the ring, no emulator) and already
+resident in HBM when the timed region starts.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     — the step's dominant kernel, timed live with HIP events on the library stream inside the
+                 timed region; algorithmic bytes/flops per launch from DESIGN.md / SURVEY.md §8d.
+  cpu_baseline — the numpy oracle (a restatement: kind "port") timed on this host's cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK = 8.0e12          # B/s   MI355X_MICROARCH.md (spec)
+F32_PEAK = 157.3e12        # FLOP/s fp32 MFMA == fp32 vector peak (v_mfma_f32_32x32x2_f32)
+NP4 = 1685504              # parameters at A=4
+
+
+def kernel_work(B, A):
+    """Algorithmic (compulsory) bytes and flops per launch of each kernel id (kernels.h order)."""
+    f = 4
+    npar = 8192 + 32768 + 36864 + 1605632 + 512 * A
+    w1, w2, w3, w4 = 8192 * f, 32768 * f, 36864 * f, 1605632 * f
+    a1, a2, a3, a4 = B * 400 * 32 * f, B * 81 * 64 * f, B * 49 * 64 * f, B * 512 * f
+    return {
+        0: dict(bytes=B * 5 * 7056 + 2 * a1 + 2 * w1, flops=2 * 2 * B * 400 * 32 * 256),      # fused gather+norm+conv1, both nets
+        1: dict(bytes=2 * a1 + 2 * a2 + 2 * w2, flops=2 * 2 * B * 81 * 64 * 512),
+        2: dict(bytes=2 * a2 + 2 * a3 + 2 * w3, flops=2 * 2 * B * 49 * 64 * 576),
+        3: dict(bytes=2 * a3 + 2 * w4 + 2 * a4, flops=2 * 2 * B * 512 * 3136),
+        4: dict(bytes=2 * a4 * 2 + 2 * 512 * A * f, flops=2 * 2 * B * 512 * A),
+        5: dict(bytes=a4 + w4 + 2 * a3, flops=2 * B * 512 * 3136),                             # fc4 dgrad
+        6: dict(bytes=a4 + a3 + w4, flops=2 * B * 512 * 3136),                                 # fc4 wgrad (writes g4)
+        7: dict(bytes=a3 + w3 + 2 * a2, flops=2 * B * 81 * 64 * 576),
+        8: dict(bytes=a2 + a3 + w3, flops=2 * B * 49 * 64 * 576),
+        9: dict(bytes=a2 + w2 + 2 * a1, flops=2 * B * 400 * 32 * 256),
+        10: dict(bytes=a1 + a2 + w2, flops=2 * B * 81 * 64 * 512),
+        11: dict(bytes=B * 5 * 7056 + a1 + w1, flops=2 * B * 400 * 32 * 256),
+        12: dict(bytes=npar * f * 5, flops=8 * npar),                                          # read W,s,g; write W,s
+        13: dict(bytes=npar * f, flops=0),
+        14: dict(bytes=B * 13 * 7056, flops=0),
+    }
+
+
+def roofline_entry(kid, name, ms_per_launch, B, A):
+    w = kernel_work(B, A)[kid]
+    t = ms_per_launch * 1e-3
+    t_hbm, t_f32 = w["bytes"] / HBM_PEAK, w["flops"] / F32_PEAK
+    if t_f32 > t_hbm:
+        ach = w["flops"] / t / 1e12
+        return dict(kernel=name, bound="mfma", achieved=round(ach, 3), peak=F32_PEAK / 1e12, unit="TFLOP/s",
+                    frac=round(ach / (F32_PEAK / 1e12), 4), traffic=None, us_per_launch=round(ms_per_launch * 1e3, 2),
+                    algorithmic_flops=w["flops"], algorithmic_bytes=w["bytes"])
+    ach = w["bytes"] / t / 1e9
+    return dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
+                frac=round(ach / (HBM_PEAK / 1e9), 4), traffic=None, us_per_launch=round(ms_per_launch * 1e3, 2),
+                algorithmic_flops=w["flops"], algorithmic_bytes=w["bytes"])
+
+
+def fill_ring(mem, seed, num_actions):
+    """Synthetic ring at 1M frames without minutes of RNG: a seeded 2048-frame uniform
+    uint8 block tiled (rolled + xor'd per tile so windows differ), metadata drawn in full."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    size = mem.size
+    blk = min(2048, size)
+    block = rng.randint(0, 256, size=(blk, 84, 84), dtype=np.uint8)
+    for i, s in enumerate(range(0, size, blk)):
+        n = min(blk, size - s)
+        np.bitwise_xor(np.roll(block, i, axis=0)[:n], np.uint8((i * 37) & 0xFF), out=mem.screens[s:s + n])
+    mem.actions[:] = rng.randint(0, num_actions, size=size).astype(np.uint8)
+    mem.rewards[:] = rng.randint(-1, 2, size=size)
+    mem.terminals[:] = rng.rand(size) < 0.005
+    mem.count, mem.current = size, size // 3
+    mem.sync_mirror()
+
+
+def cpu_baseline(B, A, seed, budget_s):
+    """Oracle (numpy restatement of the reference: Neon's CPU backend is itself numpy dot over im2col
+    slices) timed on this host: getMinibatch + train per step, bounded sample."""
+    import numpy as np
+    from oracle.dqn_numpy import OracleDQN, xavier_weights
+    from oracle.replay_numpy import ReplayOracle, synthetic_fill, MT19937
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    ring = 20000
+    mem = ReplayOracle(ring, batch_size=B)
+    synthetic_fill(mem, seed, num_actions=A)
+    net = OracleDQN(A, batch_size=B, weights=xavier_weights(A, seed + 1))
+    rng = MT19937(seed + 2)
+    net.train(mem.getMinibatch(rng))                      # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        net.train(mem.getMinibatch(rng))
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 400:
+            break
+    return dict(value=round(n / el, 2), unit="train_steps/sec", cores=int(threads), kind="port",
+                sample="%d steps of oracle ReplayOracle.getMinibatch + OracleDQN.train (numpy fp32, B=%d, A=%d, ring %d frames)"
+                       % (n, B, A, ring), ms_per_step=round(el / n * 1e3, 2))
+
+
+def q_mae_vs_oracle(sd, B, A, seed):
+    """'Q-value MAE vs CPU ref' of the metric: one fused step from identical weights, HIP vs oracle."""
+    import numpy as np
+    from util import make_args
+    from oracle.dqn_numpy import OracleDQN, xavier_weights
+    from oracle.replay_numpy import ReplayOracle, synthetic_fill
+    size = 4000
+    args = make_args(batch_size=B)
+    mem, omem = sd.ReplayMemory(size, args), ReplayOracle(size, batch_size=B)
+    synthetic_fill(mem, seed, num_actions=A)
+    synthetic_fill(omem, seed, num_actions=A)
+    mem.sync_mirror()
+    net = sd.DeepQNetwork(A, args)
+    ws = xavier_weights(A, seed + 1)
+    net.set_weights(ws, 0)
+    net.update_target_network()
+    o = OracleDQN(A, batch_size=B, weights=ws)
+    random.seed(seed + 2)
+    st = random.getstate()
+    omb = omem.getMinibatch()
+    random.setstate(st)
+    net.train_from_memory(mem, 1)
+    o.train(omb)
+    hold = omem.getMinibatch()[0]
+    e = np.abs(net.predict(hold) - o.predict(hold))
+    return float(e.mean()), float(e.max())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--batch-size", type=int, default=32)
+    ap.add_argument("--num-actions", type=int, default=4)
+    ap.add_argument("--replay-size", type=int, default=1000000)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--zero-copy", action="store_true", help="gather from the pinned host ring over PCIe (no HBM mirror)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+
+    # torch FIRST (its bundled HIP runtime has the same soname as ROCm's; one runtime per process)
+    import torch
+    import torch.distributed as dist
+    import numpy as np
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        # control plane (id exchange, barriers, max-reduce of the time) on gloo; the data path's only
+        # collective — the gradient all-reduce — is RCCL over xGMI inside libsdqn_hip (sdqn_dp_init)
+        dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+
+    import simple_dqn_amd as sd
+    from simple_dqn_amd import _lib
+    from simple_dqn_amd.deepqnetwork import dp_unique_id
+    from util import make_args
+    _lib.check(sd.load().sdqn_set_device(local_rank))
+
+    B, A = a.batch_size, a.num_actions
+    args = make_args(batch_size=B, random_seed=a.seed + 1)            # identical initial weights on every rank
+    mem = sd.ReplayMemory(a.replay_size, args, flags=2 if a.zero_copy else 1)
+    fill_ring(mem, a.seed + 1000 * rank, A)                            # own experience per learner
+    net = sd.DeepQNetwork(A, args)
+    net.update_target_network()
+    if world > 1:
+        ids = [dp_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        net.dp_init(ids[0], rank, world)
+
+    import ctypes as C
+    mt = (C.c_uint32 * 625)()
+    _lib.check(sd.load().sdqn_mt_seed(mt, a.seed + 2 + 1000 * rank))  # own sampler stream per learner
+
+    def run(n):
+        done = 0
+        while done < n:                                               # target sync every 2500 updates (= 10000 env steps / 4)
+            c = min(2500 - (net.train_iterations % 2500), n - done)
+            if net.train_iterations % 2500 == 0:
+                net.update_target_network()
+            net.train_from_memory(mem, c, mt_state=mt, want_cost=False)
+            done += c
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        net.sync()
+
+    # ---- warmup (untimed): includes a pass with every kernel bracketed to find the dominant one
+    run(max(a.warmup - 60, 0))
+    net.profile(True, -1)
+    net.profile_reset()
+    run(min(60, a.warmup) or 20)
+    prof = net.profile_read()
+    net.profile(False)
+    step_kernels = [p for p in prof if p["launches"] > 0]
+    dom = max(step_kernels, key=lambda p: p["total_ms"])
+    net.profile(True, dom["id"])
+    net.profile_reset()
+
+    # ---- timed region: EXACTLY K steps
+    barrier()
+    t0 = time.perf_counter()
+    run(a.steps)
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t[0])
+    live = [p for p in net.profile_read() if p["id"] == dom["id"]][0]
+    net.profile(False)
+
+    if rank == 0:
+        total_steps = a.steps * world
+        out = {
+            "metric": "train_steps/sec (batch=32, 4x84x84 uint8)" if B == 32 else "train_steps/sec (batch=%d, 4x84x84 uint8)" % B,
+            "value": round(total_steps / el, 2), "unit": "train_steps/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded uniform uint8 84x84 frames tiled into the ring; random-init Xavier weights)",
+            "config": {"workload": "BASELINE.json configs[1]: Breakout shapes, batch_size=%d, replay_size=%d, num_actions=%d, "
+                                   "HIP Q-net + device replay gather fused into conv1" % (B, a.replay_size, A),
+                       "global_batch": B * world, "parallelism": "dp%d (independent learners, RCCL grad all-reduce)" % world,
+                       "ring": "zero-copy pinned host" if a.zero_copy else "HBM mirror"},
+        }
+        out["roofline"] = roofline_entry(dom["id"], dom["name"], live["total_ms"] / max(live["launches"], 1), B, A)
+        out["kernels_us"] = {p["name"]: round(p["total_ms"] / p["launches"] * 1e3, 2) for p in step_kernels}
+        if world == 1:
+            idx = np.array(mem.sample_indexes())
+            g_ms = mem.bench_gather(idx, iters=200)
+            out["replay_gather"] = roofline_entry(14, "replay_gather_u8", g_ms, B, A)
+            mae, mx = q_mae_vs_oracle(sd, B, A, a.seed)
+            out["q_mae_vs_cpu_ref"] = {"mae": mae, "max_abs": mx, "after_steps": 1, "tolerance": 1e-4}
+            if not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(B, A, a.seed, a.cpu_baseline_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        net.dp_shutdown()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
