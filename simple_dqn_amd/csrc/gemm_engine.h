@@ -25,7 +25,6 @@ __global__ void __launch_bounds__(256) gemm_kernel(const StepArgs a) {
   static_assert(WM * WN * WK == 4, "4 waves per workgroup");
   constexpr int BM = 32 * WM, BN = 32 * WN, BK = 32;
   constexpr int LDA = BM + 1, LDB = BN + 1, LDC = BN + 1;
-  constexpr int AE = BM * BK / 256, BE = BN * BK / 256;
   constexpr int SM_AB = 2 * BK * (LDA + LDB);
   constexpr int SM_C = WK * BM * LDC;
   constexpr int SM = SM_AB > SM_C ? SM_AB : SM_C;
@@ -41,47 +40,52 @@ __global__ void __launch_bounds__(256) gemm_kernel(const StepArgs a) {
   P::ksplit(a, blockIdx.z, z, ks, kbeg, kend);
   const int M = P::M(a), N = P::N(a);
 
-  // ---- loader geometry: which (m|n, k) elements of a K-tile this thread stages ------------
-  // lane-along-k (A_K): k_l fixed = t & 31, rows t/32 + 8j.   lane-along-m: m_l fixed, k = t/BM + j*(256/BM)
-  aoff_t arow[P::A_K ? AE : 1];
-  int brow_or_col[P::B_K ? BE : 1];
+  // ---- loader geometry: every thread stages BM/32 (A) + BN/32 (B) 4-vectors of a K-tile ------------
+  // The vector always runs along the operand's memory-contiguous dimension (16 B/lane global loads,
+  // 4 B/lane for the u8 ring), and so do the lanes:
+  //   contiguous k (A_K/B_K):  k4 = t & 7 -> k = kt + 4*k4 .. +3,  x = (t >> 3) + 32*j
+  //   contiguous x (m or n):   x4 = t % (BX/4) -> x = 4*x4 .. +3,   k = kt + t / (BX/4) + (1024/BX)*j
+  constexpr int AJ = BM / 32, BJ = BN / 32;
+  aoff_t arow[P::A_K ? AJ : 1];
+  int bcol[P::B_K ? BJ : 1];
   if constexpr (P::A_K) {
 #pragma unroll
-    for (int j = 0; j < AE; ++j) { int m = m0 + (t >> 5) + 8 * j; arow[j] = P::a_row(a, z, m < M ? m : M - 1); }
+    for (int j = 0; j < AJ; ++j) { const int m = m0 + (t >> 3) + 32 * j; arow[j] = P::a_row(a, z, m < M ? m : M - 1); }
   } else {
-    int m = m0 + (t % BM); arow[0] = P::a_row(a, z, m < M ? m : M - 1);
+    const int m = m0 + 4 * (t % (BM / 4)); arow[0] = P::a_row(a, z, m + 3 < M ? m : M - 4);
   }
   if constexpr (P::B_K) {
 #pragma unroll
-    for (int j = 0; j < BE; ++j) { int n = n0 + (t >> 5) + 8 * j; brow_or_col[j] = P::b_col(a, z, n < N ? n : N - 1); }
+    for (int j = 0; j < BJ; ++j) { const int n = n0 + (t >> 3) + 32 * j; bcol[j] = P::b_col(a, z, n < N ? n : N - 1); }
   } else {
-    int n = n0 + (t % BN); brow_or_col[0] = P::b_col(a, z, n < N ? n : N - 1);
+    const int n = n0 + 4 * (t % (BN / 4)); bcol[0] = P::b_col(a, z, n + 3 < N ? n : N - 4);
   }
 
-  float ra[AE], rb[BE];
+  f4 ra[AJ], rb[BJ];
+  const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
   auto load_tile = [&](int kt) {
     if constexpr (P::A_K) {
-      const int k = kt + (t & 31); const bool ok = k < kend;
+      const int k = kt + 4 * (t & 7); const bool ok = k < kend;
       const aoff_t c = ok ? P::a_col(a, z, k) : (aoff_t)0;
 #pragma unroll
-      for (int j = 0; j < AE; ++j) ra[j] = ok ? P::a_load(a, z, arow[j] + c) : 0.0f;
+      for (int j = 0; j < AJ; ++j) ra[j] = ok ? P::a_load4(a, z, arow[j] + c) : zero4;
     } else {
 #pragma unroll
-      for (int j = 0; j < AE; ++j) {
-        const int k = kt + t / BM + j * (256 / BM);
-        ra[j] = k < kend ? P::a_load(a, z, arow[0] + P::a_col(a, z, k)) : 0.0f;
+      for (int j = 0; j < AJ; ++j) {
+        const int k = kt + t / (BM / 4) + j * (1024 / BM);
+        ra[j] = k < kend ? P::a_load4(a, z, arow[0] + P::a_col(a, z, k)) : zero4;
       }
     }
     if constexpr (P::B_K) {
-      const int k = kt + (t & 31); const bool ok = k < kend;
+      const int k = kt + 4 * (t & 7); const bool ok = k < kend;
       const int r = ok ? P::b_row(a, z, k) : 0;
 #pragma unroll
-      for (int j = 0; j < BE; ++j) rb[j] = ok ? P::b_load(a, z, r + brow_or_col[j]) : 0.0f;
+      for (int j = 0; j < BJ; ++j) rb[j] = ok ? P::b_load4(a, z, r + bcol[j]) : zero4;
     } else {
 #pragma unroll
-      for (int j = 0; j < BE; ++j) {
-        const int k = kt + t / BN + j * (256 / BN);
-        rb[j] = k < kend ? P::b_load(a, z, P::b_row(a, z, k) + brow_or_col[0]) : 0.0f;
+      for (int j = 0; j < BJ; ++j) {
+        const int k = kt + t / (BN / 4) + j * (1024 / BN);
+        rb[j] = k < kend ? P::b_load4(a, z, P::b_row(a, z, k) + bcol[0]) : zero4;
       }
     }
   };
@@ -90,17 +94,29 @@ __global__ void __launch_bounds__(256) gemm_kernel(const StepArgs a) {
     float* Bb = Bs + buf * BK * LDB;
     if constexpr (P::A_K) {
 #pragma unroll
-      for (int j = 0; j < AE; ++j) Ab[(t & 31) * LDA + (t >> 5) + 8 * j] = ra[j];
+      for (int j = 0; j < AJ; ++j) {
+        float* d = Ab + (4 * (t & 7)) * LDA + (t >> 3) + 32 * j;
+        d[0] = ra[j].x; d[LDA] = ra[j].y; d[2 * LDA] = ra[j].z; d[3 * LDA] = ra[j].w;
+      }
     } else {
 #pragma unroll
-      for (int j = 0; j < AE; ++j) Ab[(t / BM + j * (256 / BM)) * LDA + (t % BM)] = ra[j];
+      for (int j = 0; j < AJ; ++j) {
+        float* d = Ab + (t / (BM / 4) + j * (1024 / BM)) * LDA + 4 * (t % (BM / 4));
+        d[0] = ra[j].x; d[1] = ra[j].y; d[2] = ra[j].z; d[3] = ra[j].w;
+      }
     }
     if constexpr (P::B_K) {
 #pragma unroll
-      for (int j = 0; j < BE; ++j) Bb[(t & 31) * LDB + (t >> 5) + 8 * j] = rb[j];
+      for (int j = 0; j < BJ; ++j) {
+        float* d = Bb + (4 * (t & 7)) * LDB + (t >> 3) + 32 * j;
+        d[0] = rb[j].x; d[LDB] = rb[j].y; d[2 * LDB] = rb[j].z; d[3 * LDB] = rb[j].w;
+      }
     } else {
 #pragma unroll
-      for (int j = 0; j < BE; ++j) Bb[(t / BN + j * (256 / BN)) * LDB + (t % BN)] = rb[j];
+      for (int j = 0; j < BJ; ++j) {
+        float* d = Bb + (t / (BN / 4) + j * (1024 / BN)) * LDB + 4 * (t % (BN / 4));
+        d[0] = rb[j].x; d[1] = rb[j].y; d[2] = rb[j].z; d[3] = rb[j].w;
+      }
     }
   };
 

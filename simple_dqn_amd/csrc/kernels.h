@@ -9,13 +9,22 @@ namespace sdqn {
 enum KernelId {
   K_CONV1_FWD = 0, K_CONV2_FWD, K_CONV3_FWD, K_FC4_FWD, K_HEAD,
   K_FC4_DGRAD, K_FC4_WGRAD, K_CONV3_DGRAD, K_CONV3_WGRAD, K_CONV2_DGRAD, K_CONV2_WGRAD,
-  K_CONV1_WGRAD, K_UPDATE, K_ALLREDUCE, K_GATHER, K_COUNT
+  K_CONV1_WGRAD, K_UPDATE, K_ALLREDUCE, K_GATHER, K_PREP, K_COUNT
 };
 const char* kernel_name(int id);
 
+struct PrepArgs {                // pinned index slot + ring metadata -> device-resident (idx, a, r, t) of this step
+  const int64_t* idx_pinned;    // [B] zero-copy view of the pinned slot
+  const MetaRec* meta;          // ring metadata mirror
+  int64_t* idx;                 // [B] device
+  uint8_t* actions;             // [B] device staging shared with the host-minibatch path
+  int64_t* rewards;
+  uint8_t* terminals;
+  int B;
+};
+
 struct HeadArgs {
-  const MetaRec* meta;          // ring metadata mirror (from_ring)
-  const uint8_t* st_actions;    // staged host minibatch (else)
+  const uint8_t* st_actions;    // minibatch metadata (staged from the host, or gathered by prep_kernel)
   const int64_t* st_rewards;
   const uint8_t* st_terminals;
   float* q;                     // [2][B][A] q-values of both nets
@@ -60,5 +69,6 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s);     // the G
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s);
 hipError_t launch_update(const UpdateArgs& u, hipStream_t s);
 hipError_t launch_gather(const GatherArgs& g, hipStream_t s);
+hipError_t launch_prep(const PrepArgs& p, hipStream_t s);
 
 }  // namespace sdqn

@@ -52,7 +52,7 @@ struct MetaRec {            // device mirror of (rewards, actions, terminals) of
 
 struct StepArgs {
   const uint8_t* src;       // ring mirror (from_ring) or staging states [2][B][STATE]
-  const int64_t* idx;       // sampled indexes [B] (from_ring)
+  const int64_t* idx;       // sampled indexes [B] in DEVICE memory (copied from the pinned slot by prep_kernel)
   int from_ring;
   int B, A, nz;
   const float* theta[2];    // flat parameter buffers: [0] online, [1] target
@@ -77,7 +77,31 @@ SDQN_HD int64_t sbase(const StepArgs& a, int z, int n) {
   // replay_memory.py:71-72: prestate = screens[i-4:i], poststate = screens[i-3:i+1]
   return a.from_ring ? (a.idx[n] - C0 + z) * (int64_t)FRAME : ((int64_t)z * a.B + n) * (int64_t)STATE;
 }
-SDQN_HD float norm_u8(uint8_t v) { return (float)v / 255.0f; }   // deepqnetwork.py:100 be.divide(input, 255)
+// deepqnetwork.py:100 be.divide(input, 255): correctly-rounded x/255 without a divide — q = x*r, one fma
+// Newton correction (bit-identical to IEEE x/255.0f for all 256 byte values: tests/test_emul.py checks).
+SDQN_HD float norm_u8(uint32_t v) {
+  const float x = (float)v, r = 1.0f / 255.0f;
+  const float q = x * r;
+  const float e = fmaf(-q, 255.0f, x);
+  return fmaf(e, r, q);
+}
+struct f4 { float x, y, z, w; };
+SDQN_HD f4 ld4(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float4 v = *reinterpret_cast<const float4*>(p); f4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
+#else
+  f4 o; o.x = p[0]; o.y = p[1]; o.z = p[2]; o.w = p[3]; return o;
+#endif
+}
+SDQN_HD f4 ld4_u8(const uint8_t* p) {       // 4 consecutive bytes (4-byte aligned by construction) -> 4 normalised floats
+  uint32_t w;
+#if defined(__HIP_DEVICE_COMPILE__)
+  w = *reinterpret_cast<const uint32_t*>(p);
+#else
+  w = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+#endif
+  f4 o; o.x = norm_u8(w & 255u); o.y = norm_u8((w >> 8) & 255u); o.z = norm_u8((w >> 16) & 255u); o.w = norm_u8(w >> 24); return o;
+}
 
 SDQN_HD int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
@@ -108,7 +132,7 @@ SDQN_HD int prow2(int m) {                                   // (n,p,q) of conv2
 
 // =========================== forward =====================================================
 struct Conv1Fwd {   // fused gather + normalise + conv1 + ReLU: replay_memory.py:71-72 + deepqnetwork.py:94-100,83
-  static constexpr int WM = 2, WN = 1, WK = 2; static constexpr bool A_K = false, B_K = false;
+  static constexpr int WM = 2, WN = 1, WK = 2; static constexpr bool A_K = true, B_K = false;
   typedef int64_t aoff_t;
   SDQN_HD static int M(const StepArgs& a) { return a.B * PIX1; }
   SDQN_HD static int N(const StepArgs&) { return K1; }
@@ -117,9 +141,11 @@ struct Conv1Fwd {   // fused gather + normalise + conv1 + ReLU: replay_memory.py
   SDQN_HD static aoff_t a_row(const StepArgs& a, int z, int m) { return row1(a, z, m); }
   SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) { return col1(k); }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return norm_u8(a.src[o]); }
+  SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4_u8(a.src + o); }
   SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * K1; }
   SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
   SDQN_HD static float b_load(const StepArgs& a, int z, int o) { return a.theta[z][OFF1 + o]; }
+  SDQN_HD static f4 b_load4(const StepArgs& a, int z, int o) { return ld4(a.theta[z] + OFF1 + o); }
   SDQN_HD static void store(const StepArgs& a, int z, int, int m, int n, float v) {
     a.a1[((int64_t)z * M(a) + m) * K1 + n] = fmaxf(v, 0.0f);
   }
@@ -135,9 +161,11 @@ struct Conv2Fwd {   // deepqnetwork.py:85
   SDQN_HD static aoff_t a_row(const StepArgs& a, int z, int m) { return row2(a, z, m); }
   SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) { return col2(k); }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a1[o]; }
+  SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4(a.a1 + o); }
   SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * K2; }
   SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
   SDQN_HD static float b_load(const StepArgs& a, int z, int o) { return a.theta[z][OFF2 + o]; }
+  SDQN_HD static f4 b_load4(const StepArgs& a, int z, int o) { return ld4(a.theta[z] + OFF2 + o); }
   SDQN_HD static void store(const StepArgs& a, int z, int, int m, int n, float v) {
     a.a2[((int64_t)z * M(a) + m) * K2 + n] = fmaxf(v, 0.0f);
   }
@@ -153,9 +181,11 @@ struct Conv3Fwd {   // deepqnetwork.py:87
   SDQN_HD static aoff_t a_row(const StepArgs& a, int z, int m) { return row3(a, z, m); }
   SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) { return col3(k); }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a2[o]; }
+  SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4(a.a2 + o); }
   SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * K3; }
   SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
   SDQN_HD static float b_load(const StepArgs& a, int z, int o) { return a.theta[z][OFF3 + o]; }
+  SDQN_HD static f4 b_load4(const StepArgs& a, int z, int o) { return ld4(a.theta[z] + OFF3 + o); }
   SDQN_HD static void store(const StepArgs& a, int z, int, int m, int n, float v) {
     a.a3[((int64_t)z * M(a) + m) * K3 + n] = fmaxf(v, 0.0f);
   }
@@ -175,9 +205,11 @@ struct Fc4Fwd {     // deepqnetwork.py:89, split-K over S4 slabs; bias-free, ReL
   SDQN_HD static aoff_t a_row(const StepArgs& a, int z, int m) { return (z * a.B + m) * NIN4; }
   SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) { return k; }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a3[o]; }
+  SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4(a.a3 + o); }
   SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * NFC; }
   SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
   SDQN_HD static float b_load(const StepArgs& a, int z, int o) { return a.theta[z][OFF4 + o]; }
+  SDQN_HD static f4 b_load4(const StepArgs& a, int z, int o) { return ld4(a.theta[z] + OFF4 + o); }
   SDQN_HD static void store(const StepArgs& a, int z, int ks, int m, int n, float v) {
     a.slab4[(((int64_t)ks * 2 + z) * a.B + m) * NFC + n] = v;
   }
@@ -194,9 +226,11 @@ struct Fc4Dgrad {   // delta3 = (W4^T delta4) * 1[a3 > 0]  (A5, A8), written str
   SDQN_HD static aoff_t a_row(const StepArgs&, int, int m) { return m * NFC; }
   SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) { return k; }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.d4[o]; }
+  SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4(a.d4 + o); }
   SDQN_HD static int b_row(const StepArgs&, int, int k) { return k; }
   SDQN_HD static int b_col(const StepArgs&, int, int n) { return n * NFC; }
   SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.theta[0][OFF4 + o]; }
+  SDQN_HD static f4 b_load4(const StepArgs& a, int, int o) { return ld4(a.theta[0] + OFF4 + o); }
   SDQN_HD static void store(const StepArgs& a, int, int, int m, int n, float v) {
     int pix = n >> 6, f = n & 63, p = pix / Q3, q = pix - p * Q3;
     bool on = a.a3[(int64_t)m * NIN4 + n] > 0.0f;
@@ -214,9 +248,11 @@ struct Fc4Wgrad {   // gW4 = delta4 . a3^T (sum over batch, A8) in the W4i layou
   SDQN_HD static aoff_t a_row(const StepArgs&, int, int m) { return m; }
   SDQN_HD static aoff_t a_col(const StepArgs&, int, int k) { return k * NIN4; }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a3[o]; }
+  SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4(a.a3 + o); }
   SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * NFC; }
   SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
   SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.d4[o]; }
+  SDQN_HD static f4 b_load4(const StepArgs& a, int, int o) { return ld4(a.d4 + o); }
   SDQN_HD static void store(const StepArgs& a, int, int, int m, int n, float v) { a.g[OFF4 + (int64_t)m * NFC + n] = v; }
 };
 
@@ -236,9 +272,11 @@ struct Conv3Dgrad { // delta2 = full-correlation(d3p, W3) * 1[a2 > 0], written i
     return -(r * PD3 + s) * K3 + f;
   }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.d3p[o]; }
+  SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4(a.d3p + o); }
   SDQN_HD static int b_row(const StepArgs&, int, int k) { return (k >> 6) * (K2 * K3) + (k & 63); }
   SDQN_HD static int b_col(const StepArgs&, int, int c) { return c * K3; }
   SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.theta[0][OFF3 + o]; }
+  SDQN_HD static f4 b_load4(const StepArgs& a, int, int o) { return ld4(a.theta[0] + OFF3 + o); }
   SDQN_HD static void store(const StepArgs& a, int, int, int m, int c, float v) {
     bool on = a.a2[(int64_t)m * K2 + c] > 0.0f;
     a.d2p[prow2(m) + c] = on ? v : 0.0f;
@@ -258,9 +296,11 @@ struct Conv3Wgrad { // gW3[(r,s,c)][f] = sum_(n,p,q) a2 patch * delta3   (Neon u
   SDQN_HD static aoff_t a_row(const StepArgs&, int, int m) { return col3(m); }
   SDQN_HD static aoff_t a_col(const StepArgs& a, int, int k) { return row3(a, 0, k); }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a2[o]; }
+  SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4(a.a2 + o); }
   SDQN_HD static int b_row(const StepArgs&, int, int k) { return prow3(k); }
   SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
   SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.d3p[o]; }
+  SDQN_HD static f4 b_load4(const StepArgs& a, int, int o) { return ld4(a.d3p + o); }
   SDQN_HD static void store(const StepArgs& a, int, int ks, int m, int n, float v) { a.slab3[(int64_t)ks * NW3 + m * K3 + n] = v; }
 };
 
@@ -280,12 +320,14 @@ struct Conv2Dgrad { // stride-2 dgrad as 4 parity classes (z = py*2+px), each a 
     return -(aa * PD2 + bb) * K2 + f;
   }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.d2p[o]; }
+  SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4(a.d2p + o); }
   SDQN_HD static int b_row(const StepArgs&, int z, int k) {
     int py = z >> 1, px = z & 1, ab = k >> 6, f = k & 63, aa = ab >> 1, bb = ab & 1;
     return ((py + 2 * aa) * 4 + (px + 2 * bb)) * (K1 * K2) + f;
   }
   SDQN_HD static int b_col(const StepArgs&, int, int c) { return c * K2; }
   SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.theta[0][OFF2 + o]; }
+  SDQN_HD static f4 b_load4(const StepArgs& a, int, int o) { return ld4(a.theta[0] + OFF2 + o); }
   SDQN_HD static void store(const StepArgs& a, int z, int, int m, int c, float v) {
     int py = z >> 1, px = z & 1;
     int n = m / 100, pix = m - n * 100, i = pix / 10, j = pix - i * 10;
@@ -307,9 +349,11 @@ struct Conv2Wgrad {
   SDQN_HD static aoff_t a_row(const StepArgs&, int, int m) { return col2(m); }
   SDQN_HD static aoff_t a_col(const StepArgs& a, int, int k) { return row2(a, 0, k); }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a1[o]; }
+  SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4(a.a1 + o); }
   SDQN_HD static int b_row(const StepArgs&, int, int k) { return prow2(k); }
   SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
   SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.d2p[o]; }
+  SDQN_HD static f4 b_load4(const StepArgs& a, int, int o) { return ld4(a.d2p + o); }
   SDQN_HD static void store(const StepArgs& a, int, int ks, int m, int n, float v) { a.slab2[(int64_t)ks * NW2 + m * K2 + n] = v; }
 };
 
@@ -326,9 +370,11 @@ struct Conv1Wgrad { // re-gathers the normalised u8 patches from the ring (no fp
   SDQN_HD static aoff_t a_row(const StepArgs&, int, int m) { return col1(m); }
   SDQN_HD static aoff_t a_col(const StepArgs& a, int, int k) { return row1(a, 0, k); }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return norm_u8(a.src[o]); }
+  SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4_u8(a.src + o); }
   SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * K1; }
   SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
   SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.d1[o]; }
+  SDQN_HD static f4 b_load4(const StepArgs& a, int, int o) { return ld4(a.d1 + o); }
   SDQN_HD static void store(const StepArgs& a, int, int ks, int m, int n, float v) { a.slab1[(int64_t)ks * NW1 + m * K1 + n] = v; }
 };
 

@@ -288,7 +288,7 @@ struct sdqn_net_s {
   float *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *slab4 = nullptr, *a4 = nullptr, *d4 = nullptr;
   float *d3p = nullptr, *d2p = nullptr, *d1 = nullptr, *slab1 = nullptr, *slab2 = nullptr, *slab3 = nullptr;
   float *q = nullptr, *maxq = nullptr, *dq = nullptr, *cost_terms = nullptr, *cost_out = nullptr; double* cost_accum = nullptr;
-  uint8_t *st_states = nullptr, *st_act = nullptr, *st_term = nullptr; int64_t* st_rew = nullptr;
+  uint8_t *st_states = nullptr, *st_act = nullptr, *st_term = nullptr; int64_t* st_rew = nullptr; int64_t* d_idx = nullptr;
   float* h_f = nullptr;                    // pinned scratch for small read-backs
   int S4 = 14, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
   int64_t train_iterations = 0;
@@ -361,6 +361,7 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->st_states, (size_t)2 * B * STATE));
   NCHK(dalloc(h, (void**)&h->st_act, B)); NCHK(dalloc(h, (void**)&h->st_term, B));
   NCHK(dalloc(h, (void**)&h->st_rew, (size_t)B * 8));
+  NCHK(dalloc(h, (void**)&h->d_idx, (size_t)B * 8));
   { hipError_t e = hipHostMalloc((void**)&h->h_f, (size_t)(2 * B * MAX_ACTIONS + B + 64) * 8, hipHostMallocMapped);
     if (e != hipSuccess) { set_error("hipHostMalloc -> %s", hipGetErrorString(e)); net_free(h); return SDQN_ERR_HIP; } }
 #undef NCHK
@@ -532,9 +533,12 @@ extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8
   return SDQN_OK;
 }
 
-static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* didx) {
-  StepArgs a = step_args(h); a.from_ring = 1; a.src = r->d_ring; a.idx = didx;
-  HeadArgs hd = head_args(h, 1); hd.meta = r->d_meta;
+static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pinned_idx) {
+  PrepArgs p; p.idx_pinned = pinned_idx; p.meta = r->d_meta; p.idx = h->d_idx; p.actions = h->st_act;
+  p.rewards = h->st_rew; p.terminals = h->st_term; p.B = h->B;
+  LAUNCH(K_PREP, launch_prep(p, g_stream));
+  StepArgs a = step_args(h); a.from_ring = 1; a.src = r->d_ring; a.idx = h->d_idx;
+  HeadArgs hd = head_args(h, 1);
   return run_train(h, a, hd);
 }
 extern "C" int sdqn_net_train_replay(sdqn_net_t h, sdqn_replay_t r, const int64_t* idx_host, float* cost_out) {

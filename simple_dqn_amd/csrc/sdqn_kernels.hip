@@ -12,7 +12,7 @@ namespace sdqn {
 static const char* k_names[K_COUNT] = {
   "conv1_fwd(gather+norm+conv+relu)", "conv2_fwd", "conv3_fwd", "fc4_fwd(splitK)", "head(fc5+td+delta)",
   "fc4_dgrad", "fc4_wgrad", "conv3_dgrad", "conv3_wgrad", "conv2_dgrad", "conv2_wgrad",
-  "conv1_wgrad", "update(reduce+fc5wgrad+rmsprop)", "rccl_allreduce", "replay_gather_u8"};
+  "conv1_wgrad", "update(reduce+fc5wgrad+rmsprop)", "rccl_allreduce", "replay_gather_u8", "prep(idx+meta)"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? k_names[id] : "?"; }
 
 hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
@@ -41,9 +41,19 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   __shared__ float sh_dc;
   __shared__ int sh_act;
   float a4v[2] = {0.0f, 0.0f};
+  int m_act = 0, m_term = 0; int64_t m_rew = 0;
+  if (h.train && j == 0) { m_act = h.st_actions[n]; m_rew = h.st_rewards[n]; m_term = h.st_terminals[n]; }  // in flight early
   for (int z = 0; z < a.nz; ++z) {
     float v = 0.0f;
-    for (int s = 0; s < a.S4; ++s) v += a.slab4[(((int64_t)s * 2 + z) * a.B + n) * NFC + j];   // fixed order
+    const float* sp = a.slab4 + ((int64_t)z * a.B + n) * NFC + j;
+    const int64_t sstride = (int64_t)2 * a.B * NFC;
+    int s = 0;
+    for (; s + 7 <= a.S4; s += 7) {                                                              // 7 loads in flight
+      float t0 = sp[(s + 0) * sstride], t1 = sp[(s + 1) * sstride], t2 = sp[(s + 2) * sstride], t3 = sp[(s + 3) * sstride];
+      float t4 = sp[(s + 4) * sstride], t5 = sp[(s + 5) * sstride], t6 = sp[(s + 6) * sstride];
+      v += t0; v += t1; v += t2; v += t3; v += t4; v += t5; v += t6;                             // fixed order
+    }
+    for (; s < a.S4; ++s) v += sp[s * sstride];
     v = fmaxf(v, 0.0f);                                                                          // Rectlin, :89
     a4v[z] = v;
     a.a4[((int64_t)z * a.B + n) * NFC + j] = v;
@@ -67,9 +77,7 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   __syncthreads();
   if (j == 0) {
 #pragma clang fp contract(off)
-    int act, term; int64_t rew;
-    if (a.from_ring) { const MetaRec rec = h.meta[a.idx[n]]; act = rec.action; rew = rec.reward; term = rec.terminal; }
-    else { act = h.st_actions[n]; rew = h.st_rewards[n]; term = h.st_terminals[n]; }
+    const int act = m_act, term = m_term; const int64_t rew = m_rew;
     float m = sh_q[1][0];
     for (int k = 1; k < a.A; ++k) m = fmaxf(m, sh_q[1][k]);                                     // be.max(postq, axis=0), :124
     double rr = (double)rew;                                                                     // np.clip(rewards, ..), :136
@@ -102,22 +110,68 @@ __device__ inline float rms_apply(float w, float& st, float gsum, const UpdateAr
   return w - (g * u.lr) / (sqrtf(st + u.eps) + u.eps);
 }
 
+// Two kinds of workgroups in one launch:
+//   blockIdx.x <  CONV_BLOCKS : conv parameters (77824 floats): split-K slab reduction, slab-parallel —
+//                               32 float4 columns x 8 slab groups per workgroup, fixed-order LDS combine
+//   blockIdx.x >= CONV_BLOCKS : fc4 (g written by fc4_wgrad) and fc5 (wgrad computed here), elementwise
+constexpr int CONV_F4 = OFF4 / 4;                 // 19456 float4 of conv parameters
+constexpr int CONV_BLOCKS = CONV_F4 / 32;         // 608
+
 __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
-  const int64_t NP4 = (OFF5 + (int64_t)u.A * NFC) / 4;
-  for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < NP4; i4 += (int64_t)gridDim.x * 256) {
-    const int64_t e = i4 * 4;
-    float4 gs;
-    if (u.mode == 2 || (e >= OFF4 && e < OFF5)) {
-      gs = *reinterpret_cast<const float4*>(u.g + e);              // fc4 wgrad wrote g directly; mode 2: all-reduced g
-    } else if (e < OFF4) {
-      const int L = e < OFF2 ? 0 : (e < OFF3 ? 1 : 2);
+  __shared__ float4 part[8][32];
+  const int t = threadIdx.x;
+  if ((int)blockIdx.x < CONV_BLOCKS) {
+    const int c4 = t & 31, sg = t >> 5;
+    const int64_t e = ((int64_t)blockIdx.x * 32 + c4) * 4;
+    float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (u.mode == 2) {
+      if (sg == 0) gs = *reinterpret_cast<const float4*>(u.g + e);
+    } else {
+      const int L = e < OFF2 ? 0 : (e < OFF3 ? 1 : 2);                       // uniform per workgroup (128-float groups)
       const int64_t off = e - (L == 0 ? OFF1 : (L == 1 ? OFF2 : OFF3));
       const int64_t nw = L == 0 ? NW1 : (L == 1 ? NW2 : NW3);
-      gs = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s = 0; s < u.ns[L]; ++s) {                          // fixed order: deterministic
-        const float4 v = *reinterpret_cast<const float4*>(u.slab[L] + (int64_t)s * nw + off);
+      const float* sp = u.slab[L] + off;
+      const int ns = u.ns[L];
+      int s = sg;
+      for (; s + 24 < ns; s += 32) {                                          // 4 independent 16 B loads in flight
+        const float4 v0 = *reinterpret_cast<const float4*>(sp + (int64_t)s * nw);
+        const float4 v1 = *reinterpret_cast<const float4*>(sp + (int64_t)(s + 8) * nw);
+        const float4 v2 = *reinterpret_cast<const float4*>(sp + (int64_t)(s + 16) * nw);
+        const float4 v3 = *reinterpret_cast<const float4*>(sp + (int64_t)(s + 24) * nw);
+        gs.x += v0.x; gs.y += v0.y; gs.z += v0.z; gs.w += v0.w;
+        gs.x += v1.x; gs.y += v1.y; gs.z += v1.z; gs.w += v1.w;
+        gs.x += v2.x; gs.y += v2.y; gs.z += v2.z; gs.w += v2.w;
+        gs.x += v3.x; gs.y += v3.y; gs.z += v3.z; gs.w += v3.w;
+      }
+      for (; s < ns; s += 8) {
+        const float4 v = *reinterpret_cast<const float4*>(sp + (int64_t)s * nw);
         gs.x += v.x; gs.y += v.y; gs.z += v.z; gs.w += v.w;
       }
+      part[sg][c4] = gs;
+      __syncthreads();
+      if (sg == 0) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { const float4 v = part[k][c4]; gs.x += v.x; gs.y += v.y; gs.z += v.z; gs.w += v.w; }  // fixed order
+        *reinterpret_cast<float4*>(u.g + e) = gs;
+      }
+    }
+    if (sg == 0 && u.mode != 1) {
+      float4 w = *reinterpret_cast<float4*>(u.theta + e);
+      float4 st = *reinterpret_cast<float4*>(u.state + e);
+      w.x = rms_apply(w.x, st.x, gs.x, u); w.y = rms_apply(w.y, st.y, gs.y, u);
+      w.z = rms_apply(w.z, st.z, gs.z, u); w.w = rms_apply(w.w, st.w, gs.w, u);
+      *reinterpret_cast<float4*>(u.theta + e) = w;
+      *reinterpret_cast<float4*>(u.state + e) = st;
+    }
+    return;
+  }
+  const int64_t NP4 = (OFF5 + (int64_t)u.A * NFC) / 4;
+  const int nb = gridDim.x - CONV_BLOCKS;
+  for (int64_t i4 = CONV_F4 + (int64_t)(blockIdx.x - CONV_BLOCKS) * 256 + t; i4 < NP4; i4 += (int64_t)nb * 256) {
+    const int64_t e = i4 * 4;
+    float4 gs;
+    if (u.mode == 2 || e < OFF5) {
+      gs = *reinterpret_cast<const float4*>(u.g + e);              // fc4 wgrad wrote g directly; mode 2: all-reduced g
     } else {                                                       // fc5 wgrad: delta . a4^T  (A x 512, tiny)
       const int64_t o = e - OFF5;
       const int act = (int)(o / NFC), j0 = (int)(o - (int64_t)act * NFC);
@@ -127,8 +181,8 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
         const float4 v = *reinterpret_cast<const float4*>(u.a4 + (int64_t)n * NFC + j0);
         gs.x += d * v.x; gs.y += d * v.y; gs.z += d * v.z; gs.w += d * v.w;
       }
+      *reinterpret_cast<float4*>(u.g + e) = gs;
     }
-    if (u.mode != 2 && !(e >= OFF4 && e < OFF5)) *reinterpret_cast<float4*>(u.g + e) = gs;
     if (u.mode != 1) {
       float4 w = *reinterpret_cast<float4*>(u.theta + e);
       float4 st = *reinterpret_cast<float4*>(u.state + e);
@@ -138,7 +192,7 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
       *reinterpret_cast<float4*>(u.state + e) = st;
     }
   }
-  if (u.mode != 2 && blockIdx.x == 0 && threadIdx.x == 0) {        // get_cost: mean over the batch, :154
+  if (u.mode != 2 && (int)blockIdx.x == CONV_BLOCKS && t == 0) {   // get_cost: mean over the batch, :154
     float c = 0.0f;
     for (int n = 0; n < u.B; ++n) c += u.cost_terms[n];
     c = c / (float)u.B;
@@ -148,10 +202,27 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
 }
 
 hipError_t launch_update(const UpdateArgs& u, hipStream_t s) {
-  const int64_t NP4 = (OFF5 + (int64_t)u.A * NFC) / 4;
+  const int64_t NP4 = (OFF5 + (int64_t)u.A * NFC) / 4 - CONV_F4;
   int blocks = (int)((NP4 + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(update_kernel, dim3(blocks), dim3(256), 0, s, u);
+  if (blocks > 1792) blocks = 1792;
+  hipLaunchKernelGGL(update_kernel, dim3(CONV_BLOCKS + blocks), dim3(256), 0, s, u);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: the sampled indexes arrive in a pinned host slot; one tiny workgroup copies them into device
+// memory and gathers (a, r, t) = (actions, rewards, terminals)[idx] (replay_memory.py:76-78) so that no
+// later kernel of the step touches host memory.
+__global__ void __launch_bounds__(256) prep_kernel(const PrepArgs p) {
+  for (int n = threadIdx.x; n < p.B; n += 256) {
+    const int64_t i = p.idx_pinned[n];
+    p.idx[n] = i;
+    const MetaRec rec = p.meta[i];
+    p.actions[n] = rec.action; p.rewards[n] = rec.reward; p.terminals[n] = rec.terminal;
+  }
+}
+hipError_t launch_prep(const PrepArgs& p, hipStream_t s) {
+  hipLaunchKernelGGL(prep_kernel, dim3(1), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 

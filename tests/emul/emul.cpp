@@ -33,6 +33,8 @@ static void run(const StepArgs& a) {
   }
 }
 
+extern "C" void emul_norm_u8(float* out256) { for (int i = 0; i < 256; ++i) out256[i] = norm_u8((uint32_t)i); }
+
 extern "C" int emul_step(int B, int A, const float* const* w_online /*5, Neon*/, const float* const* w_target,
                          const uint8_t* pre, const uint8_t* act, const int64_t* rew, const uint8_t* post,
                          const uint8_t* term, double discount, double clip, double minr, double maxr,

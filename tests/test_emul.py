@@ -44,3 +44,10 @@ def test_problem_index_math(emul, B, A, seed):
     assert abs(cst.value - float(cost)) < 1e-5
     for i in range(5):
         assert np.abs(gout[i] - g[i]).max() < 2e-5 * max(1.0, np.abs(g[i]).max()), i
+
+
+def test_normalisation_is_exact_division(emul):
+    # deepqnetwork.py:100 be.divide(input, 255): the division-free device formula must equal IEEE x/255
+    out = np.zeros(256, np.float32)
+    emul.emul_norm_u8(out.ctypes.data_as(C.POINTER(C.c_float)))
+    assert np.array_equal(out, np.arange(256, dtype=np.float32) / np.float32(255))
