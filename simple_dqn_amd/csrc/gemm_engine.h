@@ -1,13 +1,21 @@
 // gemm_engine.h — the one tile engine behind every GEMM-shaped stage (problems.h).
 //
-// CDNA4 mapping: 256-thread workgroup = 4 wave64s arranged WM x WN x WK.  Each wave owns one
-// 32x32 fp32 accumulator tile (16 VGPR/AGPR per lane) fed by v_mfma_f32_32x32x2_f32
-// (exact fp32, bitwise an fmaf chain — required for the 1e-4 Q-value parity).  The WK waves
-// of a tile split every 32-deep K-tile between them and are summed through LDS in the
-// epilogue.  K-tiles are staged global -> VGPR -> LDS (double-buffered, one barrier per
-// tile): the loader performs the separable im2col gather A(m,k) = srcA[row(m) + col(k)], so
-// the LDS image is a dense [k][m] / [k][n] panel (row pitch +1 dword: conflict-free for both
-// the lane-along-k stores and the lane-along-m MFMA operand reads).
+// Regime: at B=32 every stage is a few hundred MFLOP — far too small to fill 256 CUs with classic
+// block-tiled GEMMs, and a per-K-tile __syncthreads pipeline is a serial chain of memory latencies
+// (measured: ~10 us per stage for ~1 us of MFMA work).  So the engine is organised for latency:
+//
+//   * one workgroup = ONE 32x32 fp32 output tile (a single v_mfma_f32_32x32x2_f32 accumulator:
+//     exact fp32, bitwise an fmaf chain — needed for the 1e-4 Q-value parity);
+//   * its NW wave64s (1..16) split the reduction dimension: wave w owns the 32-deep K-chunks
+//     w, w+NW, ... and runs them autonomously — NO workgroup barrier in the main loop, every wave
+//     has its next chunk's global loads in flight while it issues the current chunk's 16 MFMAs;
+//   * operands whose memory-contiguous dimension is m/n (weights [k][n], deltas [m][f], the wgrad
+//     im2col rows) are loaded straight into the MFMA operand layout (lane l <- [k + (l>>5)][x0 + (l&31)],
+//     two coalesced 128-B rows per instruction, no LDS);
+//   * operands contiguous along k (im2col patches, activations, dgrad weights) are fetched with
+//     16 B/lane vector loads (4 B/lane for the u8 ring) and transposed through a WAVE-PRIVATE LDS
+//     panel [k][x] (pitch 33: conflict-free for both the k-major stores and the x-major reads);
+//   * the NW partial tiles are summed through LDS in a fixed order (deterministic), then P::store.
 //
 // MFMA operand maps (guide §3): lane l holds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
 // D register r of lane l is D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].
@@ -19,104 +27,66 @@ namespace sdqn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <class P>
-__global__ void __launch_bounds__(256) gemm_kernel(const StepArgs a) {
-  constexpr int WM = P::WM, WN = P::WN, WK = P::WK;
-  static_assert(WM * WN * WK == 4, "4 waves per workgroup");
-  constexpr int BM = 32 * WM, BN = 32 * WN, BK = 32;
-  constexpr int LDA = BM + 1, LDB = BN + 1, LDC = BN + 1;
-  constexpr int SM_AB = 2 * BK * (LDA + LDB);
-  constexpr int SM_C = WK * BM * LDC;
-  constexpr int SM = SM_AB > SM_C ? SM_AB : SM_C;
-  __shared__ float smem[SM];
-  float* As = smem;
-  float* Bs = smem + 2 * BK * LDA;
+constexpr int PANEL = 32 * 33;      // one [32 k][32 x] fp32 panel, pitch 33
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // wave-private LDS hand-off between lanes of ONE wave: LDS ops of a wave execute in order, so only
+  // the compiler has to be kept from reordering the stores past the loads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class P, int NW>
+__global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
+  constexpr int NPAN = (P::A_K ? 1 : 0) + (P::B_K ? 1 : 0);
+  constexpr int WAVE_LDS = (NPAN > 0 ? NPAN : 1) * PANEL;
+  __shared__ float smem[NW * WAVE_LDS];
   typedef typename P::aoff_t aoff_t;
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   int z, ks, kbeg, kend;
   P::ksplit(a, blockIdx.z, z, ks, kbeg, kend);
   const int M = P::M(a), N = P::N(a);
+  float* pa = smem + wave * WAVE_LDS;
+  float* pb = pa + (P::A_K ? PANEL : 0);
 
-  // ---- loader geometry: every thread stages BM/32 (A) + BN/32 (B) 4-vectors of a K-tile ------------
-  // The vector always runs along the operand's memory-contiguous dimension (16 B/lane global loads,
-  // 4 B/lane for the u8 ring), and so do the lanes:
-  //   contiguous k (A_K/B_K):  k4 = t & 7 -> k = kt + 4*k4 .. +3,  x = (t >> 3) + 32*j
-  //   contiguous x (m or n):   x4 = t % (BX/4) -> x = 4*x4 .. +3,   k = kt + t / (BX/4) + (1024/BX)*j
-  constexpr int AJ = BM / 32, BJ = BN / 32;
-  aoff_t arow[P::A_K ? AJ : 1];
-  int bcol[P::B_K ? BJ : 1];
+  // ---- per-lane operand geometry ---------------------------------------------------------------
+  // k-contiguous operand: lane -> (k4 = l & 7, x = (l >> 3) + 8j), one 4-vector per j < 4
+  // x-contiguous operand: lane -> (x = l & 31, k = 2i + (l >> 5)),  one scalar per i < 16 (MFMA layout)
+  aoff_t arow[P::A_K ? 4 : 1];
+  int bcol[P::B_K ? 4 : 1];
   if constexpr (P::A_K) {
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) { const int m = m0 + (t >> 3) + 32 * j; arow[j] = P::a_row(a, z, m < M ? m : M - 1); }
+    for (int j = 0; j < 4; ++j) { const int m = m0 + (lane >> 3) + 8 * j; arow[j] = P::a_row(a, z, m < M ? m : M - 1); }
   } else {
-    const int m = m0 + 4 * (t % (BM / 4)); arow[0] = P::a_row(a, z, m + 3 < M ? m : M - 4);
+    const int m = m0 + (lane & 31); arow[0] = P::a_row(a, z, m < M ? m : M - 1);
   }
   if constexpr (P::B_K) {
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) { const int n = n0 + (t >> 3) + 32 * j; bcol[j] = P::b_col(a, z, n < N ? n : N - 1); }
+    for (int j = 0; j < 4; ++j) { const int n = n0 + (lane >> 3) + 8 * j; bcol[j] = P::b_col(a, z, n < N ? n : N - 1); }
   } else {
-    const int n = n0 + 4 * (t % (BN / 4)); bcol[0] = P::b_col(a, z, n + 3 < N ? n : N - 4);
+    const int n = n0 + (lane & 31); bcol[0] = P::b_col(a, z, n < N ? n : N - 1);
   }
 
-  f4 ra[AJ], rb[BJ];
-  const f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-  auto load_tile = [&](int kt) {
+  float ra[16], rb[16];                       // next chunk's operands (4 x f4, or 16 scalars in MFMA layout)
+  auto load_chunk = [&](int kc) {
     if constexpr (P::A_K) {
-      const int k = kt + 4 * (t & 7); const bool ok = k < kend;
-      const aoff_t c = ok ? P::a_col(a, z, k) : (aoff_t)0;
+      const aoff_t c = P::a_col(a, z, kc + 4 * (lane & 7));
 #pragma unroll
-      for (int j = 0; j < AJ; ++j) ra[j] = ok ? P::a_load4(a, z, arow[j] + c) : zero4;
+      for (int j = 0; j < 4; ++j) { const f4 v = P::a_load4(a, z, arow[j] + c); ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w; }
     } else {
 #pragma unroll
-      for (int j = 0; j < AJ; ++j) {
-        const int k = kt + t / (BM / 4) + j * (1024 / BM);
-        ra[j] = k < kend ? P::a_load4(a, z, arow[0] + P::a_col(a, z, k)) : zero4;
-      }
+      for (int i = 0; i < 16; ++i) { const int k = kc + 2 * i + (lane >> 5); ra[i] = k < kend ? P::a_load(a, z, arow[0] + P::a_col(a, z, k)) : 0.0f; }
     }
     if constexpr (P::B_K) {
-      const int k = kt + 4 * (t & 7); const bool ok = k < kend;
-      const int r = ok ? P::b_row(a, z, k) : 0;
+      const int r = P::b_row(a, z, kc + 4 * (lane & 7));
 #pragma unroll
-      for (int j = 0; j < BJ; ++j) rb[j] = ok ? P::b_load4(a, z, r + bcol[j]) : zero4;
+      for (int j = 0; j < 4; ++j) { const f4 v = P::b_load4(a, z, r + bcol[j]); rb[4 * j] = v.x; rb[4 * j + 1] = v.y; rb[4 * j + 2] = v.z; rb[4 * j + 3] = v.w; }
     } else {
 #pragma unroll
-      for (int j = 0; j < BJ; ++j) {
-        const int k = kt + t / (BN / 4) + j * (1024 / BN);
-        rb[j] = k < kend ? P::b_load4(a, z, P::b_row(a, z, k) + bcol[0]) : zero4;
-      }
-    }
-  };
-  auto store_tile = [&](int buf) {
-    float* Ab = As + buf * BK * LDA;
-    float* Bb = Bs + buf * BK * LDB;
-    if constexpr (P::A_K) {
-#pragma unroll
-      for (int j = 0; j < AJ; ++j) {
-        float* d = Ab + (4 * (t & 7)) * LDA + (t >> 3) + 32 * j;
-        d[0] = ra[j].x; d[LDA] = ra[j].y; d[2 * LDA] = ra[j].z; d[3 * LDA] = ra[j].w;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < AJ; ++j) {
-        float* d = Ab + (t / (BM / 4) + j * (1024 / BM)) * LDA + 4 * (t % (BM / 4));
-        d[0] = ra[j].x; d[1] = ra[j].y; d[2] = ra[j].z; d[3] = ra[j].w;
-      }
-    }
-    if constexpr (P::B_K) {
-#pragma unroll
-      for (int j = 0; j < BJ; ++j) {
-        float* d = Bb + (4 * (t & 7)) * LDB + (t >> 3) + 32 * j;
-        d[0] = rb[j].x; d[LDB] = rb[j].y; d[2 * LDB] = rb[j].z; d[3 * LDB] = rb[j].w;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < BJ; ++j) {
-        float* d = Bb + (t / (BN / 4) + j * (1024 / BN)) * LDB + 4 * (t % (BN / 4));
-        d[0] = rb[j].x; d[1] = rb[j].y; d[2] = rb[j].z; d[3] = rb[j].w;
-      }
+      for (int i = 0; i < 16; ++i) { const int k = kc + 2 * i + (lane >> 5); rb[i] = k < kend ? P::b_load(a, z, P::b_row(a, z, k) + bcol[0]) : 0.0f; }
     }
   };
 
@@ -124,49 +94,75 @@ __global__ void __launch_bounds__(256) gemm_kernel(const StepArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
-  const int T = (kend - kbeg + BK - 1) / BK;
-  if (T > 0) {
-    load_tile(kbeg);
-    store_tile(0);
-    __syncthreads();
-    constexpr int KW = BK / WK;
-    for (int it = 0; it < T; ++it) {
-      const bool more = it + 1 < T;
-      if (more) load_tile(kbeg + (it + 1) * BK);           // global gathers in flight under the MFMAs
-      const float* Ab = As + (it & 1) * BK * LDA + wm * 32 + (lane & 31);
-      const float* Bb = Bs + (it & 1) * BK * LDB + wn * 32 + (lane & 31);
+  int kc = kbeg + wave * 32;
+  if (kc < kend) load_chunk(kc);
+  while (kc < kend) {
+    // ---- move the fetched chunk to its MFMA operands (through the wave-private panels if k-contiguous)
+    float fa[16], fb[16];
+    if constexpr (P::A_K) {
+      float* d = pa + (4 * (lane & 7)) * 33 + (lane >> 3);
 #pragma unroll
-      for (int kk = 0; kk < KW; kk += 2) {
-        const int k2 = wk * KW + kk + (lane >> 5);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ab[k2 * LDA], Bb[k2 * LDB], acc, 0, 0, 0);
-      }
-      if (more) store_tile((it + 1) & 1);
-      __syncthreads();
+      for (int j = 0; j < 4; ++j) { d[8 * j] = ra[4 * j]; d[33 + 8 * j] = ra[4 * j + 1]; d[66 + 8 * j] = ra[4 * j + 2]; d[99 + 8 * j] = ra[4 * j + 3]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) fa[i] = ra[i];
     }
+    if constexpr (P::B_K) {
+      float* d = pb + (4 * (lane & 7)) * 33 + (lane >> 3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { d[8 * j] = rb[4 * j]; d[33 + 8 * j] = rb[4 * j + 1]; d[66 + 8 * j] = rb[4 * j + 2]; d[99 + 8 * j] = rb[4 * j + 3]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) fb[i] = rb[i];
+    }
+    const int knext = kc + NW * 32;
+    if (knext < kend) load_chunk(knext);                 // next chunk's global loads fly under the MFMAs
+    if constexpr (P::A_K || P::B_K) wave_lds_sync();
+    if constexpr (P::A_K) {
+      const float* s = pa + (lane >> 5) * 33 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) fa[i] = s[66 * i];
+    }
+    if constexpr (P::B_K) {
+      const float* s = pb + (lane >> 5) * 33 + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) fb[i] = s[66 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc, 0, 0, 0);
+    if constexpr (P::A_K || P::B_K) wave_lds_sync();      // panel reads done before the next chunk's stores
+    kc = knext;
   }
 
-  // ---- epilogue: WK partial tiles -> LDS -> summed in fixed order -> P::store (lanes along n) ----
-  float* Cs = smem;
+  // ---- epilogue: NW partial tiles -> LDS -> summed in fixed order -> P::store (lanes along n) ----
+  if constexpr (NW > 1) {
+    float* cw = smem + wave * WAVE_LDS;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    Cs[(wk * BM + wm * 32 + row) * LDC + wn * 32 + (lane & 31)] = acc[r];
-  }
-  __syncthreads();
-  for (int e = t; e < BM * BN; e += 256) {
-    const int ml = e / BN, nl = e - ml * BN;
-    float v = Cs[ml * LDC + nl];
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      cw[row * 33 + (lane & 31)] = acc[r];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += NW * 64) {
+      const int ml = e >> 5, nl = e & 31;
+      float v = smem[ml * 33 + nl];
 #pragma unroll
-    for (int w = 1; w < WK; ++w) v += Cs[(w * BM + ml) * LDC + nl];
-    if (m0 + ml < M && n0 + nl < N) P::store(a, z, ks, m0 + ml, n0 + nl, v);
+      for (int w = 1; w < NW; ++w) v += smem[w * WAVE_LDS + ml * 33 + nl];
+      if (m0 + ml < M && n0 + nl < N) P::store(a, z, ks, m0 + ml, n0 + nl, v);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl = lane & 31;
+      if (m0 + ml < M && n0 + nl < N) P::store(a, z, ks, m0 + ml, n0 + nl, acc[r]);
+    }
   }
 }
 
-template <class P>
+template <class P, int NW>
 inline hipError_t launch_gemm(const StepArgs& a, hipStream_t stream) {
-  constexpr int BM = 32 * P::WM, BN = 32 * P::WN;
-  dim3 grid((P::M(a) + BM - 1) / BM, (P::N(a) + BN - 1) / BN, P::nbz(a));
-  hipLaunchKernelGGL(gemm_kernel<P>, grid, dim3(256), 0, stream, a);
+  dim3 grid((P::M(a) + 31) / 32, (P::N(a) + 31) / 32, P::nbz(a));
+  hipLaunchKernelGGL((gemm_kernel<P, NW>), grid, dim3(NW * 64), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -290,7 +290,7 @@ struct sdqn_net_s {
   float *q = nullptr, *maxq = nullptr, *dq = nullptr, *cost_terms = nullptr, *cost_out = nullptr; double* cost_accum = nullptr;
   uint8_t *st_states = nullptr, *st_act = nullptr, *st_term = nullptr; int64_t* st_rew = nullptr; int64_t* d_idx = nullptr;
   float* h_f = nullptr;                    // pinned scratch for small read-backs
-  int S4 = 14, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
+  int S4 = 7, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
   int64_t train_iterations = 0;
   // profiler
   bool prof_on = false; int prof_filter = -1;
@@ -330,11 +330,12 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n);
   const int B = h->B;
   auto pick = [](int T, int target) { int t = (T + target - 1) / target; return t < 1 ? 1 : t; };
+  // wgrad split-K: 16 waves per workgroup take one 32-deep chunk each at B = 32 (more per wave for larger B)
   const int big = B >= 128 ? 2 : 1;
   const int T1 = ceil_div(B * PIX1, 32), T2 = ceil_div(B * PIX2, 32), T3 = ceil_div(B * PIX3, 32);
-  h->tps1 = pick(T1, 100 * big); h->tps2 = pick(T2, 27 * big); h->tps3 = pick(T3, 25 * big);
+  h->tps1 = pick(T1, 25 * big); h->tps2 = pick(T2, 6 * big); h->tps3 = pick(T3, 4 * big);
   h->ns1 = ceil_div(T1, h->tps1); h->ns2 = ceil_div(T2, h->tps2); h->ns3 = ceil_div(T3, h->tps3);
-  h->S4 = 14;
+  h->S4 = 7;
 #define NCHK(x) do { int r_ = (x); if (r_) { net_free(h); return r_; } } while (0)
   NCHK(dalloc(h, (void**)&h->theta, h->NP * 4));
   if (c->target_enabled) NCHK(dalloc(h, (void**)&h->theta_t, h->NP * 4)); else h->theta_t = h->theta;   // deepqnetwork.py:64-73

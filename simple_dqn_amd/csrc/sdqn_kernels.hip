@@ -15,19 +15,24 @@ static const char* k_names[K_COUNT] = {
   "conv1_wgrad", "update(reduce+fc5wgrad+rmsprop)", "rccl_allreduce", "replay_gather_u8", "prep(idx+meta)"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? k_names[id] : "?"; }
 
+// Waves per workgroup = how many 32-deep K-chunks run concurrently on one output tile (gemm_engine.h).
 hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
   switch (id) {
-    case K_CONV1_FWD: return launch_gemm<Conv1Fwd>(a, s);
-    case K_CONV2_FWD: return launch_gemm<Conv2Fwd>(a, s);
-    case K_CONV3_FWD: return launch_gemm<Conv3Fwd>(a, s);
-    case K_FC4_FWD: return launch_gemm<Fc4Fwd>(a, s);
-    case K_FC4_DGRAD: return launch_gemm<Fc4Dgrad>(a, s);
-    case K_FC4_WGRAD: return launch_gemm<Fc4Wgrad>(a, s);
-    case K_CONV3_DGRAD: return launch_gemm<Conv3Dgrad>(a, s);
-    case K_CONV3_WGRAD: return launch_gemm<Conv3Wgrad>(a, s);
-    case K_CONV2_DGRAD: return launch_gemm<Conv2Dgrad>(a, s);
-    case K_CONV2_WGRAD: return launch_gemm<Conv2Wgrad>(a, s);
-    case K_CONV1_WGRAD: return launch_gemm<Conv1Wgrad>(a, s);
+    case K_CONV1_FWD: return launch_gemm<Conv1Fwd, 8>(a, s);        // K = 256  -> 8 chunks
+    case K_CONV2_FWD: return launch_gemm<Conv2Fwd, 16>(a, s);       // K = 512  -> 16 chunks
+    case K_CONV3_FWD: return launch_gemm<Conv3Fwd, 9>(a, s);        // K = 576  -> 18 chunks, 2 per wave
+    case K_FC4_FWD: return launch_gemm<Fc4Fwd, 14>(a, s);           // K = 3136 -> 98 chunks = S4(7) x 14
+    case K_FC4_DGRAD: return launch_gemm<Fc4Dgrad, 16>(a, s);       // K = 512
+    case K_FC4_WGRAD:                                               // K = B
+      if (a.B <= 32) return launch_gemm<Fc4Wgrad, 1>(a, s);
+      if (a.B <= 64) return launch_gemm<Fc4Wgrad, 2>(a, s);
+      if (a.B <= 128) return launch_gemm<Fc4Wgrad, 4>(a, s);
+      return launch_gemm<Fc4Wgrad, 8>(a, s);
+    case K_CONV3_DGRAD: return launch_gemm<Conv3Dgrad, 9>(a, s);    // K = 576
+    case K_CONV3_WGRAD: return launch_gemm<Conv3Wgrad, 16>(a, s);   // K = B*49 split over slabs
+    case K_CONV2_DGRAD: return launch_gemm<Conv2Dgrad, 8>(a, s);    // K = 256 per parity class
+    case K_CONV2_WGRAD: return launch_gemm<Conv2Wgrad, 16>(a, s);
+    case K_CONV1_WGRAD: return launch_gemm<Conv1Wgrad, 16>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
