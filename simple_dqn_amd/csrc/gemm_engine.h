@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
   __shared__ float smem[NW * WAVE_LDS];
   typedef typename P::aoff_t aoff_t;
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // provably wave-uniform -> SGPR index math
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   int z, ks, kbeg, kend;
   P::ksplit(a, blockIdx.z, z, ks, kbeg, kend);
@@ -54,7 +55,9 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
 
   // ---- per-lane operand geometry ---------------------------------------------------------------
   // k-contiguous operand: lane -> (k4 = l & 7, x = (l >> 3) + 8j), one 4-vector per j < 4
-  // x-contiguous operand: lane -> (x = l & 31, k = 2i + (l >> 5)),  one scalar per i < 16 (MFMA layout)
+  // x-contiguous operand: lane -> (x = l & 31, k = i + 16*(l >> 5)), one scalar per i < 16 (MFMA layout).
+  //   Both candidate k's of step i are wave-uniform, so the (n,p,q) im2col decomposition of the
+  //   reduction index runs on the scalar unit and the lanes only select (v_cndmask) + add.
   aoff_t arow[P::A_K ? 4 : 1];
   int bcol[P::B_K ? 4 : 1];
   if constexpr (P::A_K) {
@@ -78,7 +81,13 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
       for (int j = 0; j < 4; ++j) { const f4 v = P::a_load4(a, z, arow[j] + c); ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w; }
     } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { const int k = kc + 2 * i + (lane >> 5); ra[i] = k < kend ? P::a_load(a, z, arow[0] + P::a_col(a, z, k)) : 0.0f; }
+      for (int i = 0; i < 16; ++i) {
+        const int k0 = kc + i, k1 = kc + 16 + i;
+        const bool ok0 = k0 < kend, ok1 = k1 < kend;
+        const aoff_t c0 = P::a_col(a, z, ok0 ? k0 : kbeg), c1 = P::a_col(a, z, ok1 ? k1 : kbeg);
+        const bool hi = lane >= 32;
+        ra[i] = (hi ? ok1 : ok0) ? P::a_load(a, z, arow[0] + (hi ? c1 : c0)) : 0.0f;
+      }
     }
     if constexpr (P::B_K) {
       const int r = P::b_row(a, z, kc + 4 * (lane & 7));
@@ -86,7 +95,13 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
       for (int j = 0; j < 4; ++j) { const f4 v = P::b_load4(a, z, r + bcol[j]); rb[4 * j] = v.x; rb[4 * j + 1] = v.y; rb[4 * j + 2] = v.z; rb[4 * j + 3] = v.w; }
     } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { const int k = kc + 2 * i + (lane >> 5); rb[i] = k < kend ? P::b_load(a, z, P::b_row(a, z, k) + bcol[0]) : 0.0f; }
+      for (int i = 0; i < 16; ++i) {
+        const int k0 = kc + i, k1 = kc + 16 + i;
+        const bool ok0 = k0 < kend, ok1 = k1 < kend;
+        const int r0 = P::b_row(a, z, ok0 ? k0 : kbeg), r1 = P::b_row(a, z, ok1 ? k1 : kbeg);
+        const bool hi = lane >= 32;
+        rb[i] = (hi ? ok1 : ok0) ? P::b_load(a, z, (hi ? r1 : r0) + bcol[0]) : 0.0f;
+      }
     }
   };
 
@@ -94,7 +109,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
-  int kc = kbeg + wave * 32;
+  int kc = kbeg + wave * 32;                              // wave-uniform
   if (kc < kend) load_chunk(kc);
   while (kc < kend) {
     // ---- move the fetched chunk to its MFMA operands (through the wave-private panels if k-contiguous)
@@ -119,14 +134,14 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
     if (knext < kend) load_chunk(knext);                 // next chunk's global loads fly under the MFMAs
     if constexpr (P::A_K || P::B_K) wave_lds_sync();
     if constexpr (P::A_K) {
-      const float* s = pa + (lane >> 5) * 33 + (lane & 31);
+      const float* s = pa + (lane >> 5) * (16 * 33) + (lane & 31);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) fa[i] = s[66 * i];
+      for (int i = 0; i < 16; ++i) fa[i] = s[33 * i];
     }
     if constexpr (P::B_K) {
-      const float* s = pb + (lane >> 5) * 33 + (lane & 31);
+      const float* s = pb + (lane >> 5) * (16 * 33) + (lane & 31);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) fb[i] = s[66 * i];
+      for (int i = 0; i < 16; ++i) fb[i] = s[33 * i];
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc, 0, 0, 0);

@@ -49,6 +49,7 @@ struct UpdateArgs {
   double* cost_accum;           // running sum over steps
   int B, A;
   int mode;                     // 0 fused reduce+apply, 1 reduce only (-> g), 2 apply only (g already reduced)
+  int skip_fc4;                 // fc4 already updated inside fc4_wgrad's epilogue (StepArgs::fuse_rms)
   float bsz;                    // divisor of A9 (B, or R*B under data parallel)
   float rho, one_minus_rho, lr, eps;
 };

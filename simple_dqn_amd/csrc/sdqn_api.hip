@@ -25,13 +25,17 @@ static void set_error(const char* fmt, ...) {
   set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); return SDQN_ERR_HIP; } } while (0)
 #define ARGCHK(c, ...) do { if (!(c)) { set_error(__VA_ARGS__); return SDQN_ERR_ARG; } } while (0)
 
-static hipStream_t g_stream = nullptr;
+static hipStream_t g_stream = nullptr;      // the library stream: everything is ordered on it
+static hipStream_t g_side = nullptr;        // side stream: weight-gradient kernels run beside the dgrad chain
+static hipEvent_t g_ev[5];                  // fork/join events between the two (timing disabled)
 static int ensure_stream() {
   if (g_stream) return SDQN_OK;
   int n = 0;
   HIPCHK(hipGetDeviceCount(&n));
   if (n <= 0) { set_error("no HIP device visible (libsdqn_hip has no CPU path)"); return SDQN_ERR_HIP; }
   HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+  for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming));
   return SDQN_OK;
 }
 #define STREAMCHK() do { int r_ = ensure_stream(); if (r_) return r_; } while (0)
@@ -292,6 +296,8 @@ struct sdqn_net_s {
   float* h_f = nullptr;                    // pinned scratch for small read-backs
   int S4 = 7, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
   int64_t train_iterations = 0;
+  bool keep_grads = false;                 // true: fc4 gradient materialised in g (readable with which=3), no fused RMSProp
+  bool two_streams = true;                 // weight-gradient kernels on the side stream
   // profiler
   bool prof_on = false; int prof_filter = -1;
   std::vector<ProfPair> prof_pending; std::vector<hipEvent_t> prof_free;
@@ -404,6 +410,7 @@ extern "C" int sdqn_net_get_weights(sdqn_net_t h, int which, int layer, float* w
 static int prof_collect(sdqn_net_s* h) {
   if (h->prof_pending.empty()) return SDQN_OK;
   HIPCHK(hipStreamSynchronize(g_stream));
+  HIPCHK(hipStreamSynchronize(g_side));
   for (auto& p : h->prof_pending) {
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
     h->prof_ms[p.id] += ms; h->prof_n[p.id] += 1;
@@ -416,15 +423,16 @@ static int prof_event(sdqn_net_s* h, hipEvent_t* e) {
   if (!h->prof_free.empty()) { *e = h->prof_free.back(); h->prof_free.pop_back(); return SDQN_OK; }
   HIPCHK(hipEventCreate(e)); return SDQN_OK;
 }
-#define LAUNCH(KID, expr) do { \
+#define LAUNCH_ON(STRM, KID, expr) do { \
   const bool pf_ = h->prof_on && (h->prof_filter < 0 || h->prof_filter == (KID)); ProfPair pp_; \
   if (pf_) { pp_.id = (KID); int r1_ = prof_event(h, &pp_.a); if (r1_) return r1_; r1_ = prof_event(h, &pp_.b); if (r1_) return r1_; \
-             HIPCHK(hipEventRecord(pp_.a, g_stream)); } \
+             HIPCHK(hipEventRecord(pp_.a, (STRM))); } \
   hipError_t le_ = (expr); \
   if (le_ != hipSuccess) { set_error("launch %s -> %s", kernel_name(KID), hipGetErrorString(le_)); return SDQN_ERR_HIP; } \
-  if (pf_) { HIPCHK(hipEventRecord(pp_.b, g_stream)); h->prof_pending.push_back(pp_); \
+  if (pf_) { HIPCHK(hipEventRecord(pp_.b, (STRM))); h->prof_pending.push_back(pp_); \
              if (h->prof_pending.size() > 16384) { int r2_ = prof_collect(h); if (r2_) return r2_; } } \
 } while (0)
+#define LAUNCH(KID, expr) LAUNCH_ON(g_stream, KID, expr)
 
 extern "C" int sdqn_net_profile(sdqn_net_t h, int enable, int kernel) {
   ARGCHK(h && kernel < K_COUNT, "bad arguments"); h->prof_on = enable != 0; h->prof_filter = kernel; return SDQN_OK;
@@ -448,6 +456,10 @@ static StepArgs step_args(sdqn_net_s* h) {
   a.a1 = h->a1; a.a2 = h->a2; a.a3 = h->a3; a.slab4 = h->slab4; a.a4 = h->a4; a.d4 = h->d4; a.d3p = h->d3p; a.d2p = h->d2p;
   a.d1 = h->d1; a.g = h->g; a.slab1 = h->slab1; a.slab2 = h->slab2; a.slab3 = h->slab3;
   a.S4 = h->S4; a.tps1 = h->tps1; a.tps2 = h->tps2; a.tps3 = h->tps3;
+  a.fuse_rms = (!h->comm && !h->keep_grads) ? 1 : 0;
+  a.theta_w = h->theta; a.state = h->state; a.bsz = (float)h->B;
+  a.rho = (float)h->cfg.decay_rate; a.one_minus_rho = (float)(1.0 - h->cfg.decay_rate);
+  a.lr = (float)h->cfg.learning_rate; a.eps = (float)h->cfg.epsilon;
   return a;
 }
 static HeadArgs head_args(sdqn_net_s* h, int train) {
@@ -468,13 +480,21 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
 }
 static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
   int rc = run_forward(h, a, hd); if (rc) return rc;
+  // Backward.  Critical path on the library stream: fc4_dgrad -> conv3_dgrad -> conv2_dgrad -> conv1_wgrad.
+  // The three other weight-gradient kernels only need the delta of their layer, so they run beside it
+  // on the side stream (fork after the producer of their delta, join before the update).
+  hipStream_t ss = h->two_streams ? g_side : g_stream;
+  if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[0], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[0], 0)); }
+  LAUNCH_ON(ss, K_FC4_WGRAD, launch_kernel(K_FC4_WGRAD, a, ss));            // needs d4, a3
   LAUNCH(K_FC4_DGRAD, launch_kernel(K_FC4_DGRAD, a, g_stream));
-  LAUNCH(K_FC4_WGRAD, launch_kernel(K_FC4_WGRAD, a, g_stream));
+  if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[1], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[1], 0)); }
+  LAUNCH_ON(ss, K_CONV3_WGRAD, launch_kernel(K_CONV3_WGRAD, a, ss));        // needs d3p, a2
   LAUNCH(K_CONV3_DGRAD, launch_kernel(K_CONV3_DGRAD, a, g_stream));
-  LAUNCH(K_CONV3_WGRAD, launch_kernel(K_CONV3_WGRAD, a, g_stream));
+  if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[2], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[2], 0)); }
+  LAUNCH_ON(ss, K_CONV2_WGRAD, launch_kernel(K_CONV2_WGRAD, a, ss));        // needs d2p, a1
   LAUNCH(K_CONV2_DGRAD, launch_kernel(K_CONV2_DGRAD, a, g_stream));
-  LAUNCH(K_CONV2_WGRAD, launch_kernel(K_CONV2_WGRAD, a, g_stream));
   LAUNCH(K_CONV1_WGRAD, launch_kernel(K_CONV1_WGRAD, a, g_stream));
+  if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[3], ss)); HIPCHK(hipStreamWaitEvent(g_stream, g_ev[3], 0)); }
   UpdateArgs u; memset(&u, 0, sizeof u);
   u.theta = h->theta; u.state = h->state; u.g = h->g;
   u.slab[0] = h->slab1; u.slab[1] = h->slab2; u.slab[2] = h->slab3; u.ns[0] = h->ns1; u.ns[1] = h->ns2; u.ns[2] = h->ns3;
@@ -482,6 +502,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
   u.B = h->B; u.A = h->A;
   u.rho = (float)h->cfg.decay_rate; u.one_minus_rho = (float)(1.0 - h->cfg.decay_rate);
   u.lr = (float)h->cfg.learning_rate; u.eps = (float)h->cfg.epsilon;
+  u.skip_fc4 = a.fuse_rms;
   if (h->comm) {
     // synchronous data parallel: local gradient sums -> one RCCL all-reduce of the flat buffer -> identical RMSProp
     u.mode = 1; u.bsz = (float)h->B;
@@ -587,6 +608,14 @@ extern "C" int sdqn_net_last_q(sdqn_net_t h, float* preq, float* maxpostq) {
   return SDQN_OK;
 }
 extern "C" int sdqn_net_train_iterations(sdqn_net_t h, int64_t* n) { ARGCHK(h && n, "NULL"); *n = h->train_iterations; return SDQN_OK; }
+
+extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
+  ARGCHK(h && name, "NULL argument");
+  if (!strcmp(name, "keep_gradients")) h->keep_grads = value != 0;
+  else if (!strcmp(name, "two_streams")) h->two_streams = value != 0;
+  else { set_error("unknown option %s", name); return SDQN_ERR_ARG; }
+  return SDQN_OK;
+}
 
 // test hook: raw read of an internal device buffer (internal layouts, see problems.h)
 extern "C" int sdqn_net_debug_read(sdqn_net_t h, const char* name, float* out, int64_t n) {

@@ -109,10 +109,7 @@ hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------
 __device__ inline float rms_apply(float w, float& st, float gsum, const UpdateArgs& u) {
-#pragma clang fp contract(off)
-  const float g = gsum / u.bsz;                                    // A9: grad / be.bsz
-  st = u.rho * st + (g * g) * u.one_minus_rho;                     // A10
-  return w - (g * u.lr) / (sqrtf(st + u.eps) + u.eps);
+  return rms_step(w, st, gsum, u.bsz, u.rho, u.one_minus_rho, u.lr, u.eps);
 }
 
 // Two kinds of workgroups in one launch:
@@ -172,7 +169,8 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
   }
   const int64_t NP4 = (OFF5 + (int64_t)u.A * NFC) / 4;
   const int nb = gridDim.x - CONV_BLOCKS;
-  for (int64_t i4 = CONV_F4 + (int64_t)(blockIdx.x - CONV_BLOCKS) * 256 + t; i4 < NP4; i4 += (int64_t)nb * 256) {
+  const int64_t first4 = u.skip_fc4 ? OFF5 / 4 : CONV_F4;
+  for (int64_t i4 = first4 + (int64_t)(blockIdx.x - CONV_BLOCKS) * 256 + t; i4 < NP4; i4 += (int64_t)nb * 256) {
     const int64_t e = i4 * 4;
     float4 gs;
     if (u.mode == 2 || e < OFF5) {
@@ -207,7 +205,7 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
 }
 
 hipError_t launch_update(const UpdateArgs& u, hipStream_t s) {
-  const int64_t NP4 = (OFF5 + (int64_t)u.A * NFC) / 4 - CONV_F4;
+  const int64_t NP4 = (OFF5 + (int64_t)u.A * NFC) / 4 - (u.skip_fc4 ? OFF5 / 4 : CONV_F4);
   int blocks = (int)((NP4 + 255) / 256);
   if (blocks > 1792) blocks = 1792;
   hipLaunchKernelGGL(update_kernel, dim3(CONV_BLOCKS + blocks), dim3(256), 0, s, u);

@@ -173,6 +173,10 @@ class DeepQNetwork:
         self.train_iterations += 1
         return cost.value if want_cost else None
 
+    def set_option(self, name, value):
+        """'keep_gradients' (materialise the fc4 gradient; disables the fused fc4 RMSProp), 'two_streams'."""
+        _lib.check(self._lib.sdqn_net_set_option(self._h, name.encode(), int(value)))
+
     def sync(self):
         _lib.check(self._lib.sdqn_net_sync(self._h))
 

@@ -20,7 +20,7 @@ def emul():
     src = os.path.join(HERE, "emul", "emul.cpp")
     hdr = os.path.join(HERE, "..", "simple_dqn_amd", "csrc", "problems.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", so, src])
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src])
     return C.CDLL(so)
 
 

@@ -74,6 +74,7 @@ def test_forward_stages(sd):
 @pytest.mark.parametrize("A,B,clip", [(4, 32, 1.0), (6, 16, 0.0), (3, 40, 0.5)])
 def test_one_step_gradients_and_update(sd, A, B, clip):
     net, o = _pair(sd, A, B, 7, clip_error=clip)
+    net.set_option("keep_gradients", 1)               # unfused path: gradients readable (which=3)
     mb = random_minibatch(B, A, 8, reward_range=(-3, 4))
     costs = []
     net.callback = type("CB", (), {"on_train": lambda self, c: costs.append(c)})()
@@ -206,6 +207,28 @@ def test_train_replay_equals_train_host(sd):
         assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
 
 
+def test_fused_and_streamed_paths_bit_identical(sd):
+    """fc4 RMSProp fused into the wgrad epilogue and the two-stream backward must give bit-identical weights
+    to the plain single-stream, materialised-gradient path."""
+    A, B = 4, 32
+    nets = []
+    for keep, two in ((0, 1), (1, 1), (0, 0), (1, 0)):
+        n, _ = _pair(sd, A, B, 81)
+        n.set_option("keep_gradients", keep)
+        n.set_option("two_streams", two)
+        nets.append(n)
+    for s in range(4):
+        mb = random_minibatch(B, A, 82 + s)
+        for n in nets:
+            n.train(mb)
+    ref = nets[3].get_weights(0)
+    for n in nets[:3]:
+        for a, b in zip(n.get_weights(0), ref):
+            assert np.array_equal(a, b)
+        for a, b in zip(n.get_weights(2), nets[3].get_weights(2)):
+            assert np.array_equal(a, b)
+
+
 def test_target_network_semantics(sd):
     A, B = 4, 8
     net, o = _pair(sd, A, B, 41)
@@ -243,6 +266,7 @@ def test_batch256_one_step(sd):
     """BASELINE.json configs[2] shape (B=256, A=3 per the 2015 Pong log)."""
     A, B = 3, 256
     net, o = _pair(sd, A, B, 61)
+    net.set_option("keep_gradients", 1)
     mb = random_minibatch(B, A, 62)
     g, cost, _, preq = o.gradients(mb)
     net.train(mb)
