@@ -37,6 +37,19 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// offset of step i for this lane's half: lanes 0-31 take lane i's value, lanes 32-63 lane (i+16)'s.
+// v_readlane (VALU -> SGPR, no LDS round trip) x2 + v_cndmask; i is a compile-time constant after unrolling.
+__device__ __forceinline__ int pick_half(int v, int i, bool hi) {
+  const int lo = __builtin_amdgcn_readlane(v, i), up = __builtin_amdgcn_readlane(v, i + 16);
+  return hi ? up : lo;
+}
+__device__ __forceinline__ int64_t pick_half(int64_t v, int i, bool hi) {
+  const int l0 = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFF), i), l1 = __builtin_amdgcn_readlane((int)(v >> 32), i);
+  const int u0 = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFF), i + 16), u1 = __builtin_amdgcn_readlane((int)(v >> 32), i + 16);
+  const int64_t lo = ((int64_t)l1 << 32) | (uint32_t)l0, up = ((int64_t)u1 << 32) | (uint32_t)u0;
+  return hi ? up : lo;
+}
+
 template <class P, int NW>
 __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
   constexpr int NPAN = (P::A_K ? 1 : 0) + (P::B_K ? 1 : 0);
@@ -56,8 +69,6 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
   // ---- per-lane operand geometry ---------------------------------------------------------------
   // k-contiguous operand: lane -> (k4 = l & 7, x = (l >> 3) + 8j), one 4-vector per j < 4
   // x-contiguous operand: lane -> (x = l & 31, k = i + 16*(l >> 5)), one scalar per i < 16 (MFMA layout).
-  //   Both candidate k's of step i are wave-uniform, so the (n,p,q) im2col decomposition of the
-  //   reduction index runs on the scalar unit and the lanes only select (v_cndmask) + add.
   aoff_t arow[P::A_K ? 4 : 1];
   int bcol[P::B_K ? 4 : 1];
   if constexpr (P::A_K) {
@@ -80,13 +91,15 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { const f4 v = P::a_load4(a, z, arow[j] + c); ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w; }
     } else {
+      // one im2col decomposition per lane per chunk (lane <-> k = kc + (l & 31)); step i fetches its
+      // offset from lane i (+16 for the upper half-wave) with v_readlane
+      const int kl = kc + (lane & 31);
+      const aoff_t cv = P::a_col(a, z, kl < kend ? kl : kbeg);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int k0 = kc + i, k1 = kc + 16 + i;
-        const bool ok0 = k0 < kend, ok1 = k1 < kend;
-        const aoff_t c0 = P::a_col(a, z, ok0 ? k0 : kbeg), c1 = P::a_col(a, z, ok1 ? k1 : kbeg);
         const bool hi = lane >= 32;
-        ra[i] = (hi ? ok1 : ok0) ? P::a_load(a, z, arow[0] + (hi ? c1 : c0)) : 0.0f;
+        const aoff_t c = pick_half(cv, i, hi);
+        ra[i] = kc + i + (hi ? 16 : 0) < kend ? P::a_load(a, z, arow[0] + c) : 0.0f;
       }
     }
     if constexpr (P::B_K) {
@@ -94,13 +107,13 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { const f4 v = P::b_load4(a, z, r + bcol[j]); rb[4 * j] = v.x; rb[4 * j + 1] = v.y; rb[4 * j + 2] = v.z; rb[4 * j + 3] = v.w; }
     } else {
+      const int kl = kc + (lane & 31);
+      const int rv = P::b_row(a, z, kl < kend ? kl : kbeg);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int k0 = kc + i, k1 = kc + 16 + i;
-        const bool ok0 = k0 < kend, ok1 = k1 < kend;
-        const int r0 = P::b_row(a, z, ok0 ? k0 : kbeg), r1 = P::b_row(a, z, ok1 ? k1 : kbeg);
         const bool hi = lane >= 32;
-        rb[i] = (hi ? ok1 : ok0) ? P::b_load(a, z, (hi ? r1 : r0) + bcol[0]) : 0.0f;
+        const int r = pick_half(rv, i, hi);
+        rb[i] = kc + i + (hi ? 16 : 0) < kend ? P::b_load(a, z, r + bcol[0]) : 0.0f;
       }
     }
   };
@@ -166,11 +179,10 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
       if (m0 + ml < M && n0 + nl < N) P::store(a, z, ks, m0 + ml, n0 + nl, v);
     }
   } else {
+    float v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl = lane & 31;
-      if (m0 + ml < M && n0 + nl < N) P::store(a, z, ks, m0 + ml, n0 + nl, acc[r]);
-    }
+    for (int r = 0; r < 16; ++r) v[r] = acc[r];
+    P::store16(a, z, ks, m0, n0, lane, M, N, v);          // lane holds rows (r&3)+8(r>>2)+4(l>>5), column l&31
   }
 }
 

@@ -74,8 +74,8 @@ struct StepArgs {
   // single-GPU fast path: RMSProp of the fc4 weights (95 % of all parameters) fused into the fc4 wgrad
   // epilogue, so the 6.4 MB gradient is never written to / re-read from HBM
   int fuse_rms;
-  float* theta_w;           // online parameters, writable alias of theta[0]
-  float* state;             // RMSProp state
+  float* __restrict__ theta_w;   // online parameters, writable alias of theta[0]
+  float* __restrict__ state;     // RMSProp state
   float bsz, rho, one_minus_rho, lr, eps;
 };
 
@@ -153,6 +153,9 @@ SDQN_HD int prow2(int m) {                                   // (n,p,q) of conv2
 struct Conv1Fwd {   // fused gather + normalise + conv1 + ReLU: replay_memory.py:71-72 + deepqnetwork.py:94-100,83
   static constexpr int WM = 2, WN = 1, WK = 2; static constexpr bool A_K = true, B_K = false;
   typedef int64_t aoff_t;
+#if defined(__HIPCC__)
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+#endif
   SDQN_HD static int M(const StepArgs& a) { return a.B * PIX1; }
   SDQN_HD static int N(const StepArgs&) { return K1; }
   SDQN_HD static int nbz(const StepArgs& a) { return a.nz; }
@@ -173,6 +176,9 @@ struct Conv1Fwd {   // fused gather + normalise + conv1 + ReLU: replay_memory.py
 struct Conv2Fwd {   // deepqnetwork.py:85
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = false;
   typedef int aoff_t;
+#if defined(__HIPCC__)
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+#endif
   SDQN_HD static int M(const StepArgs& a) { return a.B * PIX2; }
   SDQN_HD static int N(const StepArgs&) { return K2; }
   SDQN_HD static int nbz(const StepArgs& a) { return a.nz; }
@@ -193,6 +199,9 @@ struct Conv2Fwd {   // deepqnetwork.py:85
 struct Conv3Fwd {   // deepqnetwork.py:87
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = false;
   typedef int aoff_t;
+#if defined(__HIPCC__)
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+#endif
   SDQN_HD static int M(const StepArgs& a) { return a.B * PIX3; }
   SDQN_HD static int N(const StepArgs&) { return K3; }
   SDQN_HD static int nbz(const StepArgs& a) { return a.nz; }
@@ -213,6 +222,9 @@ struct Conv3Fwd {   // deepqnetwork.py:87
 struct Fc4Fwd {     // deepqnetwork.py:89, split-K over S4 slabs; bias-free, ReLU applied by the head kernel
   static constexpr int WM = 1, WN = 2, WK = 2; static constexpr bool A_K = true, B_K = false;
   typedef int aoff_t;
+#if defined(__HIPCC__)
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+#endif
   SDQN_HD static int M(const StepArgs& a) { return a.B; }
   SDQN_HD static int N(const StepArgs&) { return NFC; }
   SDQN_HD static int nbz(const StepArgs& a) { return a.nz * a.S4; }
@@ -238,6 +250,9 @@ struct Fc4Fwd {     // deepqnetwork.py:89, split-K over S4 slabs; bias-free, ReL
 struct Fc4Dgrad {   // delta3 = (W4^T delta4) * 1[a3 > 0]  (A5, A8), written straight into the padded d3p
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
   typedef int aoff_t;
+#if defined(__HIPCC__)
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+#endif
   SDQN_HD static int M(const StepArgs& a) { return a.B; }
   SDQN_HD static int N(const StepArgs&) { return NIN4; }
   SDQN_HD static int nbz(const StepArgs&) { return 1; }
@@ -277,11 +292,39 @@ struct Fc4Wgrad {   // gW4 = delta4 . a3^T (sum over batch, A8) in the W4i layou
     if (a.fuse_rms) { float st = a.state[e]; a.theta_w[e] = rms_step(a.theta_w[e], st, v, a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps); a.state[e] = st; }
     else a.g[e] = v;
   }
+#if defined(__HIPCC__)
+  // single-wave epilogue (B <= 32): all 32 loads of the read-modify-write in flight before the math
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v) {
+    if (!a.fuse_rms) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); a.g[OFF4 + (int64_t)(m0 + ml) * NFC + n0 + (lane & 31)] = v[r]; }
+      return;
+    }
+    float w[16], st[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int64_t e = OFF4 + (int64_t)(m0 + ml) * NFC + n0 + (lane & 31);
+      w[r] = a.theta_w[e]; st[r] = a.state[e];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[r] = rms_step(w[r], st[r], v[r], a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int64_t e = OFF4 + (int64_t)(m0 + ml) * NFC + n0 + (lane & 31);
+      a.theta_w[e] = w[r]; a.state[e] = st[r];
+    }
+  }
+#endif
 };
 
 struct Conv3Dgrad { // delta2 = full-correlation(d3p, W3) * 1[a2 > 0], written into the padded d2p
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
   typedef int aoff_t;
+#if defined(__HIPCC__)
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+#endif
   SDQN_HD static int M(const StepArgs& a) { return a.B * PIX2; }
   SDQN_HD static int N(const StepArgs&) { return K2; }
   SDQN_HD static int nbz(const StepArgs&) { return 1; }
@@ -309,6 +352,9 @@ struct Conv3Dgrad { // delta2 = full-correlation(d3p, W3) * 1[a2 > 0], written i
 struct Conv3Wgrad { // gW3[(r,s,c)][f] = sum_(n,p,q) a2 patch * delta3   (Neon update_conv), split-K slabs
   static constexpr int WM = 2, WN = 2, WK = 1; static constexpr bool A_K = false, B_K = false;
   typedef int aoff_t;
+#if defined(__HIPCC__)
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+#endif
   SDQN_HD static int Kt(const StepArgs& a) { return a.B * PIX3; }
   SDQN_HD static int M(const StepArgs&) { return CRS3; }
   SDQN_HD static int N(const StepArgs&) { return K3; }
@@ -330,6 +376,9 @@ struct Conv3Wgrad { // gW3[(r,s,c)][f] = sum_(n,p,q) a2 patch * delta3   (Neon u
 struct Conv2Dgrad { // stride-2 dgrad as 4 parity classes (z = py*2+px), each a dense 2x2 correlation over d2p
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
   typedef int aoff_t;
+#if defined(__HIPCC__)
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+#endif
   SDQN_HD static int M(const StepArgs& a) { return a.B * 100; }
   SDQN_HD static int N(const StepArgs&) { return K1; }
   SDQN_HD static int nbz(const StepArgs&) { return 4; }
@@ -362,6 +411,9 @@ struct Conv2Dgrad { // stride-2 dgrad as 4 parity classes (z = py*2+px), each a 
 struct Conv2Wgrad {
   static constexpr int WM = 2, WN = 2, WK = 1; static constexpr bool A_K = false, B_K = false;
   typedef int aoff_t;
+#if defined(__HIPCC__)
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+#endif
   SDQN_HD static int Kt(const StepArgs& a) { return a.B * PIX2; }
   SDQN_HD static int M(const StepArgs&) { return CRS2; }
   SDQN_HD static int N(const StepArgs&) { return K2; }
@@ -383,6 +435,9 @@ struct Conv2Wgrad {
 struct Conv1Wgrad { // re-gathers the normalised u8 patches from the ring (no fp32 input copy is ever stored)
   static constexpr int WM = 2, WN = 1, WK = 2; static constexpr bool A_K = false, B_K = false;
   typedef int64_t aoff_t;
+#if defined(__HIPCC__)
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+#endif
   SDQN_HD static int Kt(const StepArgs& a) { return a.B * PIX1; }
   SDQN_HD static int M(const StepArgs&) { return CRS1; }
   SDQN_HD static int N(const StepArgs&) { return K1; }
@@ -400,6 +455,22 @@ struct Conv1Wgrad { // re-gathers the normalised u8 patches from the ring (no fp
   SDQN_HD static f4 b_load4(const StepArgs& a, int, int o) { return ld4(a.d1 + o); }
   SDQN_HD static void store(const StepArgs& a, int, int ks, int m, int n, float v) { a.slab1[(int64_t)ks * NW1 + m * K1 + n] = v; }
 };
+
+#if defined(__HIPCC__)
+#define SDQN_STORE16_DEFAULT(P) __device__ inline void P::store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v) { \
+  _Pragma("unroll") for (int r = 0; r < 16; ++r) { const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl = lane & 31; \
+    if (m0 + ml < M && n0 + nl < N) P::store(a, z, ks, m0 + ml, n0 + nl, v[r]); } }
+SDQN_STORE16_DEFAULT(Conv1Fwd)
+SDQN_STORE16_DEFAULT(Conv2Fwd)
+SDQN_STORE16_DEFAULT(Conv3Fwd)
+SDQN_STORE16_DEFAULT(Fc4Fwd)
+SDQN_STORE16_DEFAULT(Fc4Dgrad)
+SDQN_STORE16_DEFAULT(Conv3Dgrad)
+SDQN_STORE16_DEFAULT(Conv3Wgrad)
+SDQN_STORE16_DEFAULT(Conv2Dgrad)
+SDQN_STORE16_DEFAULT(Conv2Wgrad)
+SDQN_STORE16_DEFAULT(Conv1Wgrad)
+#endif
 
 // ---- Neon <-> internal parameter layouts (host side; C ABI boundary) ---------------------------
 // returns the internal flat index (relative to the layer's OFFx) of Neon element (row, col)

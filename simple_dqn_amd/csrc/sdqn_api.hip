@@ -484,10 +484,10 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
   // The three other weight-gradient kernels only need the delta of their layer, so they run beside it
   // on the side stream (fork after the producer of their delta, join before the update).
   hipStream_t ss = h->two_streams ? g_side : g_stream;
-  if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[0], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[0], 0)); }
-  LAUNCH_ON(ss, K_FC4_WGRAD, launch_kernel(K_FC4_WGRAD, a, ss));            // needs d4, a3
   LAUNCH(K_FC4_DGRAD, launch_kernel(K_FC4_DGRAD, a, g_stream));
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[1], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[1], 0)); }
+  // fc4_wgrad may update W4 in place (fused RMSProp): it must not start before fc4_dgrad has read W4
+  LAUNCH_ON(ss, K_FC4_WGRAD, launch_kernel(K_FC4_WGRAD, a, ss));            // needs d4, a3
   LAUNCH_ON(ss, K_CONV3_WGRAD, launch_kernel(K_CONV3_WGRAD, a, ss));        // needs d3p, a2
   LAUNCH(K_CONV3_DGRAD, launch_kernel(K_CONV3_DGRAD, a, g_stream));
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[2], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[2], 0)); }

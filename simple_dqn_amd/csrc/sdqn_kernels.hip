@@ -179,7 +179,8 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
       const int64_t o = e - OFF5;
       const int act = (int)(o / NFC), j0 = (int)(o - (int64_t)act * NFC);
       gs = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int n = 0; n < u.B; ++n) {
+#pragma unroll 8
+      for (int n = 0; n < u.B; ++n) {                                // 8 independent 16 B loads in flight
         const float d = u.dq[(int64_t)n * u.A + act];
         const float4 v = *reinterpret_cast<const float4*>(u.a4 + (int64_t)n * NFC + j0);
         gs.x += d * v.x; gs.y += d * v.y; gs.z += d * v.z; gs.w += d * v.w;
