@@ -57,6 +57,9 @@ class DeepQNetwork:
         h = C.c_void_p()
         _lib.check(self._lib.sdqn_net_create(C.byref(h), C.byref(cfg)))
         self._h = h
+        import os
+        if os.environ.get("SDQN_TWO_STREAMS") is not None:            # A/B switch for benchmarking
+            _lib.check(self._lib.sdqn_net_set_option(h, b"two_streams", int(os.environ["SDQN_TWO_STREAMS"])))
         self.train_iterations = 0
         self.callback = None
         self.save_weights_prefix = getattr(args, "save_weights_prefix", None)
