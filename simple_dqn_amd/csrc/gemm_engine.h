@@ -84,6 +84,9 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
     const int n = n0 + (lane & 31); bcol[0] = P::b_col(a, z, n < N ? n : N - 1);
   }
 
+  typename P::Epi epi;
+  if constexpr (NW == 1) P::epi_begin(a, m0, n0, lane, epi);
+
   float ra[16], rb[16];                       // next chunk's operands (4 x f4, or 16 scalars in MFMA layout)
   auto load_chunk = [&](int kc) {
     if constexpr (P::A_K) {
@@ -182,7 +185,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = acc[r];
-    P::store16(a, z, ks, m0, n0, lane, M, N, v);          // lane holds rows (r&3)+8(r>>2)+4(l>>5), column l&31
+    P::store16(a, z, ks, m0, n0, lane, M, N, v, epi);          // lane holds rows (r&3)+8(r>>2)+4(l>>5), column l&31
   }
 }
 

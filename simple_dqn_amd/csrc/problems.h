@@ -79,17 +79,11 @@ struct StepArgs {
   float bsz, rho, one_minus_rho, lr, eps;
 };
 
-// A9 + A10 in Neon's operation order; explicit round-to-nearest ops so no fma contraction can change it
+// A9 + A10 in Neon's operation order (the library is built with -ffp-contract=off: one rounding per op)
 SDQN_HD float rms_step(float w, float& st, float gsum, float bsz, float rho, float omr, float lr, float eps) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const float g = __fdiv_rn(gsum, bsz);                                        // grad / be.bsz
-  st = __fadd_rn(__fmul_rn(rho, st), __fmul_rn(__fmul_rn(g, g), omr));         // state = rho*state + g^2*(1-rho)
-  return __fsub_rn(w, __fdiv_rn(__fmul_rn(g, lr), __fadd_rn(__fsqrt_rn(__fadd_rn(st, eps)), eps)));
-#else
-  const float g = gsum / bsz;
-  st = rho * st + (g * g) * omr;
+  const float g = gsum / bsz;                         // grad / be.bsz
+  st = rho * st + (g * g) * omr;                      // state = rho*state + g^2*(1-rho)
   return w - (g * lr) / (sqrtf(st + eps) + eps);
-#endif
 }
 
 SDQN_HD int64_t sbase(const StepArgs& a, int z, int n) {
@@ -154,7 +148,9 @@ struct Conv1Fwd {   // fused gather + normalise + conv1 + ReLU: replay_memory.py
   static constexpr int WM = 2, WN = 1, WK = 2; static constexpr bool A_K = true, B_K = false;
   typedef int64_t aoff_t;
 #if defined(__HIPCC__)
-  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+  struct Epi {};
+  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&);
 #endif
   SDQN_HD static int M(const StepArgs& a) { return a.B * PIX1; }
   SDQN_HD static int N(const StepArgs&) { return K1; }
@@ -177,7 +173,9 @@ struct Conv2Fwd {   // deepqnetwork.py:85
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = false;
   typedef int aoff_t;
 #if defined(__HIPCC__)
-  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+  struct Epi {};
+  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&);
 #endif
   SDQN_HD static int M(const StepArgs& a) { return a.B * PIX2; }
   SDQN_HD static int N(const StepArgs&) { return K2; }
@@ -200,7 +198,9 @@ struct Conv3Fwd {   // deepqnetwork.py:87
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = false;
   typedef int aoff_t;
 #if defined(__HIPCC__)
-  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+  struct Epi {};
+  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&);
 #endif
   SDQN_HD static int M(const StepArgs& a) { return a.B * PIX3; }
   SDQN_HD static int N(const StepArgs&) { return K3; }
@@ -223,7 +223,9 @@ struct Fc4Fwd {     // deepqnetwork.py:89, split-K over S4 slabs; bias-free, ReL
   static constexpr int WM = 1, WN = 2, WK = 2; static constexpr bool A_K = true, B_K = false;
   typedef int aoff_t;
 #if defined(__HIPCC__)
-  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+  struct Epi {};
+  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&);
 #endif
   SDQN_HD static int M(const StepArgs& a) { return a.B; }
   SDQN_HD static int N(const StepArgs&) { return NFC; }
@@ -251,7 +253,9 @@ struct Fc4Dgrad {   // delta3 = (W4^T delta4) * 1[a3 > 0]  (A5, A8), written str
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
   typedef int aoff_t;
 #if defined(__HIPCC__)
-  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+  struct Epi {};
+  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&);
 #endif
   SDQN_HD static int M(const StepArgs& a) { return a.B; }
   SDQN_HD static int N(const StepArgs&) { return NIN4; }
@@ -293,27 +297,31 @@ struct Fc4Wgrad {   // gW4 = delta4 . a3^T (sum over batch, A8) in the W4i layou
     else a.g[e] = v;
   }
 #if defined(__HIPCC__)
-  // single-wave epilogue (B <= 32): all 32 loads of the read-modify-write in flight before the math
-  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v) {
+  // single-wave epilogue (B <= 32): the read-modify-write's 32 loads (theta, state) are issued at kernel
+  // entry (epi_begin) so they fly under the operand loads and the MFMAs
+  struct Epi { float w[16], st[16]; };
+  __device__ static void epi_begin(const StepArgs& a, int m0, int n0, int lane, Epi& e) {
+    if (!a.fuse_rms) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int64_t o = OFF4 + (int64_t)(m0 + ml) * NFC + n0 + (lane & 31);
+      e.w[r] = a.theta_w[o]; e.st[r] = a.state[o];
+    }
+  }
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi& e) {
     if (!a.fuse_rms) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); a.g[OFF4 + (int64_t)(m0 + ml) * NFC + n0 + (lane & 31)] = v[r]; }
       return;
     }
-    float w[16], st[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e.w[r] = rms_step(e.w[r], e.st[r], v[r], a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int64_t e = OFF4 + (int64_t)(m0 + ml) * NFC + n0 + (lane & 31);
-      w[r] = a.theta_w[e]; st[r] = a.state[e];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) w[r] = rms_step(w[r], st[r], v[r], a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int64_t e = OFF4 + (int64_t)(m0 + ml) * NFC + n0 + (lane & 31);
-      a.theta_w[e] = w[r]; a.state[e] = st[r];
+      const int64_t o = OFF4 + (int64_t)(m0 + ml) * NFC + n0 + (lane & 31);
+      a.theta_w[o] = e.w[r]; a.state[o] = e.st[r];
     }
   }
 #endif
@@ -323,7 +331,9 @@ struct Conv3Dgrad { // delta2 = full-correlation(d3p, W3) * 1[a2 > 0], written i
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
   typedef int aoff_t;
 #if defined(__HIPCC__)
-  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+  struct Epi {};
+  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&);
 #endif
   SDQN_HD static int M(const StepArgs& a) { return a.B * PIX2; }
   SDQN_HD static int N(const StepArgs&) { return K2; }
@@ -353,7 +363,9 @@ struct Conv3Wgrad { // gW3[(r,s,c)][f] = sum_(n,p,q) a2 patch * delta3   (Neon u
   static constexpr int WM = 2, WN = 2, WK = 1; static constexpr bool A_K = false, B_K = false;
   typedef int aoff_t;
 #if defined(__HIPCC__)
-  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+  struct Epi {};
+  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&);
 #endif
   SDQN_HD static int Kt(const StepArgs& a) { return a.B * PIX3; }
   SDQN_HD static int M(const StepArgs&) { return CRS3; }
@@ -377,7 +389,9 @@ struct Conv2Dgrad { // stride-2 dgrad as 4 parity classes (z = py*2+px), each a 
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
   typedef int aoff_t;
 #if defined(__HIPCC__)
-  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+  struct Epi {};
+  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&);
 #endif
   SDQN_HD static int M(const StepArgs& a) { return a.B * 100; }
   SDQN_HD static int N(const StepArgs&) { return K1; }
@@ -412,7 +426,9 @@ struct Conv2Wgrad {
   static constexpr int WM = 2, WN = 2, WK = 1; static constexpr bool A_K = false, B_K = false;
   typedef int aoff_t;
 #if defined(__HIPCC__)
-  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+  struct Epi {};
+  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&);
 #endif
   SDQN_HD static int Kt(const StepArgs& a) { return a.B * PIX2; }
   SDQN_HD static int M(const StepArgs&) { return CRS2; }
@@ -436,7 +452,9 @@ struct Conv1Wgrad { // re-gathers the normalised u8 patches from the ring (no fp
   static constexpr int WM = 2, WN = 1, WK = 2; static constexpr bool A_K = false, B_K = false;
   typedef int64_t aoff_t;
 #if defined(__HIPCC__)
-  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v);
+  struct Epi {};
+  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&);
 #endif
   SDQN_HD static int Kt(const StepArgs& a) { return a.B * PIX1; }
   SDQN_HD static int M(const StepArgs&) { return CRS1; }
@@ -457,7 +475,7 @@ struct Conv1Wgrad { // re-gathers the normalised u8 patches from the ring (no fp
 };
 
 #if defined(__HIPCC__)
-#define SDQN_STORE16_DEFAULT(P) __device__ inline void P::store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v) { \
+#define SDQN_STORE16_DEFAULT(P) __device__ inline void P::store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, P::Epi&) { \
   _Pragma("unroll") for (int r = 0; r < 16; ++r) { const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl = lane & 31; \
     if (m0 + ml < M && n0 + nl < N) P::store(a, z, ks, m0 + ml, n0 + nl, v[r]); } }
 SDQN_STORE16_DEFAULT(Conv1Fwd)

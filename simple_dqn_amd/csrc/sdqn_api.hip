@@ -297,7 +297,7 @@ struct sdqn_net_s {
   int S4 = 7, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
   int64_t train_iterations = 0;
   bool keep_grads = false;                 // true: fc4 gradient materialised in g (readable with which=3), no fused RMSProp
-  bool two_streams = true;                 // weight-gradient kernels on the side stream
+  bool two_streams = false;                // weight-gradient kernels on the side stream (measured slower eagerly: event waits)
   // profiler
   bool prof_on = false; int prof_filter = -1;
   std::vector<ProfPair> prof_pending; std::vector<hipEvent_t> prof_free;
