@@ -55,6 +55,9 @@ def kernel_work(B, A):
         12: dict(bytes=npar * f * 5, flops=8 * npar),                                          # read W,s,g; write W,s
         13: dict(bytes=npar * f, flops=0),
         14: dict(bytes=B * 13 * 7056, flops=0),
+        15: dict(bytes=1024, flops=0),
+        16: dict(bytes=(a3 + w3 + 2 * a2) + (a2 + a3 + w3) + (a4 + a3 + 4 * w4), flops=2 * B * 81 * 64 * 576 + 2 * B * 49 * 64 * 576 + 2 * B * 512 * 3136),
+        17: dict(bytes=(a2 + w2 + 2 * a1) + (a1 + a2 + w2), flops=2 * B * 400 * 32 * 256 + 2 * B * 81 * 64 * 512),
     }
 
 

@@ -21,6 +21,7 @@
 // D register r of lane l is D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].
 #pragma once
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include "problems.h"
 
 namespace sdqn {
@@ -50,20 +51,27 @@ __device__ __forceinline__ int64_t pick_half(int64_t v, int i, bool hi) {
   return hi ? up : lo;
 }
 
+// LDS floats one workgroup of NW waves needs for problem P
 template <class P, int NW>
-__global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
+constexpr int tile_lds() { return NW * (((P::A_K ? 1 : 0) + (P::B_K ? 1 : 0)) > 0 ? ((P::A_K ? 1 : 0) + (P::B_K ? 1 : 0)) : 1) * PANEL; }
+
+// One 32x32 output tile (bx, by, bz) of problem P computed by the first NW waves of a workgroup of NT threads
+// (waves >= NW idle through the epilogue barrier).  NW == 1 inside a wider workgroup is handled by the caller
+// (one tile per wave, no barrier): see gemm_multi_kernel.
+template <class P, int NW, int NT>
+__device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int bz, float* smem) {
   constexpr int NPAN = (P::A_K ? 1 : 0) + (P::B_K ? 1 : 0);
   constexpr int WAVE_LDS = (NPAN > 0 ? NPAN : 1) * PANEL;
-  __shared__ float smem[NW * WAVE_LDS];
   typedef typename P::aoff_t aoff_t;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // provably wave-uniform -> SGPR index math
-  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int m0 = bx * 32, n0 = by * 32;
   int z, ks, kbeg, kend;
-  P::ksplit(a, blockIdx.z, z, ks, kbeg, kend);
+  P::ksplit(a, bz, z, ks, kbeg, kend);
+  if (NW * 64 < NT && wave >= NW) kend = kbeg;          // surplus waves of a wider workgroup: no chunks
   const int M = P::M(a), N = P::N(a);
-  float* pa = smem + wave * WAVE_LDS;
+  float* pa = smem + (wave < NW ? wave : 0) * WAVE_LDS;
   float* pb = pa + (P::A_K ? PANEL : 0);
 
   // ---- per-lane operand geometry ---------------------------------------------------------------
@@ -125,7 +133,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
-  int kc = kbeg + wave * 32;                              // wave-uniform
+  int kc = kbeg + (wave < NW ? wave : 0) * 32;            // wave-uniform
   if (kc < kend) load_chunk(kc);
   while (kc < kend) {
     // ---- move the fetched chunk to its MFMA operands (through the wave-private panels if k-contiguous)
@@ -167,14 +175,16 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
 
   // ---- epilogue: NW partial tiles -> LDS -> summed in fixed order -> P::store (lanes along n) ----
   if constexpr (NW > 1) {
-    float* cw = smem + wave * WAVE_LDS;
+    if (wave < NW) {
+      float* cw = smem + wave * WAVE_LDS;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      cw[row * 33 + (lane & 31)] = acc[r];
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        cw[row * 33 + (lane & 31)] = acc[r];
+      }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 1024; e += NW * 64) {
+    for (int e = threadIdx.x; e < 1024; e += NT) {
       const int ml = e >> 5, nl = e & 31;
       float v = smem[ml * 33 + nl];
 #pragma unroll
@@ -185,14 +195,98 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = acc[r];
-    P::store16(a, z, ks, m0, n0, lane, M, N, v, epi);          // lane holds rows (r&3)+8(r>>2)+4(l>>5), column l&31
+    P::store16(a, z, ks, m0, n0, lane, M, N, v, epi);     // lane holds rows (r&3)+8(r>>2)+4(l>>5), column l&31
   }
 }
+
+template <class P, int NW>
+__global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
+  __shared__ float smem[tile_lds<P, NW>()];
+  gemm_tile<P, NW, NW * 64>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// ---- several independent problems in ONE launch -------------------------------------------------------
+// Stages that depend on the same producer (e.g. conv3_dgrad, conv3_wgrad and fc4_wgrad all wait for
+// fc4_dgrad only) run as one grid: workgroup ranges dispatch to different problem structs, so their latency
+// chains overlap without cross-stream event waits and two launch ramps disappear.  A problem with NW == 1
+// (fc4_wgrad at B <= 32) gets one TILE PER WAVE of the 1024-thread workgroup.
+struct MultiDims { int n[3]; int gx[3], gy[3]; };       // workgroups per problem and its (x, y) tile grid
+
+template <class P, int NW, int NT>
+__device__ __forceinline__ void multi_dispatch(const StepArgs& a, const MultiDims& d, int which, int local, float* smem) {
+  if constexpr (NW == 1) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = local * (NT / 64) + wave;
+    const int per_z = d.gx[which] * d.gy[which];
+    if (tile < per_z * P::nbz(a)) {
+      const int bz = tile / per_z, r = tile - bz * per_z;
+      gemm_tile<P, 1, 64>(a, r % d.gx[which], r / d.gx[which], bz, smem);
+    }
+  } else {
+    const int per_z = d.gx[which] * d.gy[which];
+    const int bz = local / per_z, r = local - bz * per_z;
+    gemm_tile<P, NW, NT>(a, r % d.gx[which], r / d.gx[which], bz, smem);
+  }
+}
+
+template <class P0, int NW0, class P1, int NW1, class P2, int NW2>
+__global__ void __launch_bounds__(1024) gemm_multi_kernel(const StepArgs a, const MultiDims d) {
+  constexpr int L0 = tile_lds<P0, NW0>(), L1 = tile_lds<P1, NW1>(), L2 = tile_lds<P2, NW2>();
+  constexpr int L = L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2);
+  __shared__ float smem[L];
+  const int b = blockIdx.x;                               // problem choice is workgroup-uniform
+  if (b < d.n[0]) multi_dispatch<P0, NW0, 1024>(a, d, 0, b, smem);
+  else if (b < d.n[0] + d.n[1]) multi_dispatch<P1, NW1, 1024>(a, d, 1, b - d.n[0], smem);
+  else multi_dispatch<P2, NW2, 1024>(a, d, 2, b - d.n[0] - d.n[1], smem);
+}
+
+struct NoProblem {            // placeholder third problem for two-problem launches (never dispatched: n[2] = 0)
+  static constexpr bool A_K = false, B_K = false; typedef int aoff_t; struct Epi {};
+  SDQN_HD static int M(const StepArgs&) { return 0; }
+  SDQN_HD static int N(const StepArgs&) { return 0; }
+  SDQN_HD static int nbz(const StepArgs&) { return 0; }
+  SDQN_HD static void ksplit(const StepArgs&, int, int& z, int& ks, int& kb, int& ke) { z = ks = kb = ke = 0; }
+  SDQN_HD static int a_row(const StepArgs&, int, int) { return 0; }
+  SDQN_HD static int a_col(const StepArgs&, int, int) { return 0; }
+  SDQN_HD static float a_load(const StepArgs&, int, int) { return 0.f; }
+  SDQN_HD static int b_row(const StepArgs&, int, int) { return 0; }
+  SDQN_HD static int b_col(const StepArgs&, int, int) { return 0; }
+  SDQN_HD static float b_load(const StepArgs&, int, int) { return 0.f; }
+  SDQN_HD static void store(const StepArgs&, int, int, int, int, float) {}
+  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
+  __device__ static void store16(const StepArgs&, int, int, int, int, int, int, int, const float*, Epi&) {}
+};
+  __device__ static int M(const StepArgs&) { return 0; } __device__ static int N(const StepArgs&) { return 0; }
+  __device__ static int nbz(const StepArgs&) { return 0; }
+  __device__ static void ksplit(const StepArgs&, int, int& z, int& ks, int& kb, int& ke) { z = ks = kb = ke = 0; }
+  __device__ static int a_row(const StepArgs&, int, int) { return 0; } __device__ static int a_col(const StepArgs&, int, int) { return 0; }
+  __device__ static float a_load(const StepArgs&, int, int) { return 0.f; }
+  __device__ static int b_row(const StepArgs&, int, int) { return 0; } __device__ static int b_col(const StepArgs&, int, int) { return 0; }
+  __device__ static float b_load(const StepArgs&, int, int) { return 0.f; }
+  __device__ static void store(const StepArgs&, int, int, int, int, float) {}
+  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
+  __device__ static void store16(const StepArgs&, int, int, int, int, int, int, int, const float*, Epi&) {}
+};
 
 template <class P, int NW>
 inline hipError_t launch_gemm(const StepArgs& a, hipStream_t stream) {
   dim3 grid((P::M(a) + 31) / 32, (P::N(a) + 31) / 32, P::nbz(a));
   hipLaunchKernelGGL((gemm_kernel<P, NW>), grid, dim3(NW * 64), 0, stream, a);
+  return hipGetLastError();
+}
+
+template <class P, int NW>
+inline void multi_fill(const StepArgs& a, MultiDims& d, int i) {
+  d.gx[i] = (P::M(a) + 31) / 32; d.gy[i] = (P::N(a) + 31) / 32;
+  const int tiles = d.gx[i] * d.gy[i] * P::nbz(a);
+  d.n[i] = NW == 1 ? (tiles + 15) / 16 : tiles;          // NW == 1: 16 tiles (one per wave) per workgroup
+}
+template <class P0, int NW0, class P1, int NW1, class P2, int NW2>
+inline hipError_t launch_multi(const StepArgs& a, bool has2, hipStream_t stream) {
+  MultiDims d; memset(&d, 0, sizeof d);
+  multi_fill<P0, NW0>(a, d, 0); multi_fill<P1, NW1>(a, d, 1);
+  if (has2) multi_fill<P2, NW2>(a, d, 2);
+  hipLaunchKernelGGL((gemm_multi_kernel<P0, NW0, P1, NW1, P2, NW2>), dim3(d.n[0] + d.n[1] + d.n[2]), dim3(1024), 0, stream, a, d);
   return hipGetLastError();
 }
 

@@ -9,7 +9,10 @@ namespace sdqn {
 enum KernelId {
   K_CONV1_FWD = 0, K_CONV2_FWD, K_CONV3_FWD, K_FC4_FWD, K_HEAD,
   K_FC4_DGRAD, K_FC4_WGRAD, K_CONV3_DGRAD, K_CONV3_WGRAD, K_CONV2_DGRAD, K_CONV2_WGRAD,
-  K_CONV1_WGRAD, K_UPDATE, K_ALLREDUCE, K_GATHER, K_PREP, K_COUNT
+  K_CONV1_WGRAD, K_UPDATE, K_ALLREDUCE, K_GATHER, K_PREP,
+  K_BWD3,      // one launch: conv3_dgrad + conv3_wgrad + fc4_wgrad (all depend on fc4_dgrad only)
+  K_BWD2,      // one launch: conv2_dgrad + conv2_wgrad (both depend on conv3_dgrad only)
+  K_COUNT
 };
 const char* kernel_name(int id);
 

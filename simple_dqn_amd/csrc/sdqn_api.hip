@@ -297,6 +297,7 @@ struct sdqn_net_s {
   int S4 = 7, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
   int64_t train_iterations = 0;
   bool keep_grads = false;                 // true: fc4 gradient materialised in g (readable with which=3), no fused RMSProp
+  bool fused_launches = true;              // independent backward stages share one launch (K_BWD3, K_BWD2)
   bool two_streams = false;                // weight-gradient kernels on the side stream (measured slower eagerly: event waits)
   // profiler
   bool prof_on = false; int prof_filter = -1;
@@ -485,6 +486,11 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
   // on the side stream (fork after the producer of their delta, join before the update).
   hipStream_t ss = h->two_streams ? g_side : g_stream;
   LAUNCH(K_FC4_DGRAD, launch_kernel(K_FC4_DGRAD, a, g_stream));
+  if (h->fused_launches && !h->two_streams) {
+    LAUNCH(K_BWD3, launch_kernel(K_BWD3, a, g_stream));
+    LAUNCH(K_BWD2, launch_kernel(K_BWD2, a, g_stream));
+    LAUNCH(K_CONV1_WGRAD, launch_kernel(K_CONV1_WGRAD, a, g_stream));
+  } else {
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[1], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[1], 0)); }
   // fc4_wgrad may update W4 in place (fused RMSProp): it must not start before fc4_dgrad has read W4
   LAUNCH_ON(ss, K_FC4_WGRAD, launch_kernel(K_FC4_WGRAD, a, ss));            // needs d4, a3
@@ -495,6 +501,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
   LAUNCH(K_CONV2_DGRAD, launch_kernel(K_CONV2_DGRAD, a, g_stream));
   LAUNCH(K_CONV1_WGRAD, launch_kernel(K_CONV1_WGRAD, a, g_stream));
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[3], ss)); HIPCHK(hipStreamWaitEvent(g_stream, g_ev[3], 0)); }
+  }
   UpdateArgs u; memset(&u, 0, sizeof u);
   u.theta = h->theta; u.state = h->state; u.g = h->g;
   u.slab[0] = h->slab1; u.slab[1] = h->slab2; u.slab[2] = h->slab3; u.ns[0] = h->ns1; u.ns[1] = h->ns2; u.ns[2] = h->ns3;
@@ -613,6 +620,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   ARGCHK(h && name, "NULL argument");
   if (!strcmp(name, "keep_gradients")) h->keep_grads = value != 0;
   else if (!strcmp(name, "two_streams")) h->two_streams = value != 0;
+  else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else { set_error("unknown option %s", name); return SDQN_ERR_ARG; }
   return SDQN_OK;
 }

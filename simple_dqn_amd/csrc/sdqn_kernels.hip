@@ -12,7 +12,8 @@ namespace sdqn {
 static const char* k_names[K_COUNT] = {
   "conv1_fwd(gather+norm+conv+relu)", "conv2_fwd", "conv3_fwd", "fc4_fwd(splitK)", "head(fc5+td+delta)",
   "fc4_dgrad", "fc4_wgrad", "conv3_dgrad", "conv3_wgrad", "conv2_dgrad", "conv2_wgrad",
-  "conv1_wgrad", "update(reduce+fc5wgrad+rmsprop)", "rccl_allreduce", "replay_gather_u8", "prep(idx+meta)"};
+  "conv1_wgrad", "update(reduce+fc5wgrad+rmsprop)", "rccl_allreduce", "replay_gather_u8", "prep(idx+meta)",
+  "bwd3(conv3_dgrad+conv3_wgrad+fc4_wgrad)", "bwd2(conv2_dgrad+conv2_wgrad)"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? k_names[id] : "?"; }
 
 // Waves per workgroup = how many 32-deep K-chunks run concurrently on one output tile (gemm_engine.h).
@@ -33,6 +34,10 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
     case K_CONV2_DGRAD: return launch_gemm<Conv2Dgrad, 8>(a, s);    // K = 256 per parity class
     case K_CONV2_WGRAD: return launch_gemm<Conv2Wgrad, 16>(a, s);
     case K_CONV1_WGRAD: return launch_gemm<Conv1Wgrad, 16>(a, s);
+    case K_BWD3:
+      if (a.B <= 32) return launch_multi<Conv3Dgrad, 9, Conv3Wgrad, 16, Fc4Wgrad, 1>(a, true, s);
+      return launch_multi<Conv3Dgrad, 9, Conv3Wgrad, 16, Fc4Wgrad, 8>(a, true, s);
+    case K_BWD2: return launch_multi<Conv2Dgrad, 8, Conv2Wgrad, 16, NoProblem, 2>(a, false, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -58,8 +58,9 @@ class DeepQNetwork:
         _lib.check(self._lib.sdqn_net_create(C.byref(h), C.byref(cfg)))
         self._h = h
         import os
-        if os.environ.get("SDQN_TWO_STREAMS") is not None:            # A/B switch for benchmarking
-            _lib.check(self._lib.sdqn_net_set_option(h, b"two_streams", int(os.environ["SDQN_TWO_STREAMS"])))
+        for env, opt in (("SDQN_TWO_STREAMS", b"two_streams"), ("SDQN_FUSED_LAUNCHES", b"fused_launches")):
+            if os.environ.get(env) is not None:                       # A/B switches for benchmarking
+                _lib.check(self._lib.sdqn_net_set_option(h, opt, int(os.environ[env])))
         self.train_iterations = 0
         self.callback = None
         self.save_weights_prefix = getattr(args, "save_weights_prefix", None)

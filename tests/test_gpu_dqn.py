@@ -212,20 +212,21 @@ def test_fused_and_streamed_paths_bit_identical(sd):
     to the plain single-stream, materialised-gradient path."""
     A, B = 4, 32
     nets = []
-    for keep, two in ((0, 1), (1, 1), (0, 0), (1, 0)):
+    for keep, two, fl in ((0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1), (0, 0, 0), (1, 0, 0)):
         n, _ = _pair(sd, A, B, 81)
         n.set_option("keep_gradients", keep)
         n.set_option("two_streams", two)
+        n.set_option("fused_launches", fl)
         nets.append(n)
     for s in range(4):
         mb = random_minibatch(B, A, 82 + s)
         for n in nets:
             n.train(mb)
-    ref = nets[3].get_weights(0)
-    for n in nets[:3]:
+    ref = nets[-1].get_weights(0)
+    for n in nets[:-1]:
         for a, b in zip(n.get_weights(0), ref):
             assert np.array_equal(a, b)
-        for a, b in zip(n.get_weights(2), nets[3].get_weights(2)):
+        for a, b in zip(n.get_weights(2), nets[-1].get_weights(2)):
             assert np.array_equal(a, b)
 
 
