@@ -256,17 +256,6 @@ struct NoProblem {            // placeholder third problem for two-problem launc
   __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
   __device__ static void store16(const StepArgs&, int, int, int, int, int, int, int, const float*, Epi&) {}
 };
-  __device__ static int M(const StepArgs&) { return 0; } __device__ static int N(const StepArgs&) { return 0; }
-  __device__ static int nbz(const StepArgs&) { return 0; }
-  __device__ static void ksplit(const StepArgs&, int, int& z, int& ks, int& kb, int& ke) { z = ks = kb = ke = 0; }
-  __device__ static int a_row(const StepArgs&, int, int) { return 0; } __device__ static int a_col(const StepArgs&, int, int) { return 0; }
-  __device__ static float a_load(const StepArgs&, int, int) { return 0.f; }
-  __device__ static int b_row(const StepArgs&, int, int) { return 0; } __device__ static int b_col(const StepArgs&, int, int) { return 0; }
-  __device__ static float b_load(const StepArgs&, int, int) { return 0.f; }
-  __device__ static void store(const StepArgs&, int, int, int, int, float) {}
-  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
-  __device__ static void store16(const StepArgs&, int, int, int, int, int, int, int, const float*, Epi&) {}
-};
 
 template <class P, int NW>
 inline hipError_t launch_gemm(const StepArgs& a, hipStream_t stream) {
