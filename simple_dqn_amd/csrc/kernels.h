@@ -16,15 +16,6 @@ enum KernelId {
 };
 const char* kernel_name(int id);
 
-struct PrepArgs {                // pinned index slot + ring metadata -> device-resident (idx, a, r, t) of this step
-  const int64_t* idx_pinned;    // [B] zero-copy view of the pinned slot
-  const MetaRec* meta;          // ring metadata mirror
-  int64_t* idx;                 // [B] device
-  uint8_t* actions;             // [B] device staging shared with the host-minibatch path
-  int64_t* rewards;
-  uint8_t* terminals;
-  int B;
-};
 
 struct HeadArgs {
   const uint8_t* st_actions;    // minibatch metadata (staged from the host, or gathered by prep_kernel)
@@ -37,6 +28,16 @@ struct HeadArgs {
   double discount, min_reward, max_reward;
   float clip_error;
   int train;                    // 0: predict only (z = 0)
+};
+
+struct PrepArgs {                // pinned index slot + ring metadata -> device-resident (idx, a, r, t) of this step
+  const int64_t* idx_pinned;    // [B] zero-copy view of the pinned slot
+  const MetaRec* meta;          // ring metadata mirror
+  int64_t* idx;                 // [B] device
+  uint8_t* actions;             // [B] device staging shared with the host-minibatch path
+  int64_t* rewards;
+  uint8_t* terminals;
+  int B;
 };
 
 struct UpdateArgs {
@@ -53,6 +54,7 @@ struct UpdateArgs {
   int B, A;
   int mode;                     // 0 fused reduce+apply, 1 reduce only (-> g), 2 apply only (g already reduced)
   int skip_fc4;                 // fc4 already updated inside fc4_wgrad's epilogue (StepArgs::fuse_rms)
+  PrepArgs next;                // next.B > 0: also do the NEXT step's prep (train_many samples one step ahead)
   float bsz;                    // divisor of A9 (B, or R*B under data parallel)
   float rho, one_minus_rho, lr, eps;
 };

@@ -479,7 +479,7 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
   LAUNCH(K_HEAD, launch_head(a, hd, g_stream));
   return SDQN_OK;
 }
-static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
+static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const PrepArgs* next = nullptr) {
   int rc = run_forward(h, a, hd); if (rc) return rc;
   // Backward.  Critical path on the library stream: fc4_dgrad -> conv3_dgrad -> conv2_dgrad -> conv1_wgrad.
   // The three other weight-gradient kernels only need the delta of their layer, so they run beside it
@@ -510,13 +510,15 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
   u.rho = (float)h->cfg.decay_rate; u.one_minus_rho = (float)(1.0 - h->cfg.decay_rate);
   u.lr = (float)h->cfg.learning_rate; u.eps = (float)h->cfg.epsilon;
   u.skip_fc4 = a.fuse_rms;
+  if (next) u.next = *next;                 // (memset above left next.B = 0 otherwise)
   if (h->comm) {
     // synchronous data parallel: local gradient sums -> one RCCL all-reduce of the flat buffer -> identical RMSProp
-    u.mode = 1; u.bsz = (float)h->B;
+    u.mode = 1; u.bsz = (float)h->B; u.next.B = 0;
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
     LAUNCH(K_ALLREDUCE, (g_rccl.AllReduce(h->g, h->g, (size_t)h->NP, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, g_stream) == 0
                          ? hipSuccess : hipErrorUnknown));
     u.mode = 2; u.bsz = (float)h->B * (float)h->nranks;
+    if (next) u.next = *next;
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
   } else {
     u.mode = 0; u.bsz = (float)h->B;
@@ -562,12 +564,18 @@ extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8
   return SDQN_OK;
 }
 
-static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pinned_idx) {
+static PrepArgs prep_args(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pinned_idx) {
   PrepArgs p; p.idx_pinned = pinned_idx; p.meta = r->d_meta; p.idx = h->d_idx; p.actions = h->st_act;
   p.rewards = h->st_rew; p.terminals = h->st_term; p.B = h->B;
-  LAUNCH(K_PREP, launch_prep(p, g_stream));
+  return p;
+}
+// do_prep: launch the standalone prep for THIS step; next_pinned: fold the NEXT step's prep into the update
+static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pinned_idx, bool do_prep = true,
+                             const int64_t* next_pinned = nullptr) {
+  if (do_prep) { PrepArgs p = prep_args(h, r, pinned_idx); LAUNCH(K_PREP, launch_prep(p, g_stream)); }
   StepArgs a = step_args(h); a.from_ring = 1; a.src = r->d_ring; a.idx = h->d_idx;
   HeadArgs hd = head_args(h, 1);
+  if (next_pinned) { PrepArgs np = prep_args(h, r, next_pinned); return run_train(h, a, hd, &np); }
   return run_train(h, a, hd);
 }
 extern "C" int sdqn_net_train_replay(sdqn_net_t h, sdqn_replay_t r, const int64_t* idx_host, float* cost_out) {
@@ -584,11 +592,21 @@ extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, 
   ARGCHK(r->B == h->B, "replay batch_size %d != network batch_size %d", r->B, h->B);
   std::vector<int64_t> idx((size_t)r->B);
   HIPCHK(hipMemsetAsync(h->cost_accum, 0, 8, g_stream));
-  for (int i = 0; i < n_steps; ++i) {
+  // sample one step ahead: step i's update launch also performs step i+1's prep (index copy + metadata gather)
+  int slot = -1, next_slot = -1; const int64_t *pinned = nullptr, *next_pinned = nullptr;
+  if (n_steps > 0) {
     int rc = sample_checked(mt, r->terminals, r->count, r->current, r->hist, r->B, idx.data(), nullptr); if (rc) return rc;
-    int slot; const int64_t* didx; rc = replay_push_idx(r, idx.data(), &slot, &didx); if (rc) return rc;
-    rc = train_replay_slot(h, r, didx); if (rc) return rc;
+    rc = replay_push_idx(r, idx.data(), &slot, &pinned); if (rc) return rc;
+  }
+  for (int i = 0; i < n_steps; ++i) {
+    next_pinned = nullptr;
+    if (i + 1 < n_steps) {
+      int rc = sample_checked(mt, r->terminals, r->count, r->current, r->hist, r->B, idx.data(), nullptr); if (rc) return rc;
+      rc = replay_push_idx(r, idx.data(), &next_slot, &next_pinned); if (rc) return rc;
+    }
+    int rc = train_replay_slot(h, r, pinned, /*do_prep=*/i == 0, next_pinned); if (rc) return rc;
     rc = replay_release_idx(r, slot); if (rc) return rc;
+    slot = next_slot; pinned = next_pinned;
   }
   if (mean_cost) {
     HIPCHK(hipMemcpyAsync(h->h_f, h->cost_accum, 8, hipMemcpyDeviceToHost, g_stream));

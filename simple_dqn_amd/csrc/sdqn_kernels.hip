@@ -201,6 +201,14 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
       *reinterpret_cast<float4*>(u.state + e) = st;
     }
   }
+  if (u.next.B > 0 && (int)blockIdx.x == CONV_BLOCKS + 1) {         // next step's prep rides along (every reader of idx is done)
+    for (int n = t; n < u.next.B; n += 256) {
+      const int64_t i = u.next.idx_pinned[n];
+      u.next.idx[n] = i;
+      const MetaRec rec = u.next.meta[i];
+      u.next.actions[n] = rec.action; u.next.rewards[n] = rec.reward; u.next.terminals[n] = rec.terminal;
+    }
+  }
   if (u.mode != 2 && (int)blockIdx.x == CONV_BLOCKS && t == 0) {   // get_cost: mean over the batch, :154
     float c = 0.0f;
     for (int n = 0; n < u.B; ++n) c += u.cost_terms[n];
@@ -214,6 +222,7 @@ hipError_t launch_update(const UpdateArgs& u, hipStream_t s) {
   const int64_t NP4 = (OFF5 + (int64_t)u.A * NFC) / 4 - (u.skip_fc4 ? OFF5 / 4 : CONV_F4);
   int blocks = (int)((NP4 + 255) / 256);
   if (blocks > 1792) blocks = 1792;
+  if (blocks < 2) blocks = 2;                                      // block CONV_BLOCKS+1 hosts the ride-along prep
   hipLaunchKernelGGL(update_kernel, dim3(CONV_BLOCKS + blocks), dim3(256), 0, s, u);
   return hipGetLastError();
 }
