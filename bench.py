@@ -61,7 +61,25 @@ def kernel_work(B, A):
     }
 
 
+def pmc_traffic(name, B, A):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    FETCH_SIZE / WRITE_SIZE collected separately, gfx950 FETCH x2 correction); None if not collected for this shape."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if d["batch_size"] == B and d["num_actions"] == A:
+            return d["kernels"][name]["traffic_bytes"]
+    except Exception:
+        pass
+    return None
+
+
 def roofline_entry(kid, name, ms_per_launch, B, A):
+    e = _roofline_entry(kid, name, ms_per_launch, B, A)
+    e["traffic"] = pmc_traffic(name, B, A)
+    return e
+
+
+def _roofline_entry(kid, name, ms_per_launch, B, A):
     w = kernel_work(B, A)[kid]
     t = ms_per_launch * 1e-3
     t_hbm, t_f32 = w["bytes"] / HBM_PEAK, w["flops"] / F32_PEAK
