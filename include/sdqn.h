@@ -120,6 +120,10 @@ int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const float* w, int
 int sdqn_net_get_weights(sdqn_net_t h, int which, int layer, float* w, int64_t n);   /* sync */
 /* DeepQNetwork.predict, deepqnetwork.py:174-186: states u8[B,4,84,84] -> q float[B,A] (sync) */
 int sdqn_net_predict(sdqn_net_t h, const uint8_t* states, float* q_out);
+/* acting path: Q-values of ONE state u8[4,84,84] -> float[A].  The reference pads the
+ * current state to a full minibatch of zero rows only because Neon cannot change its batch size
+ * (src/state_buffer.py:13-24, src/agent.py:55-61) and then uses row 0; this computes exactly that row. */
+int sdqn_net_predict_one(sdqn_net_t h, const uint8_t* state, float* q_out);
 /* DeepQNetwork.train, deepqnetwork.py:107-172, minibatch given as host arrays.
  * cost_out nullable: NULL -> no synchronisation. */
 int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8_t* actions, const int64_t* rewards,

@@ -15,5 +15,6 @@ from .deepqnetwork import DeepQNetwork  # noqa: F401
 from .state_buffer import StateBuffer  # noqa: F401
 from .agent import Agent  # noqa: F401
 from .environment import SyntheticEnvironment  # noqa: F401
+from .statistics import Statistics  # noqa: F401
 
-__all__ = ["ReplayMemory", "DeepQNetwork", "StateBuffer", "Agent", "SyntheticEnvironment", "load", "lib_path"]
+__all__ = ["ReplayMemory", "DeepQNetwork", "StateBuffer", "Agent", "SyntheticEnvironment", "Statistics", "load", "lib_path"]

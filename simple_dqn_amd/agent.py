@@ -60,10 +60,15 @@ class Agent:
         if random.random() < exploration_rate:
             action = random.randrange(self.num_actions)
         else:
-            state = self.buf.getStateMinibatch()
-            qvalues = self.net.predict(state)
-            assert len(qvalues[0]) == self.num_actions
-            action = int(np.argmax(qvalues[0]))
+            if hasattr(self.net, "predict_one"):
+                # batch-1 fast path: same numbers as predict(getStateMinibatch())[0], no zero-row padding
+                q0 = self.net.predict_one(self.buf.getState())
+            else:
+                state = self.buf.getStateMinibatch()
+                qvalues = self.net.predict(state)
+                q0 = qvalues[0]
+            assert len(q0) == self.num_actions
+            action = int(np.argmax(q0))
         reward = self.env.act(action)
         screen = self.env.getScreen()
         terminal = self.env.isTerminal()

@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -297,6 +298,8 @@ struct sdqn_net_s {
   int S4 = 7, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
   int64_t train_iterations = 0;
   bool keep_grads = false;                 // true: fc4 gradient materialised in g (readable with which=3), no fused RMSProp
+  int nw_override[12] = {0};               // tuning hook
+  int S4_override = 0, tps_override[3] = {0, 0, 0};
   bool fused_launches = true;              // independent backward stages share one launch (K_BWD3, K_BWD2)
   bool two_streams = false;                // weight-gradient kernels on the side stream (measured slower eagerly: event waits)
   // profiler
@@ -457,6 +460,7 @@ static StepArgs step_args(sdqn_net_s* h) {
   a.a1 = h->a1; a.a2 = h->a2; a.a3 = h->a3; a.slab4 = h->slab4; a.a4 = h->a4; a.d4 = h->d4; a.d3p = h->d3p; a.d2p = h->d2p;
   a.d1 = h->d1; a.g = h->g; a.slab1 = h->slab1; a.slab2 = h->slab2; a.slab3 = h->slab3;
   a.S4 = h->S4; a.tps1 = h->tps1; a.tps2 = h->tps2; a.tps3 = h->tps3;
+  for (int i = 0; i < 12; ++i) a.nw_override[i] = h->nw_override[i];
   a.fuse_rms = (!h->comm && !h->keep_grads) ? 1 : 0;
   a.theta_w = h->theta; a.state = h->state; a.bsz = (float)h->B;
   a.rho = (float)h->cfg.decay_rate; a.one_minus_rho = (float)(1.0 - h->cfg.decay_rate);
@@ -543,6 +547,18 @@ extern "C" int sdqn_net_predict(sdqn_net_t h, const uint8_t* states, float* q_ou
   HIPCHK(hipMemcpyAsync(h->h_f, h->q, (size_t)h->B * h->A * 4, hipMemcpyDeviceToHost, g_stream));
   HIPCHK(hipStreamSynchronize(g_stream));
   memcpy(q_out, h->h_f, (size_t)h->B * h->A * 4);                             // (B, A): deepqnetwork.py:186 qvalues.T
+  return SDQN_OK;
+}
+
+extern "C" int sdqn_net_predict_one(sdqn_net_t h, const uint8_t* state, float* q_out) {
+  ARGCHK(h && state && q_out, "NULL argument");
+  HIPCHK(hipMemcpyAsync(h->st_states, state, (size_t)STATE, hipMemcpyHostToDevice, g_stream));
+  StepArgs a = step_args(h); a.B = 1; a.nz = 1; a.from_ring = 0; a.src = h->st_states;   // same buffers, batch of one
+  HeadArgs hd = head_args(h, 0);
+  int rc = run_forward(h, a, hd); if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(h->h_f, h->q, (size_t)h->A * 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  memcpy(q_out, h->h_f, (size_t)h->A * 4);
   return SDQN_OK;
 }
 
@@ -639,6 +655,11 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   if (!strcmp(name, "keep_gradients")) h->keep_grads = value != 0;
   else if (!strcmp(name, "two_streams")) h->two_streams = value != 0;
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
+  else if (!strncmp(name, "nw:", 3)) {                     // tuning: waves per tile of kernel id
+    int id = atoi(name + 3);
+    if (id < 0 || id >= 12 || !(value == 0 || value == 2 || value == 4 || value == 8 || value == 16)) { set_error("bad nw override"); return SDQN_ERR_ARG; }
+    h->nw_override[id] = value;
+  }
   else { set_error("unknown option %s", name); return SDQN_ERR_ARG; }
   return SDQN_OK;
 }

@@ -16,8 +16,35 @@ static const char* k_names[K_COUNT] = {
   "bwd3(conv3_dgrad+conv3_wgrad+fc4_wgrad)", "bwd2(conv2_dgrad+conv2_wgrad)"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? k_names[id] : "?"; }
 
+template <class P>
+static hipError_t launch_nw(int nw, const StepArgs& a, hipStream_t s) {
+  switch (nw) {
+    case 2: return launch_gemm<P, 2>(a, s);
+    case 4: return launch_gemm<P, 4>(a, s);
+    case 8: return launch_gemm<P, 8>(a, s);
+    case 16: return launch_gemm<P, 16>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 // Waves per workgroup = how many 32-deep K-chunks run concurrently on one output tile (gemm_engine.h).
 hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
+  if (id >= 0 && id < 12 && a.nw_override[id] > 0) {          // tuning hook (sdqn_net_set_option "nw:<id>")
+    const int nw = a.nw_override[id];
+    switch (id) {
+      case K_CONV1_FWD: return launch_nw<Conv1Fwd>(nw, a, s);
+      case K_CONV2_FWD: return launch_nw<Conv2Fwd>(nw, a, s);
+      case K_CONV3_FWD: return launch_nw<Conv3Fwd>(nw, a, s);
+      case K_FC4_FWD: return launch_nw<Fc4Fwd>(nw, a, s);
+      case K_FC4_DGRAD: return launch_nw<Fc4Dgrad>(nw, a, s);
+      case K_CONV3_DGRAD: return launch_nw<Conv3Dgrad>(nw, a, s);
+      case K_CONV3_WGRAD: return launch_nw<Conv3Wgrad>(nw, a, s);
+      case K_CONV2_DGRAD: return launch_nw<Conv2Dgrad>(nw, a, s);
+      case K_CONV2_WGRAD: return launch_nw<Conv2Wgrad>(nw, a, s);
+      case K_CONV1_WGRAD: return launch_nw<Conv1Wgrad>(nw, a, s);
+      default: break;
+    }
+  }
   switch (id) {
     case K_CONV1_FWD: return launch_gemm<Conv1Fwd, 8>(a, s);        // K = 256  -> 8 chunks
     case K_CONV2_FWD: return launch_gemm<Conv2Fwd, 16>(a, s);       // K = 512  -> 16 chunks

@@ -130,6 +130,15 @@ class DeepQNetwork:
         _lib.check(self._lib.sdqn_net_predict(self._h, _lib.ptr(st, C.c_uint8), _lib.ptr(q, C.c_float)))
         return q
 
+    def predict_one(self, state):
+        """Acting-path fast path: Q-values of one state u8[4,84,84] -> float32[A]; identical to
+        predict(padded_batch)[0] (agent.py:55-61) without computing the zero rows."""
+        assert state.shape == (self.history_length,) + self.screen_dim
+        st = np.ascontiguousarray(state, dtype=np.uint8)
+        q = np.empty((self.num_actions,), dtype=np.float32)
+        _lib.check(self._lib.sdqn_net_predict_one(self._h, _lib.ptr(st, C.c_uint8), _lib.ptr(q, C.c_float)))
+        return q
+
     def load_weights(self, load_path):                             # :188-189 (own .npz; Neon pickles: SURVEY.md §8f)
         with np.load(load_path) as f:
             for which, key in ((0, "W"), (1, "Wt"), (2, "S")):

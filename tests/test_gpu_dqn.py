@@ -56,6 +56,24 @@ def test_predict_parity(sd, A, B):
         net.predict(st[:-1])                                        # deepqnetwork.py:176
 
 
+def test_predict_one_equals_padded_batch(sd):
+    """Acting path: predict_one(state) is bit-identical to predict(StateBuffer batch)[0]."""
+    A, B = 6, 32
+    net, o = _pair(sd, A, B, 13)
+    buf = sd.StateBuffer(make_args(batch_size=B))
+    rng = np.random.RandomState(3)
+    for _ in range(6):
+        buf.add(rng.randint(0, 256, (84, 84), dtype=np.uint8))
+    full = net.predict(buf.getStateMinibatch())
+    one = net.predict_one(buf.getState())
+    assert one.shape == (A,) and np.array_equal(one, full[0])
+    assert np.all(full[1:] == 0)
+    assert np.abs(one - o.predict(buf.getStateMinibatch())[0]).max() < Q_TOL
+    mb = random_minibatch(B, A, 14)
+    net.train(mb)                                   # batch-sized buffers still fine after a batch-1 pass
+    assert np.array_equal(net.predict_one(buf.getState()), net.predict(buf.getStateMinibatch())[0])
+
+
 def test_forward_stages(sd):
     """Stage-by-stage check of the internal NHWC activations against the oracle's NCHW ones."""
     A, B = 4, 8
@@ -311,3 +329,23 @@ def test_agent_loop_plumbing(sd):
     agent.test(10, 0)
     q = net.predict(agent.buf.getStateMinibatch())
     assert np.isfinite(q).all()
+
+
+def test_main_loop_with_statistics_csv(sd, tmp_path):
+    """BASELINE.json configs[0] plumbing end to end: the reference's main loop (random fill, train epoch, save,
+    test epoch) with the Statistics CSV, on the synthetic environment."""
+    import csv
+    from simple_dqn_amd import main as M
+    from simple_dqn_amd.statistics import COLUMNS
+    csvp = str(tmp_path / "run.csv")
+    args = M.build_parser().parse_args(
+        ["--replay_size", "3000", "--random_steps", "300", "--train_steps", "200", "--test_steps", "40", "--epochs", "2",
+         "--exploration_decay_steps", "200", "--target_steps", "64", "--random_seed", "7", "--csv_file", csvp,
+         "--save_weights_prefix", str(tmp_path / "snap")])
+    stats = M.run(args)
+    rows = list(csv.reader(open(csvp)))
+    assert tuple(rows[0]) == COLUMNS and [r[1] for r in rows[1:]] == ["random", "train", "test", "train", "test"]
+    assert int(rows[-1][12]) == 2 * 200 // 4          # weight_updates: one per train_frequency env steps
+    assert float(rows[2][11]) > 0                      # meancost of the first train phase
+    assert (tmp_path / "snap_2.npz").exists()
+    assert np.isfinite(float(rows[-1][10]))            # meanq on the validation minibatch

@@ -1,0 +1,49 @@
+"""CPU test of the Statistics restatement (reference statistics.py:8-124) with stand-in agent/net/mem objects."""
+import csv
+
+import numpy as np
+
+from simple_dqn_amd.statistics import COLUMNS, Statistics
+from util import make_args
+
+
+class _Net:
+    train_iterations = 0
+    callback = None
+
+    def predict(self, states):
+        return np.tile(np.arange(4, dtype=np.float32), (states.shape[0], 1))
+
+
+class _Mem:
+    count, batch_size = 100, 8
+    prestates = np.zeros((8, 4, 84, 84), np.uint8)
+
+    def getMinibatch(self):
+        return self.prestates, None, None, None, None
+
+
+class _Agent:
+    callback = None
+    total_train_steps = 42
+
+
+def test_statistics_csv_columns_and_running_means(tmp_path):
+    p = str(tmp_path / "s.csv")
+    agent, net, mem = _Agent(), _Net(), _Mem()
+    st = Statistics(agent, net, mem, None, make_args(csv_file=p))
+    assert agent.callback is st and net.callback is st
+    st.reset()
+    for i, (r, t) in enumerate([(1, False), (0, False), (2, True), (-1, False), (1, True)]):
+        st.on_step(0, r, t, None, 0.5)
+    assert (st.num_games, st.min_game_reward, st.max_game_reward) == (2, 0, 3) and st.average_reward == 1.5
+    for i, c in enumerate([1.0, 3.0]):
+        net.train_iterations = i + 1
+        st.on_train(c)
+    assert st.average_cost == 2.0                      # running mean over train_iterations (:71)
+    st.write(1, "train")
+    st.close()
+    rows = list(csv.reader(open(p)))
+    assert tuple(rows[0]) == COLUMNS and len(rows[0]) == 16
+    assert rows[1][:4] == ["1", "train", "5", "2"] and float(rows[1][10]) == 3.0 and rows[1][8] == "42"
+    assert st.validation_states is mem.prestates       # the reference's aliasing (:85-86)
