@@ -95,7 +95,8 @@ typedef struct {
   int screen_width;        /* :22 (must be 84) */
   int num_actions;         /* :18 */
   int target_enabled;      /* bool(args.target_steps) :64 */
-  int reserved0[2];
+  int optimizer;           /* args.optimizer :50-59: 0 rmsprop, 1 adam, 2 adadelta */
+  int reserved0;
   /* Python floats (doubles) exactly as argparse hands them over; the library rounds to fp32
    * where Neon's fp32 backend would (lr, decay, epsilon, clip) and keeps doubles where the
    * reference does host-side float math (discount, reward clip: deepqnetwork.py:136-143).  */
@@ -105,14 +106,17 @@ typedef struct {
   double max_reward;       /* :25 */
   double learning_rate;    /* :51 */
   double decay_rate;       /* :52 */
-  double epsilon;          /* Neon RMSProp default 1e-6 */
-  double reserved1[4];
+  double epsilon;          /* Neon defaults: RMSProp 1e-6, Adam 1e-8, Adadelta 1e-6 */
+  double beta_1;           /* Adam (Neon default 0.9) */
+  double beta_2;           /* Adam (Neon default 0.999) */
+  double reserved1[2];
 } sdqn_net_cfg;
 
 /* DeepQNetwork.__init__, deepqnetwork.py:16-75 (weights start at zero: inject with set_weights) */
 int sdqn_net_create(sdqn_net_t* h, const sdqn_net_cfg* cfg);
 int sdqn_net_destroy(sdqn_net_t h);
-/* which: 0 online theta, 1 target theta-, 2 RMSProp state, 3 last gradient sum (get only).
+/* which: 0 online theta, 1 target theta-, 2 optimizer state (RMSProp s / Adam m / Adadelta E[g^2]),
+ * 3 last gradient sum (get only), 4 second optimizer state (Adam v / Adadelta E[dx^2]).
  * layer: 0..4 = conv1, conv2, conv3, fc4, fc5.  Data in Neon layout:
  * conv (C*R*S, K) rows c*R*S+r*S+s; fc4 (512, 3136) nin in (K,P,Q) order; fc5 (A, 512).  */
 int sdqn_net_layer_size(sdqn_net_t h, int layer, int64_t* n);
@@ -141,6 +145,8 @@ int sdqn_net_sync(sdqn_net_t h);
 /* q-values of the last train step: preq float[B,A] (online, prestates), maxpostq float[B] (sync) */
 int sdqn_net_last_q(sdqn_net_t h, float* preq, float* maxpostq);
 int sdqn_net_train_iterations(sdqn_net_t h, int64_t* n);     /* deepqnetwork.py:168 */
+/* the `epoch` argument of DeepQNetwork.train (deepqnetwork.py:107,165): Neon's Adam bias-corrects with t = epoch + 1 */
+int sdqn_net_set_epoch(sdqn_net_t h, int epoch);
 
 /* options: "keep_gradients" (1: the fc4 gradient is materialised and readable with which=3; 0 (default): on one
  * GPU RMSProp of fc4 is fused into the wgrad epilogue), "two_streams" (0 default; 1: wgrad kernels overlap the dgrad chain on a side stream) */

@@ -76,8 +76,8 @@ def _col2im(dcols, C, H, W, R, S, st):
 class OracleDQN:
     def __init__(self, num_actions, batch_size=32, history_length=4, screen_height=84, screen_width=84,
                  discount_rate=0.99, clip_error=1.0, min_reward=-1.0, max_reward=1.0,
-                 learning_rate=0.00025, decay_rate=0.95, epsilon=1e-6, target_steps=10000,
-                 dtype=np.float32, weights=None, seed=0):
+                 learning_rate=0.00025, decay_rate=0.95, epsilon=None, target_steps=10000,
+                 dtype=np.float32, weights=None, seed=0, optimizer="rmsprop", beta_1=0.9, beta_2=0.999):
         self.num_actions = num_actions
         self.batch_size = batch_size
         self.history_length = history_length
@@ -85,12 +85,17 @@ class OracleDQN:
         self.discount_rate = discount_rate
         self.clip_error = clip_error
         self.min_reward, self.max_reward = min_reward, max_reward
+        assert optimizer in ("rmsprop", "adam", "adadelta")               # deepqnetwork.py:50-61
+        self.optimizer, self.beta_1, self.beta_2 = optimizer, beta_1, beta_2
+        if epsilon is None:                                                # Neon defaults [neon-recalled]
+            epsilon = 1e-8 if optimizer == "adam" else 1e-6
         self.lr, self.rho, self.eps = learning_rate, decay_rate, epsilon
         self.dtype = np.dtype(dtype).type
         ws = weights if weights is not None else xavier_weights(num_actions, seed, dtype, history_length,
                                                                 screen_height, screen_width)
         self.W = [np.array(w, dtype=dtype) for w in ws]
-        self.S = [np.zeros_like(w) for w in self.W]               # RMSProp state (A10: init 0)
+        self.S = [np.zeros_like(w) for w in self.W]               # RMSProp state / Adam m / Adadelta E[g^2] (init 0)
+        self.S2 = [np.zeros_like(w) for w in self.W]              # Adam v / Adadelta E[dx^2]
         # deepqnetwork.py:64-73: separate target model iff target_steps, else alias
         self.target_enabled = bool(target_steps)
         self.Wt = [w.copy() for w in self.W] if self.target_enabled else self.W
@@ -186,9 +191,40 @@ class OracleDQN:
             self.S[i] = (t(self.rho) * self.S[i] + (gr * gr) * t(1.0 - self.rho)).astype(t)
             self.W[i] = (self.W[i] - (gr * t(self.lr)) / (np.sqrt(self.S[i] + t(self.eps)) + t(self.eps))).astype(t)
 
+    def adam(self, grads, batch, epoch):
+        """Neon Adam.optimize [neon-recalled]: t = epoch + 1; l = lr*sqrt(1-b2^t)/(1-b1^t);
+        m = m*b1 + (1-b1)*g; v = v*b2 + (1-b2)*g*g; param -= l*m / (sqrt(v) + eps)."""
+        t = self.dtype
+        tt = epoch + 1
+        l = self.lr * np.sqrt(1 - self.beta_2 ** tt) / (1 - self.beta_1 ** tt)
+        for i in range(5):
+            gr = (grads[i] / t(batch)).astype(t)
+            self.S[i] = (self.S[i] * t(self.beta_1) + t(1.0 - self.beta_1) * gr).astype(t)
+            self.S2[i] = (self.S2[i] * t(self.beta_2) + (t(1.0 - self.beta_2) * gr) * gr).astype(t)
+            self.W[i] = (self.W[i] - (t(l) * self.S[i]) / (np.sqrt(self.S2[i]) + t(self.eps))).astype(t)
+
+    def adadelta(self, grads, batch):
+        """Neon Adadelta.optimize [neon-recalled]: E[g^2] = d*E[g^2] + (1-d)*g*g; dx = sqrt((E[dx^2]+eps)/(E[g^2]+eps))*g;
+        E[dx^2] = d*E[dx^2] + (1-d)*dx*dx; param -= dx."""
+        t = self.dtype
+        for i in range(5):
+            gr = (grads[i] / t(batch)).astype(t)
+            self.S[i] = (self.S[i] * t(self.rho) + (t(1.0 - self.rho) * gr) * gr).astype(t)
+            upd = (np.sqrt((self.S2[i] + t(self.eps)) / (self.S[i] + t(self.eps))) * gr).astype(t)
+            self.S2[i] = (self.S2[i] * t(self.rho) + (t(1.0 - self.rho) * upd) * upd).astype(t)
+            self.W[i] = (self.W[i] - upd).astype(t)
+
+    def optimize(self, grads, batch, epoch=0):
+        if self.optimizer == "rmsprop":
+            self.rmsprop(grads, batch)
+        elif self.optimizer == "adam":
+            self.adam(grads, batch, epoch)
+        else:
+            self.adadelta(grads, batch)
+
     def train(self, minibatch, epoch=0):                                      # :107-172
         grads, cost, _, _ = self.gradients(minibatch)
-        self.rmsprop(grads, minibatch[0].shape[0])
+        self.optimize(grads, minibatch[0].shape[0], epoch)
         self.train_iterations += 1
         self.last_cost = cost
         if self.callback:

@@ -23,10 +23,10 @@ def lib_path():
 class NetCfg(C.Structure):
     _fields_ = [("batch_size", C.c_int), ("history_length", C.c_int), ("screen_height", C.c_int),
                 ("screen_width", C.c_int), ("num_actions", C.c_int), ("target_enabled", C.c_int),
-                ("reserved0", C.c_int * 2),
+                ("optimizer", C.c_int), ("reserved0", C.c_int),
                 ("discount_rate", C.c_double), ("clip_error", C.c_double), ("min_reward", C.c_double),
                 ("max_reward", C.c_double), ("learning_rate", C.c_double), ("decay_rate", C.c_double),
-                ("epsilon", C.c_double), ("reserved1", C.c_double * 4)]
+                ("epsilon", C.c_double), ("beta_1", C.c_double), ("beta_2", C.c_double), ("reserved1", C.c_double * 2)]
 
 
 _u8p, _i64p, _f32p, _u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
@@ -70,6 +70,7 @@ SIGNATURES = {
     "sdqn_net_last_q": (C.c_int, [_vp, _f32p, _f32p]),
     "sdqn_net_train_iterations": (C.c_int, [_vp, _i64p]),
     "sdqn_net_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "sdqn_net_set_epoch": (C.c_int, [_vp, C.c_int]),
     "sdqn_net_debug_read": (C.c_int, [_vp, C.c_char_p, _f32p, C.c_int64]),
     "sdqn_net_profile": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sdqn_net_profile_count": (C.c_int, [C.POINTER(C.c_int)]),

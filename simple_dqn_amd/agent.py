@@ -93,6 +93,8 @@ class Agent:
                 self.net.update_target_network()
             if self.mem.count > self.mem.batch_size and i % self.train_frequency == 0:
                 if self.fused:
+                    if hasattr(self.net, "set_epoch"):
+                        self.net.set_epoch(epoch)                   # net.train(minibatch, epoch), agent.py:114
                     self.net.train_from_memory(self.mem, self.train_repeat)
                 else:
                     for j in range(self.train_repeat):

@@ -57,6 +57,9 @@ struct UpdateArgs {
   PrepArgs next;                // next.B > 0: also do the NEXT step's prep (train_many samples one step ahead)
   float bsz;                    // divisor of A9 (B, or R*B under data parallel)
   float rho, one_minus_rho, lr, eps;
+  int opt;                      // 0 RMSProp, 1 Adam, 2 Adadelta (deepqnetwork.py:50-59)
+  float* state2;                // Adam v / Adadelta E[dx^2]
+  float beta1, one_minus_beta1, beta2, one_minus_beta2, lr_t;   // Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), t = epoch+1
 };
 
 struct GatherArgs {

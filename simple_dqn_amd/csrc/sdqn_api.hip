@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -289,7 +290,8 @@ static int rccl_load(const char* path) {
 struct ProfPair { int id; hipEvent_t a, b; };
 struct sdqn_net_s {
   sdqn_net_cfg cfg; int B = 0, A = 0; int64_t NP = 0;
-  float *theta = nullptr, *theta_t = nullptr, *state = nullptr, *g = nullptr;
+  float *theta = nullptr, *theta_t = nullptr, *state = nullptr, *state2 = nullptr, *g = nullptr;
+  int epoch = 0;
   float *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *slab4 = nullptr, *a4 = nullptr, *d4 = nullptr;
   float *d3p = nullptr, *d2p = nullptr, *d1 = nullptr, *slab1 = nullptr, *slab2 = nullptr, *slab3 = nullptr;
   float *q = nullptr, *maxq = nullptr, *dq = nullptr, *cost_terms = nullptr, *cost_out = nullptr; double* cost_accum = nullptr;
@@ -332,6 +334,7 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   ARGCHK(out && c, "NULL argument");
   ARGCHK(c->batch_size > 0 && c->batch_size <= 4096, "bad batch_size %d", c->batch_size);
   ARGCHK(c->num_actions > 0 && c->num_actions <= MAX_ACTIONS, "num_actions must be in 1..%d (got %d)", MAX_ACTIONS, c->num_actions);
+  ARGCHK(c->optimizer >= 0 && c->optimizer <= 2, "unknown optimizer %d", c->optimizer);
   ARGCHK(c->screen_height == H0 && c->screen_width == W0 && c->history_length == C0,
          "this build supports 84x84 screens with history_length 4 (got %dx%d, %d)", c->screen_height, c->screen_width, c->history_length);
   STREAMCHK();
@@ -350,6 +353,7 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->theta, h->NP * 4));
   if (c->target_enabled) NCHK(dalloc(h, (void**)&h->theta_t, h->NP * 4)); else h->theta_t = h->theta;   // deepqnetwork.py:64-73
   NCHK(dalloc(h, (void**)&h->state, h->NP * 4));
+  if (c->optimizer != 0) NCHK(dalloc(h, (void**)&h->state2, h->NP * 4));
   NCHK(dalloc(h, (void**)&h->g, h->NP * 4));
   NCHK(dalloc(h, (void**)&h->a1, (size_t)2 * B * PIX1 * K1 * 4));
   NCHK(dalloc(h, (void**)&h->a2, (size_t)2 * B * PIX2 * K2 * 4));
@@ -387,10 +391,12 @@ extern "C" int sdqn_net_layer_size(sdqn_net_t h, int layer, int64_t* n) {
   int64_t r, c, o; layer_dims(layer, h->A, r, c, o); *n = r * c; return SDQN_OK;
 }
 static float* which_buf(sdqn_net_s* h, int which) {
-  switch (which) { case 0: return h->theta; case 1: return h->theta_t; case 2: return h->state; case 3: return h->g; default: return nullptr; }
+  switch (which) { case 0: return h->theta; case 1: return h->theta_t; case 2: return h->state; case 3: return h->g;
+                   case 4: return h->state2; default: return nullptr; }
 }
 extern "C" int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const float* w, int64_t n) {
-  ARGCHK(h && w && layer >= 0 && layer < 5 && which >= 0 && which <= 2, "bad arguments");
+  ARGCHK(h && w && layer >= 0 && layer < 5 && (which == 0 || which == 1 || which == 2 || which == 4), "bad arguments");
+  ARGCHK(which_buf(h, which), "this optimizer has no second state");
   int64_t rows, cols, off; layer_dims(layer, h->A, rows, cols, off);
   ARGCHK(n == rows * cols, "layer %d holds %lld values, got %lld", layer, (long long)(rows * cols), (long long)n);
   std::vector<float> tmp((size_t)n);
@@ -400,7 +406,8 @@ extern "C" int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const fl
   return SDQN_OK;
 }
 extern "C" int sdqn_net_get_weights(sdqn_net_t h, int which, int layer, float* w, int64_t n) {
-  ARGCHK(h && w && layer >= 0 && layer < 5 && which >= 0 && which <= 3, "bad arguments");
+  ARGCHK(h && w && layer >= 0 && layer < 5 && which >= 0 && which <= 4, "bad arguments");
+  ARGCHK(which_buf(h, which), "this optimizer has no second state");
   int64_t rows, cols, off; layer_dims(layer, h->A, rows, cols, off);
   ARGCHK(n == rows * cols, "layer %d holds %lld values, got %lld", layer, (long long)(rows * cols), (long long)n);
   std::vector<float> tmp((size_t)n);
@@ -461,7 +468,7 @@ static StepArgs step_args(sdqn_net_s* h) {
   a.d1 = h->d1; a.g = h->g; a.slab1 = h->slab1; a.slab2 = h->slab2; a.slab3 = h->slab3;
   a.S4 = h->S4; a.tps1 = h->tps1; a.tps2 = h->tps2; a.tps3 = h->tps3;
   for (int i = 0; i < 12; ++i) a.nw_override[i] = h->nw_override[i];
-  a.fuse_rms = (!h->comm && !h->keep_grads) ? 1 : 0;
+  a.fuse_rms = (!h->comm && !h->keep_grads && h->cfg.optimizer == 0) ? 1 : 0;
   a.theta_w = h->theta; a.state = h->state; a.bsz = (float)h->B;
   a.rho = (float)h->cfg.decay_rate; a.one_minus_rho = (float)(1.0 - h->cfg.decay_rate);
   a.lr = (float)h->cfg.learning_rate; a.eps = (float)h->cfg.epsilon;
@@ -514,6 +521,12 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   u.rho = (float)h->cfg.decay_rate; u.one_minus_rho = (float)(1.0 - h->cfg.decay_rate);
   u.lr = (float)h->cfg.learning_rate; u.eps = (float)h->cfg.epsilon;
   u.skip_fc4 = a.fuse_rms;
+  u.opt = h->cfg.optimizer; u.state2 = h->state2;
+  if (u.opt == 1) {            // Neon Adam [neon-recalled]: t = epoch + 1, l = lr*sqrt(1-b2^t)/(1-b1^t), math in Python floats
+    const double b1 = h->cfg.beta_1, b2 = h->cfg.beta_2, t = (double)h->epoch + 1.0;
+    u.beta1 = (float)b1; u.one_minus_beta1 = (float)(1.0 - b1); u.beta2 = (float)b2; u.one_minus_beta2 = (float)(1.0 - b2);
+    u.lr_t = (float)(h->cfg.learning_rate * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t)));
+  }
   if (next) u.next = *next;                 // (memset above left next.B = 0 otherwise)
   if (h->comm) {
     // synchronous data parallel: local gradient sums -> one RCCL all-reduce of the flat buffer -> identical RMSProp
@@ -649,6 +662,8 @@ extern "C" int sdqn_net_last_q(sdqn_net_t h, float* preq, float* maxpostq) {
   return SDQN_OK;
 }
 extern "C" int sdqn_net_train_iterations(sdqn_net_t h, int64_t* n) { ARGCHK(h && n, "NULL"); *n = h->train_iterations; return SDQN_OK; }
+
+extern "C" int sdqn_net_set_epoch(sdqn_net_t h, int epoch) { ARGCHK(h && epoch >= 0, "bad epoch"); h->epoch = epoch; return SDQN_OK; }
 
 extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   ARGCHK(h && name, "NULL argument");

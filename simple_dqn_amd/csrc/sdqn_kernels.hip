@@ -140,8 +140,32 @@ hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__device__ inline float rms_apply(float w, float& st, float gsum, const UpdateArgs& u) {
-  return rms_step(w, st, gsum, u.bsz, u.rho, u.one_minus_rho, u.lr, u.eps);
+// one parameter of Neon's optimizers [neon-recalled, SURVEY.md A9/A10 + §8a-bis "non-default branches"];
+// every one starts with grad = grad / be.bsz
+__device__ inline float opt_apply(float w, float& s1, float& s2, float gsum, const UpdateArgs& u) {
+  if (u.opt == 0) return rms_step(w, s1, gsum, u.bsz, u.rho, u.one_minus_rho, u.lr, u.eps);
+  const float g = gsum / u.bsz;
+  if (u.opt == 1) {                                   // Adam: m, v; bias correction folded into lr_t (t = epoch + 1)
+    s1 = s1 * u.beta1 + u.one_minus_beta1 * g;
+    s2 = s2 * u.beta2 + (u.one_minus_beta2 * g) * g;
+    return w - (u.lr_t * s1) / (sqrtf(s2) + u.eps);
+  }
+  s1 = s1 * u.rho + (u.one_minus_rho * g) * g;        // Adadelta: E[g^2], E[dx^2]
+  const float upd = sqrtf((s2 + u.eps) / (s1 + u.eps)) * g;
+  s2 = s2 * u.rho + (u.one_minus_rho * upd) * upd;
+  return w - upd;
+}
+__device__ inline void opt_apply4(float* __restrict__ theta, float* __restrict__ st1, float* __restrict__ st2,
+                                  int64_t e, const float4& gs, const UpdateArgs& u) {
+  float4 w = *reinterpret_cast<float4*>(theta + e);
+  float4 a = *reinterpret_cast<float4*>(st1 + e);
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (u.opt != 0) b = *reinterpret_cast<float4*>(st2 + e);
+  w.x = opt_apply(w.x, a.x, b.x, gs.x, u); w.y = opt_apply(w.y, a.y, b.y, gs.y, u);
+  w.z = opt_apply(w.z, a.z, b.z, gs.z, u); w.w = opt_apply(w.w, a.w, b.w, gs.w, u);
+  *reinterpret_cast<float4*>(theta + e) = w;
+  *reinterpret_cast<float4*>(st1 + e) = a;
+  if (u.opt != 0) *reinterpret_cast<float4*>(st2 + e) = b;
 }
 
 // Two kinds of workgroups in one launch:
@@ -189,14 +213,7 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
         *reinterpret_cast<float4*>(u.g + e) = gs;
       }
     }
-    if (sg == 0 && u.mode != 1) {
-      float4 w = *reinterpret_cast<float4*>(u.theta + e);
-      float4 st = *reinterpret_cast<float4*>(u.state + e);
-      w.x = rms_apply(w.x, st.x, gs.x, u); w.y = rms_apply(w.y, st.y, gs.y, u);
-      w.z = rms_apply(w.z, st.z, gs.z, u); w.w = rms_apply(w.w, st.w, gs.w, u);
-      *reinterpret_cast<float4*>(u.theta + e) = w;
-      *reinterpret_cast<float4*>(u.state + e) = st;
-    }
+    if (sg == 0 && u.mode != 1) opt_apply4(u.theta, u.state, u.state2, e, gs, u);
     return;
   }
   const int64_t NP4 = (OFF5 + (int64_t)u.A * NFC) / 4;
@@ -219,14 +236,7 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
       }
       *reinterpret_cast<float4*>(u.g + e) = gs;
     }
-    if (u.mode != 1) {
-      float4 w = *reinterpret_cast<float4*>(u.theta + e);
-      float4 st = *reinterpret_cast<float4*>(u.state + e);
-      w.x = rms_apply(w.x, st.x, gs.x, u); w.y = rms_apply(w.y, st.y, gs.y, u);
-      w.z = rms_apply(w.z, st.z, gs.z, u); w.w = rms_apply(w.w, st.w, gs.w, u);
-      *reinterpret_cast<float4*>(u.theta + e) = w;
-      *reinterpret_cast<float4*>(u.state + e) = st;
-    }
+    if (u.mode != 1) opt_apply4(u.theta, u.state, u.state2, e, gs, u);
   }
   if (u.next.B > 0 && (int)blockIdx.x == CONV_BLOCKS + 1) {         // next step's prep rides along (every reader of idx is done)
     for (int n = t; n < u.next.B; n += 256) {

@@ -38,10 +38,8 @@ class DeepQNetwork:
         if str(getattr(args, "datatype", "float32")) not in ("float32", "<class 'numpy.float32'>"):
             raise NotImplementedError("only float32 is implemented (fp16 activations: SURVEY.md config 5, next)")
         optimizer = getattr(args, "optimizer", "rmsprop")
-        if optimizer != "rmsprop":
-            if optimizer in ("adam", "adadelta"):
-                raise NotImplementedError("optimizer %s is not implemented yet (SURVEY.md §8f)" % optimizer)
-            assert False, "Unknown optimizer"                      # deepqnetwork.py:61
+        assert optimizer in ("rmsprop", "adam", "adadelta"), "Unknown optimizer"      # deepqnetwork.py:61
+        self.optimizer = optimizer
         dev = getattr(args, "device_id", None)
         cfg = _lib.NetCfg()
         cfg.batch_size, cfg.history_length = self.batch_size, self.history_length
@@ -52,7 +50,10 @@ class DeepQNetwork:
         cfg.min_reward, cfg.max_reward = float(self.min_reward), float(self.max_reward)
         cfg.learning_rate = float(getattr(args, "learning_rate", 0.00025))
         cfg.decay_rate = float(getattr(args, "decay_rate", 0.95))
-        cfg.epsilon = float(getattr(args, "rmsprop_epsilon", 1e-6))                    # Neon RMSProp default (A10)
+        cfg.optimizer = ("rmsprop", "adam", "adadelta").index(optimizer)              # :50-59
+        # Neon's defaults (the reference passes none): RMSProp/Adadelta epsilon 1e-6, Adam epsilon 1e-8, betas 0.9/0.999
+        cfg.epsilon = float(getattr(args, "optimizer_epsilon", 1e-8 if optimizer == "adam" else 1e-6))
+        cfg.beta_1, cfg.beta_2 = float(getattr(args, "beta_1", 0.9)), float(getattr(args, "beta_2", 0.999))
         self._dev = dev
         h = C.c_void_p()
         _lib.check(self._lib.sdqn_net_create(C.byref(h), C.byref(cfg)))
@@ -116,6 +117,8 @@ class DeepQNetwork:
         term = np.ascontiguousarray(terminals).astype(np.uint8)
         cost = C.c_float()
         want = self.callback is not None
+        if self.optimizer == "adam":
+            _lib.check(self._lib.sdqn_net_set_epoch(self._h, int(epoch)))        # optimizer.optimize(.., epoch), :165
         _lib.check(self._lib.sdqn_net_train_host(self._h, _lib.ptr(pre, C.c_uint8), _lib.ptr(act, C.c_uint8),
                                                  _lib.ptr(rew, C.c_int64), _lib.ptr(post, C.c_uint8),
                                                  _lib.ptr(term, C.c_uint8), C.byref(cost) if want else None))
@@ -141,7 +144,7 @@ class DeepQNetwork:
 
     def load_weights(self, load_path):                             # :188-189 (own .npz; Neon pickles: SURVEY.md §8f)
         with np.load(load_path) as f:
-            for which, key in ((0, "W"), (1, "Wt"), (2, "S")):
+            for which, key in ((0, "W"), (1, "Wt"), (2, "S"), (4, "S2")):
                 for i in range(5):
                     name = "%s%d" % (key, i)
                     if name in f:
@@ -151,7 +154,7 @@ class DeepQNetwork:
 
     def save_weights(self, save_path):                             # :191-192
         d = {}
-        for which, key in ((0, "W"), (1, "Wt"), (2, "S")):
+        for which, key in ((0, "W"), (1, "Wt"), (2, "S")) + ((() if self.optimizer == "rmsprop" else ((4, "S2"),))):
             for i in range(5):
                 d["%s%d" % (key, i)] = self.get_layer(i, which)
         d["train_iterations"] = np.int64(self.train_iterations)
@@ -159,6 +162,9 @@ class DeepQNetwork:
             np.savez(f, **d)
 
     # ---- additive fast paths (SURVEY.md §8b "new, additive") ------------------------------------------
+    def set_epoch(self, epoch):
+        _lib.check(self._lib.sdqn_net_set_epoch(self._h, int(epoch)))
+
     def train_from_memory(self, mem, n_steps=1, use_global_random=True, mt_state=None, want_cost=None):
         """n_steps x { sample ; fused gather+train } entirely inside the library (agent.py:108-114's
         loop body).  Consumes Python's global random stream unless an explicit 625-word mt_state

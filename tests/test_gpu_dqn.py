@@ -349,3 +349,88 @@ def test_main_loop_with_statistics_csv(sd, tmp_path):
     assert float(rows[2][11]) > 0                      # meancost of the first train phase
     assert (tmp_path / "snap_2.npz").exists()
     assert np.isfinite(float(rows[-1][10]))            # meanq on the validation minibatch
+
+
+def test_hyperparameters_reach_the_kernels(sd):
+    """Non-default discount / reward range / clip / lr / decay (main.py:33-45 flags) are honoured."""
+    A, B = 5, 16
+    kw = dict(discount_rate=0.9, min_reward=-2.0, max_reward=0.5, clip_error=0.25, learning_rate=0.001, decay_rate=0.9)
+    net, _ = _pair(sd, A, B, 91, **kw)
+    o = OracleDQN(A, batch_size=B, weights=xavier_weights(A, 91), **kw)
+    o.Wt = [w.copy() for w in xavier_weights(A, 92)]
+    net.set_option("keep_gradients", 1)
+    mb = random_minibatch(B, A, 93, reward_range=(-4, 5))
+    g, cost, _, _ = o.gradients(mb)
+    costs = []
+    net.callback = type("CB", (), {"on_train": lambda self, c: costs.append(c)})()
+    net.train(mb)
+    assert abs(costs[0] - float(cost)) < 1e-5 * max(1.0, float(cost))
+    for i in range(5):
+        assert np.abs(net.get_layer(i, 3) - g[i]).max() < 1e-4 * max(1e-3, np.abs(g[i]).max()), i
+    o.rmsprop(g, B)
+    assert np.abs(net.predict(mb[0]) - o.predict(mb[0])).max() < Q_TOL
+
+
+def test_train_from_zero_copy_ring(sd):
+    """SDQN_REPLAY_ZERO_COPY: kernels gather straight from the pinned host ring over PCIe — same numbers."""
+    A, B, size = 4, 32, 3000
+    args = make_args(batch_size=B)
+    m1, m2 = sd.ReplayMemory(size, args, flags=1), sd.ReplayMemory(size, args, flags=2)
+    for m in (m1, m2):
+        synthetic_fill(m, 5, num_actions=A, count=2500, current=2500)     # partially filled ring
+        m.sync_mirror()
+    n1, _ = _pair(sd, A, B, 95)
+    n2, _ = _pair(sd, A, B, 95)
+    random.seed(3)
+    n1.train_from_memory(m1, 4)
+    random.seed(3)
+    n2.train_from_memory(m2, 4)
+    for i in range(5):
+        assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
+    # zero-copy ring sees host writes without sync_mirror(): add() after training keeps both consistent
+    scr = np.full((84, 84), 7, np.uint8)
+    m1.add(1, 1, scr, False); m2.add(1, 1, scr, False)
+    random.seed(4); a = [x.copy() for x in m1.getMinibatch()]
+    random.seed(4); b = m2.getMinibatch()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("opt", ["adam", "adadelta"])
+def test_other_optimizers(sd, opt):
+    """deepqnetwork.py:54-59: Adam / Adadelta with Neon's defaults [neon-recalled]; 3 steps (epochs 0, 0, 2)."""
+    A, B = 4, 16
+    net, _ = _pair(sd, A, B, 201, optimizer=opt)
+    o = OracleDQN(A, batch_size=B, weights=xavier_weights(A, 201), optimizer=opt)
+    o.Wt = [w.copy() for w in xavier_weights(A, 202)]
+    for s, epoch in enumerate((0, 0, 2)):
+        mb = random_minibatch(B, A, 203 + s)
+        net.train(mb, epoch)
+        o.train(mb, epoch)
+    for i in range(5):
+        big = np.abs(o.W[i] - xavier_weights(A, 201)[i]) > 0
+        assert np.abs(net.get_layer(i, 2) - o.S[i]).max() < 1e-6 + 2e-3 * np.abs(o.S[i]).max(), i
+        assert np.abs(net.get_layer(i, 4) - o.S2[i]).max() < 1e-7 + 2e-3 * np.abs(o.S2[i]).max(), i
+    assert np.abs(net.predict(mb[0]) - o.predict(mb[0])).max() < (Q_TOL if opt == "adadelta" else 5e-3)
+
+
+def test_preconditions_raise_like_the_reference(sd):
+    A, B = 4, 8
+    net, _ = _pair(sd, A, B, 97)
+    pre, act, rew, post, term = random_minibatch(B, A, 98)
+    with pytest.raises(AssertionError):
+        net.train((pre, act, rew, post[:, :3], term))                # deepqnetwork.py:115
+    with pytest.raises(AssertionError):
+        net.train((pre, act[:-1], rew, post, term))                  # :116
+    bad = act.copy(); bad[0] = A
+    with pytest.raises(AssertionError):
+        net.train((pre, bad, rew, post, term))                       # action out of range (IndexError in the reference)
+    mem = sd.ReplayMemory(50, make_args(batch_size=B))
+    with pytest.raises(AssertionError):
+        mem.getMinibatch()                                           # replay_memory.py:52
+    with pytest.raises(AssertionError):
+        mem.getState(0)                                              # :38
+    with pytest.raises(NotImplementedError):
+        sd.DeepQNetwork(A, make_args(batch_size=B, batch_norm=True))
+    with pytest.raises(AssertionError):
+        sd.DeepQNetwork(A, make_args(batch_size=B, optimizer="sgd"))  # deepqnetwork.py:61
