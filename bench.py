@@ -56,9 +56,11 @@ def kernel_work(B, A):
         13: dict(bytes=npar * f, flops=0),
         14: dict(bytes=B * 13 * 7056, flops=0),
         15: dict(bytes=1024, flops=0),
-        16: dict(bytes=(a3 + w3 + 2 * a2) + (a2 + a3 + w3) + (a4 + a3 + 4 * w4), flops=2 * B * 81 * 64 * 576 + 2 * B * 49 * 64 * 576 + 2 * B * 512 * 3136),
-        17: dict(bytes=(a2 + w2 + 2 * a1) + (a1 + a2 + w2), flops=2 * B * 400 * 32 * 256 + 2 * B * 81 * 64 * 512),
+        16: dict(bytes=(a3 + w3 + 2 * a2) + (a2 + a3 + w3) + (a4 + a3 + 4 * w4) // 3, flops=2 * B * 81 * 64 * 576 + 2 * B * 49 * 64 * 576 + 2 * B * 512 * 3136 // 3),
+        17: dict(bytes=(a2 + w2 + 2 * a1) + (a1 + a2 + w2) + (a4 + a3 + 4 * w4) // 3, flops=2 * B * 400 * 32 * 256 + 2 * B * 81 * 64 * 512 + 2 * B * 512 * 3136 // 3),
+        18: dict(bytes=B * 5 * 7056 + a1 + w1 + (a4 + a3 + 4 * w4) // 3, flops=2 * B * 400 * 32 * 256 + 2 * B * 512 * 3136 // 3),
     }
+    # (at B <= 32 the fc4 wgrad + fused RMSProp tiles are split ~1/3 each over bwd3 / bwd2 / bwd1)
 
 
 def pmc_traffic(name, B, A):

@@ -215,10 +215,12 @@ struct MultiDims { int n[3]; int gx[3], gy[3]; };       // workgroups per proble
 template <class P, int NW, int NT>
 __device__ __forceinline__ void multi_dispatch(const StepArgs& a, const MultiDims& d, int which, int local, float* smem) {
   if constexpr (NW == 1) {
+    // one tile per wave; the launch owns the tile range [a.f4w_first, a.f4w_first + a.f4w_count)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = local * (NT / 64) + wave;
+    const int t = local * (NT / 64) + wave;
     const int per_z = d.gx[which] * d.gy[which];
-    if (tile < per_z * P::nbz(a)) {
+    if (t < a.f4w_count) {
+      const int tile = a.f4w_first + t;
       const int bz = tile / per_z, r = tile - bz * per_z;
       gemm_tile<P, 1, 64>(a, r % d.gx[which], r / d.gx[which], bz, smem);
     }
@@ -268,13 +270,15 @@ template <class P, int NW>
 inline void multi_fill(const StepArgs& a, MultiDims& d, int i) {
   d.gx[i] = (P::M(a) + 31) / 32; d.gy[i] = (P::N(a) + 31) / 32;
   const int tiles = d.gx[i] * d.gy[i] * P::nbz(a);
-  d.n[i] = NW == 1 ? (tiles + 15) / 16 : tiles;          // NW == 1: 16 tiles (one per wave) per workgroup
+  d.n[i] = NW == 1 ? (a.f4w_count + 15) / 16 : tiles;    // NW == 1: 16 tiles (one per wave) per workgroup, range from StepArgs
 }
 template <class P0, int NW0, class P1, int NW1, class P2, int NW2>
-inline hipError_t launch_multi(const StepArgs& a, bool has2, hipStream_t stream) {
+inline hipError_t launch_multi(const StepArgs& a, bool has1, bool has2, hipStream_t stream) {
   MultiDims d; memset(&d, 0, sizeof d);
-  multi_fill<P0, NW0>(a, d, 0); multi_fill<P1, NW1>(a, d, 1);
+  multi_fill<P0, NW0>(a, d, 0);
+  if (has1) multi_fill<P1, NW1>(a, d, 1);
   if (has2) multi_fill<P2, NW2>(a, d, 2);
+  if (d.n[0] + d.n[1] + d.n[2] == 0) return hipSuccess;
   hipLaunchKernelGGL((gemm_multi_kernel<P0, NW0, P1, NW1, P2, NW2>), dim3(d.n[0] + d.n[1] + d.n[2]), dim3(1024), 0, stream, a, d);
   return hipGetLastError();
 }

@@ -11,7 +11,8 @@ enum KernelId {
   K_FC4_DGRAD, K_FC4_WGRAD, K_CONV3_DGRAD, K_CONV3_WGRAD, K_CONV2_DGRAD, K_CONV2_WGRAD,
   K_CONV1_WGRAD, K_UPDATE, K_ALLREDUCE, K_GATHER, K_PREP,
   K_BWD3,      // one launch: conv3_dgrad + conv3_wgrad + fc4_wgrad (all depend on fc4_dgrad only)
-  K_BWD2,      // one launch: conv2_dgrad + conv2_wgrad (both depend on conv3_dgrad only)
+  K_BWD2,      // one launch: conv2_dgrad + conv2_wgrad (both depend on conv3_dgrad only) + a share of fc4_wgrad
+  K_BWD1,      // one launch: conv1_wgrad + the last share of fc4_wgrad
   K_COUNT
 };
 const char* kernel_name(int id);

@@ -74,6 +74,8 @@ struct StepArgs {
   // single-GPU fast path: RMSProp of the fc4 weights (95 % of all parameters) fused into the fc4 wgrad
   // epilogue, so the 6.4 MB gradient is never written to / re-read from HBM
   int fuse_rms;
+  int f4w_first, f4w_count; // fc4 wgrad tiles [first, first+count) handled by THIS launch (tiles are spread over
+                            // the three backward launches so the 25.7 MB fused RMSProp RMW streams in the background)
   int nw_override[12];      // tuning hook: waves per tile for kernel id i (0 = built-in choice)
   float* __restrict__ theta_w;   // online parameters, writable alias of theta[0]
   float* __restrict__ state;     // RMSProp state

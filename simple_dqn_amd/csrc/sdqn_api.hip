@@ -301,6 +301,7 @@ struct sdqn_net_s {
   int64_t train_iterations = 0;
   bool keep_grads = false;                 // true: fc4 gradient materialised in g (readable with which=3), no fused RMSProp
   int nw_override[12] = {0};               // tuning hook
+  int f4_share[2] = {34, 33};              // % of the fc4-wgrad tiles in bwd3 / bwd2 (rest in bwd1)
   int S4_override = 0, tps_override[3] = {0, 0, 0};
   bool fused_launches = true;              // independent backward stages share one launch (K_BWD3, K_BWD2)
   bool two_streams = false;                // weight-gradient kernels on the side stream (measured slower eagerly: event waits)
@@ -468,6 +469,7 @@ static StepArgs step_args(sdqn_net_s* h) {
   a.d1 = h->d1; a.g = h->g; a.slab1 = h->slab1; a.slab2 = h->slab2; a.slab3 = h->slab3;
   a.S4 = h->S4; a.tps1 = h->tps1; a.tps2 = h->tps2; a.tps3 = h->tps3;
   for (int i = 0; i < 12; ++i) a.nw_override[i] = h->nw_override[i];
+  a.f4w_first = 0; a.f4w_count = (NIN4 / 32) * (NFC / 32);
   a.fuse_rms = (!h->comm && !h->keep_grads && h->cfg.optimizer == 0) ? 1 : 0;
   a.theta_w = h->theta; a.state = h->state; a.bsz = (float)h->B;
   a.rho = (float)h->cfg.decay_rate; a.one_minus_rho = (float)(1.0 - h->cfg.decay_rate);
@@ -498,9 +500,19 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   hipStream_t ss = h->two_streams ? g_side : g_stream;
   LAUNCH(K_FC4_DGRAD, launch_kernel(K_FC4_DGRAD, a, g_stream));
   if (h->fused_launches && !h->two_streams) {
-    LAUNCH(K_BWD3, launch_kernel(K_BWD3, a, g_stream));
-    LAUNCH(K_BWD2, launch_kernel(K_BWD2, a, g_stream));
-    LAUNCH(K_CONV1_WGRAD, launch_kernel(K_CONV1_WGRAD, a, g_stream));
+    // fc4 wgrad (1568 tiles at B <= 32) is spread over the three backward launches as background traffic;
+    // for B > 32 (K-split workgroups) it all rides in the first one
+    const int f4_tiles = (NIN4 / 32) * (NFC / 32);
+    StepArgs b3 = a, b2 = a, b1 = a;
+    if (h->B <= 32) {
+      const int s3 = h->f4_share[0] * f4_tiles / 100, s2 = h->f4_share[1] * f4_tiles / 100;
+      b3.f4w_first = 0; b3.f4w_count = s3;
+      b2.f4w_first = s3; b2.f4w_count = s2;
+      b1.f4w_first = s3 + s2; b1.f4w_count = f4_tiles - s3 - s2;
+    } else { b3.f4w_first = 0; b3.f4w_count = f4_tiles; b2.f4w_count = b1.f4w_count = 0; }
+    LAUNCH(K_BWD3, launch_kernel(K_BWD3, b3, g_stream));
+    LAUNCH(K_BWD2, launch_kernel(K_BWD2, b2, g_stream));
+    LAUNCH(K_BWD1, launch_kernel(K_BWD1, b1, g_stream));
   } else {
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[1], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[1], 0)); }
   // fc4_wgrad may update W4 in place (fused RMSProp): it must not start before fc4_dgrad has read W4
@@ -670,6 +682,8 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   if (!strcmp(name, "keep_gradients")) h->keep_grads = value != 0;
   else if (!strcmp(name, "two_streams")) h->two_streams = value != 0;
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
+  else if (!strcmp(name, "f4_share3")) h->f4_share[0] = value;
+  else if (!strcmp(name, "f4_share2")) h->f4_share[1] = value;
   else if (!strncmp(name, "nw:", 3)) {                     // tuning: waves per tile of kernel id
     int id = atoi(name + 3);
     if (id < 0 || id >= 12 || !(value == 0 || value == 2 || value == 4 || value == 8 || value == 16)) { set_error("bad nw override"); return SDQN_ERR_ARG; }

@@ -13,7 +13,7 @@ static const char* k_names[K_COUNT] = {
   "conv1_fwd(gather+norm+conv+relu)", "conv2_fwd", "conv3_fwd", "fc4_fwd(splitK)", "head(fc5+td+delta)",
   "fc4_dgrad", "fc4_wgrad", "conv3_dgrad", "conv3_wgrad", "conv2_dgrad", "conv2_wgrad",
   "conv1_wgrad", "update(reduce+fc5wgrad+rmsprop)", "rccl_allreduce", "replay_gather_u8", "prep(idx+meta)",
-  "bwd3(conv3_dgrad+conv3_wgrad+fc4_wgrad)", "bwd2(conv2_dgrad+conv2_wgrad)"};
+  "bwd3(conv3_dgrad+conv3_wgrad+fc4_wgrad)", "bwd2(conv2_dgrad+conv2_wgrad+fc4_wgrad)", "bwd1(conv1_wgrad+fc4_wgrad)"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? k_names[id] : "?"; }
 
 template <class P>
@@ -61,10 +61,17 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
     case K_CONV2_DGRAD: return launch_gemm<Conv2Dgrad, 8>(a, s);    // K = 256 per parity class
     case K_CONV2_WGRAD: return launch_gemm<Conv2Wgrad, 16>(a, s);
     case K_CONV1_WGRAD: return launch_gemm<Conv1Wgrad, 16>(a, s);
+    // multi-problem launches; Fc4Wgrad is the "fc4 share" problem, always first so its memory-bound
+    // read-modify-write stream starts earliest (single tile per wave when B <= 32, else 8 K-split waves)
     case K_BWD3:
-      if (a.B <= 32) return launch_multi<Conv3Dgrad, 9, Conv3Wgrad, 16, Fc4Wgrad, 1>(a, true, s);
-      return launch_multi<Conv3Dgrad, 9, Conv3Wgrad, 16, Fc4Wgrad, 8>(a, true, s);
-    case K_BWD2: return launch_multi<Conv2Dgrad, 8, Conv2Wgrad, 16, NoProblem, 2>(a, false, s);
+      if (a.B <= 32) return launch_multi<Fc4Wgrad, 1, Conv3Dgrad, 9, Conv3Wgrad, 16>(a, true, true, s);
+      return launch_multi<Fc4Wgrad, 8, Conv3Dgrad, 9, Conv3Wgrad, 16>(a, true, true, s);
+    case K_BWD2:
+      if (a.B <= 32) return launch_multi<Fc4Wgrad, 1, Conv2Dgrad, 8, Conv2Wgrad, 16>(a, true, true, s);
+      return launch_multi<NoProblem, 2, Conv2Dgrad, 8, Conv2Wgrad, 16>(a, true, true, s);
+    case K_BWD1:
+      if (a.B <= 32) return launch_multi<Fc4Wgrad, 1, Conv1Wgrad, 16, NoProblem, 2>(a, true, false, s);
+      return launch_multi<NoProblem, 2, Conv1Wgrad, 16, NoProblem, 2>(a, true, false, s);
     default: return hipErrorInvalidValue;
   }
 }

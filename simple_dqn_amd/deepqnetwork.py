@@ -62,6 +62,10 @@ class DeepQNetwork:
         for env, opt in (("SDQN_TWO_STREAMS", b"two_streams"), ("SDQN_FUSED_LAUNCHES", b"fused_launches")):
             if os.environ.get(env) is not None:                       # A/B switches for benchmarking
                 _lib.check(self._lib.sdqn_net_set_option(h, opt, int(os.environ[env])))
+        if os.environ.get("SDQN_F4_SHARE"):                           # tuning: "s3,s2" percent of fc4-wgrad tiles in bwd3 / bwd2
+            s3, s2 = [int(x) for x in os.environ["SDQN_F4_SHARE"].split(",")]
+            _lib.check(self._lib.sdqn_net_set_option(h, b"f4_share3", s3))
+            _lib.check(self._lib.sdqn_net_set_option(h, b"f4_share2", s2))
         self.train_iterations = 0
         self.callback = None
         self.save_weights_prefix = getattr(args, "save_weights_prefix", None)
