@@ -52,6 +52,14 @@ __device__ __forceinline__ int64_t pick_half(int64_t v, int i, bool hi) {
 }
 
 // LDS floats one workgroup of NW waves needs for problem P
+#ifdef SDQN_TIMING
+// phase stamps (s_memtime) of wave 0 of every workgroup: dbg[(block*8 + phase)]; NOT in the product build
+__device__ unsigned long long* g_sdqn_dbg = nullptr;
+#define SDQN_STAMP(ph) do { if (g_sdqn_dbg && threadIdx.x == 0) g_sdqn_dbg[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8) + (ph)] = clock64(); } while (0)
+#else
+#define SDQN_STAMP(ph) do {} while (0)
+#endif
+
 template <class P, int NW>
 constexpr int tile_lds() { return NW * (((P::A_K ? 1 : 0) + (P::B_K ? 1 : 0)) > 0 ? ((P::A_K ? 1 : 0) + (P::B_K ? 1 : 0)) : 1) * PANEL; }
 
@@ -64,6 +72,7 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
   constexpr int WAVE_LDS = (NPAN > 0 ? NPAN : 1) * PANEL;
   typedef typename P::aoff_t aoff_t;
 
+  SDQN_STAMP(0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // provably wave-uniform -> SGPR index math
   const int m0 = bx * 32, n0 = by * 32;
@@ -92,6 +101,14 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
     const int n = n0 + (lane & 31); bcol[0] = P::b_col(a, z, n < N ? n : N - 1);
   }
 
+  // fast-path pointers: regular operands get a per-lane pointer (row 0 for lanes 0-31, row 16 for 32-63)
+  const float* abase = P::a_ptr(a, z);
+  const float* bbase = P::b_ptr(a, z);
+  const float* areg = nullptr; const float* breg = nullptr;
+  if constexpr (!P::A_K && P::A_REG) areg = abase + (uint32_t)arow[0] + (lane >= 32 ? 16 * P::A_LD : 0);
+  if constexpr (!P::B_K && P::B_REG) breg = bbase + (uint32_t)bcol[0] + (lane >= 32 ? 16 * P::B_LD : 0);
+  (void)abase; (void)bbase; (void)areg; (void)breg;
+
   typename P::Epi epi;
   if constexpr (NW == 1) P::epi_begin(a, m0, n0, lane, epi);
 
@@ -102,15 +119,29 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
 #pragma unroll
       for (int j = 0; j < 4; ++j) { const f4 v = P::a_load4(a, z, arow[j] + c); ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w; }
     } else {
-      // one im2col decomposition per lane per chunk (lane <-> k = kc + (l & 31)); step i fetches its
-      // offset from lane i (+16 for the upper half-wave) with v_readlane
-      const int kl = kc + (lane & 31);
-      const aoff_t cv = P::a_col(a, z, kl < kend ? kl : kbeg);
+      if constexpr (P::A_REG) {
+        // plain row-major [k][m] matrix: per-lane pointer fixed for the whole tile, 16 loads at k-row offsets
+        if (kc + 32 <= kend) {
+          const float* p = areg + (size_t)kc * P::A_LD;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+          for (int i = 0; i < 16; ++i) ra[i] = p[(size_t)i * P::A_LD];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { const int k = kc + i + (lane >= 32 ? 16 : 0); ra[i] = k < kend ? areg[(size_t)(k - (lane >= 32 ? 16 : 0)) * P::A_LD] : 0.0f; }
+        }
+      } else {
+        // one im2col decomposition per lane per chunk (lane <-> k = kc + (l & 31)); step i fetches its
+        // offset from lane i (+16 for the upper half-wave) with v_readlane
+        const int kl = kc + (lane & 31);
+        const aoff_t cv = P::a_col(a, z, kl < kend ? kl : kbeg);
         const bool hi = lane >= 32;
-        const aoff_t c = pick_half(cv, i, hi);
-        ra[i] = kc + i + (hi ? 16 : 0) < kend ? P::a_load(a, z, arow[0] + c) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const aoff_t c = pick_half(cv, i, hi);
+          const bool ok = kc + i + (hi ? 16 : 0) < kend;
+          if constexpr (P::A_U8) ra[i] = ok ? P::a_load(a, z, arow[0] + c) : 0.0f;
+          else ra[i] = ok ? abase[(uint32_t)(arow[0] + c)] : 0.0f;       // uniform base + 32-bit lane offset
+        }
       }
     }
     if constexpr (P::B_K) {
@@ -118,13 +149,24 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
 #pragma unroll
       for (int j = 0; j < 4; ++j) { const f4 v = P::b_load4(a, z, r + bcol[j]); rb[4 * j] = v.x; rb[4 * j + 1] = v.y; rb[4 * j + 2] = v.z; rb[4 * j + 3] = v.w; }
     } else {
-      const int kl = kc + (lane & 31);
-      const int rv = P::b_row(a, z, kl < kend ? kl : kbeg);
+      if constexpr (P::B_REG) {
+        if (kc + 32 <= kend) {
+          const float* p = breg + (size_t)kc * P::B_LD;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+          for (int i = 0; i < 16; ++i) rb[i] = p[(size_t)i * P::B_LD];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { const int k = kc + i + (lane >= 32 ? 16 : 0); rb[i] = k < kend ? breg[(size_t)(k - (lane >= 32 ? 16 : 0)) * P::B_LD] : 0.0f; }
+        }
+      } else {
+        const int kl = kc + (lane & 31);
+        const int rv = P::b_row(a, z, kl < kend ? kl : kbeg);
         const bool hi = lane >= 32;
-        const int r = pick_half(rv, i, hi);
-        rb[i] = kc + i + (hi ? 16 : 0) < kend ? P::b_load(a, z, r + bcol[0]) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int r = pick_half(rv, i, hi);
+          rb[i] = kc + i + (hi ? 16 : 0) < kend ? bbase[(uint32_t)(r + bcol[0])] : 0.0f;
+        }
       }
     }
   };
@@ -134,7 +176,9 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
   int kc = kbeg + (wave < NW ? wave : 0) * 32;            // wave-uniform
+  SDQN_STAMP(1);
   if (kc < kend) load_chunk(kc);
+  SDQN_STAMP(2);
   while (kc < kend) {
     // ---- move the fetched chunk to its MFMA operands (through the wave-private panels if k-contiguous)
     float fa[16], fb[16];
@@ -167,6 +211,10 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
 #pragma unroll
       for (int i = 0; i < 16; ++i) fb[i] = s[33 * i];
     }
+#ifdef SDQN_TIMING
+    asm volatile("" :: "v"(fa[0]), "v"(fb[0]), "v"(fa[15]), "v"(fb[15]));      // operands landed
+    SDQN_STAMP(3);
+#endif
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc, 0, 0, 0);
     if constexpr (P::A_K || P::B_K) wave_lds_sync();      // panel reads done before the next chunk's stores
@@ -174,6 +222,10 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
   }
 
   // ---- epilogue: NW partial tiles -> LDS -> summed in fixed order -> P::store (lanes along n) ----
+#ifdef SDQN_TIMING
+  asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
+  SDQN_STAMP(4);
+#endif
   if constexpr (NW > 1) {
     if (wave < NW) {
       float* cw = smem + wave * WAVE_LDS;
@@ -184,6 +236,7 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
       }
     }
     __syncthreads();
+    SDQN_STAMP(5);
     for (int e = threadIdx.x; e < 1024; e += NT) {
       const int ml = e >> 5, nl = e & 31;
       float v = smem[ml * 33 + nl];
@@ -197,6 +250,7 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
     for (int r = 0; r < 16; ++r) v[r] = acc[r];
     P::store16(a, z, ks, m0, n0, lane, M, N, v, epi);     // lane holds rows (r&3)+8(r>>2)+4(l>>5), column l&31
   }
+  SDQN_STAMP(6);
 }
 
 template <class P, int NW>
@@ -244,6 +298,9 @@ __global__ void __launch_bounds__(1024) gemm_multi_kernel(const StepArgs a, cons
 
 struct NoProblem {            // placeholder third problem for two-problem launches (never dispatched: n[2] = 0)
   static constexpr bool A_K = false, B_K = false; typedef int aoff_t; struct Epi {};
+  static constexpr bool A_REG = false, A_U8 = false, B_REG = false; static constexpr int A_LD = 0, B_LD = 0;
+  SDQN_HD static const float* a_ptr(const StepArgs&, int) { return nullptr; }
+  SDQN_HD static const float* b_ptr(const StepArgs&, int) { return nullptr; }
   SDQN_HD static int M(const StepArgs&) { return 0; }
   SDQN_HD static int N(const StepArgs&) { return 0; }
   SDQN_HD static int nbz(const StepArgs&) { return 0; }

@@ -64,6 +64,8 @@ struct StepArgs {
   float* d4;                // [B][512]
   float* d3p;               // [B][11][11][64]
   float* d2p;               // [B][11][11][64]
+  float* d3;                // [B*49][64]  dense copy of the conv3-output delta (regular B operand of conv3 wgrad)
+  float* d2;                // [B*81][64]  dense copy of the conv2-output delta (regular B operand of conv2 wgrad)
   float* d1;                // [B][20][20][32]
   float* g;                 // flat gradient sum (internal layout)
   float* slab1;             // conv wgrad split-K slabs [ns][NWx]
@@ -150,6 +152,10 @@ SDQN_HD int prow2(int m) {                                   // (n,p,q) of conv2
 struct Conv1Fwd {   // fused gather + normalise + conv1 + ReLU: replay_memory.py:71-72 + deepqnetwork.py:94-100,83
   static constexpr int WM = 2, WN = 1, WK = 2; static constexpr bool A_K = true, B_K = false;
   typedef int64_t aoff_t;
+  // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
+  static constexpr bool A_REG = false, A_U8 = true, B_REG = true; static constexpr int A_LD = 0, B_LD = K1;
+  SDQN_HD static const float* a_ptr(const StepArgs& a, int z) { (void)z; return (const float*)nullptr; }
+  SDQN_HD static const float* b_ptr(const StepArgs& a, int z) { (void)z; return a.theta[z] + OFF1; }
 #if defined(__HIPCC__)
   struct Epi {};
   __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
@@ -175,6 +181,10 @@ struct Conv1Fwd {   // fused gather + normalise + conv1 + ReLU: replay_memory.py
 struct Conv2Fwd {   // deepqnetwork.py:85
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = false;
   typedef int aoff_t;
+  // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
+  static constexpr bool A_REG = false, A_U8 = false, B_REG = true; static constexpr int A_LD = 0, B_LD = K2;
+  SDQN_HD static const float* a_ptr(const StepArgs& a, int z) { (void)z; return a.a1; }
+  SDQN_HD static const float* b_ptr(const StepArgs& a, int z) { (void)z; return a.theta[z] + OFF2; }
 #if defined(__HIPCC__)
   struct Epi {};
   __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
@@ -200,6 +210,10 @@ struct Conv2Fwd {   // deepqnetwork.py:85
 struct Conv3Fwd {   // deepqnetwork.py:87
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = false;
   typedef int aoff_t;
+  // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
+  static constexpr bool A_REG = false, A_U8 = false, B_REG = true; static constexpr int A_LD = 0, B_LD = K3;
+  SDQN_HD static const float* a_ptr(const StepArgs& a, int z) { (void)z; return a.a2; }
+  SDQN_HD static const float* b_ptr(const StepArgs& a, int z) { (void)z; return a.theta[z] + OFF3; }
 #if defined(__HIPCC__)
   struct Epi {};
   __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
@@ -225,6 +239,10 @@ struct Conv3Fwd {   // deepqnetwork.py:87
 struct Fc4Fwd {     // deepqnetwork.py:89, split-K over S4 slabs; bias-free, ReLU applied by the head kernel
   static constexpr int WM = 1, WN = 2, WK = 2; static constexpr bool A_K = true, B_K = false;
   typedef int aoff_t;
+  // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
+  static constexpr bool A_REG = false, A_U8 = false, B_REG = true; static constexpr int A_LD = 0, B_LD = NFC;
+  SDQN_HD static const float* a_ptr(const StepArgs& a, int z) { (void)z; return a.a3; }
+  SDQN_HD static const float* b_ptr(const StepArgs& a, int z) { (void)z; return a.theta[z] + OFF4; }
 #if defined(__HIPCC__)
   struct Epi {};
   __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
@@ -255,6 +273,10 @@ struct Fc4Fwd {     // deepqnetwork.py:89, split-K over S4 slabs; bias-free, ReL
 struct Fc4Dgrad {   // delta3 = (W4^T delta4) * 1[a3 > 0]  (A5, A8), written straight into the padded d3p
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
   typedef int aoff_t;
+  // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
+  static constexpr bool A_REG = false, A_U8 = false, B_REG = false; static constexpr int A_LD = 0, B_LD = 0;
+  SDQN_HD static const float* a_ptr(const StepArgs& a, int z) { (void)z; return a.d4; }
+  SDQN_HD static const float* b_ptr(const StepArgs& a, int z) { (void)z; return a.theta[0] + OFF4; }
 #if defined(__HIPCC__)
   struct Epi {};
   __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
@@ -275,13 +297,19 @@ struct Fc4Dgrad {   // delta3 = (W4^T delta4) * 1[a3 > 0]  (A5, A8), written str
   SDQN_HD static void store(const StepArgs& a, int, int, int m, int n, float v) {
     int pix = n >> 6, f = n & 63, p = pix / Q3, q = pix - p * Q3;
     bool on = a.a3[(int64_t)m * NIN4 + n] > 0.0f;
-    a.d3p[((m * PD3 + p + 2) * PD3 + q + 2) * K3 + f] = on ? v : 0.0f;
+    const float dv = on ? v : 0.0f;
+    a.d3p[((m * PD3 + p + 2) * PD3 + q + 2) * K3 + f] = dv;      // padded plane: operand of conv3 dgrad
+    a.d3[(int64_t)m * NIN4 + n] = dv;                             // dense [(n,pix)][f]: operand of conv3 wgrad
   }
 };
 
 struct Fc4Wgrad {   // gW4 = delta4 . a3^T (sum over batch, A8) in the W4i layout; no split (K = B)
   static constexpr int WM = 2, WN = 2, WK = 1; static constexpr bool A_K = false, B_K = false;
   typedef int aoff_t;
+  // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
+  static constexpr bool A_REG = true, A_U8 = false, B_REG = true; static constexpr int A_LD = NIN4, B_LD = NFC;
+  SDQN_HD static const float* a_ptr(const StepArgs& a, int z) { (void)z; return a.a3; }
+  SDQN_HD static const float* b_ptr(const StepArgs& a, int z) { (void)z; return a.d4; }
   SDQN_HD static int M(const StepArgs&) { return NIN4; }
   SDQN_HD static int N(const StepArgs&) { return NFC; }
   SDQN_HD static int nbz(const StepArgs&) { return 1; }
@@ -333,6 +361,10 @@ struct Fc4Wgrad {   // gW4 = delta4 . a3^T (sum over batch, A8) in the W4i layou
 struct Conv3Dgrad { // delta2 = full-correlation(d3p, W3) * 1[a2 > 0], written into the padded d2p
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
   typedef int aoff_t;
+  // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
+  static constexpr bool A_REG = false, A_U8 = false, B_REG = false; static constexpr int A_LD = 0, B_LD = 0;
+  SDQN_HD static const float* a_ptr(const StepArgs& a, int z) { (void)z; return a.d3p; }
+  SDQN_HD static const float* b_ptr(const StepArgs& a, int z) { (void)z; return a.theta[0] + OFF3; }
 #if defined(__HIPCC__)
   struct Epi {};
   __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
@@ -358,13 +390,19 @@ struct Conv3Dgrad { // delta2 = full-correlation(d3p, W3) * 1[a2 > 0], written i
   SDQN_HD static f4 b_load4(const StepArgs& a, int, int o) { return ld4(a.theta[0] + OFF3 + o); }
   SDQN_HD static void store(const StepArgs& a, int, int, int m, int c, float v) {
     bool on = a.a2[(int64_t)m * K2 + c] > 0.0f;
-    a.d2p[prow2(m) + c] = on ? v : 0.0f;
+    const float dv = on ? v : 0.0f;
+    a.d2p[prow2(m) + c] = dv;                                     // padded plane: operand of conv2 dgrad
+    a.d2[(int64_t)m * K2 + c] = dv;                               // dense: operand of conv2 wgrad
   }
 };
 
 struct Conv3Wgrad { // gW3[(r,s,c)][f] = sum_(n,p,q) a2 patch * delta3   (Neon update_conv), split-K slabs
   static constexpr int WM = 2, WN = 2, WK = 1; static constexpr bool A_K = false, B_K = false;
   typedef int aoff_t;
+  // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
+  static constexpr bool A_REG = false, A_U8 = false, B_REG = true; static constexpr int A_LD = 0, B_LD = K3;
+  SDQN_HD static const float* a_ptr(const StepArgs& a, int z) { (void)z; return a.a2; }
+  SDQN_HD static const float* b_ptr(const StepArgs& a, int z) { (void)z; return a.d3; }
 #if defined(__HIPCC__)
   struct Epi {};
   __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
@@ -381,16 +419,20 @@ struct Conv3Wgrad { // gW3[(r,s,c)][f] = sum_(n,p,q) a2 patch * delta3   (Neon u
   SDQN_HD static aoff_t a_col(const StepArgs& a, int, int k) { return row3(a, 0, k); }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a2[o]; }
   SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4(a.a2 + o); }
-  SDQN_HD static int b_row(const StepArgs&, int, int k) { return prow3(k); }
+  SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * K3; }
   SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
-  SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.d3p[o]; }
-  SDQN_HD static f4 b_load4(const StepArgs& a, int, int o) { return ld4(a.d3p + o); }
+  SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.d3[o]; }
+  SDQN_HD static f4 b_load4(const StepArgs& a, int, int o) { return ld4(a.d3 + o); }
   SDQN_HD static void store(const StepArgs& a, int, int ks, int m, int n, float v) { a.slab3[(int64_t)ks * NW3 + m * K3 + n] = v; }
 };
 
 struct Conv2Dgrad { // stride-2 dgrad as 4 parity classes (z = py*2+px), each a dense 2x2 correlation over d2p
   static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
   typedef int aoff_t;
+  // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
+  static constexpr bool A_REG = false, A_U8 = false, B_REG = false; static constexpr int A_LD = 0, B_LD = 0;
+  SDQN_HD static const float* a_ptr(const StepArgs& a, int z) { (void)z; return a.d2p; }
+  SDQN_HD static const float* b_ptr(const StepArgs& a, int z) { (void)z; return a.theta[0] + OFF2; }
 #if defined(__HIPCC__)
   struct Epi {};
   __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
@@ -428,6 +470,10 @@ struct Conv2Dgrad { // stride-2 dgrad as 4 parity classes (z = py*2+px), each a 
 struct Conv2Wgrad {
   static constexpr int WM = 2, WN = 2, WK = 1; static constexpr bool A_K = false, B_K = false;
   typedef int aoff_t;
+  // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
+  static constexpr bool A_REG = false, A_U8 = false, B_REG = true; static constexpr int A_LD = 0, B_LD = K2;
+  SDQN_HD static const float* a_ptr(const StepArgs& a, int z) { (void)z; return a.a1; }
+  SDQN_HD static const float* b_ptr(const StepArgs& a, int z) { (void)z; return a.d2; }
 #if defined(__HIPCC__)
   struct Epi {};
   __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
@@ -444,16 +490,20 @@ struct Conv2Wgrad {
   SDQN_HD static aoff_t a_col(const StepArgs& a, int, int k) { return row2(a, 0, k); }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return a.a1[o]; }
   SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4(a.a1 + o); }
-  SDQN_HD static int b_row(const StepArgs&, int, int k) { return prow2(k); }
+  SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * K2; }
   SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
-  SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.d2p[o]; }
-  SDQN_HD static f4 b_load4(const StepArgs& a, int, int o) { return ld4(a.d2p + o); }
+  SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.d2[o]; }
+  SDQN_HD static f4 b_load4(const StepArgs& a, int, int o) { return ld4(a.d2 + o); }
   SDQN_HD static void store(const StepArgs& a, int, int ks, int m, int n, float v) { a.slab2[(int64_t)ks * NW2 + m * K2 + n] = v; }
 };
 
 struct Conv1Wgrad { // re-gathers the normalised u8 patches from the ring (no fp32 input copy is ever stored)
   static constexpr int WM = 2, WN = 1, WK = 2; static constexpr bool A_K = false, B_K = false;
   typedef int64_t aoff_t;
+  // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
+  static constexpr bool A_REG = false, A_U8 = true, B_REG = true; static constexpr int A_LD = 0, B_LD = K1;
+  SDQN_HD static const float* a_ptr(const StepArgs& a, int z) { (void)z; return (const float*)nullptr; }
+  SDQN_HD static const float* b_ptr(const StepArgs& a, int z) { (void)z; return a.d1; }
 #if defined(__HIPCC__)
   struct Epi {};
   __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}

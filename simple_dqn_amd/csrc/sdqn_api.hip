@@ -293,6 +293,7 @@ struct sdqn_net_s {
   float *theta = nullptr, *theta_t = nullptr, *state = nullptr, *state2 = nullptr, *g = nullptr;
   int epoch = 0;
   float *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *slab4 = nullptr, *a4 = nullptr, *d4 = nullptr;
+  float *d3 = nullptr, *d2 = nullptr;
   float *d3p = nullptr, *d2p = nullptr, *d1 = nullptr, *slab1 = nullptr, *slab2 = nullptr, *slab3 = nullptr;
   float *q = nullptr, *maxq = nullptr, *dq = nullptr, *cost_terms = nullptr, *cost_out = nullptr; double* cost_accum = nullptr;
   uint8_t *st_states = nullptr, *st_act = nullptr, *st_term = nullptr; int64_t* st_rew = nullptr; int64_t* d_idx = nullptr;
@@ -365,6 +366,8 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->d3p, (size_t)B * PD3 * PD3 * K3 * 4));    // borders stay zero for ever
   NCHK(dalloc(h, (void**)&h->d2p, (size_t)B * PD2 * PD2 * K2 * 4));
   NCHK(dalloc(h, (void**)&h->d1, (size_t)B * PIX1 * K1 * 4));
+  NCHK(dalloc(h, (void**)&h->d3, (size_t)B * PIX3 * K3 * 4));
+  NCHK(dalloc(h, (void**)&h->d2, (size_t)B * PIX2 * K2 * 4));
   NCHK(dalloc(h, (void**)&h->slab1, (size_t)h->ns1 * NW1 * 4));
   NCHK(dalloc(h, (void**)&h->slab2, (size_t)h->ns2 * NW2 * 4));
   NCHK(dalloc(h, (void**)&h->slab3, (size_t)h->ns3 * NW3 * 4));
@@ -465,7 +468,7 @@ extern "C" int sdqn_net_profile_reset(sdqn_net_t h) {
 static StepArgs step_args(sdqn_net_s* h) {
   StepArgs a; memset(&a, 0, sizeof a);
   a.B = h->B; a.A = h->A; a.nz = 2; a.theta[0] = h->theta; a.theta[1] = h->theta_t;
-  a.a1 = h->a1; a.a2 = h->a2; a.a3 = h->a3; a.slab4 = h->slab4; a.a4 = h->a4; a.d4 = h->d4; a.d3p = h->d3p; a.d2p = h->d2p;
+  a.a1 = h->a1; a.a2 = h->a2; a.a3 = h->a3; a.slab4 = h->slab4; a.a4 = h->a4; a.d4 = h->d4; a.d3p = h->d3p; a.d2p = h->d2p; a.d3 = h->d3; a.d2 = h->d2;
   a.d1 = h->d1; a.g = h->g; a.slab1 = h->slab1; a.slab2 = h->slab2; a.slab3 = h->slab3;
   a.S4 = h->S4; a.tps1 = h->tps1; a.tps2 = h->tps2; a.tps3 = h->tps3;
   for (int i = 0; i < 12; ++i) a.nw_override[i] = h->nw_override[i];
@@ -732,3 +735,25 @@ extern "C" int sdqn_dp_shutdown(sdqn_net_t h) {
   h->rank = 0; h->nranks = 1;
   return SDQN_OK;
 }
+
+#ifdef SDQN_TIMING
+namespace sdqn { hipError_t set_timing_buffer(unsigned long long* p); }
+// experiment-only build (make timing): run ONE kernel id of the step with phase stamps; returns [blocks][8] cycles
+extern "C" int sdqn_debug_time_kernel(sdqn_net_t h, sdqn_replay_t r, const int64_t* idx_host, int kernel, unsigned long long* out, int max_blocks) {
+  ARGCHK(h && r && idx_host && out, "NULL");
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, (size_t)max_blocks * 64));
+  HIPCHK(hipMemset(d, 0, (size_t)max_blocks * 64));
+  int slot; const int64_t* pinned; int rc = replay_push_idx(r, idx_host, &slot, &pinned); if (rc) return rc;
+  PrepArgs p = prep_args(h, r, pinned); HIPCHK(launch_prep(p, g_stream));
+  StepArgs a = step_args(h); a.from_ring = 1; a.src = r->d_ring; a.idx = h->d_idx;
+  HIPCHK(hipStreamSynchronize(g_stream));
+  HIPCHK(set_timing_buffer(d));
+  for (int rep = 0; rep < 3; ++rep) HIPCHK(launch_kernel(kernel, a, g_stream));   // last launch's stamps survive
+  HIPCHK(hipStreamSynchronize(g_stream));
+  HIPCHK(set_timing_buffer(nullptr));
+  HIPCHK(hipMemcpy(out, d, (size_t)max_blocks * 64, hipMemcpyDeviceToHost));
+  hipFree(d);
+  return replay_release_idx(r, slot);
+}
+#endif

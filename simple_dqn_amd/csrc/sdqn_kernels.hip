@@ -141,6 +141,10 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   if (j < a.A) h.dq[(int64_t)n * a.A + j] = (j == act) ? dc : 0.0f;
 }
 
+#ifdef SDQN_TIMING
+hipError_t set_timing_buffer(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sdqn_dbg), &p, sizeof p); }
+#endif
+
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
   hipLaunchKernelGGL(head_kernel, dim3(a.B), dim3(512), 0, s, a, h);
   return hipGetLastError();

@@ -55,11 +55,11 @@ extern "C" int emul_step(int B, int A, const float* const* w_online /*5, Neon*/,
   a.S4 = 7; a.tps1 = 3; a.tps2 = 2; a.tps3 = 2;
   std::vector<float> a1((size_t)2 * B * PIX1 * K1), a2((size_t)2 * B * PIX2 * K2), a3((size_t)2 * B * PIX3 * K3),
       slab4((size_t)a.S4 * 2 * B * NFC), a4((size_t)2 * B * NFC), d4((size_t)B * NFC), d3p((size_t)B * PD3 * PD3 * K3, 0.f),
-      d2p((size_t)B * PD2 * PD2 * K2, 0.f), d1((size_t)B * PIX1 * K1);
+      d2p((size_t)B * PD2 * PD2 * K2, 0.f), d1((size_t)B * PIX1 * K1), d3((size_t)B * PIX3 * K3), d2((size_t)B * PIX2 * K2);
   const int ns1 = Conv1Wgrad::nbz(a), ns2 = Conv2Wgrad::nbz(a), ns3 = Conv3Wgrad::nbz(a);
   std::vector<float> s1((size_t)ns1 * NW1), s2((size_t)ns2 * NW2), s3((size_t)ns3 * NW3);
   a.a1 = a1.data(); a.a2 = a2.data(); a.a3 = a3.data(); a.slab4 = slab4.data(); a.a4 = a4.data(); a.d4 = d4.data();
-  a.d3p = d3p.data(); a.d2p = d2p.data(); a.d1 = d1.data(); a.g = g.data(); a.slab1 = s1.data(); a.slab2 = s2.data(); a.slab3 = s3.data();
+  a.d3p = d3p.data(); a.d2p = d2p.data(); a.d3 = d3.data(); a.d2 = d2.data(); a.d1 = d1.data(); a.g = g.data(); a.slab1 = s1.data(); a.slab2 = s2.data(); a.slab3 = s3.data();
   run<Conv1Fwd>(a); run<Conv2Fwd>(a); run<Conv3Fwd>(a); run<Fc4Fwd>(a);
   // head (mirrors head_kernel in sdqn_kernels.hip)
   std::vector<float> dq((size_t)B * A, 0.f);
