@@ -302,7 +302,7 @@ struct sdqn_net_s {
   int64_t train_iterations = 0;
   bool keep_grads = false;                 // true: fc4 gradient materialised in g (readable with which=3), no fused RMSProp
   int nw_override[12] = {0};               // tuning hook
-  int f4_share[2] = {34, 33};              // % of the fc4-wgrad tiles in bwd3 / bwd2 (rest in bwd1)
+  int f4_share[2] = {100, 0};               // % of the fc4-wgrad tiles in bwd3 / bwd2 (rest in bwd1)
   int S4_override = 0, tps_override[3] = {0, 0, 0};
   bool fused_launches = true;              // independent backward stages share one launch (K_BWD3, K_BWD2)
   bool two_streams = false;                // weight-gradient kernels on the side stream (measured slower eagerly: event waits)

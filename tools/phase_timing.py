@@ -1,6 +1,6 @@
 """Experiment (not product): per-phase s_memtime stamps of the tile engine, from the -DSDQN_TIMING build."""
 import ctypes as C, os, sys, random
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import simple_dqn_amd._lib as L
 L.lib_path = lambda: os.path.join(os.path.dirname(os.path.abspath(L.__file__)), "libsdqn_hip_timing.so")

@@ -1,6 +1,6 @@
 """Tuning helper (not product): per-kernel HIP-event time for different waves-per-tile settings."""
 import sys, os, random, json
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import simple_dqn_amd as sd
 from util import make_args
