@@ -185,6 +185,7 @@ __device__ inline void opt_apply4(float* __restrict__ theta, float* __restrict__
 //   blockIdx.x >= CONV_BLOCKS : fc4 (g written by fc4_wgrad) and fc5 (wgrad computed here), elementwise
 constexpr int CONV_F4 = OFF4 / 4;                 // 19456 float4 of conv parameters
 constexpr int CONV_BLOCKS = CONV_F4 / 32;         // 608
+constexpr int FC5_BLOCKS_PER_ACTION = NFC / 4 / 32;   // 4 workgroups of 32 float4 columns per action row
 
 __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
   __shared__ float4 part[8][32];
@@ -227,29 +228,57 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
     if (sg == 0 && u.mode != 1) opt_apply4(u.theta, u.state, u.state2, e, gs, u);
     return;
   }
-  const int64_t NP4 = (OFF5 + (int64_t)u.A * NFC) / 4;
-  const int nb = gridDim.x - CONV_BLOCKS;
-  const int64_t first4 = u.skip_fc4 ? OFF5 / 4 : CONV_F4;
-  for (int64_t i4 = first4 + (int64_t)(blockIdx.x - CONV_BLOCKS) * 256 + t; i4 < NP4; i4 += (int64_t)nb * 256) {
-    const int64_t e = i4 * 4;
-    float4 gs;
-    if (u.mode == 2 || e < OFF5) {
-      gs = *reinterpret_cast<const float4*>(u.g + e);              // fc4 wgrad wrote g directly; mode 2: all-reduced g
-    } else {                                                       // fc5 wgrad: delta . a4^T  (A x 512, tiny)
-      const int64_t o = e - OFF5;
-      const int act = (int)(o / NFC), j0 = (int)(o - (int64_t)act * NFC);
-      gs = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-      for (int n = 0; n < u.B; ++n) {                                // 8 independent 16 B loads in flight
+  const int fc5_blocks = u.A * FC5_BLOCKS_PER_ACTION;
+  if ((int)blockIdx.x < CONV_BLOCKS + fc5_blocks) {
+    // fc5 wgrad (delta . a4^T, A x 512) + its update: the batch plays the role of the slabs — 8 sample groups
+    // per workgroup, fixed-order LDS combine (deterministic)
+    const int fb = blockIdx.x - CONV_BLOCKS, c4 = t & 31, sg = t >> 5;
+    const int act = fb / FC5_BLOCKS_PER_ACTION, j0 = ((fb - act * FC5_BLOCKS_PER_ACTION) * 32 + c4) * 4;
+    const int64_t e = OFF5 + (int64_t)act * NFC + j0;
+    float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (u.mode == 2) {
+      if (sg == 0) gs = *reinterpret_cast<const float4*>(u.g + e);
+    } else {
+      int n = sg;
+      for (; n + 24 < u.B; n += 32) {
+        const float d0 = u.dq[(int64_t)n * u.A + act], d1 = u.dq[(int64_t)(n + 8) * u.A + act];
+        const float d2 = u.dq[(int64_t)(n + 16) * u.A + act], d3 = u.dq[(int64_t)(n + 24) * u.A + act];
+        const float4 v0 = *reinterpret_cast<const float4*>(u.a4 + (int64_t)n * NFC + j0);
+        const float4 v1 = *reinterpret_cast<const float4*>(u.a4 + (int64_t)(n + 8) * NFC + j0);
+        const float4 v2 = *reinterpret_cast<const float4*>(u.a4 + (int64_t)(n + 16) * NFC + j0);
+        const float4 v3 = *reinterpret_cast<const float4*>(u.a4 + (int64_t)(n + 24) * NFC + j0);
+        gs.x += d0 * v0.x; gs.y += d0 * v0.y; gs.z += d0 * v0.z; gs.w += d0 * v0.w;
+        gs.x += d1 * v1.x; gs.y += d1 * v1.y; gs.z += d1 * v1.z; gs.w += d1 * v1.w;
+        gs.x += d2 * v2.x; gs.y += d2 * v2.y; gs.z += d2 * v2.z; gs.w += d2 * v2.w;
+        gs.x += d3 * v3.x; gs.y += d3 * v3.y; gs.z += d3 * v3.z; gs.w += d3 * v3.w;
+      }
+      for (; n < u.B; n += 8) {
         const float d = u.dq[(int64_t)n * u.A + act];
         const float4 v = *reinterpret_cast<const float4*>(u.a4 + (int64_t)n * NFC + j0);
         gs.x += d * v.x; gs.y += d * v.y; gs.z += d * v.z; gs.w += d * v.w;
       }
-      *reinterpret_cast<float4*>(u.g + e) = gs;
+      part[sg][c4] = gs;
+      __syncthreads();
+      if (sg == 0) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) { const float4 v = part[k][c4]; gs.x += v.x; gs.y += v.y; gs.z += v.z; gs.w += v.w; }
+        *reinterpret_cast<float4*>(u.g + e) = gs;
+      }
     }
-    if (u.mode != 1) opt_apply4(u.theta, u.state, u.state2, e, gs, u);
+    if (sg == 0 && u.mode != 1) opt_apply4(u.theta, u.state, u.state2, e, gs, u);
+    return;
   }
-  if (u.next.B > 0 && (int)blockIdx.x == CONV_BLOCKS + 1) {         // next step's prep rides along (every reader of idx is done)
+  // fc4: g written by fc4_wgrad (or all-reduced), elementwise; skipped when fused into fc4_wgrad's epilogue
+  const int first_dense = CONV_BLOCKS + fc5_blocks;
+  const int nb = gridDim.x - first_dense;
+  if (!u.skip_fc4) {
+    for (int64_t i4 = CONV_F4 + (int64_t)(blockIdx.x - first_dense) * 256 + t; i4 < OFF5 / 4; i4 += (int64_t)nb * 256) {
+      const int64_t e = i4 * 4;
+      const float4 gs = *reinterpret_cast<const float4*>(u.g + e);
+      if (u.mode != 1) opt_apply4(u.theta, u.state, u.state2, e, gs, u);
+    }
+  }
+  if (u.next.B > 0 && (int)blockIdx.x == first_dense) {             // next step's prep rides along (every reader of idx is done)
     for (int n = t; n < u.next.B; n += 256) {
       const int64_t i = u.next.idx_pinned[n];
       u.next.idx[n] = i;
@@ -257,7 +286,7 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
       u.next.actions[n] = rec.action; u.next.rewards[n] = rec.reward; u.next.terminals[n] = rec.terminal;
     }
   }
-  if (u.mode != 2 && (int)blockIdx.x == CONV_BLOCKS && t == 0) {   // get_cost: mean over the batch, :154
+  if (u.mode != 2 && (int)blockIdx.x == first_dense + (nb > 1 ? 1 : 0) && t == 0) {   // get_cost: mean over the batch, :154
     float c = 0.0f;
     for (int n = 0; n < u.B; ++n) c += u.cost_terms[n];
     c = c / (float)u.B;
@@ -267,11 +296,9 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
 }
 
 hipError_t launch_update(const UpdateArgs& u, hipStream_t s) {
-  const int64_t NP4 = (OFF5 + (int64_t)u.A * NFC) / 4 - (u.skip_fc4 ? OFF5 / 4 : CONV_F4);
-  int blocks = (int)((NP4 + 255) / 256);
-  if (blocks > 1792) blocks = 1792;
-  if (blocks < 2) blocks = 2;                                      // block CONV_BLOCKS+1 hosts the ride-along prep
-  hipLaunchKernelGGL(update_kernel, dim3(CONV_BLOCKS + blocks), dim3(256), 0, s, u);
+  int dense = 2;                                                   // hosts the ride-along prep and the cost mean
+  if (!u.skip_fc4) { dense = (NW4 / 4 + 255) / 256; if (dense > 1792) dense = 1792; }
+  hipLaunchKernelGGL(update_kernel, dim3(CONV_BLOCKS + u.A * FC5_BLOCKS_PER_ACTION + dense), dim3(256), 0, s, u);
   return hipGetLastError();
 }
 
