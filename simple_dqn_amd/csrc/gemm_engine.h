@@ -112,61 +112,62 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
   typename P::Epi epi;
   if constexpr (NW == 1) P::epi_begin(a, m0, n0, lane, epi);
 
-  float ra[16], rb[16];                       // next chunk's operands (4 x f4, or 16 scalars in MFMA layout)
-  auto load_chunk = [&](int kc) {
+  // k-contiguous operands are software-prefetched one chunk ahead (registers -> wave-private LDS panel);
+  // x-contiguous operands are loaded straight into their MFMA registers at the top of the chunk (no second
+  // register set: keeps the kernels under ~80 VGPRs so 6-7 waves/SIMD stay resident and hide the latency)
+  float ra[P::A_K ? 16 : 1], rb[P::B_K ? 16 : 1];
+  auto load_a = [&](int kc, float* dst) {
     if constexpr (P::A_K) {
       const aoff_t c = P::a_col(a, z, kc + 4 * (lane & 7));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const f4 v = P::a_load4(a, z, arow[j] + c); ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w; }
-    } else {
-      if constexpr (P::A_REG) {
-        // plain row-major [k][m] matrix: per-lane pointer fixed for the whole tile, 16 loads at k-row offsets
-        if (kc + 32 <= kend) {
-          const float* p = areg + (size_t)kc * P::A_LD;
+      for (int j = 0; j < 4; ++j) { const f4 v = P::a_load4(a, z, arow[j] + c); dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w; }
+    } else if constexpr (P::A_REG) {
+      // plain row-major [k][m] matrix: per-lane pointer fixed for the whole tile, 16 loads at k-row offsets
+      if (kc + 32 <= kend) {
+        const float* p = areg + (size_t)kc * P::A_LD;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) ra[i] = p[(size_t)i * P::A_LD];
-        } else {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) { const int k = kc + i + (lane >= 32 ? 16 : 0); ra[i] = k < kend ? areg[(size_t)(k - (lane >= 32 ? 16 : 0)) * P::A_LD] : 0.0f; }
-        }
+        for (int i = 0; i < 16; ++i) dst[i] = p[(size_t)i * P::A_LD];
       } else {
-        // one im2col decomposition per lane per chunk (lane <-> k = kc + (l & 31)); step i fetches its
-        // offset from lane i (+16 for the upper half-wave) with v_readlane
-        const int kl = kc + (lane & 31);
-        const aoff_t cv = P::a_col(a, z, kl < kend ? kl : kbeg);
-        const bool hi = lane >= 32;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const aoff_t c = pick_half(cv, i, hi);
-          const bool ok = kc + i + (hi ? 16 : 0) < kend;
-          if constexpr (P::A_U8) ra[i] = ok ? P::a_load(a, z, arow[0] + c) : 0.0f;
-          else ra[i] = ok ? abase[(uint32_t)(arow[0] + c)] : 0.0f;       // uniform base + 32-bit lane offset
-        }
+        for (int i = 0; i < 16; ++i) { const int k = kc + i + (lane >= 32 ? 16 : 0); dst[i] = k < kend ? areg[(size_t)(kc + i) * P::A_LD] : 0.0f; }
+      }
+    } else {
+      // one im2col decomposition per lane per chunk (lane <-> k = kc + (l & 31)); step i fetches its
+      // offset from lane i (+16 for the upper half-wave) with v_readlane
+      const int kl = kc + (lane & 31);
+      const aoff_t cv = P::a_col(a, z, kl < kend ? kl : kbeg);
+      const bool hi = lane >= 32;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const aoff_t c = pick_half(cv, i, hi);
+        const bool ok = kc + i + (hi ? 16 : 0) < kend;
+        if constexpr (P::A_U8) dst[i] = ok ? P::a_load(a, z, arow[0] + c) : 0.0f;
+        else dst[i] = ok ? abase[(uint32_t)(arow[0] + c)] : 0.0f;       // uniform base + 32-bit lane offset
       }
     }
+  };
+  auto load_b = [&](int kc, float* dst) {
     if constexpr (P::B_K) {
       const int r = P::b_row(a, z, kc + 4 * (lane & 7));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const f4 v = P::b_load4(a, z, r + bcol[j]); rb[4 * j] = v.x; rb[4 * j + 1] = v.y; rb[4 * j + 2] = v.z; rb[4 * j + 3] = v.w; }
-    } else {
-      if constexpr (P::B_REG) {
-        if (kc + 32 <= kend) {
-          const float* p = breg + (size_t)kc * P::B_LD;
+      for (int j = 0; j < 4; ++j) { const f4 v = P::b_load4(a, z, r + bcol[j]); dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w; }
+    } else if constexpr (P::B_REG) {
+      if (kc + 32 <= kend) {
+        const float* p = breg + (size_t)kc * P::B_LD;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) rb[i] = p[(size_t)i * P::B_LD];
-        } else {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) { const int k = kc + i + (lane >= 32 ? 16 : 0); rb[i] = k < kend ? breg[(size_t)(k - (lane >= 32 ? 16 : 0)) * P::B_LD] : 0.0f; }
-        }
+        for (int i = 0; i < 16; ++i) dst[i] = p[(size_t)i * P::B_LD];
       } else {
-        const int kl = kc + (lane & 31);
-        const int rv = P::b_row(a, z, kl < kend ? kl : kbeg);
-        const bool hi = lane >= 32;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int r = pick_half(rv, i, hi);
-          rb[i] = kc + i + (hi ? 16 : 0) < kend ? bbase[(uint32_t)(r + bcol[0])] : 0.0f;
-        }
+        for (int i = 0; i < 16; ++i) { const int k = kc + i + (lane >= 32 ? 16 : 0); dst[i] = k < kend ? breg[(size_t)(kc + i) * P::B_LD] : 0.0f; }
+      }
+    } else {
+      const int kl = kc + (lane & 31);
+      const int rv = P::b_row(a, z, kl < kend ? kl : kbeg);
+      const bool hi = lane >= 32;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = pick_half(rv, i, hi);
+        dst[i] = kc + i + (hi ? 16 : 0) < kend ? bbase[(uint32_t)(r + bcol[0])] : 0.0f;
       }
     }
   };
@@ -177,29 +178,31 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
 
   int kc = kbeg + (wave < NW ? wave : 0) * 32;            // wave-uniform
   SDQN_STAMP(1);
-  if (kc < kend) load_chunk(kc);
+  if (kc < kend) {
+    if constexpr (P::A_K) load_a(kc, ra);
+    if constexpr (P::B_K) load_b(kc, rb);
+  }
   SDQN_STAMP(2);
   while (kc < kend) {
-    // ---- move the fetched chunk to its MFMA operands (through the wave-private panels if k-contiguous)
     float fa[16], fb[16];
+    if constexpr (!P::A_K) load_a(kc, fa);
+    if constexpr (!P::B_K) load_b(kc, fb);
+    // ---- k-contiguous operands: registers -> wave-private panel
     if constexpr (P::A_K) {
       float* d = pa + (4 * (lane & 7)) * 33 + (lane >> 3);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { d[8 * j] = ra[4 * j]; d[33 + 8 * j] = ra[4 * j + 1]; d[66 + 8 * j] = ra[4 * j + 2]; d[99 + 8 * j] = ra[4 * j + 3]; }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) fa[i] = ra[i];
     }
     if constexpr (P::B_K) {
       float* d = pb + (4 * (lane & 7)) * 33 + (lane >> 3);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { d[8 * j] = rb[4 * j]; d[33 + 8 * j] = rb[4 * j + 1]; d[66 + 8 * j] = rb[4 * j + 2]; d[99 + 8 * j] = rb[4 * j + 3]; }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) fb[i] = rb[i];
     }
     const int knext = kc + NW * 32;
-    if (knext < kend) load_chunk(knext);                 // next chunk's global loads fly under the MFMAs
+    if (knext < kend) {                                   // next chunk's k-contiguous loads fly under the MFMAs
+      if constexpr (P::A_K) load_a(knext, ra);
+      if constexpr (P::B_K) load_b(knext, rb);
+    }
     if constexpr (P::A_K || P::B_K) wave_lds_sync();
     if constexpr (P::A_K) {
       const float* s = pa + (lane >> 5) * (16 * 33) + (lane & 31);
@@ -285,15 +288,15 @@ __device__ __forceinline__ void multi_dispatch(const StepArgs& a, const MultiDim
   }
 }
 
-template <class P0, int NW0, class P1, int NW1, class P2, int NW2>
-__global__ void __launch_bounds__(1024) gemm_multi_kernel(const StepArgs a, const MultiDims d) {
+template <int NT, class P0, int NW0, class P1, int NW1, class P2, int NW2>
+__global__ void __launch_bounds__(NT) gemm_multi_kernel(const StepArgs a, const MultiDims d) {
   constexpr int L0 = tile_lds<P0, NW0>(), L1 = tile_lds<P1, NW1>(), L2 = tile_lds<P2, NW2>();
   constexpr int L = L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2);
   __shared__ float smem[L];
   const int b = blockIdx.x;                               // problem choice is workgroup-uniform
-  if (b < d.n[0]) multi_dispatch<P0, NW0, 1024>(a, d, 0, b, smem);
-  else if (b < d.n[0] + d.n[1]) multi_dispatch<P1, NW1, 1024>(a, d, 1, b - d.n[0], smem);
-  else multi_dispatch<P2, NW2, 1024>(a, d, 2, b - d.n[0] - d.n[1], smem);
+  if (b < d.n[0]) multi_dispatch<P0, NW0, NT>(a, d, 0, b, smem);
+  else if (b < d.n[0] + d.n[1]) multi_dispatch<P1, NW1, NT>(a, d, 1, b - d.n[0], smem);
+  else multi_dispatch<P2, NW2, NT>(a, d, 2, b - d.n[0] - d.n[1], smem);
 }
 
 struct NoProblem {            // placeholder third problem for two-problem launches (never dispatched: n[2] = 0)
@@ -323,20 +326,21 @@ inline hipError_t launch_gemm(const StepArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <class P, int NW>
+template <int NT, class P, int NW>
 inline void multi_fill(const StepArgs& a, MultiDims& d, int i) {
   d.gx[i] = (P::M(a) + 31) / 32; d.gy[i] = (P::N(a) + 31) / 32;
   const int tiles = d.gx[i] * d.gy[i] * P::nbz(a);
-  d.n[i] = NW == 1 ? (a.f4w_count + 15) / 16 : tiles;    // NW == 1: 16 tiles (one per wave) per workgroup, range from StepArgs
+  d.n[i] = NW == 1 ? (a.f4w_count + NT / 64 - 1) / (NT / 64) : tiles;    // NW == 1: one tile per wave, range from StepArgs
 }
-template <class P0, int NW0, class P1, int NW1, class P2, int NW2>
+template <int NT, class P0, int NW0, class P1, int NW1, class P2, int NW2>
 inline hipError_t launch_multi(const StepArgs& a, bool has1, bool has2, hipStream_t stream) {
+  static_assert(NW0 * 64 <= NT && NW1 * 64 <= NT && NW2 * 64 <= NT, "waves per tile exceed the workgroup");
   MultiDims d; memset(&d, 0, sizeof d);
-  multi_fill<P0, NW0>(a, d, 0);
-  if (has1) multi_fill<P1, NW1>(a, d, 1);
-  if (has2) multi_fill<P2, NW2>(a, d, 2);
+  multi_fill<NT, P0, NW0>(a, d, 0);
+  if (has1) multi_fill<NT, P1, NW1>(a, d, 1);
+  if (has2) multi_fill<NT, P2, NW2>(a, d, 2);
   if (d.n[0] + d.n[1] + d.n[2] == 0) return hipSuccess;
-  hipLaunchKernelGGL((gemm_multi_kernel<P0, NW0, P1, NW1, P2, NW2>), dim3(d.n[0] + d.n[1] + d.n[2]), dim3(1024), 0, stream, a, d);
+  hipLaunchKernelGGL((gemm_multi_kernel<NT, P0, NW0, P1, NW1, P2, NW2>), dim3(d.n[0] + d.n[1] + d.n[2]), dim3(NT), 0, stream, a, d);
   return hipGetLastError();
 }
 
