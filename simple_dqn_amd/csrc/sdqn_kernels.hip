@@ -61,17 +61,19 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
     case K_CONV2_DGRAD: return launch_gemm<Conv2Dgrad, 8>(a, s);    // K = 256 per parity class
     case K_CONV2_WGRAD: return launch_gemm<Conv2Wgrad, 16>(a, s);
     case K_CONV1_WGRAD: return launch_gemm<Conv1Wgrad, 16>(a, s);
-    // multi-problem launches; Fc4Wgrad is the "fc4 share" problem, always first so its memory-bound
-    // read-modify-write stream starts earliest (single tile per wave when B <= 32, else 8 K-split waves)
+    // multi-problem launches.  512-thread workgroups (8 waves): at <= 90 VGPRs two of them are resident per CU,
+    // so every tile of the launch is resident at once and the problems' latency chains overlap.  Fc4Wgrad is the
+    // first problem so its memory-bound read-modify-write stream starts earliest (one tile per wave at B <= 32).
     case K_BWD3:
-      if (a.B <= 32) return launch_multi<Fc4Wgrad, 1, Conv3Dgrad, 9, Conv3Wgrad, 16>(a, true, true, s);
-      return launch_multi<Fc4Wgrad, 8, Conv3Dgrad, 9, Conv3Wgrad, 16>(a, true, true, s);
+      if (a.B <= 32 && a.f4w_count > 0) return launch_multi<512, Fc4Wgrad, 1, Conv3Dgrad, 8, Conv3Wgrad, 8>(a, true, true, s);
+      if (a.f4w_count > 0) return launch_multi<512, Fc4Wgrad, 8, Conv3Dgrad, 8, Conv3Wgrad, 8>(a, true, true, s);
+      return launch_multi<512, NoProblem, 2, Conv3Dgrad, 8, Conv3Wgrad, 8>(a, true, true, s);
     case K_BWD2:
-      if (a.B <= 32) return launch_multi<Fc4Wgrad, 1, Conv2Dgrad, 8, Conv2Wgrad, 16>(a, true, true, s);
-      return launch_multi<NoProblem, 2, Conv2Dgrad, 8, Conv2Wgrad, 16>(a, true, true, s);
+      if (a.B <= 32 && a.f4w_count > 0) return launch_multi<512, Fc4Wgrad, 1, Conv2Dgrad, 8, Conv2Wgrad, 8>(a, true, true, s);
+      return launch_multi<512, NoProblem, 2, Conv2Dgrad, 8, Conv2Wgrad, 8>(a, true, true, s);
     case K_BWD1:
-      if (a.B <= 32) return launch_multi<Fc4Wgrad, 1, Conv1Wgrad, 16, NoProblem, 2>(a, true, false, s);
-      return launch_multi<NoProblem, 2, Conv1Wgrad, 16, NoProblem, 2>(a, true, false, s);
+      if (a.B <= 32 && a.f4w_count > 0) return launch_multi<1024, Fc4Wgrad, 1, Conv1Wgrad, 16, NoProblem, 2>(a, true, false, s);
+      return launch_multi<1024, NoProblem, 2, Conv1Wgrad, 16, NoProblem, 2>(a, true, false, s);
     default: return hipErrorInvalidValue;
   }
 }
