@@ -56,10 +56,10 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
       if (a.B <= 64) return launch_gemm<Fc4Wgrad, 2>(a, s);
       if (a.B <= 128) return launch_gemm<Fc4Wgrad, 4>(a, s);
       return launch_gemm<Fc4Wgrad, 8>(a, s);
-    case K_CONV3_DGRAD: return launch_gemm<Conv3Dgrad, 9>(a, s);    // K = 576
-    case K_CONV3_WGRAD: return launch_gemm<Conv3Wgrad, 16>(a, s);   // K = B*49 split over slabs
+    case K_CONV3_DGRAD: return launch_gemm<Conv3Dgrad, 8>(a, s);    // K = 576 (same split as inside K_BWD3: bit-identical)
+    case K_CONV3_WGRAD: return launch_gemm<Conv3Wgrad, 8>(a, s);    // K = B*49 split over slabs
     case K_CONV2_DGRAD: return launch_gemm<Conv2Dgrad, 8>(a, s);    // K = 256 per parity class
-    case K_CONV2_WGRAD: return launch_gemm<Conv2Wgrad, 16>(a, s);
+    case K_CONV2_WGRAD: return launch_gemm<Conv2Wgrad, 8>(a, s);
     case K_CONV1_WGRAD: return launch_gemm<Conv1Wgrad, 16>(a, s);
     // multi-problem launches.  512-thread workgroups (8 waves): at <= 90 VGPRs two of them are resident per CU,
     // so every tile of the launch is resident at once and the problems' latency chains overlap.  Fc4Wgrad is the
