@@ -52,15 +52,15 @@ def kernel_work(B, A):
         9: dict(bytes=a2 + w2 + 2 * a1, flops=2 * B * 400 * 32 * 256),
         10: dict(bytes=a1 + a2 + w2, flops=2 * B * 81 * 64 * 512),
         11: dict(bytes=B * 5 * 7056 + a1 + w1, flops=2 * B * 400 * 32 * 256),
-        12: dict(bytes=npar * f * 5, flops=8 * npar),                                          # read W,s,g; write W,s
+        12: dict(bytes=(npar - 1605632) * f * 5 + (25 * w1 + 6 * w2 + 4 * w3), flops=8 * (npar - 1605632)),   # conv+fc5 params (fc4 is fused into bwd3) + slabs
         13: dict(bytes=npar * f, flops=0),
         14: dict(bytes=B * 13 * 7056, flops=0),
         15: dict(bytes=1024, flops=0),
-        16: dict(bytes=(a3 + w3 + 2 * a2) + (a2 + a3 + w3) + (a4 + a3 + 4 * w4) // 3, flops=2 * B * 81 * 64 * 576 + 2 * B * 49 * 64 * 576 + 2 * B * 512 * 3136 // 3),
-        17: dict(bytes=(a2 + w2 + 2 * a1) + (a1 + a2 + w2) + (a4 + a3 + 4 * w4) // 3, flops=2 * B * 400 * 32 * 256 + 2 * B * 81 * 64 * 512 + 2 * B * 512 * 3136 // 3),
-        18: dict(bytes=B * 5 * 7056 + a1 + w1 + (a4 + a3 + 4 * w4) // 3, flops=2 * B * 400 * 32 * 256 + 2 * B * 512 * 3136 // 3),
+        16: dict(bytes=(a3 + w3 + 2 * a2) + (a2 + a3 + w3) + (a4 + a3 + 4 * w4), flops=2 * B * 81 * 64 * 576 + 2 * B * 49 * 64 * 576 + 2 * B * 512 * 3136),
+        17: dict(bytes=(a2 + w2 + 2 * a1) + (a1 + a2 + w2), flops=2 * B * 400 * 32 * 256 + 2 * B * 81 * 64 * 512),
+        18: dict(bytes=B * 5 * 7056 + a1 + w1, flops=2 * B * 400 * 32 * 256),
     }
-    # (at B <= 32 the fc4 wgrad + fused RMSProp tiles are split ~1/3 each over bwd3 / bwd2 / bwd1)
+    # (default tile split: the whole fc4 wgrad + fused RMSProp read-modify-write — theta, s read and written — rides in bwd3)
 
 
 def pmc_traffic(name, B, A):
@@ -131,16 +131,27 @@ def cpu_baseline(B, A, seed, budget_s):
     net = OracleDQN(A, batch_size=B, weights=xavier_weights(A, seed + 1))
     rng = MT19937(seed + 2)
     net.train(mem.getMinibatch(rng))                      # warm
-    n, t0 = 0, time.perf_counter()
-    while True:
-        net.train(mem.getMinibatch(rng))
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 400:
-            break
+
+    def timed(budget):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            net.train(mem.getMinibatch(rng))
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget or n >= 400:
+                return n, el
+    # all host cores vs a 16-thread BLAS pool (many-core hosts oversubscribe on these small GEMMs): report the faster
+    runs = [(threads,) + timed(budget_s / 2)]
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=16):
+            runs.append((min(16, threads),) + timed(budget_s / 2))
+    except Exception:
+        pass
+    threads, n, el = max(runs, key=lambda r: r[1] / r[2])
     return dict(value=round(n / el, 2), unit="train_steps/sec", cores=int(threads), kind="port",
-                sample="%d steps of oracle ReplayOracle.getMinibatch + OracleDQN.train (numpy fp32, B=%d, A=%d, ring %d frames)"
-                       % (n, B, A, ring), ms_per_step=round(el / n * 1e3, 2))
+                sample="%d steps of oracle ReplayOracle.getMinibatch + OracleDQN.train (numpy fp32, B=%d, A=%d, ring %d frames); "
+                       "tried BLAS pools %s" % (n, B, A, ring, [r[0] for r in runs]), ms_per_step=round(el / n * 1e3, 2))
 
 
 def q_mae_vs_oracle(sd, B, A, seed):
