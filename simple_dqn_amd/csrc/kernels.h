@@ -75,7 +75,7 @@ struct GatherArgs {
   int B;
 };
 
-hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s);     // the GEMM-shaped stages
+hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s);     // the GEMM-shaped stages (single or multi-problem launches)
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s);
 hipError_t launch_update(const UpdateArgs& u, hipStream_t s);
 hipError_t launch_gather(const GatherArgs& g, hipStream_t s);

@@ -1,9 +1,10 @@
 // problems.h — every GEMM-shaped stage of the DQN train step expressed as
 //   C(m, n) = sum_k A(m, k) * B(k, n)      A(m,k) = srcA[a_row(m) + a_col(k)]
 //                                            B(k,n) = srcB[b_row(k) + b_col(n)]
-// i.e. im2col is never materialised: it is a separable gather the tile loader
-// performs while staging LDS tiles (gemm_engine.h).  The functions are
-// __host__ __device__ so tests/emul can execute the very same index math on the CPU.
+// i.e. im2col is never materialised: it is a separable gather performed by the tile engine's operand
+// loaders (gemm_engine.h).  The functions are __host__ __device__ so tests/emul can execute the very
+// same index math on the CPU.  Per problem: A_K/B_K say which dimension of the operand is contiguous in
+// memory, *_REG mark plain row-major matrices (fast path), store() is the fused epilogue.
 //
 // Reference: the layer stack of src/deepqnetwork.py:83-91 and Neon's
 // fprop/bprop/update semantics.
@@ -15,8 +16,8 @@
 //   W3i [(r,s,c)=576][64]   rows permuted from Neon's (c,r,s)
 //   W4i [(pix,f)=3136][512] == transpose of Neon (512, 3136[(f,pix)])
 //   W5i [A][512]            == Neon
-//   d3p [n][11][11][64]  conv3-output delta, zero-padded by 2 (full correlation for dgrad)
-//   d2p [n][11][11][64]  conv2-output delta, zero-padded by 1 (stride-2 parity decomposition)
+//   d3p [n][11][11][64]  conv3-output delta, zero-padded by 2 (full correlation for dgrad); d3 = dense copy
+//   d2p [n][11][11][64]  conv2-output delta, zero-padded by 1 (stride-2 parity decomposition); d2 = dense copy
 #pragma once
 #include <stdint.h>
 #include <math.h>
@@ -150,7 +151,7 @@ SDQN_HD int prow2(int m) {                                   // (n,p,q) of conv2
 
 // =========================== forward =====================================================
 struct Conv1Fwd {   // fused gather + normalise + conv1 + ReLU: replay_memory.py:71-72 + deepqnetwork.py:94-100,83
-  static constexpr int WM = 2, WN = 1, WK = 2; static constexpr bool A_K = true, B_K = false;
+  static constexpr bool A_K = true, B_K = false;     // operand contiguous along k (-> LDS transpose) or along m/n
   typedef int64_t aoff_t;
   // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
   static constexpr bool A_REG = false, A_U8 = true, B_REG = true; static constexpr int A_LD = 0, B_LD = K1;
@@ -179,7 +180,7 @@ struct Conv1Fwd {   // fused gather + normalise + conv1 + ReLU: replay_memory.py
 };
 
 struct Conv2Fwd {   // deepqnetwork.py:85
-  static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = false;
+  static constexpr bool A_K = true, B_K = false;     // operand contiguous along k (-> LDS transpose) or along m/n
   typedef int aoff_t;
   // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
   static constexpr bool A_REG = false, A_U8 = false, B_REG = true; static constexpr int A_LD = 0, B_LD = K2;
@@ -208,7 +209,7 @@ struct Conv2Fwd {   // deepqnetwork.py:85
 };
 
 struct Conv3Fwd {   // deepqnetwork.py:87
-  static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = false;
+  static constexpr bool A_K = true, B_K = false;     // operand contiguous along k (-> LDS transpose) or along m/n
   typedef int aoff_t;
   // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
   static constexpr bool A_REG = false, A_U8 = false, B_REG = true; static constexpr int A_LD = 0, B_LD = K3;
@@ -237,7 +238,7 @@ struct Conv3Fwd {   // deepqnetwork.py:87
 };
 
 struct Fc4Fwd {     // deepqnetwork.py:89, split-K over S4 slabs; bias-free, ReLU applied by the head kernel
-  static constexpr int WM = 1, WN = 2, WK = 2; static constexpr bool A_K = true, B_K = false;
+  static constexpr bool A_K = true, B_K = false;     // operand contiguous along k (-> LDS transpose) or along m/n
   typedef int aoff_t;
   // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
   static constexpr bool A_REG = false, A_U8 = false, B_REG = true; static constexpr int A_LD = 0, B_LD = NFC;
@@ -271,7 +272,7 @@ struct Fc4Fwd {     // deepqnetwork.py:89, split-K over S4 slabs; bias-free, ReL
 
 // =========================== backward (online net, z = 0) ===================================
 struct Fc4Dgrad {   // delta3 = (W4^T delta4) * 1[a3 > 0]  (A5, A8), written straight into the padded d3p
-  static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
+  static constexpr bool A_K = true, B_K = true;     // operand contiguous along k (-> LDS transpose) or along m/n
   typedef int aoff_t;
   // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
   static constexpr bool A_REG = false, A_U8 = false, B_REG = false; static constexpr int A_LD = 0, B_LD = 0;
@@ -304,7 +305,7 @@ struct Fc4Dgrad {   // delta3 = (W4^T delta4) * 1[a3 > 0]  (A5, A8), written str
 };
 
 struct Fc4Wgrad {   // gW4 = delta4 . a3^T (sum over batch, A8) in the W4i layout; no split (K = B)
-  static constexpr int WM = 2, WN = 2, WK = 1; static constexpr bool A_K = false, B_K = false;
+  static constexpr bool A_K = false, B_K = false;     // operand contiguous along k (-> LDS transpose) or along m/n
   typedef int aoff_t;
   // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
   static constexpr bool A_REG = true, A_U8 = false, B_REG = true; static constexpr int A_LD = NIN4, B_LD = NFC;
@@ -359,7 +360,7 @@ struct Fc4Wgrad {   // gW4 = delta4 . a3^T (sum over batch, A8) in the W4i layou
 };
 
 struct Conv3Dgrad { // delta2 = full-correlation(d3p, W3) * 1[a2 > 0], written into the padded d2p
-  static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
+  static constexpr bool A_K = true, B_K = true;     // operand contiguous along k (-> LDS transpose) or along m/n
   typedef int aoff_t;
   // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
   static constexpr bool A_REG = false, A_U8 = false, B_REG = false; static constexpr int A_LD = 0, B_LD = 0;
@@ -397,7 +398,7 @@ struct Conv3Dgrad { // delta2 = full-correlation(d3p, W3) * 1[a2 > 0], written i
 };
 
 struct Conv3Wgrad { // gW3[(r,s,c)][f] = sum_(n,p,q) a2 patch * delta3   (Neon update_conv), split-K slabs
-  static constexpr int WM = 2, WN = 2, WK = 1; static constexpr bool A_K = false, B_K = false;
+  static constexpr bool A_K = false, B_K = false;     // operand contiguous along k (-> LDS transpose) or along m/n
   typedef int aoff_t;
   // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
   static constexpr bool A_REG = false, A_U8 = false, B_REG = true; static constexpr int A_LD = 0, B_LD = K3;
@@ -427,7 +428,7 @@ struct Conv3Wgrad { // gW3[(r,s,c)][f] = sum_(n,p,q) a2 patch * delta3   (Neon u
 };
 
 struct Conv2Dgrad { // stride-2 dgrad as 4 parity classes (z = py*2+px), each a dense 2x2 correlation over d2p
-  static constexpr int WM = 1, WN = 1, WK = 4; static constexpr bool A_K = true, B_K = true;
+  static constexpr bool A_K = true, B_K = true;     // operand contiguous along k (-> LDS transpose) or along m/n
   typedef int aoff_t;
   // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
   static constexpr bool A_REG = false, A_U8 = false, B_REG = false; static constexpr int A_LD = 0, B_LD = 0;
@@ -468,7 +469,7 @@ struct Conv2Dgrad { // stride-2 dgrad as 4 parity classes (z = py*2+px), each a 
 };
 
 struct Conv2Wgrad {
-  static constexpr int WM = 2, WN = 2, WK = 1; static constexpr bool A_K = false, B_K = false;
+  static constexpr bool A_K = false, B_K = false;     // operand contiguous along k (-> LDS transpose) or along m/n
   typedef int aoff_t;
   // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
   static constexpr bool A_REG = false, A_U8 = false, B_REG = true; static constexpr int A_LD = 0, B_LD = K2;
@@ -498,7 +499,7 @@ struct Conv2Wgrad {
 };
 
 struct Conv1Wgrad { // re-gathers the normalised u8 patches from the ring (no fp32 input copy is ever stored)
-  static constexpr int WM = 2, WN = 1, WK = 2; static constexpr bool A_K = false, B_K = false;
+  static constexpr bool A_K = false, B_K = false;     // operand contiguous along k (-> LDS transpose) or along m/n
   typedef int64_t aoff_t;
   // operand descriptors for the engine's fast paths: *_REG = plain row-major [k][x] matrix with row pitch *_LD
   static constexpr bool A_REG = false, A_U8 = true, B_REG = true; static constexpr int A_LD = 0, B_LD = K1;

@@ -351,6 +351,24 @@ def test_main_loop_with_statistics_csv(sd, tmp_path):
     assert np.isfinite(float(rows[-1][10]))            # meanq on the validation minibatch
 
 
+def test_ragged_batch_and_max_actions(sd):
+    """Batch sizes that are not multiples of the 32-wide tiles / chunks and the largest action set (Seaquest: 18)."""
+    for A, B in ((18, 10), (2, 34)):
+        net, o = _pair(sd, A, B, 301 + B)
+        net.set_option("keep_gradients", 1)
+        for s in range(2):
+            mb = random_minibatch(B, A, 310 + s)
+            g, cost, _, preq = o.gradients(mb)
+            net.train(mb)
+            q, _ = net.last_q()
+            assert np.abs(q - preq).max() < Q_TOL
+            for i in range(5):
+                assert np.abs(net.get_layer(i, 3) - g[i]).max() < 1e-4 * max(1e-3, np.abs(g[i]).max()), (A, B, i)
+            o.rmsprop(g, B)
+            net.set_weights(o.W, 0)
+            net.set_weights(o.S, 2)
+
+
 def test_hyperparameters_reach_the_kernels(sd):
     """Non-default discount / reward range / clip / lr / decay (main.py:33-45 flags) are honoured."""
     A, B = 5, 16
