@@ -86,29 +86,48 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   __shared__ float sh_q[2][MAX_ACTIONS];
   __shared__ float sh_dc;
   __shared__ int sh_act;
-  float a4v[2] = {0.0f, 0.0f};
+  // ---- everything this thread will ever load is issued up front (one memory round trip) ----------------
   int m_act = 0, m_term = 0; int64_t m_rew = 0;
-  if (h.train && j == 0) { m_act = h.st_actions[n]; m_rew = h.st_rewards[n]; m_term = h.st_terminals[n]; }  // in flight early
-  for (int z = 0; z < a.nz; ++z) {
-    float v = 0.0f;
-    const float* sp = a.slab4 + ((int64_t)z * a.B + n) * NFC + j;
-    const int64_t sstride = (int64_t)2 * a.B * NFC;
-    int s = 0;
-    for (; s + 7 <= a.S4; s += 7) {                                                              // 7 loads in flight
-      float t0 = sp[(s + 0) * sstride], t1 = sp[(s + 1) * sstride], t2 = sp[(s + 2) * sstride], t3 = sp[(s + 3) * sstride];
-      float t4 = sp[(s + 4) * sstride], t5 = sp[(s + 5) * sstride], t6 = sp[(s + 6) * sstride];
-      v += t0; v += t1; v += t2; v += t3; v += t4; v += t5; v += t6;                             // fixed order
-    }
-    for (; s < a.S4; ++s) v += sp[s * sstride];
-    v = fmaxf(v, 0.0f);                                                                          // Rectlin, :89
+  if (h.train && j == 0) { m_act = h.st_actions[n]; m_rew = h.st_rewards[n]; m_term = h.st_terminals[n]; }
+  float w5[2][MAX_ACTIONS];
+#pragma unroll
+  for (int z = 0; z < 2; ++z)
+#pragma unroll
+    for (int act = 0; act < MAX_ACTIONS; ++act)
+      w5[z][act] = (z < a.nz && act < a.A) ? a.theta[z][OFF5 + act * NFC + j] : 0.0f;            // Affine(A) rows, :91
+  float a4v[2] = {0.0f, 0.0f};
+  const int64_t sstride = (int64_t)2 * a.B * NFC;
+  if (a.S4 == 7) {                                   // the built-in split: 14 independent loads in flight
+    float t[2][7];
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+#pragma unroll
+      for (int s = 0; s < 7; ++s) t[z][s] = z < a.nz ? a.slab4[s * sstride + ((int64_t)z * a.B + n) * NFC + j] : 0.0f;
+#pragma unroll
+    for (int z = 0; z < 2; ++z) { float v = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 7; ++s) v += t[z][s];                                                   // fixed order
+      a4v[z] = v; }
+  } else {
+#pragma unroll
+    for (int z = 0; z < 2; ++z) { float v = 0.0f;
+      if (z < a.nz) for (int s = 0; s < a.S4; ++s) v += a.slab4[s * sstride + ((int64_t)z * a.B + n) * NFC + j];
+      a4v[z] = v; }
+  }
+#pragma unroll
+  for (int z = 0; z < 2; ++z) {                      // static indices only: w5 / a4v stay in registers
+    if (z >= a.nz) continue;
+    const float v = fmaxf(a4v[z], 0.0f);                                                          // Rectlin, :89
     a4v[z] = v;
     a.a4[((int64_t)z * a.B + n) * NFC + j] = v;
-    const float* W5 = a.theta[z] + OFF5;
-    for (int act = 0; act < a.A; ++act) {                                                        // Affine(A), :91
-      float p = W5[act * NFC + j] * v;
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);                       // wavefront reduction
-      if (lane == 0) red[z][act][wave] = p;
+    for (int act = 0; act < MAX_ACTIONS; ++act) {
+      if (act < a.A) {
+        float p = w5[z][act] * v;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);                      // wavefront reduction
+        if (lane == 0) red[z][act][wave] = p;
+      }
     }
   }
   __syncthreads();
@@ -122,7 +141,6 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   if (!h.train) return;
   __syncthreads();
   if (j == 0) {
-#pragma clang fp contract(off)
     const int act = m_act, term = m_term; const int64_t rew = m_rew;
     float m = sh_q[1][0];
     for (int k = 1; k < a.A; ++k) m = fmaxf(m, sh_q[1][k]);                                     // be.max(postq, axis=0), :124
@@ -138,14 +156,13 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   }
   __syncthreads();
   const float dc = sh_dc; const int act = sh_act;
-  // fc5 dgrad: delta4 = W5^T delta * 1[a4 > 0]; delta is non-zero on the taken action only
-  a.d4[(int64_t)n * NFC + j] = a4v[0] > 0.0f ? a.theta[0][OFF5 + act * NFC + j] * dc : 0.0f;
+  // fc5 dgrad: delta4 = W5^T delta * 1[a4 > 0]; delta is non-zero on the taken action only (W5 row already in registers)
+  float wa = 0.0f;
+#pragma unroll
+  for (int k = 0; k < MAX_ACTIONS; ++k) wa = (k == act) ? w5[0][k] : wa;
+  a.d4[(int64_t)n * NFC + j] = a4v[0] > 0.0f ? wa * dc : 0.0f;
   if (j < a.A) h.dq[(int64_t)n * a.A + j] = (j == act) ? dc : 0.0f;
 }
-
-#ifdef SDQN_TIMING
-hipError_t set_timing_buffer(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sdqn_dbg), &p, sizeof p); }
-#endif
 
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
   hipLaunchKernelGGL(head_kernel, dim3(a.B), dim3(512), 0, s, a, h);
