@@ -256,10 +256,23 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
   SDQN_STAMP(6);
 }
 
+// XCD-aware workgroup -> tile map (guide T1).  The dispatcher places workgroup b on XCD b % 8, each XCD with its
+// own L2.  Tiles are numbered x-fastest (then y, then split/net z), so NEIGHBOURING tile ids share operands
+// (adjacent im2col rows and halos; the same K-range of activations for all (crs, f) tiles of a wgrad split).
+// Giving every XCD one CONTIGUOUS run of tile ids keeps those re-reads in one L2 instead of eight.  Bijective
+// for any workgroup count; placement only changes speed, never results.
+__device__ __forceinline__ int xcd_tile_id(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, i = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
 template <class P, int NW>
 __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
   __shared__ float smem[tile_lds<P, NW>()];
-  gemm_tile<P, NW, NW * 64>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+  const int gx = gridDim.x, gy = gridDim.y;
+  const int t = xcd_tile_id(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+  const int bz = t / (gx * gy), r = t - bz * (gx * gy);
+  gemm_tile<P, NW, NW * 64>(a, r % gx, r / gx, bz, smem);
 }
 
 // ---- several independent problems in ONE launch -------------------------------------------------------
@@ -293,7 +306,7 @@ __global__ void __launch_bounds__(NT) gemm_multi_kernel(const StepArgs a, const 
   constexpr int L0 = tile_lds<P0, NW0>(), L1 = tile_lds<P1, NW1>(), L2 = tile_lds<P2, NW2>();
   constexpr int L = L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2);
   __shared__ float smem[L];
-  const int b = blockIdx.x;                               // problem choice is workgroup-uniform
+  const int b = xcd_tile_id(blockIdx.x, gridDim.x);       // XCD-contiguous tile runs; problem choice is workgroup-uniform
   if (b < d.n[0]) multi_dispatch<P0, NW0, NT>(a, d, 0, b, smem);
   else if (b < d.n[0] + d.n[1]) multi_dispatch<P1, NW1, NT>(a, d, 1, b - d.n[0], smem);
   else multi_dispatch<P2, NW2, NT>(a, d, 2, b - d.n[0] - d.n[1], smem);
