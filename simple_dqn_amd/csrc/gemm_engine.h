@@ -265,6 +265,20 @@ __device__ __forceinline__ int xcd_tile_id(int b, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, i = b >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
+// the same for a sub-range [s, s + n) of a grid (one problem of a multi-problem launch): workgroup b's XCD is
+// still b % 8; the range's workgroups on XCD x get one contiguous run of the range's n tile ids
+__device__ __forceinline__ int xcd_tile_id_range(int b, int s, int n) {
+  const int x = b & 7;
+  int before = 0, mine_first = 0;
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    const int first = s + ((y - (s & 7) + 8) & 7);              // first workgroup of the range on XCD y
+    const int cnt = first < s + n ? (s + n - first + 7) >> 3 : 0;
+    if (y < x) before += cnt;
+    if (y == x) mine_first = first;
+  }
+  return before + ((b - mine_first) >> 3);
+}
 
 template <class P, int NW>
 __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
@@ -306,10 +320,10 @@ __global__ void __launch_bounds__(NT) gemm_multi_kernel(const StepArgs a, const 
   constexpr int L0 = tile_lds<P0, NW0>(), L1 = tile_lds<P1, NW1>(), L2 = tile_lds<P2, NW2>();
   constexpr int L = L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2);
   __shared__ float smem[L];
-  const int b = xcd_tile_id(blockIdx.x, gridDim.x);       // XCD-contiguous tile runs; problem choice is workgroup-uniform
-  if (b < d.n[0]) multi_dispatch<P0, NW0, NT>(a, d, 0, b, smem);
-  else if (b < d.n[0] + d.n[1]) multi_dispatch<P1, NW1, NT>(a, d, 1, b - d.n[0], smem);
-  else multi_dispatch<P2, NW2, NT>(a, d, 2, b - d.n[0] - d.n[1], smem);
+  const int b = blockIdx.x;                               // problem choice is workgroup-uniform; XCD-contiguous runs per problem
+  if (b < d.n[0]) multi_dispatch<P0, NW0, NT>(a, d, 0, xcd_tile_id_range(b, 0, d.n[0]), smem);
+  else if (b < d.n[0] + d.n[1]) multi_dispatch<P1, NW1, NT>(a, d, 1, xcd_tile_id_range(b, d.n[0], d.n[1]), smem);
+  else multi_dispatch<P2, NW2, NT>(a, d, 2, xcd_tile_id_range(b, d.n[0] + d.n[1], d.n[2]), smem);
 }
 
 struct NoProblem {            // placeholder third problem for two-problem launches (never dispatched: n[2] = 0)
