@@ -260,7 +260,10 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
 // own L2.  Tiles are numbered x-fastest (then y, then split/net z), so NEIGHBOURING tile ids share operands
 // (adjacent im2col rows and halos; the same K-range of activations for all (crs, f) tiles of a wgrad split).
 // Giving every XCD one CONTIGUOUS run of tile ids keeps those re-reads in one L2 instead of eight.  Bijective
-// for any workgroup count; placement only changes speed, never results.
+// for any workgroup count; placement only changes speed, never results.  Measured (profiles/README.md): fabric
+// traffic drops to ~1.0-1.7x algorithmic (bwd1 15.0 -> 3.8 MB) but the step gets 3-4 % SLOWER at B=32 and B=256 —
+// these launches are latency-bound and eight L2s fetching a tile's neighbourhood in parallel beat one — so the
+// map is an option (StepArgs::xcd_map, sdqn_net_set_option "xcd_map"), off by default.
 __device__ __forceinline__ int xcd_tile_id(int b, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, i = b >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
@@ -284,7 +287,8 @@ template <class P, int NW>
 __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
   __shared__ float smem[tile_lds<P, NW>()];
   const int gx = gridDim.x, gy = gridDim.y;
-  const int t = xcd_tile_id(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+  const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const int t = a.xcd_map ? xcd_tile_id(lin, gx * gy * gridDim.z) : lin;
   const int bz = t / (gx * gy), r = t - bz * (gx * gy);
   gemm_tile<P, NW, NW * 64>(a, r % gx, r / gx, bz, smem);
 }
@@ -321,9 +325,10 @@ __global__ void __launch_bounds__(NT) gemm_multi_kernel(const StepArgs a, const 
   constexpr int L = L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2);
   __shared__ float smem[L];
   const int b = blockIdx.x;                               // problem choice is workgroup-uniform; XCD-contiguous runs per problem
-  if (b < d.n[0]) multi_dispatch<P0, NW0, NT>(a, d, 0, xcd_tile_id_range(b, 0, d.n[0]), smem);
-  else if (b < d.n[0] + d.n[1]) multi_dispatch<P1, NW1, NT>(a, d, 1, xcd_tile_id_range(b, d.n[0], d.n[1]), smem);
-  else multi_dispatch<P2, NW2, NT>(a, d, 2, xcd_tile_id_range(b, d.n[0] + d.n[1], d.n[2]), smem);
+  const bool xm = a.xcd_map != 0;
+  if (b < d.n[0]) multi_dispatch<P0, NW0, NT>(a, d, 0, xm ? xcd_tile_id_range(b, 0, d.n[0]) : b, smem);
+  else if (b < d.n[0] + d.n[1]) multi_dispatch<P1, NW1, NT>(a, d, 1, xm ? xcd_tile_id_range(b, d.n[0], d.n[1]) : b - d.n[0], smem);
+  else multi_dispatch<P2, NW2, NT>(a, d, 2, xm ? xcd_tile_id_range(b, d.n[0] + d.n[1], d.n[2]) : b - d.n[0] - d.n[1], smem);
 }
 
 struct NoProblem {            // placeholder third problem for two-problem launches (never dispatched: n[2] = 0)

@@ -79,6 +79,7 @@ struct StepArgs {
   int fuse_rms;
   int f4w_first, f4w_count; // fc4 wgrad tiles [first, first+count) handled by THIS launch (tiles are spread over
                             // the three backward launches so the 25.7 MB fused RMSProp RMW streams in the background)
+  int xcd_map;              // 1: XCD-contiguous workgroup->tile map (cuts fabric traffic to ~algorithmic, measured 3-4 % slower)
   int nw_override[12];      // tuning hook: waves per tile for kernel id i (0 = built-in choice)
   float* __restrict__ theta_w;   // online parameters, writable alias of theta[0]
   float* __restrict__ state;     // RMSProp state

@@ -230,11 +230,12 @@ def test_fused_and_streamed_paths_bit_identical(sd):
     to the plain single-stream, materialised-gradient path."""
     A, B = 4, 32
     nets = []
-    for keep, two, fl in ((0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1), (0, 0, 0), (1, 0, 0)):
+    for keep, two, fl, xm in ((0, 1, 0, 0), (1, 1, 0, 0), (0, 0, 1, 0), (1, 0, 1, 1), (0, 0, 1, 1), (0, 0, 0, 0), (1, 0, 0, 0)):
         n, _ = _pair(sd, A, B, 81)
         n.set_option("keep_gradients", keep)
         n.set_option("two_streams", two)
         n.set_option("fused_launches", fl)
+        n.set_option("xcd_map", xm)              # placement may only change speed, never results
         nets.append(n)
     for s in range(4):
         mb = random_minibatch(B, A, 82 + s)
