@@ -96,7 +96,8 @@ typedef struct {
   int num_actions;         /* :18 */
   int target_enabled;      /* bool(args.target_steps) :64 */
   int optimizer;           /* args.optimizer :50-59: 0 rmsprop, 1 adam, 2 adadelta */
-  int reserved0;
+  int datatype;            /* args.datatype :33: 0 float32; 1 float16 = half activations/deltas/MFMA weight operands,
+                              fp32 accumulation, master weights and optimizer state (BASELINE.json configs[4]) */
   /* Python floats (doubles) exactly as argparse hands them over; the library rounds to fp32
    * where Neon's fp32 backend would (lr, decay, epsilon, clip) and keeps doubles where the
    * reference does host-side float math (discount, reward clip: deepqnetwork.py:136-143).  */
@@ -109,7 +110,8 @@ typedef struct {
   double epsilon;          /* Neon defaults: RMSProp 1e-6, Adam 1e-8, Adadelta 1e-6 */
   double beta_1;           /* Adam (Neon default 0.9) */
   double beta_2;           /* Adam (Neon default 0.999) */
-  double reserved1[2];
+  double loss_scale;       /* float16 mode: static power-of-two scale of the stored deltas (0 -> 1024) */
+  double reserved1;
 } sdqn_net_cfg;
 
 /* DeepQNetwork.__init__, deepqnetwork.py:16-75 (weights start at zero: inject with set_weights) */

@@ -77,7 +77,8 @@ class OracleDQN:
     def __init__(self, num_actions, batch_size=32, history_length=4, screen_height=84, screen_width=84,
                  discount_rate=0.99, clip_error=1.0, min_reward=-1.0, max_reward=1.0,
                  learning_rate=0.00025, decay_rate=0.95, epsilon=None, target_steps=10000,
-                 dtype=np.float32, weights=None, seed=0, optimizer="rmsprop", beta_1=0.9, beta_2=0.999):
+                 dtype=np.float32, weights=None, seed=0, optimizer="rmsprop", beta_1=0.9, beta_2=0.999,
+                 half_activations=False):
         self.num_actions = num_actions
         self.batch_size = batch_size
         self.history_length = history_length
@@ -91,6 +92,11 @@ class OracleDQN:
             epsilon = 1e-8 if optimizer == "adam" else 1e-6
         self.lr, self.rho, self.eps = learning_rate, decay_rate, epsilon
         self.dtype = np.dtype(dtype).type
+        # --datatype float16 mode of the HIP path (BASELINE.json configs[4]; semantics are OURS — Neon's fp16 backend is
+        # GPU-only and unpinned): activations, deltas and the MFMA weight operands are rounded to IEEE half, every
+        # accumulation, the master weights, the gradients and the optimizer state stay fp32.
+        self.half = bool(half_activations)
+        self.loss_scale = 1024.0                                  # deltas are stored as half(delta * 1024) (power of two: exact)
         ws = weights if weights is not None else xavier_weights(num_actions, seed, dtype, history_length,
                                                                 screen_height, screen_width)
         self.W = [np.array(w, dtype=dtype) for w in ws]
@@ -107,19 +113,34 @@ class OracleDQN:
     def _normalize(self, states_u8):                              # _setInput :94-100
         return states_u8.astype(self.dtype) / self.dtype(255)
 
+    def _h(self, x):
+        """round to half and back (no-op unless half_activations)"""
+        return x.astype(np.float16).astype(self.dtype) if self.half else x
+
+    def _hd(self, d):
+        """a delta tensor as the HIP path stores it: half(d * loss_scale), used as (stored / loss_scale)"""
+        if not self.half:
+            return d
+        s = self.dtype(self.loss_scale)
+        return (d * s).astype(np.float16).astype(self.dtype) / s
+
     def fprop(self, W, x, keep=False):
         """x (N, C, H, W) normalised. Returns q (N, A) [+ saved tensors]."""
+        x32 = x
+        x = self._h(x)
         acts, cols_all = [x], []
         a = x
         for li, (R, S, K, st) in enumerate(CONV):
             cols, P, Q = _im2col(a, R, S, st)
-            z = cols @ W[li]                                      # (N, PQ, K)
-            z = np.maximum(z, 0)                                  # Rectlin (A5)
+            z = cols @ self._h(W[li])                             # (N, PQ, K)
+            z = self._h(np.maximum(z, 0))                         # Rectlin (A5)
             a = np.ascontiguousarray(z.transpose(0, 2, 1)).reshape(x.shape[0], K, P, Q)
             acts.append(a)
             cols_all.append(cols)
+        if self.half:                                             # conv1 wgrad re-reads the fp32-normalised frames
+            cols_all[0] = _im2col(x32, CONV[0][0], CONV[0][1], CONV[0][3])[0]
         a3f = a.reshape(x.shape[0], -1)                           # (K,P,Q) flatten (A2)
-        a4 = np.maximum(a3f @ W[3].T, 0)
+        a4 = np.maximum(a3f @ self._h(W[3]).T, 0)                 # a4 and fc5 stay fp32
         q = a4 @ W[4].T
         if keep:
             return q, (acts, cols_all, a3f, a4)
@@ -163,9 +184,9 @@ class OracleDQN:
         # ---- bprop (A8) :162
         g = [None] * 5
         g[4] = deltas.T @ a4                                                  # (A, 512)
-        d4 = (deltas @ self.W[4]) * (a4 > 0)
+        d4 = self._hd((deltas @ self.W[4]) * (a4 > 0))
         g[3] = d4.T @ a3f                                                     # (512, 3136)
-        d = (d4 @ self.W[3]) * (a3f > 0)                                      # (N, 3136) in (K,P,Q)
+        d = self._hd((d4 @ self._h(self.W[3])) * (a3f > 0))                   # (N, 3136) in (K,P,Q)
         for li in (2, 1, 0):
             R, S, K, st = CONV[li]
             a_out = acts[li + 1]
@@ -175,8 +196,8 @@ class OracleDQN:
             g[li] = np.einsum('nmc,nmk->ck', cols, dmat, optimize=True).astype(self.dtype)
             if li > 0:
                 a_in = acts[li]
-                dcols = dmat @ self.W[li].T                                   # (N, PQ, CRS)
-                d = _col2im(dcols, a_in.shape[1], a_in.shape[2], a_in.shape[3], R, S, st) * (a_in > 0)
+                dcols = dmat @ self._h(self.W[li]).T                          # (N, PQ, CRS)
+                d = self._hd(_col2im(dcols, a_in.shape[1], a_in.shape[2], a_in.shape[3], R, S, st) * (a_in > 0))
         return g, cost, deltas, preq
 
     def rmsprop(self, grads, batch):

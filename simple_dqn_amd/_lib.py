@@ -23,10 +23,10 @@ def lib_path():
 class NetCfg(C.Structure):
     _fields_ = [("batch_size", C.c_int), ("history_length", C.c_int), ("screen_height", C.c_int),
                 ("screen_width", C.c_int), ("num_actions", C.c_int), ("target_enabled", C.c_int),
-                ("optimizer", C.c_int), ("reserved0", C.c_int),
+                ("optimizer", C.c_int), ("datatype", C.c_int),
                 ("discount_rate", C.c_double), ("clip_error", C.c_double), ("min_reward", C.c_double),
                 ("max_reward", C.c_double), ("learning_rate", C.c_double), ("decay_rate", C.c_double),
-                ("epsilon", C.c_double), ("beta_1", C.c_double), ("beta_2", C.c_double), ("reserved1", C.c_double * 2)]
+                ("epsilon", C.c_double), ("beta_1", C.c_double), ("beta_2", C.c_double), ("loss_scale", C.c_double), ("reserved1", C.c_double)]
 
 
 _u8p, _i64p, _f32p, _u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_uint32)

@@ -28,6 +28,14 @@ namespace sdqn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// element type of an x-contiguous operand (float unless the problem says otherwise: the fp16-mode wgrads read half)
+template <class P, class = void> struct a_elem { typedef float type; };
+template <class P> struct a_elem<P, decltype((void)sizeof(typename P::AT))> { typedef typename P::AT type; };
+template <class P, class = void> struct b_elem { typedef float type; };
+template <class P> struct b_elem<P, decltype((void)sizeof(typename P::BT))> { typedef typename P::BT type; };
+template <class P, class = void> struct uses_f16_mfma { static constexpr bool value = false; };
+template <class P> struct uses_f16_mfma<P, decltype((void)P::F16_MFMA)> { static constexpr bool value = P::F16_MFMA; };
+
 constexpr int PANEL = 32 * 33;      // one [32 k][32 x] fp32 panel, pitch 33
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -102,9 +110,10 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
   }
 
   // fast-path pointers: regular operands get a per-lane pointer (row 0 for lanes 0-31, row 16 for 32-63)
-  const float* abase = P::a_ptr(a, z);
-  const float* bbase = P::b_ptr(a, z);
-  const float* areg = nullptr; const float* breg = nullptr;
+  typedef typename a_elem<P>::type AT; typedef typename b_elem<P>::type BT;
+  const AT* abase = P::a_ptr(a, z);
+  const BT* bbase = P::b_ptr(a, z);
+  const AT* areg = nullptr; const BT* breg = nullptr;
   if constexpr (!P::A_K && P::A_REG) areg = abase + (uint32_t)arow[0] + (lane >= 32 ? 16 * P::A_LD : 0);
   if constexpr (!P::B_K && P::B_REG) breg = bbase + (uint32_t)bcol[0] + (lane >= 32 ? 16 * P::B_LD : 0);
   (void)abase; (void)bbase; (void)areg; (void)breg;
@@ -124,12 +133,12 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
     } else if constexpr (P::A_REG) {
       // plain row-major [k][m] matrix: per-lane pointer fixed for the whole tile, 16 loads at k-row offsets
       if (kc + 32 <= kend) {
-        const float* p = areg + (size_t)kc * P::A_LD;
+        const AT* p = areg + (size_t)kc * P::A_LD;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dst[i] = p[(size_t)i * P::A_LD];
+        for (int i = 0; i < 16; ++i) dst[i] = (float)p[(size_t)i * P::A_LD];
       } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { const int k = kc + i + (lane >= 32 ? 16 : 0); dst[i] = k < kend ? areg[(size_t)(kc + i) * P::A_LD] : 0.0f; }
+        for (int i = 0; i < 16; ++i) { const int k = kc + i + (lane >= 32 ? 16 : 0); dst[i] = k < kend ? (float)areg[(size_t)(kc + i) * P::A_LD] : 0.0f; }
       }
     } else {
       // one im2col decomposition per lane per chunk (lane <-> k = kc + (l & 31)); step i fetches its
@@ -142,7 +151,7 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
         const aoff_t c = pick_half(cv, i, hi);
         const bool ok = kc + i + (hi ? 16 : 0) < kend;
         if constexpr (P::A_U8) dst[i] = ok ? P::a_load(a, z, arow[0] + c) : 0.0f;
-        else dst[i] = ok ? abase[(uint32_t)(arow[0] + c)] : 0.0f;       // uniform base + 32-bit lane offset
+        else dst[i] = ok ? (float)abase[(uint32_t)(arow[0] + c)] : 0.0f;   // uniform base + 32-bit lane offset
       }
     }
   };
@@ -153,12 +162,12 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
       for (int j = 0; j < 4; ++j) { const f4 v = P::b_load4(a, z, r + bcol[j]); dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w; }
     } else if constexpr (P::B_REG) {
       if (kc + 32 <= kend) {
-        const float* p = breg + (size_t)kc * P::B_LD;
+        const BT* p = breg + (size_t)kc * P::B_LD;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dst[i] = p[(size_t)i * P::B_LD];
+        for (int i = 0; i < 16; ++i) dst[i] = (float)p[(size_t)i * P::B_LD];
       } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { const int k = kc + i + (lane >= 32 ? 16 : 0); dst[i] = k < kend ? breg[(size_t)(kc + i) * P::B_LD] : 0.0f; }
+        for (int i = 0; i < 16; ++i) { const int k = kc + i + (lane >= 32 ? 16 : 0); dst[i] = k < kend ? (float)breg[(size_t)(kc + i) * P::B_LD] : 0.0f; }
       }
     } else {
       const int kl = kc + (lane & 31);
@@ -167,7 +176,7 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int r = pick_half(rv, i, hi);
-        dst[i] = kc + i + (hi ? 16 : 0) < kend ? bbase[(uint32_t)(r + bcol[0])] : 0.0f;
+        dst[i] = kc + i + (hi ? 16 : 0) < kend ? (float)bbase[(uint32_t)(r + bcol[0])] : 0.0f;
       }
     }
   };
@@ -256,6 +265,71 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
   SDQN_STAMP(6);
 }
 
+// ---- fp16-mode tile body: packed-fp16 MFMA -------------------------------------------------------------------
+// v_mfma_f32_32x32x16_f16: lane (i = l & 31, h = l >> 5) feeds 8 consecutive k (one 16-B load) of row i of A and of
+// column i of B into k-slots 8h..8h+7; both operands of these problems are k-contiguous in memory (NHWC activations /
+// padded deltas; TRANSPOSED half weight copies for forward, master-layout half copies for dgrad), so there is no LDS
+// staging at all: 2 loads + 1 MFMA per 16 k.  A and B use the same slot <-> k assignment, so the result does not
+// depend on the hardware's internal k numbering.  fp32 accumulation, same K-split / fixed-order combine as above.
+template <class P, int NW, int NT>
+__device__ __forceinline__ void gemm_tile_h(const StepArgs& a, int bx, int by, int bz, float* smem) {
+  constexpr int WAVE_LDS = PANEL;
+  typedef typename P::aoff_t aoff_t;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m0 = bx * 32, n0 = by * 32;
+  int z, ks, kbeg, kend;
+  P::ksplit(a, bz, z, ks, kbeg, kend);
+  if (NW * 64 < NT && wave >= NW) kend = kbeg;
+  const int M = P::M(a), N = P::N(a);
+  const int i = lane & 31, h8 = (lane >> 5) * 8;
+  const aoff_t arow = P::a_row(a, z, m0 + i < M ? m0 + i : M - 1);
+  const int bcol = P::b_col(a, z, n0 + i < N ? n0 + i : N - 1);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int kc = kbeg + (wave < NW ? wave : 0) * 32; kc < kend; kc += NW * 32) {
+    const half8 fa0 = P::a_load8(a, z, arow + P::a_col(a, z, kc + h8));
+    const half8 fb0 = P::b_load8(a, z, bcol + P::b_row(a, z, kc + h8));
+    const half8 fa1 = P::a_load8(a, z, arow + P::a_col(a, z, kc + 16 + h8));
+    const half8 fb1 = P::b_load8(a, z, bcol + P::b_row(a, z, kc + 16 + h8));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, fb0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, fb1, acc, 0, 0, 0);
+  }
+  if constexpr (NW > 1) {
+    if (wave < NW) {
+      float* cw = smem + wave * WAVE_LDS;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        cw[row * 33 + (lane & 31)] = acc[r];
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += NT) {
+      const int ml = e >> 5, nl = e & 31;
+      float v = smem[ml * 33 + nl];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) v += smem[w * WAVE_LDS + ml * 33 + nl];
+      if (m0 + ml < M && n0 + nl < N) P::store(a, z, ks, m0 + ml, n0 + nl, v);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl = lane & 31;
+      if (m0 + ml < M && n0 + nl < N) P::store(a, z, ks, m0 + ml, n0 + nl, acc[r]);
+    }
+  }
+}
+
+template <class P, int NW, int NT>
+__device__ __forceinline__ void run_tile(const StepArgs& a, int bx, int by, int bz, float* smem) {
+  if constexpr (uses_f16_mfma<P>::value) gemm_tile_h<P, NW, NT>(a, bx, by, bz, smem);
+  else gemm_tile<P, NW, NT>(a, bx, by, bz, smem);
+}
+template <class P, int NW>
+constexpr int tile_lds_any() { return uses_f16_mfma<P>::value ? NW * PANEL : tile_lds<P, NW>(); }
+
 // XCD-aware workgroup -> tile map (guide T1).  The dispatcher places workgroup b on XCD b % 8, each XCD with its
 // own L2.  Tiles are numbered x-fastest (then y, then split/net z), so NEIGHBOURING tile ids share operands
 // (adjacent im2col rows and halos; the same K-range of activations for all (crs, f) tiles of a wgrad split).
@@ -285,12 +359,12 @@ __device__ __forceinline__ int xcd_tile_id_range(int b, int s, int n) {
 
 template <class P, int NW>
 __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
-  __shared__ float smem[tile_lds<P, NW>()];
+  __shared__ float smem[tile_lds_any<P, NW>()];
   const int gx = gridDim.x, gy = gridDim.y;
   const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
   const int t = a.xcd_map ? xcd_tile_id(lin, gx * gy * gridDim.z) : lin;
   const int bz = t / (gx * gy), r = t - bz * (gx * gy);
-  gemm_tile<P, NW, NW * 64>(a, r % gx, r / gx, bz, smem);
+  run_tile<P, NW, NW * 64>(a, r % gx, r / gx, bz, smem);
 }
 
 // ---- several independent problems in ONE launch -------------------------------------------------------
@@ -310,18 +384,18 @@ __device__ __forceinline__ void multi_dispatch(const StepArgs& a, const MultiDim
     if (t < a.f4w_count) {
       const int tile = a.f4w_first + t;
       const int bz = tile / per_z, r = tile - bz * per_z;
-      gemm_tile<P, 1, 64>(a, r % d.gx[which], r / d.gx[which], bz, smem);
+      run_tile<P, 1, 64>(a, r % d.gx[which], r / d.gx[which], bz, smem);
     }
   } else {
     const int per_z = d.gx[which] * d.gy[which];
     const int bz = local / per_z, r = local - bz * per_z;
-    gemm_tile<P, NW, NT>(a, r % d.gx[which], r / d.gx[which], bz, smem);
+    run_tile<P, NW, NT>(a, r % d.gx[which], r / d.gx[which], bz, smem);
   }
 }
 
 template <int NT, class P0, int NW0, class P1, int NW1, class P2, int NW2>
 __global__ void __launch_bounds__(NT) gemm_multi_kernel(const StepArgs a, const MultiDims d) {
-  constexpr int L0 = tile_lds<P0, NW0>(), L1 = tile_lds<P1, NW1>(), L2 = tile_lds<P2, NW2>();
+  constexpr int L0 = tile_lds_any<P0, NW0>(), L1 = tile_lds_any<P1, NW1>(), L2 = tile_lds_any<P2, NW2>();
   constexpr int L = L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2);
   __shared__ float smem[L];
   const int b = blockIdx.x;                               // problem choice is workgroup-uniform; XCD-contiguous runs per problem

@@ -61,6 +61,8 @@ struct UpdateArgs {
   int opt;                      // 0 RMSProp, 1 Adam, 2 Adadelta (deepqnetwork.py:50-59)
   float* state2;                // Adam v / Adadelta E[dx^2]
   float beta1, one_minus_beta1, beta2, one_minus_beta2, lr_t;   // Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), t = epoch+1
+  half_t* wh;                   // fp16 mode: half copies of theta refreshed by the update (master layout / transposed)
+  half_t* wht;
 };
 
 struct GatherArgs {
@@ -80,5 +82,6 @@ hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s);
 hipError_t launch_update(const UpdateArgs& u, hipStream_t s);
 hipError_t launch_gather(const GatherArgs& g, hipStream_t s);
 hipError_t launch_prep(const PrepArgs& p, hipStream_t s);
+hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s);   // fp16 mode: rebuild both half copies
 
 }  // namespace sdqn

@@ -44,6 +44,13 @@ constexpr int NW1 = CRS1 * K1, NW2 = CRS2 * K2, NW3 = CRS3 * K3, NW4 = NIN4 * NF
 constexpr int OFF1 = 0, OFF2 = OFF1 + NW1, OFF3 = OFF2 + NW2, OFF4 = OFF3 + NW3, OFF5 = OFF4 + NW4;
 constexpr int MAX_ACTIONS = 18;
 
+#if defined(__HIPCC__)
+typedef _Float16 half_t;                                             // IEEE binary16 storage type of the fp16 mode
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));          // one f16-MFMA operand fragment (16 B)
+#else
+typedef uint16_t half_t;                                             // opaque on the host (emulator never runs fp16 problems)
+#endif
+
 struct MetaRec {            // device mirror of (rewards, actions, terminals) of one ring slot
   int64_t reward;
   uint8_t action;
@@ -79,6 +86,14 @@ struct StepArgs {
   int fuse_rms;
   int f4w_first, f4w_count; // fc4 wgrad tiles [first, first+count) handled by THIS launch (tiles are spread over
                             // the three backward launches so the 25.7 MB fused RMSProp RMW streams in the background)
+  // ---- fp16 mode (--datatype float16): activations / deltas / MFMA weight operands in half, everything else fp32
+  half_t *h_a1, *h_a2, *h_a3;      // [2][B*PIX][K] like a1..a3
+  half_t *h_d4, *h_d3p, *h_d3, *h_d2p, *h_d2, *h_d1;   // deltas, pre-multiplied by loss_scale
+  const half_t* wh[2];             // half copy of theta / theta- in the master (internal) layout: dgrad B operand
+  const half_t* wht[2];            // half copy TRANSPOSED per layer ([n][k], k contiguous): forward B operand
+  half_t *wh_w, *wht_w;            // writable aliases of wh[0] / wht[0] (refreshed by the optimizer epilogues)
+  float loss_scale, inv_loss_scale;
+  int h16;                         // 1: fp16 mode
   int xcd_map;              // 1: XCD-contiguous workgroup->tile map (cuts fabric traffic to ~algorithmic, measured 3-4 % slower)
   int nw_override[12];      // tuning hook: waves per tile for kernel id i (0 = built-in choice)
   float* __restrict__ theta_w;   // online parameters, writable alias of theta[0]

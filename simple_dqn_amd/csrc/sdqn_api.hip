@@ -294,6 +294,9 @@ struct sdqn_net_s {
   int epoch = 0;
   float *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *slab4 = nullptr, *a4 = nullptr, *d4 = nullptr;
   float *d3 = nullptr, *d2 = nullptr;
+  // fp16 mode (cfg.datatype == 1)
+  half_t *h_a1 = nullptr, *h_a2 = nullptr, *h_a3 = nullptr, *h_d4 = nullptr, *h_d3p = nullptr, *h_d3 = nullptr,
+         *h_d2p = nullptr, *h_d2 = nullptr, *h_d1 = nullptr, *wh[2] = {nullptr, nullptr}, *wht[2] = {nullptr, nullptr};
   float *d3p = nullptr, *d2p = nullptr, *d1 = nullptr, *slab1 = nullptr, *slab2 = nullptr, *slab3 = nullptr;
   float *q = nullptr, *maxq = nullptr, *dq = nullptr, *cost_terms = nullptr, *cost_out = nullptr; double* cost_accum = nullptr;
   uint8_t *st_states = nullptr, *st_act = nullptr, *st_term = nullptr; int64_t* st_rew = nullptr; int64_t* d_idx = nullptr;
@@ -338,6 +341,7 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   ARGCHK(c->batch_size > 0 && c->batch_size <= 4096, "bad batch_size %d", c->batch_size);
   ARGCHK(c->num_actions > 0 && c->num_actions <= MAX_ACTIONS, "num_actions must be in 1..%d (got %d)", MAX_ACTIONS, c->num_actions);
   ARGCHK(c->optimizer >= 0 && c->optimizer <= 2, "unknown optimizer %d", c->optimizer);
+  ARGCHK(c->datatype == 0 || c->datatype == 1, "datatype must be 0 (float32) or 1 (float16)");
   ARGCHK(c->screen_height == H0 && c->screen_width == W0 && c->history_length == C0,
          "this build supports 84x84 screens with history_length 4 (got %dx%d, %d)", c->screen_height, c->screen_width, c->history_length);
   STREAMCHK();
@@ -372,6 +376,23 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->slab1, (size_t)h->ns1 * NW1 * 4));
   NCHK(dalloc(h, (void**)&h->slab2, (size_t)h->ns2 * NW2 * 4));
   NCHK(dalloc(h, (void**)&h->slab3, (size_t)h->ns3 * NW3 * 4));
+  if (c->datatype == 1) {
+    if (h->cfg.loss_scale == 0) h->cfg.loss_scale = 1024.0;
+    NCHK(dalloc(h, (void**)&h->h_a1, (size_t)2 * B * PIX1 * K1 * 2));
+    NCHK(dalloc(h, (void**)&h->h_a2, (size_t)2 * B * PIX2 * K2 * 2));
+    NCHK(dalloc(h, (void**)&h->h_a3, (size_t)2 * B * PIX3 * K3 * 2));
+    NCHK(dalloc(h, (void**)&h->h_d4, (size_t)B * NFC * 2));
+    NCHK(dalloc(h, (void**)&h->h_d3p, (size_t)B * PD3 * PD3 * K3 * 2));      // borders stay zero
+    NCHK(dalloc(h, (void**)&h->h_d2p, (size_t)B * PD2 * PD2 * K2 * 2));
+    NCHK(dalloc(h, (void**)&h->h_d3, (size_t)B * PIX3 * K3 * 2));
+    NCHK(dalloc(h, (void**)&h->h_d2, (size_t)B * PIX2 * K2 * 2));
+    NCHK(dalloc(h, (void**)&h->h_d1, (size_t)B * PIX1 * K1 * 2));
+    for (int zz = 0; zz < (c->target_enabled ? 2 : 1); ++zz) {
+      NCHK(dalloc(h, (void**)&h->wh[zz], (size_t)OFF5 * 2));
+      NCHK(dalloc(h, (void**)&h->wht[zz], (size_t)OFF5 * 2));
+    }
+    if (!c->target_enabled) { h->wh[1] = h->wh[0]; h->wht[1] = h->wht[0]; }
+  }
   NCHK(dalloc(h, (void**)&h->q, (size_t)2 * B * h->A * 4));
   NCHK(dalloc(h, (void**)&h->maxq, (size_t)B * 4));
   NCHK(dalloc(h, (void**)&h->dq, (size_t)B * h->A * 4));
@@ -408,6 +429,11 @@ extern "C" int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const fl
   for (int64_t r = 0; r < rows; ++r) for (int64_t c = 0; c < cols; ++c) tmp[(size_t)neon_to_internal(layer, r, c)] = w[r * cols + c];
   HIPCHK(hipStreamSynchronize(g_stream));
   HIPCHK(hipMemcpy(which_buf(h, which) + off, tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  if (h->cfg.datatype == 1 && which <= 1) {      // fp16 mode: the half copies follow the master weights
+    const int zz = (which == 1 && h->theta_t != h->theta) ? 1 : 0;
+    HIPCHK(launch_refresh16(zz ? h->theta_t : h->theta, h->wh[zz], h->wht[zz], g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+  }
   return SDQN_OK;
 }
 extern "C" int sdqn_net_get_weights(sdqn_net_t h, int which, int layer, float* w, int64_t n) {
@@ -474,6 +500,12 @@ static StepArgs step_args(sdqn_net_s* h) {
   a.S4 = h->S4; a.tps1 = h->tps1; a.tps2 = h->tps2; a.tps3 = h->tps3;
   for (int i = 0; i < 12; ++i) a.nw_override[i] = h->nw_override[i];
   a.xcd_map = h->xcd_map ? 1 : 0;
+  if (h->cfg.datatype == 1) {
+    a.h16 = 1; a.h_a1 = h->h_a1; a.h_a2 = h->h_a2; a.h_a3 = h->h_a3; a.h_d4 = h->h_d4; a.h_d3p = h->h_d3p; a.h_d3 = h->h_d3;
+    a.h_d2p = h->h_d2p; a.h_d2 = h->h_d2; a.h_d1 = h->h_d1; a.wh[0] = h->wh[0]; a.wh[1] = h->wh[1]; a.wht[0] = h->wht[0]; a.wht[1] = h->wht[1];
+    a.wh_w = h->wh[0]; a.wht_w = h->wht[0];
+    a.loss_scale = (float)h->cfg.loss_scale; a.inv_loss_scale = (float)(1.0 / h->cfg.loss_scale);
+  }
   a.f4w_first = 0; a.f4w_count = (NIN4 / 32) * (NFC / 32);
   a.fuse_rms = (!h->comm && !h->keep_grads && h->cfg.optimizer == 0) ? 1 : 0;
   a.theta_w = h->theta; a.state = h->state; a.bsz = (float)h->B;
@@ -539,6 +571,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   u.lr = (float)h->cfg.learning_rate; u.eps = (float)h->cfg.epsilon;
   u.skip_fc4 = a.fuse_rms;
   u.opt = h->cfg.optimizer; u.state2 = h->state2;
+  if (h->cfg.datatype == 1) { u.wh = h->wh[0]; u.wht = h->wht[0]; }
   if (u.opt == 1) {            // Neon Adam [neon-recalled]: t = epoch + 1, l = lr*sqrt(1-b2^t)/(1-b1^t), math in Python floats
     const double b1 = h->cfg.beta_1, b2 = h->cfg.beta_2, t = (double)h->epoch + 1.0;
     u.beta1 = (float)b1; u.one_minus_beta1 = (float)(1.0 - b1); u.beta2 = (float)b2; u.one_minus_beta2 = (float)(1.0 - b2);
@@ -663,8 +696,13 @@ extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, 
 }
 extern "C" int sdqn_net_update_target(sdqn_net_t h) {
   ARGCHK(h, "NULL handle");
-  if (h->theta_t != h->theta)
+  if (h->theta_t != h->theta) {
     HIPCHK(hipMemcpyAsync(h->theta_t, h->theta, (size_t)h->NP * 4, hipMemcpyDeviceToDevice, g_stream));   // deepqnetwork.py:102-105
+    if (h->cfg.datatype == 1) {
+      HIPCHK(hipMemcpyAsync(h->wh[1], h->wh[0], (size_t)OFF5 * 2, hipMemcpyDeviceToDevice, g_stream));
+      HIPCHK(hipMemcpyAsync(h->wht[1], h->wht[0], (size_t)OFF5 * 2, hipMemcpyDeviceToDevice, g_stream));
+    }
+  }
   return SDQN_OK;
 }
 extern "C" int sdqn_net_sync(sdqn_net_t h) { ARGCHK(h, "NULL handle"); HIPCHK(hipStreamSynchronize(g_stream)); return SDQN_OK; }

@@ -5,6 +5,7 @@
 //   * update_kernel : split-K slab reduction + fc5 wgrad + RMSProp (deepqnetwork.py:165, A9/A10)
 //   * gather_kernel : standalone replay gather of (s, a, r, s', t) (replay_memory.py:71-78)
 #include "gemm_engine.h"
+#include "problems_h16.h"
 #include "kernels.h"
 
 namespace sdqn {
@@ -28,7 +29,33 @@ static hipError_t launch_nw(int nw, const StepArgs& a, hipStream_t s) {
 }
 
 // Waves per workgroup = how many 32-deep K-chunks run concurrently on one output tile (gemm_engine.h).
+// fp16 mode: forward / dgrad on packed-fp16 MFMA (problems_h16.h), wgrad on the fp32 engine with half operands
+static hipError_t launch_kernel_h16(int id, const StepArgs& a, hipStream_t s) {
+  switch (id) {
+    case K_CONV1_FWD: return launch_gemm<Conv1FwdH, 8>(a, s);
+    case K_CONV2_FWD: return launch_gemm<Conv2FwdH, 16>(a, s);
+    case K_CONV3_FWD: return launch_gemm<Conv3FwdH, 9>(a, s);
+    case K_FC4_FWD: return launch_gemm<Fc4FwdH, 14>(a, s);
+    case K_FC4_DGRAD: return launch_gemm<Fc4DgradH, 16>(a, s);
+    case K_FC4_WGRAD:
+      if (a.B <= 32) return launch_gemm<Fc4WgradH, 1>(a, s);
+      return launch_gemm<Fc4WgradH, 8>(a, s);
+    case K_CONV3_DGRAD: return launch_gemm<Conv3DgradH, 8>(a, s);
+    case K_CONV3_WGRAD: return launch_gemm<Conv3WgradH, 8>(a, s);
+    case K_CONV2_DGRAD: return launch_gemm<Conv2DgradH, 8>(a, s);
+    case K_CONV2_WGRAD: return launch_gemm<Conv2WgradH, 8>(a, s);
+    case K_CONV1_WGRAD: return launch_gemm<Conv1WgradH, 16>(a, s);
+    case K_BWD3:
+      if (a.B <= 32) return launch_multi<512, Fc4WgradH, 1, Conv3DgradH, 8, Conv3WgradH, 8>(a, true, true, s);
+      return launch_multi<512, Fc4WgradH, 8, Conv3DgradH, 8, Conv3WgradH, 8>(a, true, true, s);
+    case K_BWD2: return launch_multi<512, NoProblem, 2, Conv2DgradH, 8, Conv2WgradH, 8>(a, true, true, s);
+    case K_BWD1: return launch_multi<1024, NoProblem, 2, Conv1WgradH, 16, NoProblem, 2>(a, true, false, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
+  if (a.h16) return launch_kernel_h16(id, a, s);
   if (id >= 0 && id < 12 && a.nw_override[id] > 0) {          // tuning hook (sdqn_net_set_option "nw:<id>")
     const int nw = a.nw_override[id];
     switch (id) {
@@ -160,7 +187,9 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   float wa = 0.0f;
 #pragma unroll
   for (int k = 0; k < MAX_ACTIONS; ++k) wa = (k == act) ? w5[0][k] : wa;
-  a.d4[(int64_t)n * NFC + j] = a4v[0] > 0.0f ? wa * dc : 0.0f;
+  const float d4v = a4v[0] > 0.0f ? wa * dc : 0.0f;
+  if (a.h16) a.h_d4[(int64_t)n * NFC + j] = (half_t)(d4v * a.loss_scale);     // fp16 mode: loss-scaled half delta
+  else a.d4[(int64_t)n * NFC + j] = d4v;
   if (j < a.A) h.dq[(int64_t)n * a.A + j] = (j == act) ? dc : 0.0f;
 }
 
@@ -196,6 +225,16 @@ __device__ inline void opt_apply4(float* __restrict__ theta, float* __restrict__
   *reinterpret_cast<float4*>(theta + e) = w;
   *reinterpret_cast<float4*>(st1 + e) = a;
   if (u.opt != 0) *reinterpret_cast<float4*>(st2 + e) = b;
+  if (u.wh && e < OFF5) {                         // fp16 mode: refresh both half copies of these 4 weights
+    const int L = e < OFF2 ? 0 : (e < OFF3 ? 1 : (e < OFF4 ? 2 : 3));
+    const int off = L == 0 ? OFF1 : (L == 1 ? OFF2 : (L == 2 ? OFF3 : OFF4));
+    const int K = L == 0 ? CRS1 : (L == 1 ? CRS2 : (L == 2 ? CRS3 : NIN4));
+    const int N = L == 0 ? K1 : (L == 1 ? K2 : (L == 2 ? K3 : NFC));
+    const int64_t r = e - off; const int k = (int)(r / N), n = (int)(r - (int64_t)k * N);
+    const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { u.wh[e + i] = (half_t)wv[i]; u.wht[off + (int64_t)(n + i) * K + k] = (half_t)wv[i]; }
+  }
 }
 
 // Two kinds of workgroups in one launch:
@@ -318,6 +357,24 @@ hipError_t launch_update(const UpdateArgs& u, hipStream_t s) {
   int dense = 2;                                                   // hosts the ride-along prep and the cost mean
   if (!u.skip_fc4) { dense = (NW4 / 4 + 255) / 256; if (dense > 1792) dense = 1792; }
   hipLaunchKernelGGL(update_kernel, dim3(CONV_BLOCKS + u.A * FC5_BLOCKS_PER_ACTION + dense), dim3(256), 0, s, u);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp16 mode: rebuild wh (master layout) and wht (per-layer transposed, k contiguous) from an fp32 parameter buffer
+__global__ void __launch_bounds__(256) refresh16_kernel(const float* theta, half_t* wh, half_t* wht) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < OFF5; e += (int64_t)gridDim.x * 256) {
+    const int L = e < OFF2 ? 0 : (e < OFF3 ? 1 : (e < OFF4 ? 2 : 3));
+    const int off = L == 0 ? OFF1 : (L == 1 ? OFF2 : (L == 2 ? OFF3 : OFF4));
+    const int K = L == 0 ? CRS1 : (L == 1 ? CRS2 : (L == 2 ? CRS3 : NIN4));
+    const int N = L == 0 ? K1 : (L == 1 ? K2 : (L == 2 ? K3 : NFC));
+    const int64_t r = e - off; const int k = (int)(r / N), n = (int)(r - (int64_t)k * N);
+    const half_t w = (half_t)theta[e];
+    wh[e] = w; wht[off + (int64_t)n * K + k] = w;
+  }
+}
+hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s) {
+  hipLaunchKernelGGL(refresh16_kernel, dim3(2048), dim3(256), 0, s, theta, wh, wht);
   return hipGetLastError();
 }
 

@@ -35,8 +35,10 @@ class DeepQNetwork:
             raise NotImplementedError("batch_norm=True is not on the MI355X hot path yet (SURVEY.md §8f)")
         if getattr(args, "backend", "hip") == "cpu":
             raise NotImplementedError("there is no CPU backend: libsdqn_hip is MI355X-only")
-        if str(getattr(args, "datatype", "float32")) not in ("float32", "<class 'numpy.float32'>"):
-            raise NotImplementedError("only float32 is implemented (fp16 activations: SURVEY.md config 5, next)")
+        dt = str(getattr(args, "datatype", "float32"))
+        if dt not in ("float32", "float16"):
+            raise NotImplementedError("datatype %s: float32 and float16 (half activations, fp32 master weights) are implemented" % dt)
+        self.datatype = dt
         optimizer = getattr(args, "optimizer", "rmsprop")
         assert optimizer in ("rmsprop", "adam", "adadelta"), "Unknown optimizer"      # deepqnetwork.py:61
         self.optimizer = optimizer
@@ -51,6 +53,8 @@ class DeepQNetwork:
         cfg.learning_rate = float(getattr(args, "learning_rate", 0.00025))
         cfg.decay_rate = float(getattr(args, "decay_rate", 0.95))
         cfg.optimizer = ("rmsprop", "adam", "adadelta").index(optimizer)              # :50-59
+        cfg.datatype = 1 if dt == "float16" else 0                                   # :33
+        cfg.loss_scale = float(getattr(args, "loss_scale", 1024.0))
         # Neon's defaults (the reference passes none): RMSProp/Adadelta epsilon 1e-6, Adam epsilon 1e-8, betas 0.9/0.999
         cfg.epsilon = float(getattr(args, "optimizer_epsilon", 1e-8 if optimizer == "adam" else 1e-6))
         cfg.beta_1, cfg.beta_2 = float(getattr(args, "beta_1", 0.9)), float(getattr(args, "beta_2", 0.999))

@@ -31,7 +31,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_cfg_struct_layout():
     assert C.sizeof(_lib.NetCfg) == 8 * 4 + 11 * 8
-    assert _lib.NetCfg.optimizer.offset == 24 and _lib.NetCfg.beta_1.offset == 32 + 7 * 8
+    assert _lib.NetCfg.optimizer.offset == 24 and _lib.NetCfg.datatype.offset == 28 and _lib.NetCfg.beta_1.offset == 32 + 7 * 8
 
 
 def test_mt_seed_and_randint_bit_exact():

@@ -453,3 +453,86 @@ def test_preconditions_raise_like_the_reference(sd):
         sd.DeepQNetwork(A, make_args(batch_size=B, batch_norm=True))
     with pytest.raises(AssertionError):
         sd.DeepQNetwork(A, make_args(batch_size=B, optimizer="sgd"))  # deepqnetwork.py:61
+
+
+# ---- float16 mode (BASELINE.json configs[4] precision on one GPU): half activations / deltas / MFMA weight operands,
+# ---- fp32 accumulation, master weights and optimizer state.  Oracle: OracleDQN(half_activations=True).
+H_TOL = 3e-3          # Q tolerance of the fp16 mode vs its oracle: a few half ulps (2^-11 relative) through 5 layers
+
+
+def _pair_h(sd, A, B, seed, **kw):
+    args = make_args(batch_size=B, datatype="float16", **kw)
+    net = sd.DeepQNetwork(A, args)
+    ws, wt = xavier_weights(A, seed), xavier_weights(A, seed + 1)
+    net.set_weights(wt, 1)
+    net.set_weights(ws, 0)
+    o = OracleDQN(A, batch_size=B, weights=ws, half_activations=True)
+    o.Wt = [w.copy() for w in wt]
+    return net, o
+
+
+@pytest.mark.parametrize("A,B", [(4, 32), (6, 8)])
+def test_fp16_predict_parity(sd, A, B):
+    net, o = _pair_h(sd, A, B, 401)
+    st = random_minibatch(B, A, 402)[0]
+    q, qo = net.predict(st), o.predict(st)
+    print("fp16 predict: max abs err %.3e (|Q| max %.3f)" % (np.abs(q - qo).max(), np.abs(qo).max()))
+    assert np.abs(q - qo).max() < H_TOL
+    o32 = OracleDQN(A, batch_size=B, weights=o.W)
+    assert np.abs(q - o32.predict(st)).max() < 2e-2                  # and close to the fp32 network
+    one = net.predict_one(st[0])
+    assert np.array_equal(one, q[0])
+
+
+def test_fp16_one_step_gradients(sd):
+    A, B = 4, 32
+    net, o = _pair_h(sd, A, B, 411)
+    net.set_option("keep_gradients", 1)
+    mb = random_minibatch(B, A, 412, reward_range=(-2, 3))
+    g, cost, _, preq = o.gradients(mb)
+    costs = []
+    net.callback = type("CB", (), {"on_train": lambda self, c: costs.append(c)})()
+    net.train(mb)
+    q, _ = net.last_q()
+    assert np.abs(q - preq).max() < H_TOL
+    assert abs(costs[0] - float(cost)) < 5e-3 * max(1.0, float(cost))
+    for i in range(5):
+        gg = net.get_layer(i, which=3)
+        rel = np.abs(gg - g[i]).max() / max(1e-6, np.abs(g[i]).max())
+        print("fp16 grad layer %d: max rel err %.3e" % (i, rel))
+        assert rel < 2e-2, i                                        # half rounding flips under fp32 accumulation
+
+
+def test_fp16_training_tracks_oracle_and_fused_path(sd):
+    A, B = 4, 32
+    net, o = _pair_h(sd, A, B, 421)
+    net2, _ = _pair_h(sd, A, B, 421)
+    net2.set_option("keep_gradients", 1)                             # unfused fc4 update: must match the fused one
+    hold = random_minibatch(B, A, 422)[0]
+    for s in range(5):
+        mb = random_minibatch(B, A, 423 + s, p_term=0.05, reward_range=(-1, 2))
+        net.train(mb); net2.train(mb); o.train(mb)
+    q, q2, qo = net.predict(hold), net2.predict(hold), o.predict(hold)
+    print("fp16 5 steps: Q max abs err vs half oracle %.3e" % np.abs(q - qo).max())
+    assert np.array_equal(q, q2)
+    assert np.abs(q - qo).max() < 2e-2                               # 5 free-running steps of a half-precision net
+    net.update_target_network()
+    assert np.isfinite(net.predict(hold)).all()
+
+
+def test_fp16_fused_replay_path(sd):
+    A, B, size = 4, 32, 3000
+    args = make_args(batch_size=B, datatype="float16")
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 5, num_actions=A)
+    mem.sync_mirror()
+    n1, _ = _pair_h(sd, A, B, 431)
+    n2, _ = _pair_h(sd, A, B, 431)
+    random.seed(6)
+    st = random.getstate()
+    for _ in range(3):
+        n1.train(mem.getMinibatch())
+    random.setstate(st)
+    n2.train_from_memory(mem, 3)
+    for i in range(5):
+        assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
