@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--datatype", choices=["float32", "float16"], default="float32",
+                    help="float16 = BASELINE.json configs[4] precision (half activations, fp32 master weights); NOT the headline")
     ap.add_argument("--zero-copy", action="store_true", help="gather from the pinned host ring over PCIe (no HBM mirror)")
     a = ap.parse_args()
 
@@ -221,7 +223,7 @@ def main():
     _lib.check(sd.load().sdqn_set_device(local_rank))
 
     B, A = a.batch_size, a.num_actions
-    args = make_args(batch_size=B, random_seed=a.seed + 1)            # identical initial weights on every rank
+    args = make_args(batch_size=B, random_seed=a.seed + 1, datatype=a.datatype)   # identical initial weights on every rank
     mem = sd.ReplayMemory(a.replay_size, args, flags=2 if a.zero_copy else 1)
     fill_ring(mem, a.seed + 1000 * rank, A)                            # own experience per learner
     net = sd.DeepQNetwork(A, args)
@@ -281,7 +283,8 @@ def main():
             "metric": "train_steps/sec (batch=32, 4x84x84 uint8)" if B == 32 else "train_steps/sec (batch=%d, 4x84x84 uint8)" % B,
             "value": round(total_steps / el, 2), "unit": "train_steps/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.datatype == "float32" else "f16 activations/deltas/MFMA operands, f32 accumulate + master weights + RMSProp",
             "data": "synthetic (seeded uniform uint8 84x84 frames tiled into the ring; random-init Xavier weights)",
             "config": {"workload": "BASELINE.json configs[1]: Breakout shapes, batch_size=%d, replay_size=%d, num_actions=%d, "
                                    "HIP Q-net + device replay gather fused into conv1" % (B, a.replay_size, A),
@@ -290,7 +293,7 @@ def main():
         }
         out["roofline"] = roofline_entry(dom["id"], dom["name"], live["total_ms"] / max(live["launches"], 1), B, A)
         out["kernels_us"] = {p["name"]: round(p["total_ms"] / p["launches"] * 1e3, 2) for p in step_kernels}
-        if world == 1:
+        if world == 1 and a.datatype == "float32":
             idx = np.array(mem.sample_indexes())
             g_ms = mem.bench_gather(idx, iters=200)
             out["replay_gather"] = roofline_entry(14, "replay_gather_u8", g_ms, B, A)
