@@ -119,13 +119,38 @@ struct Fc4WgradH : Fc4Wgrad {
       refresh_half(a, OFF4, NIN4, NFC, m, n, w);
     } else a.g[e] = g;
   }
-  struct Epi {};
-  __device__ static void epi_begin(const StepArgs&, int, int, int, Epi&) {}
-  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&) {
+  // single-wave epilogue (B <= 32), as Fc4Wgrad's: theta / state loads issued at kernel entry; the transposed half copy
+  // is written as 4-half (8 B) groups — a lane's 16 accumulator rows are 4 runs of 4 consecutive k'
+  struct Epi { float w[16], st[16]; };
+  __device__ static void epi_begin(const StepArgs& a, int m0, int n0, int lane, Epi& e) {
+    if (!a.fuse_rms) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      store(a, z, ks, m0 + ml, n0 + (lane & 31), v[r]);
+      const int64_t o = OFF4 + (int64_t)(m0 + ml) * NFC + n0 + (lane & 31);
+      e.w[r] = a.theta_w[o]; e.st[r] = a.state[o];
+    }
+  }
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi& e) {
+    const int n = n0 + (lane & 31);
+    if (!a.fuse_rms) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); a.g[OFF4 + (int64_t)(m0 + ml) * NFC + n] = v[r] * a.inv_loss_scale; }
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e.w[r] = rms_step(e.w[r], e.st[r], v[r] * a.inv_loss_scale, a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int64_t o = OFF4 + (int64_t)(m0 + ml) * NFC + n;
+      a.theta_w[o] = e.w[r]; a.state[o] = e.st[r]; a.wh_w[o] = (half_t)e.w[r];
+    }
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      half4 hv; hv[0] = (half_t)e.w[4 * g]; hv[1] = (half_t)e.w[4 * g + 1]; hv[2] = (half_t)e.w[4 * g + 2]; hv[3] = (half_t)e.w[4 * g + 3];
+      *reinterpret_cast<half4*>(a.wht_w + OFF4 + (int64_t)n * NIN4 + m0 + 8 * g + 4 * (lane >> 5)) = hv;
     }
   }
 };
