@@ -72,6 +72,15 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
       default: break;
     }
   }
+  if (a.B >= 128) {            // throughput regime (thousands of tiles per launch): tools/sweep_nw.py at B = 256
+    switch (id) {
+      case K_CONV2_FWD: return launch_gemm<Conv2Fwd, 8>(a, s);
+      case K_CONV3_FWD: return launch_gemm<Conv3Fwd, 8>(a, s);
+      case K_FC4_FWD: return launch_gemm<Fc4Fwd, 8>(a, s);
+      case K_FC4_DGRAD: return launch_gemm<Fc4Dgrad, 4>(a, s);
+      default: break;
+    }
+  }
   switch (id) {
     case K_CONV1_FWD: return launch_gemm<Conv1Fwd, 8>(a, s);        // K = 256  -> 8 chunks
     case K_CONV2_FWD: return launch_gemm<Conv2Fwd, 16>(a, s);       // K = 512  -> 16 chunks
