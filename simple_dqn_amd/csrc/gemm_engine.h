@@ -148,10 +148,15 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
       const bool hi = lane >= 32;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
+        // offsets of out-of-range k were clamped to k = kbeg above, so the load is always in bounds: load
+        // unconditionally and select afterwards (a conditional load makes hipcc branch around every element with an
+        // s_waitcnt vmcnt(0) inside — 16 serialised round trips per chunk)
         const aoff_t c = pick_half(cv, i, hi);
         const bool ok = kc + i + (hi ? 16 : 0) < kend;
-        if constexpr (P::A_U8) dst[i] = ok ? P::a_load(a, z, arow[0] + c) : 0.0f;
-        else dst[i] = ok ? (float)abase[(uint32_t)(arow[0] + c)] : 0.0f;   // uniform base + 32-bit lane offset
+        float v;
+        if constexpr (P::A_U8) v = P::a_load(a, z, arow[0] + c);
+        else v = (float)abase[(uint32_t)(arow[0] + c)];                    // uniform base + 32-bit lane offset
+        dst[i] = ok ? v : 0.0f;
       }
     }
   };
@@ -176,7 +181,8 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int r = pick_half(rv, i, hi);
-        dst[i] = kc + i + (hi ? 16 : 0) < kend ? (float)bbase[(uint32_t)(r + bcol[0])] : 0.0f;
+        const float v = (float)bbase[(uint32_t)(r + bcol[0])];             // always in bounds (clamped k), see load_a
+        dst[i] = kc + i + (hi ? 16 : 0) < kend ? v : 0.0f;
       }
     }
   };
