@@ -138,7 +138,8 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
 #pragma unroll
     for (int z = 0; z < 2; ++z)
 #pragma unroll
-      for (int s = 0; s < 7; ++s) t[z][s] = z < a.nz ? a.slab4[s * sstride + ((int64_t)z * a.B + n) * NFC + j] : 0.0f;
+      for (int s = 0; s < 7; ++s)      // unconditional loads (z clamped): a conditional load costs a branch + vmcnt(0) each
+        t[z][s] = a.slab4[s * sstride + ((int64_t)(z < a.nz ? z : 0) * a.B + n) * NFC + j];
 #pragma unroll
     for (int z = 0; z < 2; ++z) { float v = 0.0f;
 #pragma unroll
