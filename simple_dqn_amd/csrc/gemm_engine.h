@@ -10,11 +10,11 @@
 //     w, w+NW, ... and runs them autonomously — NO workgroup barrier in the main loop, every wave
 //     has its next chunk's global loads in flight while it issues the current chunk's 16 MFMAs;
 //   * operands whose memory-contiguous dimension is m/n (weights [k][n], deltas [m][f], the wgrad
-//     im2col rows) are loaded straight into the MFMA operand layout (lane l <- [k + (l>>5)][x0 + (l&31)],
+//     im2col rows) are loaded straight into the MFMA operand layout (lane l <- [kslot][x0 + (l&31)],
 //     two coalesced 128-B rows per instruction, no LDS);
-//   * operands contiguous along k (im2col patches, activations, dgrad weights) are fetched with
-//     16 B/lane vector loads (4 B/lane for the u8 ring) and transposed through a WAVE-PRIVATE LDS
-//     panel [k][x] (pitch 33: conflict-free for both the k-major stores and the x-major reads);
+//   * operands contiguous along k (im2col patches, activations, dgrad weights) need NO staging either: the MFMA's
+//     k-slot <-> logical-k assignment is free as long as A and B agree, and with kslot(t, h) = 8*(t>>2) + 4h + (t&3)
+//     a lane's 16 operand values are four 16 B loads of its own row (4 B for the u8 ring);
 //   * the NW partial tiles are summed through LDS in a fixed order (deterministic), then P::store.
 //
 // MFMA operand maps (guide §3): lane l holds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
@@ -38,28 +38,21 @@ template <class P> struct uses_f16_mfma<P, decltype((void)P::F16_MFMA)> { static
 
 constexpr int PANEL = 32 * 33;      // one [32 k][32 x] fp32 panel, pitch 33
 
-__device__ __forceinline__ void wave_lds_sync() {
-  // wave-private LDS hand-off between lanes of ONE wave: LDS ops of a wave execute in order, so only
-  // the compiler has to be kept from reordering the stores past the loads
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
-// offset of step i for this lane's half: lanes 0-31 take lane i's value, lanes 32-63 lane (i+16)'s.
-// v_readlane (VALU -> SGPR, no LDS round trip) x2 + v_cndmask; i is a compile-time constant after unrolling.
-__device__ __forceinline__ int pick_half(int v, int i, bool hi) {
-  const int lo = __builtin_amdgcn_readlane(v, i), up = __builtin_amdgcn_readlane(v, i + 16);
+// value held by lane s (lanes 0-31) / lane s+4 (lanes 32-63): the k-slot of the upper half-wave is 4 further.
+// v_readlane (VALU -> SGPR, no LDS round trip) x2 + v_cndmask; s is a compile-time constant after unrolling.
+__device__ __forceinline__ int pick_half(int v, int s, bool hi) {
+  const int lo = __builtin_amdgcn_readlane(v, s), up = __builtin_amdgcn_readlane(v, s + 4);
   return hi ? up : lo;
 }
-__device__ __forceinline__ int64_t pick_half(int64_t v, int i, bool hi) {
+__device__ __forceinline__ int64_t pick_half(int64_t v, int s, bool hi) {
+  const int i = s;
   const int l0 = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFF), i), l1 = __builtin_amdgcn_readlane((int)(v >> 32), i);
-  const int u0 = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFF), i + 16), u1 = __builtin_amdgcn_readlane((int)(v >> 32), i + 16);
+  const int u0 = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFF), i + 4), u1 = __builtin_amdgcn_readlane((int)(v >> 32), i + 4);
   const int64_t lo = ((int64_t)l1 << 32) | (uint32_t)l0, up = ((int64_t)u1 << 32) | (uint32_t)u0;
   return hi ? up : lo;
 }
 
-// LDS floats one workgroup of NW waves needs for problem P
 #ifdef SDQN_TIMING
 // phase stamps (s_memtime) of wave 0 of every workgroup: dbg[(block*8 + phase)]; NOT in the product build
 __device__ unsigned long long* g_sdqn_dbg = nullptr;
@@ -68,16 +61,21 @@ __device__ unsigned long long* g_sdqn_dbg = nullptr;
 #define SDQN_STAMP(ph) do {} while (0)
 #endif
 
+// LDS floats one workgroup of NW waves needs (only the fixed-order combine of the NW partial tiles uses LDS)
 template <class P, int NW>
-constexpr int tile_lds() { return NW * (((P::A_K ? 1 : 0) + (P::B_K ? 1 : 0)) > 0 ? ((P::A_K ? 1 : 0) + (P::B_K ? 1 : 0)) : 1) * PANEL; }
+constexpr int tile_lds() { return NW * PANEL; }
+
+// k-slot assignment shared by BOTH operands of every problem: MFMA step t (0..15) of a 32-deep chunk, half-wave h,
+// consumes logical k = kc + kslot(t, h).  Any bijection works as long as A and B agree; this one makes a k-contiguous
+// operand exactly four 16-byte loads of the lane's own row (j = t >> 2 selects the load, e = t & 3 the component):
+__device__ __forceinline__ constexpr int kslot(int t, int h) { return 8 * (t >> 2) + 4 * h + (t & 3); }
 
 // One 32x32 output tile (bx, by, bz) of problem P computed by the first NW waves of a workgroup of NT threads
 // (waves >= NW idle through the epilogue barrier).  NW == 1 inside a wider workgroup is handled by the caller
 // (one tile per wave, no barrier): see gemm_multi_kernel.
 template <class P, int NW, int NT>
 __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int bz, float* smem) {
-  constexpr int NPAN = (P::A_K ? 1 : 0) + (P::B_K ? 1 : 0);
-  constexpr int WAVE_LDS = (NPAN > 0 ? NPAN : 1) * PANEL;
+  constexpr int WAVE_LDS = PANEL;
   typedef typename P::aoff_t aoff_t;
 
   SDQN_STAMP(0);
@@ -88,101 +86,85 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
   P::ksplit(a, bz, z, ks, kbeg, kend);
   if (NW * 64 < NT && wave >= NW) kend = kbeg;          // surplus waves of a wider workgroup: no chunks
   const int M = P::M(a), N = P::N(a);
-  float* pa = smem + (wave < NW ? wave : 0) * WAVE_LDS;
-  float* pb = pa + (P::A_K ? PANEL : 0);
+  const int hb = lane >> 5;                             // half-wave: which k-slots this lane feeds
+  const bool hi = lane >= 32;
 
-  // ---- per-lane operand geometry ---------------------------------------------------------------
-  // k-contiguous operand: lane -> (k4 = l & 7, x = (l >> 3) + 8j), one 4-vector per j < 4
-  // x-contiguous operand: lane -> (x = l & 31, k = i + 16*(l >> 5)), one scalar per i < 16 (MFMA layout).
-  aoff_t arow[P::A_K ? 4 : 1];
-  int bcol[P::B_K ? 4 : 1];
-  if constexpr (P::A_K) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int m = m0 + (lane >> 3) + 8 * j; arow[j] = P::a_row(a, z, m < M ? m : M - 1); }
-  } else {
-    const int m = m0 + (lane & 31); arow[0] = P::a_row(a, z, m < M ? m : M - 1);
-  }
-  if constexpr (P::B_K) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int n = n0 + (lane >> 3) + 8 * j; bcol[j] = P::b_col(a, z, n < N ? n : N - 1); }
-  } else {
-    const int n = n0 + (lane & 31); bcol[0] = P::b_col(a, z, n < N ? n : N - 1);
-  }
-
-  // fast-path pointers: regular operands get a per-lane pointer (row 0 for lanes 0-31, row 16 for 32-63)
+  // ---- per-lane operand geometry: lane l always owns row m0 + (l & 31) of A and column n0 + (l & 31) of B ----------
+  const int mrow = m0 + (lane & 31), ncol = n0 + (lane & 31);
+  const aoff_t arow = P::a_row(a, z, mrow < M ? mrow : M - 1);
+  const int bcol = P::b_col(a, z, ncol < N ? ncol : N - 1);
   typedef typename a_elem<P>::type AT; typedef typename b_elem<P>::type BT;
   const AT* abase = P::a_ptr(a, z);
   const BT* bbase = P::b_ptr(a, z);
+  // plain row-major [k][x] operands: per-lane pointer fixed for the whole tile (row 0 / row 4 for the two half-waves)
   const AT* areg = nullptr; const BT* breg = nullptr;
-  if constexpr (!P::A_K && P::A_REG) areg = abase + (uint32_t)arow[0] + (lane >= 32 ? 16 * P::A_LD : 0);
-  if constexpr (!P::B_K && P::B_REG) breg = bbase + (uint32_t)bcol[0] + (lane >= 32 ? 16 * P::B_LD : 0);
+  if constexpr (!P::A_K && P::A_REG) areg = abase + (uint32_t)arow + (hi ? 4 * P::A_LD : 0);
+  if constexpr (!P::B_K && P::B_REG) breg = bbase + (uint32_t)bcol + (hi ? 4 * P::B_LD : 0);
   (void)abase; (void)bbase; (void)areg; (void)breg;
 
   typename P::Epi epi;
   if constexpr (NW == 1) P::epi_begin(a, m0, n0, lane, epi);
 
-  // k-contiguous operands are software-prefetched one chunk ahead (registers -> wave-private LDS panel);
-  // x-contiguous operands are loaded straight into their MFMA registers at the top of the chunk (no second
-  // register set: keeps the kernels under ~80 VGPRs so 6-7 waves/SIMD stay resident and hide the latency)
-  float ra[P::A_K ? 16 : 1], rb[P::B_K ? 16 : 1];
+  // One chunk's 16 MFMA operand values of this lane, straight from global memory into registers (no LDS staging):
+  //   k-contiguous operand : 4 x 16-byte loads (4 bytes for the u8 ring) of the lane's own row at k = kc + 8j + 4h
+  //   x-contiguous, regular: 16 dword loads off the per-lane pointer at immediate row offsets kslot(t, 0) * LD
+  //   x-contiguous, im2col : one index decomposition per lane per chunk (lane <-> k = kc + (l & 31)), distributed with
+  //                          v_readlane; offsets of out-of-range k are clamped in bounds, loads are UNconditional and the
+  //                          value is selected afterwards (a conditional load costs a branch + vmcnt(0) per element)
   auto load_a = [&](int kc, float* dst) {
     if constexpr (P::A_K) {
-      const aoff_t c = P::a_col(a, z, kc + 4 * (lane & 7));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const f4 v = P::a_load4(a, z, arow[j] + c); dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w; }
+      for (int j = 0; j < 4; ++j) {
+        const f4 v = P::a_load4(a, z, arow + P::a_col(a, z, kc + 8 * j + 4 * hb));
+        dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w;
+      }
     } else if constexpr (P::A_REG) {
-      // plain row-major [k][m] matrix: per-lane pointer fixed for the whole tile, 16 loads at k-row offsets
       if (kc + 32 <= kend) {
         const AT* p = areg + (size_t)kc * P::A_LD;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dst[i] = (float)p[(size_t)i * P::A_LD];
+        for (int t = 0; t < 16; ++t) dst[t] = (float)p[(size_t)kslot(t, 0) * P::A_LD];
       } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { const int k = kc + i + (lane >= 32 ? 16 : 0); dst[i] = k < kend ? (float)areg[(size_t)(kc + i) * P::A_LD] : 0.0f; }
+        for (int t = 0; t < 16; ++t) { const int k = kc + kslot(t, hb); dst[t] = k < kend ? (float)areg[(size_t)(kc + kslot(t, 0)) * P::A_LD] : 0.0f; }
       }
     } else {
-      // one im2col decomposition per lane per chunk (lane <-> k = kc + (l & 31)); step i fetches its
-      // offset from lane i (+16 for the upper half-wave) with v_readlane
       const int kl = kc + (lane & 31);
       const aoff_t cv = P::a_col(a, z, kl < kend ? kl : kbeg);
-      const bool hi = lane >= 32;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        // offsets of out-of-range k were clamped to k = kbeg above, so the load is always in bounds: load
-        // unconditionally and select afterwards (a conditional load makes hipcc branch around every element with an
-        // s_waitcnt vmcnt(0) inside — 16 serialised round trips per chunk)
-        const aoff_t c = pick_half(cv, i, hi);
-        const bool ok = kc + i + (hi ? 16 : 0) < kend;
+      for (int t = 0; t < 16; ++t) {
+        const aoff_t c = pick_half(cv, kslot(t, 0), hi);
+        const bool ok = kc + kslot(t, hb) < kend;
         float v;
-        if constexpr (P::A_U8) v = P::a_load(a, z, arow[0] + c);
-        else v = (float)abase[(uint32_t)(arow[0] + c)];                    // uniform base + 32-bit lane offset
-        dst[i] = ok ? v : 0.0f;
+        if constexpr (P::A_U8) v = P::a_load(a, z, arow + c);
+        else v = (float)abase[(uint32_t)(arow + c)];                      // uniform base + 32-bit lane offset
+        dst[t] = ok ? v : 0.0f;
       }
     }
   };
   auto load_b = [&](int kc, float* dst) {
     if constexpr (P::B_K) {
-      const int r = P::b_row(a, z, kc + 4 * (lane & 7));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const f4 v = P::b_load4(a, z, r + bcol[j]); dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w; }
+      for (int j = 0; j < 4; ++j) {
+        const f4 v = P::b_load4(a, z, bcol + P::b_row(a, z, kc + 8 * j + 4 * hb));
+        dst[4 * j] = v.x; dst[4 * j + 1] = v.y; dst[4 * j + 2] = v.z; dst[4 * j + 3] = v.w;
+      }
     } else if constexpr (P::B_REG) {
       if (kc + 32 <= kend) {
         const BT* p = breg + (size_t)kc * P::B_LD;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dst[i] = (float)p[(size_t)i * P::B_LD];
+        for (int t = 0; t < 16; ++t) dst[t] = (float)p[(size_t)kslot(t, 0) * P::B_LD];
       } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { const int k = kc + i + (lane >= 32 ? 16 : 0); dst[i] = k < kend ? (float)breg[(size_t)(kc + i) * P::B_LD] : 0.0f; }
+        for (int t = 0; t < 16; ++t) { const int k = kc + kslot(t, hb); dst[t] = k < kend ? (float)breg[(size_t)(kc + kslot(t, 0)) * P::B_LD] : 0.0f; }
       }
     } else {
       const int kl = kc + (lane & 31);
       const int rv = P::b_row(a, z, kl < kend ? kl : kbeg);
-      const bool hi = lane >= 32;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = pick_half(rv, i, hi);
-        const float v = (float)bbase[(uint32_t)(r + bcol[0])];             // always in bounds (clamped k), see load_a
-        dst[i] = kc + i + (hi ? 16 : 0) < kend ? v : 0.0f;
+      for (int t = 0; t < 16; ++t) {
+        const int r = pick_half(rv, kslot(t, 0), hi);
+        const float v = (float)bbase[(uint32_t)(r + bcol)];               // always in bounds (clamped k)
+        dst[t] = kc + kslot(t, hb) < kend ? v : 0.0f;
       }
     }
   };
@@ -193,50 +175,20 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
 
   int kc = kbeg + (wave < NW ? wave : 0) * 32;            // wave-uniform
   SDQN_STAMP(1);
-  if (kc < kend) {
-    if constexpr (P::A_K) load_a(kc, ra);
-    if constexpr (P::B_K) load_b(kc, rb);
-  }
   SDQN_STAMP(2);
+  // No software prefetch across chunks: one register set keeps the kernels at ~64 VGPRs, so 7-8 waves per SIMD are
+  // resident and hide each other's load latency (most waves own a single chunk at B = 32 anyway).
   while (kc < kend) {
     float fa[16], fb[16];
-    if constexpr (!P::A_K) load_a(kc, fa);
-    if constexpr (!P::B_K) load_b(kc, fb);
-    // ---- k-contiguous operands: registers -> wave-private panel
-    if constexpr (P::A_K) {
-      float* d = pa + (4 * (lane & 7)) * 33 + (lane >> 3);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { d[8 * j] = ra[4 * j]; d[33 + 8 * j] = ra[4 * j + 1]; d[66 + 8 * j] = ra[4 * j + 2]; d[99 + 8 * j] = ra[4 * j + 3]; }
-    }
-    if constexpr (P::B_K) {
-      float* d = pb + (4 * (lane & 7)) * 33 + (lane >> 3);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { d[8 * j] = rb[4 * j]; d[33 + 8 * j] = rb[4 * j + 1]; d[66 + 8 * j] = rb[4 * j + 2]; d[99 + 8 * j] = rb[4 * j + 3]; }
-    }
-    const int knext = kc + NW * 32;
-    if (knext < kend) {                                   // next chunk's k-contiguous loads fly under the MFMAs
-      if constexpr (P::A_K) load_a(knext, ra);
-      if constexpr (P::B_K) load_b(knext, rb);
-    }
-    if constexpr (P::A_K || P::B_K) wave_lds_sync();
-    if constexpr (P::A_K) {
-      const float* s = pa + (lane >> 5) * (16 * 33) + (lane & 31);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) fa[i] = s[33 * i];
-    }
-    if constexpr (P::B_K) {
-      const float* s = pb + (lane >> 5) * (16 * 33) + (lane & 31);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) fb[i] = s[33 * i];
-    }
+    load_a(kc, fa);
+    load_b(kc, fb);
 #ifdef SDQN_TIMING
     asm volatile("" :: "v"(fa[0]), "v"(fb[0]), "v"(fa[15]), "v"(fb[15]));      // operands landed
     SDQN_STAMP(3);
 #endif
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[i], acc, 0, 0, 0);
-    if constexpr (P::A_K || P::B_K) wave_lds_sync();      // panel reads done before the next chunk's stores
-    kc = knext;
+    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
+    kc += NW * 32;
   }
 
   // ---- epilogue: NW partial tiles -> LDS -> summed in fixed order -> P::store (lanes along n) ----
@@ -334,7 +286,7 @@ __device__ __forceinline__ void run_tile(const StepArgs& a, int bx, int by, int 
   else gemm_tile<P, NW, NT>(a, bx, by, bz, smem);
 }
 template <class P, int NW>
-constexpr int tile_lds_any() { return uses_f16_mfma<P>::value ? NW * PANEL : tile_lds<P, NW>(); }
+constexpr int tile_lds_any() { return NW * PANEL; }
 
 // XCD-aware workgroup -> tile map (guide T1).  The dispatcher places workgroup b on XCD b % 8, each XCD with its
 // own L2.  Tiles are numbered x-fastest (then y, then split/net z), so NEIGHBOURING tile ids share operands
