@@ -33,10 +33,25 @@ template <class P, class = void> struct a_elem { typedef float type; };
 template <class P> struct a_elem<P, decltype((void)sizeof(typename P::AT))> { typedef typename P::AT type; };
 template <class P, class = void> struct b_elem { typedef float type; };
 template <class P> struct b_elem<P, decltype((void)sizeof(typename P::BT))> { typedef typename P::BT type; };
+// k-contiguous operands: direct (4 x 16 B loads of the lane's own row: 32 cache lines per instruction, no LDS) or
+// staged (lanes (k4, x): 8 rows x 128 B per instruction, transposed through a wave-private LDS panel).  Direct wins
+// when the rows of a tile are close together and the launch is latency-bound (conv fwd/dgrad at B = 32); staged wins
+// for the fc4 GEMMs (rows 2-12 KB apart) and in the throughput regime (B >= 128).  Measured: profiles/README.md.
+template <class P, class = void> struct stages_lds { static constexpr bool value = false; };
+template <class P> struct stages_lds<P, decltype((void)P::STAGE_LDS)> { static constexpr bool value = P::STAGE_LDS; };
+template <class P> struct Staged : P { static constexpr bool STAGE_LDS = true; };      // same problem, staged operands
 template <class P, class = void> struct uses_f16_mfma { static constexpr bool value = false; };
 template <class P> struct uses_f16_mfma<P, decltype((void)P::F16_MFMA)> { static constexpr bool value = P::F16_MFMA; };
 
 constexpr int PANEL = 32 * 33;      // one [32 k][32 x] fp32 panel, pitch 33
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // wave-private LDS hand-off between lanes of ONE wave: LDS ops of a wave execute in order, so only
+  // the compiler has to be kept from reordering the stores past the loads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 
 // value held by lane s (lanes 0-31) / lane s+4 (lanes 32-63): the k-slot of the upper half-wave is 4 further.
@@ -63,7 +78,9 @@ __device__ unsigned long long* g_sdqn_dbg = nullptr;
 
 // LDS floats one workgroup of NW waves needs (only the fixed-order combine of the NW partial tiles uses LDS)
 template <class P, int NW>
-constexpr int tile_lds() { return NW * PANEL; }
+constexpr int tile_lds() {
+  return NW * PANEL * (stages_lds<P>::value && (P::A_K || P::B_K) ? ((P::A_K ? 1 : 0) + (P::B_K ? 1 : 0)) : 1);
+}
 
 // k-slot assignment shared by BOTH operands of every problem: MFMA step t (0..15) of a 32-deep chunk, half-wave h,
 // consumes logical k = kc + kslot(t, h).  Any bijection works as long as A and B agree; this one makes a k-contiguous
@@ -75,7 +92,9 @@ __device__ __forceinline__ constexpr int kslot(int t, int h) { return 8 * (t >> 
 // (one tile per wave, no barrier): see gemm_multi_kernel.
 template <class P, int NW, int NT>
 __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int bz, float* smem) {
-  constexpr int WAVE_LDS = PANEL;
+  constexpr bool STG = stages_lds<P>::value;
+  constexpr bool STG_A = STG && P::A_K, STG_B = STG && P::B_K;
+  constexpr int WAVE_LDS = PANEL * ((STG_A || STG_B) ? ((STG_A ? 1 : 0) + (STG_B ? 1 : 0)) : 1);
   typedef typename P::aoff_t aoff_t;
 
   SDQN_STAMP(0);
@@ -101,6 +120,20 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
   if constexpr (!P::A_K && P::A_REG) areg = abase + (uint32_t)arow + (hi ? 4 * P::A_LD : 0);
   if constexpr (!P::B_K && P::B_REG) breg = bbase + (uint32_t)bcol + (hi ? 4 * P::B_LD : 0);
   (void)abase; (void)bbase; (void)areg; (void)breg;
+
+  // staged operands: lane -> (k4 = l & 7, rows (l >> 3) + 8j) for the loads, wave-private panels [k][x] (pitch 33)
+  float* pan_a = smem + (wave < NW ? wave : 0) * WAVE_LDS;
+  float* pan_b = pan_a + (STG_A ? PANEL : 0);
+  aoff_t srow[STG_A ? 4 : 1]; int scol[STG_B ? 4 : 1];
+  if constexpr (STG_A) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int m = m0 + (lane >> 3) + 8 * j; srow[j] = P::a_row(a, z, m < M ? m : M - 1); }
+  }
+  if constexpr (STG_B) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int n = n0 + (lane >> 3) + 8 * j; scol[j] = P::b_col(a, z, n < N ? n : N - 1); }
+  }
+  (void)pan_a; (void)pan_b; (void)srow; (void)scol;
 
   typename P::Epi epi;
   if constexpr (NW == 1) P::epi_begin(a, m0, n0, lane, epi);
@@ -180,8 +213,30 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
   // resident and hide each other's load latency (most waves own a single chunk at B = 32 anyway).
   while (kc < kend) {
     float fa[16], fb[16];
-    load_a(kc, fa);
-    load_b(kc, fb);
+    if constexpr (STG_A) {                                 // 4 coalesced 16 B loads -> panel[k][x] -> fragment
+      const aoff_t c = P::a_col(a, z, kc + 4 * (lane & 7));
+      float* d = pan_a + (4 * (lane & 7)) * 33 + (lane >> 3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const f4 v = P::a_load4(a, z, srow[j] + c); d[8 * j] = v.x; d[33 + 8 * j] = v.y; d[66 + 8 * j] = v.z; d[99 + 8 * j] = v.w; }
+    } else load_a(kc, fa);
+    if constexpr (STG_B) {
+      const int r = P::b_row(a, z, kc + 4 * (lane & 7));
+      float* d = pan_b + (4 * (lane & 7)) * 33 + (lane >> 3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const f4 v = P::b_load4(a, z, r + scol[j]); d[8 * j] = v.x; d[33 + 8 * j] = v.y; d[66 + 8 * j] = v.z; d[99 + 8 * j] = v.w; }
+    } else load_b(kc, fb);
+    if constexpr (STG_A || STG_B) {
+      wave_lds_sync();
+      if constexpr (STG_A) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) fa[t] = pan_a[kslot(t, 0) * 33 + hb * (4 * 33) + (lane & 31)];
+      }
+      if constexpr (STG_B) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) fb[t] = pan_b[kslot(t, 0) * 33 + hb * (4 * 33) + (lane & 31)];
+      }
+      wave_lds_sync();                                     // panel reads issued before the next chunk's stores
+    }
 #ifdef SDQN_TIMING
     asm volatile("" :: "v"(fa[0]), "v"(fb[0]), "v"(fa[15]), "v"(fb[15]));      // operands landed
     SDQN_STAMP(3);
@@ -286,7 +341,7 @@ __device__ __forceinline__ void run_tile(const StepArgs& a, int bx, int by, int 
   else gemm_tile<P, NW, NT>(a, bx, by, bz, smem);
 }
 template <class P, int NW>
-constexpr int tile_lds_any() { return NW * PANEL; }
+constexpr int tile_lds_any() { return uses_f16_mfma<P>::value ? NW * PANEL : tile_lds<P, NW>(); }
 
 // XCD-aware workgroup -> tile map (guide T1).  The dispatcher places workgroup b on XCD b % 8, each XCD with its
 // own L2.  Tiles are numbered x-fastest (then y, then split/net z), so NEIGHBOURING tile ids share operands

@@ -74,10 +74,17 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
   }
   if (a.B >= 128) {            // throughput regime (thousands of tiles per launch): tools/sweep_nw.py at B = 256
     switch (id) {
-      case K_CONV2_FWD: return launch_gemm<Conv2Fwd, 8>(a, s);
-      case K_CONV3_FWD: return launch_gemm<Conv3Fwd, 8>(a, s);
-      case K_FC4_FWD: return launch_gemm<Fc4Fwd, 8>(a, s);
-      case K_FC4_DGRAD: return launch_gemm<Fc4Dgrad, 4>(a, s);
+      case K_CONV1_FWD: return launch_gemm<Conv1Fwd, 8>(a, s);
+      case K_CONV2_FWD: return launch_gemm<Staged<Conv2Fwd>, 8>(a, s);
+      case K_CONV3_FWD: return launch_gemm<Staged<Conv3Fwd>, 8>(a, s);
+      case K_FC4_FWD: return launch_gemm<Staged<Fc4Fwd>, 8>(a, s);
+      case K_FC4_DGRAD: return launch_gemm<Staged<Fc4Dgrad>, 4>(a, s);
+      case K_CONV3_DGRAD: return launch_gemm<Staged<Conv3Dgrad>, 8>(a, s);
+      case K_CONV2_DGRAD: return launch_gemm<Staged<Conv2Dgrad>, 8>(a, s);
+      case K_BWD3:
+        if (a.f4w_count > 0) return launch_multi<512, Fc4Wgrad, 8, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
+        return launch_multi<512, NoProblem, 2, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
+      case K_BWD2: return launch_multi<512, NoProblem, 2, Staged<Conv2Dgrad>, 8, Conv2Wgrad, 8>(a, true, true, s);
       default: break;
     }
   }
@@ -85,8 +92,8 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
     case K_CONV1_FWD: return launch_gemm<Conv1Fwd, 8>(a, s);        // K = 256  -> 8 chunks
     case K_CONV2_FWD: return launch_gemm<Conv2Fwd, 16>(a, s);       // K = 512  -> 16 chunks
     case K_CONV3_FWD: return launch_gemm<Conv3Fwd, 9>(a, s);        // K = 576  -> 18 chunks, 2 per wave
-    case K_FC4_FWD: return launch_gemm<Fc4Fwd, 14>(a, s);           // K = 3136 -> 98 chunks = S4(7) x 14
-    case K_FC4_DGRAD: return launch_gemm<Fc4Dgrad, 16>(a, s);       // K = 512
+    case K_FC4_FWD: return launch_gemm<Staged<Fc4Fwd>, 14>(a, s);   // K = 3136 -> 98 chunks = S4(7) x 14; rows 12.5 KB apart: staged
+    case K_FC4_DGRAD: return launch_gemm<Staged<Fc4Dgrad>, 16>(a, s);   // K = 512; rows 2 KB apart: staged
     case K_FC4_WGRAD:                                               // K = B
       if (a.B <= 32) return launch_gemm<Fc4Wgrad, 1>(a, s);
       if (a.B <= 64) return launch_gemm<Fc4Wgrad, 2>(a, s);
