@@ -211,21 +211,38 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
   SDQN_STAMP(2);
   // No software prefetch across chunks: one register set keeps the kernels at ~64 VGPRs, so 7-8 waves per SIMD are
   // resident and hide each other's load latency (most waves own a single chunk at B = 32 anyway).
+  // staged operands are software-prefetched one chunk ahead (4 x f4 per operand): registers -> panel -> fragment
+  f4 pra[STG_A ? 4 : 1], prb[STG_B ? 4 : 1];
+  auto stage_load = [&](int kk) {
+    if constexpr (STG_A) {
+      const aoff_t c = P::a_col(a, z, kk + 4 * (lane & 7));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pra[j] = P::a_load4(a, z, srow[j] + c);
+    }
+    if constexpr (STG_B) {
+      const int r = P::b_row(a, z, kk + 4 * (lane & 7));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) prb[j] = P::b_load4(a, z, r + scol[j]);
+    }
+  };
+  (void)pra; (void)prb;
+  if constexpr (STG_A || STG_B) { if (kc < kend) stage_load(kc); }
   while (kc < kend) {
     float fa[16], fb[16];
-    if constexpr (STG_A) {                                 // 4 coalesced 16 B loads -> panel[k][x] -> fragment
-      const aoff_t c = P::a_col(a, z, kc + 4 * (lane & 7));
-      float* d = pan_a + (4 * (lane & 7)) * 33 + (lane >> 3);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { const f4 v = P::a_load4(a, z, srow[j] + c); d[8 * j] = v.x; d[33 + 8 * j] = v.y; d[66 + 8 * j] = v.z; d[99 + 8 * j] = v.w; }
-    } else load_a(kc, fa);
-    if constexpr (STG_B) {
-      const int r = P::b_row(a, z, kc + 4 * (lane & 7));
-      float* d = pan_b + (4 * (lane & 7)) * 33 + (lane >> 3);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { const f4 v = P::b_load4(a, z, r + scol[j]); d[8 * j] = v.x; d[33 + 8 * j] = v.y; d[66 + 8 * j] = v.z; d[99 + 8 * j] = v.w; }
-    } else load_b(kc, fb);
+    if constexpr (!STG_A) load_a(kc, fa);
+    if constexpr (!STG_B) load_b(kc, fb);
     if constexpr (STG_A || STG_B) {
+      if constexpr (STG_A) {
+        float* d = pan_a + (4 * (lane & 7)) * 33 + (lane >> 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { d[8 * j] = pra[j].x; d[33 + 8 * j] = pra[j].y; d[66 + 8 * j] = pra[j].z; d[99 + 8 * j] = pra[j].w; }
+      }
+      if constexpr (STG_B) {
+        float* d = pan_b + (4 * (lane & 7)) * 33 + (lane >> 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { d[8 * j] = prb[j].x; d[33 + 8 * j] = prb[j].y; d[66 + 8 * j] = prb[j].z; d[99 + 8 * j] = prb[j].w; }
+      }
+      if (kc + NW * 32 < kend) stage_load(kc + NW * 32);   // next chunk's loads fly under this chunk's MFMAs
       wave_lds_sync();
       if constexpr (STG_A) {
 #pragma unroll
