@@ -195,6 +195,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--datatype", choices=["float32", "float16"], default="float32",
                     help="float16 = BASELINE.json configs[4] precision (half activations, fp32 master weights); NOT the headline")
+    ap.add_argument("--dry-run-dp", action="store_true",
+                    help="N > 1 control-plane check on a box with fewer GPUs than ranks: ranks share devices and the RCCL "
+                         "communicator is NOT created (no gradient exchange; the number is meaningless)")
     ap.add_argument("--zero-copy", action="store_true", help="gather from the pinned host ring over PCIe (no HBM mirror)")
     a = ap.parse_args()
 
@@ -210,7 +213,8 @@ def main():
     import torch
     import torch.distributed as dist
     import numpy as np
-    torch.cuda.set_device(local_rank)
+    dev = local_rank % torch.cuda.device_count() if a.dry_run_dp else local_rank
+    torch.cuda.set_device(dev)
     if world > 1:
         # control plane (id exchange, barriers, max-reduce of the time) on gloo; the data path's only
         # collective — the gradient all-reduce — is RCCL over xGMI inside libsdqn_hip (sdqn_dp_init)
@@ -220,7 +224,7 @@ def main():
     from simple_dqn_amd import _lib
     from simple_dqn_amd.deepqnetwork import dp_unique_id
     from util import make_args
-    _lib.check(sd.load().sdqn_set_device(local_rank))
+    _lib.check(sd.load().sdqn_set_device(dev))
 
     B, A = a.batch_size, a.num_actions
     args = make_args(batch_size=B, random_seed=a.seed + 1, datatype=a.datatype)   # identical initial weights on every rank
@@ -231,7 +235,9 @@ def main():
     if world > 1:
         ids = [dp_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        net.dp_init(ids[0], rank, world)
+        assert isinstance(ids[0], bytes) and len(ids[0]) == 128
+        if not a.dry_run_dp:
+            net.dp_init(ids[0], rank, world)
 
     import ctypes as C
     mt = (C.c_uint32 * 625)()
@@ -304,7 +310,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-        net.dp_shutdown()
+        if not a.dry_run_dp:
+            net.dp_shutdown()
         dist.destroy_process_group()
 
 
