@@ -91,7 +91,7 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
   switch (id) {
     case K_CONV1_FWD: return launch_gemm<Conv1Fwd, 8>(a, s);        // K = 256  -> 8 chunks
     case K_CONV2_FWD: return launch_gemm<Conv2Fwd, 16>(a, s);       // K = 512  -> 16 chunks
-    case K_CONV3_FWD: return launch_gemm<Conv3Fwd, 9>(a, s);        // K = 576  -> 18 chunks, 2 per wave
+    case K_CONV3_FWD: return launch_gemm<Staged<Conv3Fwd>, 9>(a, s);   // K = 576 -> 18 chunks, 2 per wave: staged + prefetch
     case K_FC4_FWD: return launch_gemm<Staged<Fc4Fwd>, 14>(a, s);   // K = 3136 -> 98 chunks = S4(7) x 14; rows 12.5 KB apart: staged
     case K_FC4_DGRAD: return launch_gemm<Staged<Fc4Dgrad>, 16>(a, s);   // K = 512; rows 2 KB apart: staged
     case K_FC4_WGRAD:                                               // K = B
@@ -99,7 +99,7 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
       if (a.B <= 64) return launch_gemm<Fc4Wgrad, 2>(a, s);
       if (a.B <= 128) return launch_gemm<Fc4Wgrad, 4>(a, s);
       return launch_gemm<Fc4Wgrad, 8>(a, s);
-    case K_CONV3_DGRAD: return launch_gemm<Conv3Dgrad, 8>(a, s);    // K = 576 (same split as inside K_BWD3: bit-identical)
+    case K_CONV3_DGRAD: return launch_gemm<Staged<Conv3Dgrad>, 8>(a, s);   // K = 576 (same split as inside K_BWD3: bit-identical)
     case K_CONV3_WGRAD: return launch_gemm<Conv3Wgrad, 8>(a, s);    // K = B*49 split over slabs
     case K_CONV2_DGRAD: return launch_gemm<Conv2Dgrad, 8>(a, s);    // K = 256 per parity class
     case K_CONV2_WGRAD: return launch_gemm<Conv2Wgrad, 8>(a, s);
@@ -108,9 +108,9 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
     // so every tile of the launch is resident at once and the problems' latency chains overlap.  Fc4Wgrad is the
     // first problem so its memory-bound read-modify-write stream starts earliest (one tile per wave at B <= 32).
     case K_BWD3:
-      if (a.B <= 32 && a.f4w_count > 0) return launch_multi<512, Fc4Wgrad, 1, Conv3Dgrad, 8, Conv3Wgrad, 8>(a, true, true, s);
-      if (a.f4w_count > 0) return launch_multi<512, Fc4Wgrad, 8, Conv3Dgrad, 8, Conv3Wgrad, 8>(a, true, true, s);
-      return launch_multi<512, NoProblem, 2, Conv3Dgrad, 8, Conv3Wgrad, 8>(a, true, true, s);
+      if (a.B <= 32 && a.f4w_count > 0) return launch_multi<512, Fc4Wgrad, 1, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
+      if (a.f4w_count > 0) return launch_multi<512, Fc4Wgrad, 8, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
+      return launch_multi<512, NoProblem, 2, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
     case K_BWD2:
       if (a.B <= 32 && a.f4w_count > 0) return launch_multi<512, Fc4Wgrad, 1, Conv2Dgrad, 8, Conv2Wgrad, 8>(a, true, true, s);
       return launch_multi<512, NoProblem, 2, Conv2Dgrad, 8, Conv2Wgrad, 8>(a, true, true, s);
@@ -124,8 +124,9 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // head: one 512-thread workgroup (8 wave64s) per sample; thread j owns hidden unit j.
 __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadArgs h) {
+  SDQN_STAMP(0);
   const int n = blockIdx.x, j = threadIdx.x, lane = j & 63, wave = j >> 6;
-  __shared__ float red[2][MAX_ACTIONS][8];
+  __shared__ float prod[2 * MAX_ACTIONS][NFC];        // 72 KB: one workgroup per CU is plenty for B workgroups
   __shared__ float sh_q[2][MAX_ACTIONS];
   __shared__ float sh_dc;
   __shared__ int sh_act;
@@ -158,6 +159,14 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
       if (z < a.nz) for (int s = 0; s < a.S4; ++s) v += a.slab4[s * sstride + ((int64_t)z * a.B + n) * NFC + j];
       a4v[z] = v; }
   }
+#ifdef SDQN_TIMING
+  asm volatile("" :: "v"(a4v[0]), "v"(a4v[1]), "v"(w5[0][0]));
+  SDQN_STAMP(1);
+#endif
+  // fc5 (Affine(A), :91) for both nets: every thread contributes w5[z][act][j] * a4[z][j]; the 2A block-wide sums go
+  // through LDS — products transposed into prod[row][512], then wave w reduces rows w, w+8, ... (8 values per lane +
+  // ONE 6-step butterfly per row).  A chain of __shfl_xor (= ds_bpermute, ~100 cycles each) per action on every wave
+  // measured 5400 cycles here.
 #pragma unroll
   for (int z = 0; z < 2; ++z) {                      // static indices only: w5 / a4v stay in registers
     if (z >= a.nz) continue;
@@ -165,25 +174,27 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
     a4v[z] = v;
     a.a4[((int64_t)z * a.B + n) * NFC + j] = v;
 #pragma unroll
-    for (int act = 0; act < MAX_ACTIONS; ++act) {
-      if (act < a.A) {
-        float p = w5[z][act] * v;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);                      // wavefront reduction
-        if (lane == 0) red[z][act][wave] = p;
-      }
-    }
+    for (int act = 0; act < MAX_ACTIONS; ++act)
+      if (act < a.A) prod[z * a.A + act][j] = w5[z][act] * v;
   }
+  SDQN_STAMP(2);
   __syncthreads();
-  if (j < a.nz * a.A) {
-    const int z = j / a.A, act = j - z * a.A;
-    float q = 0.0f;
-    for (int w = 0; w < 8; ++w) q += red[z][act][w];
-    sh_q[z][act] = q;
-    h.q[((int64_t)z * a.B + n) * a.A + act] = q;
+  SDQN_STAMP(3);
+  for (int row = wave; row < a.nz * a.A; row += 8) {
+    float p = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p += prod[row][lane + 64 * k];                                    // fixed order
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);                          // one wavefront reduction
+    if (lane == 0) {
+      const int z = row / a.A, act = row - z * a.A;
+      sh_q[z][act] = p;
+      h.q[((int64_t)z * a.B + n) * a.A + act] = p;
+    }
   }
   if (!h.train) return;
   __syncthreads();
+  SDQN_STAMP(4);
   if (j == 0) {
     const int act = m_act, term = m_term; const int64_t rew = m_rew;
     float m = sh_q[1][0];
@@ -198,7 +209,9 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
     h.maxq[n] = m;
     sh_dc = dc; sh_act = act;
   }
+  SDQN_STAMP(5);
   __syncthreads();
+  SDQN_STAMP(6);
   const float dc = sh_dc; const int act = sh_act;
   // fc5 dgrad: delta4 = W5^T delta * 1[a4 > 0]; delta is non-zero on the taken action only (W5 row already in registers)
   float wa = 0.0f;
@@ -208,7 +221,12 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   if (a.h16) a.h_d4[(int64_t)n * NFC + j] = (half_t)(d4v * a.loss_scale);     // fp16 mode: loss-scaled half delta
   else a.d4[(int64_t)n * NFC + j] = d4v;
   if (j < a.A) h.dq[(int64_t)n * a.A + j] = (j == act) ? dc : 0.0f;
+  SDQN_STAMP(7);
 }
+
+#ifdef SDQN_TIMING
+hipError_t set_timing_buffer(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sdqn_dbg), &p, sizeof p); }
+#endif
 
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
   hipLaunchKernelGGL(head_kernel, dim3(a.B), dim3(512), 0, s, a, h);

@@ -20,6 +20,12 @@ net.train_from_memory(mem, 20, mt_state=mt, want_cost=False); net.sync()
 random.seed(1); idx = np.array(mem.sample_indexes())
 names = {0: "conv1_fwd", 1: "conv2_fwd", 2: "conv3_fwd", 3: "fc4_fwd", 5: "fc4_dgrad", 6: "fc4_wgrad", 7: "conv3_dgrad", 8: "conv3_wgrad", 9: "conv2_dgrad", 10: "conv2_wgrad", 11: "conv1_wgrad"}
 MAXB = 4096
+out = np.zeros((MAXB, 8), np.uint64)
+L.check(lib.sdqn_debug_time_kernel(net._h, mem._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), 4, out.ctypes.data_as(C.POINTER(C.c_uint64)), MAXB))
+v = out[out[:, 0] > 0].astype(np.int64)
+d = np.diff(v[:, :8], axis=1)
+print("head: blocks %d; median cycles per phase [entry->loads landed, ->shuffles done, ->barrier1, ->q/barrier2, ->thread0 TD, ->barrier3, ->stores]: %s; block life median %d"
+      % (len(v), np.median(d, axis=0).astype(int).tolist(), int(np.median(v[:, 7] - v[:, 0]))), flush=True)
 for kid, nm in names.items():
     out = np.zeros((MAXB, 8), np.uint64)
     L.check(lib.sdqn_debug_time_kernel(net._h, mem._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), kid, out.ctypes.data_as(C.POINTER(C.c_uint64)), MAXB))
