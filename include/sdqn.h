@@ -130,6 +130,18 @@ int sdqn_net_predict(sdqn_net_t h, const uint8_t* states, float* q_out);
  * current state to a full minibatch of zero rows only because Neon cannot change its batch size
  * (src/state_buffer.py:13-24, src/agent.py:55-61) and then uses row 0; this computes exactly that row. */
 int sdqn_net_predict_one(sdqn_net_t h, const uint8_t* state, float* q_out);
+/* Device-resident StateBuffer (src/state_buffer.py:3-27): the last `hist` screens of the
+ * acting agent live in HBM, so each environment step uploads one 7 KB frame instead of a padded minibatch
+ * (src/agent.py:55-61 builds u8[B,4,84,84] per step).  A host mirror backs getState()/getStateMinibatch(). */
+typedef struct sdqn_statebuf_s* sdqn_statebuf_t;
+int sdqn_statebuf_create(sdqn_statebuf_t* out, int screen_height, int screen_width, int history_length);
+int sdqn_statebuf_destroy(sdqn_statebuf_t s);
+int sdqn_statebuf_add(sdqn_statebuf_t s, const uint8_t* screen);   /* state_buffer.py:15-18: shift left, append */
+int sdqn_statebuf_reset(sdqn_statebuf_t s);                         /* state_buffer.py:26-27 */
+int sdqn_statebuf_get(sdqn_statebuf_t s, uint8_t* state_out);       /* host mirror copy u8[hist,H,W] (no sync) */
+int sdqn_statebuf_read_device(sdqn_statebuf_t s, uint8_t* state_out);   /* test hook: D2H of the device window (sync) */
+/* Q-values of the buffered state -> float[A] (sync): sdqn_net_predict_one without the state upload */
+int sdqn_net_predict_state(sdqn_net_t h, sdqn_statebuf_t s, float* q_out);
 /* DeepQNetwork.train, deepqnetwork.py:107-172, minibatch given as host arrays.
  * cost_out nullable: NULL -> no synchronisation. */
 int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8_t* actions, const int64_t* rewards,

@@ -12,9 +12,9 @@ constructing a ReplayMemory / DeepQNetwork without a HIP device raises RuntimeEr
 from ._lib import lib_path, load, SdqnError  # noqa: F401
 from .replay_memory import ReplayMemory  # noqa: F401
 from .deepqnetwork import DeepQNetwork  # noqa: F401
-from .state_buffer import StateBuffer  # noqa: F401
+from .state_buffer import DeviceStateBuffer, StateBuffer  # noqa: F401
 from .agent import Agent  # noqa: F401
 from .environment import SyntheticEnvironment  # noqa: F401
 from .statistics import Statistics  # noqa: F401
 
-__all__ = ["ReplayMemory", "DeepQNetwork", "StateBuffer", "Agent", "SyntheticEnvironment", "Statistics", "load", "lib_path"]
+__all__ = ["ReplayMemory", "DeepQNetwork", "StateBuffer", "DeviceStateBuffer", "Agent", "SyntheticEnvironment", "Statistics", "load", "lib_path"]

@@ -62,6 +62,13 @@ SIGNATURES = {
     "sdqn_net_get_weights": (C.c_int, [_vp, C.c_int, C.c_int, _f32p, C.c_int64]),
     "sdqn_net_predict": (C.c_int, [_vp, _u8p, _f32p]),
     "sdqn_net_predict_one": (C.c_int, [_vp, _u8p, _f32p]),
+    "sdqn_statebuf_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int]),
+    "sdqn_statebuf_destroy": (C.c_int, [_vp]),
+    "sdqn_statebuf_add": (C.c_int, [_vp, _u8p]),
+    "sdqn_statebuf_reset": (C.c_int, [_vp]),
+    "sdqn_statebuf_get": (C.c_int, [_vp, _u8p]),
+    "sdqn_statebuf_read_device": (C.c_int, [_vp, _u8p]),
+    "sdqn_net_predict_state": (C.c_int, [_vp, _vp, _f32p]),
     "sdqn_net_train_host": (C.c_int, [_vp, _u8p, _u8p, _i64p, _u8p, _u8p, _f32p]),
     "sdqn_net_train_replay": (C.c_int, [_vp, _vp, _i64p, _f32p]),
     "sdqn_net_train_many": (C.c_int, [_vp, _vp, _u32p, C.c_int, _f32p]),

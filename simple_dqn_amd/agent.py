@@ -11,7 +11,7 @@ import random
 
 import numpy as np
 
-from .state_buffer import StateBuffer
+from .state_buffer import DeviceStateBuffer, StateBuffer
 
 logger = logging.getLogger(__name__)
 
@@ -21,7 +21,8 @@ class Agent:
         self.env = environment
         self.mem = replay_memory
         self.net = deep_q_network
-        self.buf = StateBuffer(args)
+        # acting state resident on the device when the network can read it there
+        self.buf = DeviceStateBuffer(args) if hasattr(deep_q_network, "predict_state") else StateBuffer(args)
         self.num_actions = self.env.numActions()
         self.random_starts = args.random_starts
         self.history_length = args.history_length
@@ -60,7 +61,9 @@ class Agent:
         if random.random() < exploration_rate:
             action = random.randrange(self.num_actions)
         else:
-            if hasattr(self.net, "predict_one"):
+            if hasattr(self.buf, "_h") and hasattr(self.net, "predict_state"):
+                q0 = self.net.predict_state(self.buf)               # state already in HBM: one 7 KB upload per env step
+            elif hasattr(self.net, "predict_one"):
                 # batch-1 fast path: same numbers as predict(getStateMinibatch())[0], no zero-row padding
                 q0 = self.net.predict_one(self.buf.getState())
             else:

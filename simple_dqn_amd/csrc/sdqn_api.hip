@@ -625,6 +625,83 @@ extern "C" int sdqn_net_predict_one(sdqn_net_t h, const uint8_t* state, float* q
   return SDQN_OK;
 }
 
+// ---- device-resident StateBuffer --------------------------------------------------------------------------
+// A ring of SB_SLOTS frame slots in HBM; frame t goes to slot `pos`, the current state is the contiguous window
+// of the `hist` slots ending there.  When the ring is full the last hist-1 frames are copied back to the start
+// (one 21 KB D2D every SB_SLOTS-hist+1 adds), so an add is ONE 7 KB H2D from a pinned staging slot.
+static constexpr int SB_SLOTS = 64;
+struct sdqn_statebuf_s {
+  uint8_t* d = nullptr;          // [SB_SLOTS][FRAME]
+  uint8_t* host = nullptr;       // [hist][FRAME] mirror in state_buffer.py order (oldest first)
+  uint8_t* stage = nullptr;      // pinned [SB_SLOTS][FRAME]: staging slot i feeds ring slot i
+  int hist = 0;
+  int pos = 0;                   // slot of the newest frame; window = slots [pos-hist+1, pos]
+};
+extern "C" int sdqn_statebuf_create(sdqn_statebuf_t* out, int H, int W, int hist) {
+  ARGCHK(out, "NULL argument");
+  ARGCHK(H == H0 && W == W0 && hist == C0, "this build supports 84x84 screens with history_length 4 (got %dx%d, %d)", H, W, hist);
+  STREAMCHK();
+  sdqn_statebuf_s* s = new sdqn_statebuf_s(); s->hist = hist; s->pos = hist - 1;
+  hipError_t e = hipMalloc((void**)&s->d, (size_t)SB_SLOTS * FRAME);
+  if (e == hipSuccess) e = hipMemsetAsync(s->d, 0, (size_t)SB_SLOTS * FRAME, g_stream);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&s->stage, (size_t)SB_SLOTS * FRAME, hipHostMallocDefault);
+  if (e != hipSuccess) { set_error("statebuf_create -> %s", hipGetErrorString(e)); sdqn_statebuf_destroy(s); return SDQN_ERR_HIP; }
+  s->host = (uint8_t*)calloc((size_t)hist, FRAME);
+  if (!s->host) { set_error("out of host memory"); sdqn_statebuf_destroy(s); return SDQN_ERR_HIP; }
+  *out = s; return SDQN_OK;
+}
+extern "C" int sdqn_statebuf_destroy(sdqn_statebuf_t s) {
+  if (!s) return SDQN_OK;
+  if (g_stream) hipStreamSynchronize(g_stream);
+  if (s->d) hipFree(s->d);
+  if (s->stage) hipHostFree(s->stage);
+  free(s->host);
+  delete s; return SDQN_OK;
+}
+extern "C" int sdqn_statebuf_add(sdqn_statebuf_t s, const uint8_t* screen) {
+  ARGCHK(s && screen, "NULL argument");
+  memmove(s->host, s->host + FRAME, (size_t)(s->hist - 1) * FRAME);           // state_buffer.py:17
+  memcpy(s->host + (size_t)(s->hist - 1) * FRAME, screen, FRAME);             // :18
+  if (s->pos + 1 == SB_SLOTS) {
+    // wrap: the newest hist-1 frames move to the front; the sync also retires every staging slot of this lap
+    HIPCHK(hipMemcpyAsync(s->d, s->d + (size_t)(SB_SLOTS - (s->hist - 1)) * FRAME, (size_t)(s->hist - 1) * FRAME,
+                          hipMemcpyDeviceToDevice, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    s->pos = s->hist - 2;
+  }
+  s->pos += 1;
+  uint8_t* src = s->stage + (size_t)s->pos * FRAME;
+  memcpy(src, screen, FRAME);
+  HIPCHK(hipMemcpyAsync(s->d + (size_t)s->pos * FRAME, src, FRAME, hipMemcpyHostToDevice, g_stream));
+  return SDQN_OK;
+}
+extern "C" int sdqn_statebuf_reset(sdqn_statebuf_t s) {
+  ARGCHK(s, "NULL handle");
+  memset(s->host, 0, (size_t)s->hist * FRAME);                                // state_buffer.py:27
+  HIPCHK(hipMemsetAsync(s->d + (size_t)(s->pos - s->hist + 1) * FRAME, 0, (size_t)s->hist * FRAME, g_stream));
+  return SDQN_OK;
+}
+extern "C" int sdqn_statebuf_get(sdqn_statebuf_t s, uint8_t* out) {
+  ARGCHK(s && out, "NULL argument"); memcpy(out, s->host, (size_t)s->hist * FRAME); return SDQN_OK;
+}
+static const uint8_t* statebuf_window(sdqn_statebuf_s* s) { return s->d + (size_t)(s->pos - s->hist + 1) * FRAME; }
+extern "C" int sdqn_statebuf_read_device(sdqn_statebuf_t s, uint8_t* out) {
+  ARGCHK(s && out, "NULL argument");
+  HIPCHK(hipMemcpyAsync(out, statebuf_window(s), (size_t)s->hist * FRAME, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  return SDQN_OK;
+}
+extern "C" int sdqn_net_predict_state(sdqn_net_t h, sdqn_statebuf_t sb, float* q_out) {
+  ARGCHK(h && sb && q_out, "NULL argument");
+  StepArgs a = step_args(h); a.B = 1; a.nz = 1; a.from_ring = 0; a.src = statebuf_window(sb);   // batch of one, read in place
+  HeadArgs hd = head_args(h, 0);
+  int rc = run_forward(h, a, hd); if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(h->h_f, h->q, (size_t)h->A * 4, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  memcpy(q_out, h->h_f, (size_t)h->A * 4);
+  return SDQN_OK;
+}
+
 extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8_t* actions, const int64_t* rewards,
                                    const uint8_t* post, const uint8_t* terminals, float* cost_out) {
   ARGCHK(h && pre && actions && rewards && post && terminals, "NULL argument");

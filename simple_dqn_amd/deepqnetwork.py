@@ -151,6 +151,13 @@ class DeepQNetwork:
         _lib.check(self._lib.sdqn_net_predict_one(self._h, _lib.ptr(st, C.c_uint8), _lib.ptr(q, C.c_float)))
         return q
 
+    def predict_state(self, state_buffer):
+        """Acting path with a DeviceStateBuffer: Q-values float32[A] of the buffered state, read in place from HBM
+        (no state upload; same numbers as predict(state_buffer.getStateMinibatch())[0])."""
+        q = np.empty((self.num_actions,), dtype=np.float32)
+        _lib.check(self._lib.sdqn_net_predict_state(self._h, state_buffer._h, _lib.ptr(q, C.c_float)))
+        return q
+
     def load_weights(self, load_path):                             # :188-189 (own .npz; Neon pickles: SURVEY.md §8f)
         with np.load(load_path) as f:
             for which, key in ((0, "W"), (1, "Wt"), (2, "S"), (4, "S2")):

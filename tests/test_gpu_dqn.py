@@ -56,6 +56,31 @@ def test_predict_parity(sd, A, B):
         net.predict(st[:-1])                                        # deepqnetwork.py:176
 
 
+def test_device_state_buffer_matches_reference_semantics(sd):
+    """DeviceStateBuffer (last 4 screens resident in HBM) behaves like src/state_buffer.py:3-27, its device
+    window always equals the host state, and predict_state() is bit-identical to predict_one(getState())."""
+    import ctypes as C
+    A, B = 6, 32
+    net, _ = _pair(sd, A, B, 71)
+    args = make_args(batch_size=B)
+    ref, dev = sd.StateBuffer(args), sd.DeviceStateBuffer(args)
+    rng = np.random.RandomState(72)
+    lib = sd.load()
+    for i in range(150):                         # > 2 laps of the 64-slot device ring
+        if i in (9, 17, 63, 64, 100):
+            ref.reset(); dev.reset()
+        f = rng.randint(0, 256, size=(84, 84), dtype=np.uint8)
+        ref.add(f); dev.add(f)
+        assert np.array_equal(ref.getState(), dev.getState())
+        assert np.array_equal(ref.getStateMinibatch(), dev.getStateMinibatch())
+        win = np.empty((4, 84, 84), np.uint8)
+        assert lib.sdqn_statebuf_read_device(dev._h, win.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+        assert np.array_equal(win, ref.getState()), i
+        q_dev = net.predict_state(dev)
+        assert np.array_equal(q_dev, net.predict_one(ref.getState()))
+    assert np.array_equal(q_dev, net.predict(ref.getStateMinibatch())[0])
+
+
 def test_predict_one_equals_padded_batch(sd):
     """Acting path: predict_one(state) is bit-identical to predict(StateBuffer batch)[0]."""
     A, B = 6, 32
