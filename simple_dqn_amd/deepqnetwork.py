@@ -158,7 +158,18 @@ class DeepQNetwork:
         _lib.check(self._lib.sdqn_net_predict_state(self._h, state_buffer._h, _lib.ptr(q, C.c_float)))
         return q
 
-    def load_weights(self, load_path):                             # :188-189 (own .npz; Neon pickles: SURVEY.md §8f)
+    def load_weights(self, load_path):                             # :188-189
+        """Own .npz snapshots, or a Neon pickle (the reference's `model.load_params`, best effort: neon_compat.py)."""
+        if not str(load_path).endswith(".npz"):
+            from .neon_compat import read_neon_pickle
+            ws, states, A = read_neon_pickle(load_path)
+            assert A == self.num_actions, "snapshot has %d actions, the network %d" % (A, self.num_actions)
+            for i in range(5):
+                self.set_layer(i, ws[i], 0)
+                if states is not None and self.optimizer == "rmsprop":
+                    self.set_layer(i, states[i], 2)
+            return                                                 # (online model only, like model.load_params: the target
+                                                                   #  net follows at the next update_target_network, agent.py:105)
         with np.load(load_path) as f:
             for which, key in ((0, "W"), (1, "Wt"), (2, "S"), (4, "S2")):
                 for i in range(5):
@@ -169,6 +180,13 @@ class DeepQNetwork:
                 self.train_iterations = int(f["train_iterations"])
 
     def save_weights(self, save_path):                             # :191-192
+        """.npz (everything needed to resume: online + target weights, optimizer state, step counter) or, for a
+        path ending in .prm / .pkl, a Neon-style pickle of the online model (neon_compat.py)."""
+        if str(save_path).endswith((".prm", ".pkl")):
+            from .neon_compat import write_neon_pickle
+            write_neon_pickle(save_path, [self.get_layer(i, 0) for i in range(5)],
+                              [self.get_layer(i, 2) for i in range(5)] if self.optimizer == "rmsprop" else None)
+            return
         d = {}
         for which, key in ((0, "W"), (1, "Wt"), (2, "S")) + ((() if self.optimizer == "rmsprop" else ((4, "S2"),))):
             for i in range(5):

@@ -307,6 +307,28 @@ def test_save_load_weights(sd, tmp_path):
         assert np.array_equal(a, b)
 
 
+def test_neon_pickle_snapshot_roundtrip(sd, tmp_path):
+    """deepqnetwork.py:188-192 with a Neon-style pickle: online weights + RMSProp state survive; like
+    model.load_params the target net is NOT touched until the next update_target_network()."""
+    A, B = 6, 8
+    net, _ = _pair(sd, A, B, 55)
+    mb = random_minibatch(B, A, 56)
+    net.train(mb)
+    p = str(tmp_path / "snap_1.prm")
+    net.save_weights(p)
+    net2 = sd.DeepQNetwork(A, make_args(batch_size=B))
+    before_t = net2.get_weights(1)
+    net2.load_weights(p)
+    for which in (0, 2):
+        for a, b in zip(net.get_weights(which), net2.get_weights(which)):
+            assert np.array_equal(a, b)
+    for a, b in zip(net2.get_weights(1), before_t):
+        assert np.array_equal(a, b)
+    assert np.array_equal(net.predict(mb[0]), net2.predict(mb[0]))
+    with pytest.raises(AssertionError):
+        sd.DeepQNetwork(4, make_args(batch_size=B)).load_weights(p)        # 6-action snapshot into a 4-action net
+
+
 def test_batch256_one_step(sd):
     """BASELINE.json configs[2] shape (B=256, A=3 per the 2015 Pong log)."""
     A, B = 3, 256
