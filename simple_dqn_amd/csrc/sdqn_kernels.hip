@@ -123,31 +123,43 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------
 // head: one 512-thread workgroup (8 wave64s) per sample; thread j owns hidden unit j.
+// AMAX = compile-time bound on num_actions (4 / 8 / 18): every load below is unconditional with a clamped index and
+// a select — a conditional load costs hipcc a branch, a scalar pointer re-load and a wait EACH (36 of them measured
+// ~3000 cycles here), and the LDS footprint follows the bucket.
+template <int AMAX>
 __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadArgs h) {
   SDQN_STAMP(0);
   const int n = blockIdx.x, j = threadIdx.x, lane = j & 63, wave = j >> 6;
-  __shared__ float prod[2 * MAX_ACTIONS][NFC];        // 72 KB: one workgroup per CU is plenty for B workgroups
-  __shared__ float sh_q[2][MAX_ACTIONS];
+  __shared__ float prod[2 * AMAX][NFC];               // 16 KB (A <= 4) .. 72 KB (A <= 18)
+  __shared__ float sh_q[2][AMAX];
   __shared__ float sh_dc;
   __shared__ int sh_act;
   // ---- everything this thread will ever load is issued up front (one memory round trip) ----------------
-  int m_act = 0, m_term = 0; int64_t m_rew = 0;
-  if (h.train && j == 0) { m_act = h.st_actions[n]; m_rew = h.st_rewards[n]; m_term = h.st_terminals[n]; }
-  float w5[2][MAX_ACTIONS];
-#pragma unroll
-  for (int z = 0; z < 2; ++z)
-#pragma unroll
-    for (int act = 0; act < MAX_ACTIONS; ++act)
-      w5[z][act] = (z < a.nz && act < a.A) ? a.theta[z][OFF5 + act * NFC + j] : 0.0f;            // Affine(A) rows, :91
+  const int nz = a.nz, A = a.A;
+  const float* __restrict__ th0 = a.theta[0];
+  const float* __restrict__ th1 = a.theta[nz > 1 ? 1 : 0];
+  const float* __restrict__ slab = a.slab4;
   float a4v[2] = {0.0f, 0.0f};
   const int64_t sstride = (int64_t)2 * a.B * NFC;
+  float t[2][7];
   if (a.S4 == 7) {                                   // the built-in split: 14 independent loads in flight
-    float t[2][7];
 #pragma unroll
     for (int z = 0; z < 2; ++z)
 #pragma unroll
-      for (int s = 0; s < 7; ++s)      // unconditional loads (z clamped): a conditional load costs a branch + vmcnt(0) each
-        t[z][s] = a.slab4[s * sstride + ((int64_t)(z < a.nz ? z : 0) * a.B + n) * NFC + j];
+      for (int s = 0; s < 7; ++s)
+        t[z][s] = slab[s * sstride + ((int64_t)(z < nz ? z : 0) * a.B + n) * NFC + j];
+  }
+  float w5[2][AMAX];
+#pragma unroll
+  for (int act = 0; act < AMAX; ++act) {
+    const int ac = act < A ? act : A - 1;
+    w5[0][act] = th0[OFF5 + ac * NFC + j];                                                        // Affine(A) rows, :91
+    w5[1][act] = th1[OFF5 + ac * NFC + j];
+  }
+  // minibatch metadata last: thread 0 only, and nothing above waits behind it
+  int m_act = 0, m_term = 0; int64_t m_rew = 0;
+  if (h.train && j == 0) { m_act = h.st_actions[n]; m_rew = h.st_rewards[n]; m_term = h.st_terminals[n]; }
+  if (a.S4 == 7) {
 #pragma unroll
     for (int z = 0; z < 2; ++z) { float v = 0.0f;
 #pragma unroll
@@ -156,7 +168,7 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   } else {
 #pragma unroll
     for (int z = 0; z < 2; ++z) { float v = 0.0f;
-      if (z < a.nz) for (int s = 0; s < a.S4; ++s) v += a.slab4[s * sstride + ((int64_t)z * a.B + n) * NFC + j];
+      if (z < nz) for (int s = 0; s < a.S4; ++s) v += slab[s * sstride + ((int64_t)z * a.B + n) * NFC + j];
       a4v[z] = v; }
   }
 #ifdef SDQN_TIMING
@@ -169,27 +181,27 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   // measured 5400 cycles here.
 #pragma unroll
   for (int z = 0; z < 2; ++z) {                      // static indices only: w5 / a4v stay in registers
-    if (z >= a.nz) continue;
+    if (z >= nz) continue;
     const float v = fmaxf(a4v[z], 0.0f);                                                          // Rectlin, :89
     a4v[z] = v;
     a.a4[((int64_t)z * a.B + n) * NFC + j] = v;
 #pragma unroll
-    for (int act = 0; act < MAX_ACTIONS; ++act)
-      if (act < a.A) prod[z * a.A + act][j] = w5[z][act] * v;
+    for (int act = 0; act < AMAX; ++act)
+      if (act < A) prod[z * A + act][j] = w5[z][act] * v;
   }
   SDQN_STAMP(2);
   __syncthreads();
   SDQN_STAMP(3);
-  for (int row = wave; row < a.nz * a.A; row += 8) {
+  for (int row = wave; row < nz * A; row += 8) {
     float p = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) p += prod[row][lane + 64 * k];                                    // fixed order
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);                          // one wavefront reduction
     if (lane == 0) {
-      const int z = row / a.A, act = row - z * a.A;
+      const int z = row / A, act = row - z * A;
       sh_q[z][act] = p;
-      h.q[((int64_t)z * a.B + n) * a.A + act] = p;
+      h.q[((int64_t)z * a.B + n) * A + act] = p;
     }
   }
   if (!h.train) return;
@@ -198,7 +210,7 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   if (j == 0) {
     const int act = m_act, term = m_term; const int64_t rew = m_rew;
     float m = sh_q[1][0];
-    for (int k = 1; k < a.A; ++k) m = fmaxf(m, sh_q[1][k]);                                     // be.max(postq, axis=0), :124
+    for (int k = 1; k < A; ++k) m = fmaxf(m, sh_q[1][k]);                                       // be.max(postq, axis=0), :124
     double rr = (double)rew;                                                                     // np.clip(rewards, ..), :136
     rr = rr < h.min_reward ? h.min_reward : (rr > h.max_reward ? h.max_reward : rr);
     const double y = term ? rr : rr + h.discount * (double)m;                                    // :139-143 (host float math)
@@ -216,11 +228,11 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   // fc5 dgrad: delta4 = W5^T delta * 1[a4 > 0]; delta is non-zero on the taken action only (W5 row already in registers)
   float wa = 0.0f;
 #pragma unroll
-  for (int k = 0; k < MAX_ACTIONS; ++k) wa = (k == act) ? w5[0][k] : wa;
+  for (int k = 0; k < AMAX; ++k) wa = (k == act) ? w5[0][k] : wa;
   const float d4v = a4v[0] > 0.0f ? wa * dc : 0.0f;
   if (a.h16) a.h_d4[(int64_t)n * NFC + j] = (half_t)(d4v * a.loss_scale);     // fp16 mode: loss-scaled half delta
   else a.d4[(int64_t)n * NFC + j] = d4v;
-  if (j < a.A) h.dq[(int64_t)n * a.A + j] = (j == act) ? dc : 0.0f;
+  if (j < A) h.dq[(int64_t)n * A + j] = (j == act) ? dc : 0.0f;
   SDQN_STAMP(7);
 }
 
@@ -229,7 +241,9 @@ hipError_t set_timing_buffer(unsigned long long* p) { return hipMemcpyToSymbol(H
 #endif
 
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
-  hipLaunchKernelGGL(head_kernel, dim3(a.B), dim3(512), 0, s, a, h);
+  if (a.A <= 4) hipLaunchKernelGGL(head_kernel<4>, dim3(a.B), dim3(512), 0, s, a, h);
+  else if (a.A <= 8) hipLaunchKernelGGL(head_kernel<8>, dim3(a.B), dim3(512), 0, s, a, h);
+  else hipLaunchKernelGGL(head_kernel<MAX_ACTIONS>, dim3(a.B), dim3(512), 0, s, a, h);
   return hipGetLastError();
 }
 
