@@ -198,6 +198,12 @@ def main():
     ap.add_argument("--dry-run-dp", action="store_true",
                     help="N > 1 control-plane check on a box with fewer GPUs than ranks: ranks share devices and the RCCL "
                          "communicator is NOT created (no gradient exchange; the number is meaningless)")
+    ap.add_argument("--single-rank-dp", action="store_true",
+                    help="N = 1 with a ONE-rank RCCL communicator: times the data-parallel code path (reduce -> all-reduce -> "
+                         "apply, fc4 part overlapped on the communication stream) on one GPU; not the headline")
+    ap.add_argument("--dp-overlap", action="store_true",
+                    help="data parallel: all-reduce + apply the fc4 gradient on a second communicator / stream under the rest of "
+                         "the step (opt-in: validated with a 1-rank communicator only; default = one all-reduce on the library stream)")
     ap.add_argument("--zero-copy", action="store_true", help="gather from the pinned host ring over PCIe (no HBM mirror)")
     a = ap.parse_args()
 
@@ -232,12 +238,17 @@ def main():
     fill_ring(mem, a.seed + 1000 * rank, A)                            # own experience per learner
     net = sd.DeepQNetwork(A, args)
     net.update_target_network()
+    net.set_option("dp_overlap", 1 if a.dp_overlap else 0)
+    if world == 1 and a.single_rank_dp:
+        net.dp_init(dp_unique_id(), 0, 1)
+        flush_c_stdio()
     if world > 1:
         ids = [dp_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         assert isinstance(ids[0], bytes) and len(ids[0]) == 128
         if not a.dry_run_dp:
             net.dp_init(ids[0], rank, world)
+            flush_c_stdio()                                            # RCCL's version banner leaves the C stdio buffer now
 
     import ctypes as C
     mt = (C.c_uint32 * 625)()
@@ -294,7 +305,9 @@ def main():
             "data": "synthetic (seeded uniform uint8 84x84 frames tiled into the ring; random-init Xavier weights)",
             "config": {"workload": "BASELINE.json configs[1]: Breakout shapes, batch_size=%d, replay_size=%d, num_actions=%d, "
                                    "HIP Q-net + device replay gather fused into conv1" % (B, a.replay_size, A),
-                       "global_batch": B * world, "parallelism": "dp%d (independent learners, RCCL grad all-reduce)" % world,
+                       "global_batch": B * world, "parallelism": ("dp%d (independent learners, RCCL grad all-reduce)" % world) +
+                                      (" [1-rank RCCL communicator: DP code path timed on one GPU]" if (world == 1 and a.single_rank_dp) else "") +
+                                      (" [fc4 all-reduce overlapped]" if a.dp_overlap else ""),
                        "ring": "zero-copy pinned host" if a.zero_copy else "HBM mirror"},
         }
         out["roofline"] = roofline_entry(dom["id"], dom["name"], live["total_ms"] / max(live["launches"], 1), B, A)
@@ -307,12 +320,30 @@ def main():
             out["q_mae_vs_cpu_ref"] = {"mae": mae, "max_abs": mx, "after_steps": 1, "tolerance": 1e-4}
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(B, A, a.seed, a.cpu_baseline_seconds)
+    # The JSON line must be the LAST line of the job's stdout.  RCCL prints a version banner through C stdio, which
+    # is block-buffered on a pipe and would otherwise be flushed at process exit — after the JSON, from every rank.
+    # So: tear the communicators down, flush C stdio on every rank, barrier, and only then let rank 0 print.
+    if world > 1 and not a.dry_run_dp:
+        net.dp_shutdown()
+    elif world == 1 and a.single_rank_dp:
+        net.dp_shutdown()
+    flush_c_stdio()
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-        if not a.dry_run_dp:
-            net.dp_shutdown()
         dist.destroy_process_group()
+
+
+def flush_c_stdio():
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 if __name__ == "__main__":

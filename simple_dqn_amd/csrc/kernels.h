@@ -54,7 +54,8 @@ struct UpdateArgs {
   double* cost_accum;           // running sum over steps
   int B, A;
   int mode;                     // 0 fused reduce+apply, 1 reduce only (-> g), 2 apply only (g already reduced)
-  int skip_fc4;                 // fc4 already updated inside fc4_wgrad's epilogue (StepArgs::fuse_rms)
+  int skip_fc4;                 // fc4 already updated inside fc4_wgrad's epilogue (StepArgs::fuse_rms), or by the only_fc4 launch
+  int only_fc4;                 // overlapped data parallel: this launch (on the comm stream) applies the fc4 range only
   PrepArgs next;                // next.B > 0: also do the NEXT step's prep (train_many samples one step ahead)
   float bsz;                    // divisor of A9 (B, or R*B under data parallel)
   float rho, one_minus_rho, lr, eps;

@@ -29,6 +29,7 @@ static void set_error(const char* fmt, ...) {
 
 static hipStream_t g_stream = nullptr;      // the library stream: everything is ordered on it
 static hipStream_t g_side = nullptr;        // side stream: weight-gradient kernels run beside the dgrad chain
+static hipStream_t g_comm = nullptr;        // data parallel: the fc4 gradient all-reduce + fc4 update run here, beside the compute stream
 static hipEvent_t g_ev[5];                  // fork/join events between the two (timing disabled)
 static int ensure_stream() {
   if (g_stream) return SDQN_OK;
@@ -37,6 +38,7 @@ static int ensure_stream() {
   if (n <= 0) { set_error("no HIP device visible (libsdqn_hip has no CPU path)"); return SDQN_ERR_HIP; }
   HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&g_comm, hipStreamNonBlocking));
   for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming));
   return SDQN_OK;
 }
@@ -265,6 +267,9 @@ struct Rccl {
   int (*CommInitRank)(void**, int, Id128, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommSplit)(void*, int, int, void**, void*) = nullptr;      // optional (second communicator for the overlapped all-reduce)
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 static Rccl g_rccl;
@@ -278,6 +283,9 @@ static int rccl_load(const char* path) {
   g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
   g_rccl.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  g_rccl.CommSplit = (int (*)(void*, int, int, void**, void*))dlsym(lib, "ncclCommSplit");
+  g_rccl.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
+  g_rccl.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
     set_error("%s lacks the nccl* entry points", p); dlclose(lib); return SDQN_ERR_RCCL;
   }
@@ -316,6 +324,10 @@ struct sdqn_net_s {
   double prof_ms[K_COUNT]; int64_t prof_n[K_COUNT];
   // data parallel
   void* comm = nullptr; int rank = 0, nranks = 1;
+  // overlapped data parallel (run_train): comm2 carries the fc4 gradient (95 % of the bytes) on g_comm while the
+  // compute stream finishes the backward pass and starts the next forward; ev_w4 = "W4 of the last step is updated"
+  void* comm2 = nullptr; hipEvent_t ev_g4 = nullptr, ev_w4 = nullptr; bool w4_pending = false;
+  bool dp_overlap = false;        // opt-in (set_option "dp_overlap" before dp_init): multi-rank behaviour is unvalidated on 1-GPU boxes
   std::vector<void*> allocs;
 };
 
@@ -324,10 +336,15 @@ static int dalloc(sdqn_net_s* h, void** p, size_t bytes, bool zero = true) {
   if (zero) HIPCHK(hipMemsetAsync(*p, 0, bytes, g_stream));
   return SDQN_OK;
 }
+static int join_comm(sdqn_net_s* h);
 static int net_free(sdqn_net_s* h) {
   if (!h) return SDQN_OK;
   if (g_stream) hipStreamSynchronize(g_stream);
+  if (g_comm) hipStreamSynchronize(g_comm);
+  if (h->comm2 && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm2);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  if (h->ev_g4) hipEventDestroy(h->ev_g4);
+  if (h->ev_w4) hipEventDestroy(h->ev_w4);
   for (void* p : h->allocs) hipFree(p);
   hipHostFree(h->h_f);
   for (auto& pp : h->prof_pending) { hipEventDestroy(pp.a); hipEventDestroy(pp.b); }
@@ -427,7 +444,7 @@ extern "C" int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const fl
   ARGCHK(n == rows * cols, "layer %d holds %lld values, got %lld", layer, (long long)(rows * cols), (long long)n);
   std::vector<float> tmp((size_t)n);
   for (int64_t r = 0; r < rows; ++r) for (int64_t c = 0; c < cols; ++c) tmp[(size_t)neon_to_internal(layer, r, c)] = w[r * cols + c];
-  HIPCHK(hipStreamSynchronize(g_stream));
+  { int rc_ = join_comm(h); if (rc_) return rc_; } HIPCHK(hipStreamSynchronize(g_stream));
   HIPCHK(hipMemcpy(which_buf(h, which) + off, tmp.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   if (h->cfg.datatype == 1 && which <= 1) {      // fp16 mode: the half copies follow the master weights
     const int zz = (which == 1 && h->theta_t != h->theta) ? 1 : 0;
@@ -442,7 +459,7 @@ extern "C" int sdqn_net_get_weights(sdqn_net_t h, int which, int layer, float* w
   int64_t rows, cols, off; layer_dims(layer, h->A, rows, cols, off);
   ARGCHK(n == rows * cols, "layer %d holds %lld values, got %lld", layer, (long long)(rows * cols), (long long)n);
   std::vector<float> tmp((size_t)n);
-  HIPCHK(hipStreamSynchronize(g_stream));
+  { int rc_ = join_comm(h); if (rc_) return rc_; } HIPCHK(hipStreamSynchronize(g_stream));
   HIPCHK(hipMemcpy(tmp.data(), which_buf(h, which) + off, (size_t)n * 4, hipMemcpyDeviceToHost));
   for (int64_t r = 0; r < rows; ++r) for (int64_t c = 0; c < cols; ++c) w[r * cols + c] = tmp[(size_t)neon_to_internal(layer, r, c)];
   return SDQN_OK;
@@ -453,6 +470,7 @@ static int prof_collect(sdqn_net_s* h) {
   if (h->prof_pending.empty()) return SDQN_OK;
   HIPCHK(hipStreamSynchronize(g_stream));
   HIPCHK(hipStreamSynchronize(g_side));
+  HIPCHK(hipStreamSynchronize(g_comm));
   for (auto& p : h->prof_pending) {
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, p.a, p.b));
     h->prof_ms[p.id] += ms; h->prof_n[p.id] += 1;
@@ -521,13 +539,38 @@ static HeadArgs head_args(sdqn_net_s* h, int train) {
   hd.clip_error = (float)h->cfg.clip_error; hd.train = train;
   return hd;
 }
+// Overlapped data parallel: the previous step's fc4 all-reduce + update may still be running on g_comm.  Everything
+// on the library stream that touches W4, its optimizer state or the fc4 gradient must come after it.
+static int join_comm(sdqn_net_s* h) {
+  if (h->w4_pending) { HIPCHK(hipStreamWaitEvent(g_stream, h->ev_w4, 0)); h->w4_pending = false; }
+  return SDQN_OK;
+}
 static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
   LAUNCH(K_CONV1_FWD, launch_kernel(K_CONV1_FWD, a, g_stream));
   LAUNCH(K_CONV2_FWD, launch_kernel(K_CONV2_FWD, a, g_stream));
   LAUNCH(K_CONV3_FWD, launch_kernel(K_CONV3_FWD, a, g_stream));
+  { int rc = join_comm(h); if (rc) return rc; }                // conv1..3 of this step overlap the previous step's fc4 all-reduce
   LAUNCH(K_FC4_FWD, launch_kernel(K_FC4_FWD, a, g_stream));
   LAUNCH(K_HEAD, launch_head(a, hd, g_stream));
   return SDQN_OK;
+}
+static UpdateArgs make_update_args(sdqn_net_s* h, const StepArgs& a) {
+  UpdateArgs u; memset(&u, 0, sizeof u);
+  u.theta = h->theta; u.state = h->state; u.g = h->g;
+  u.slab[0] = h->slab1; u.slab[1] = h->slab2; u.slab[2] = h->slab3; u.ns[0] = h->ns1; u.ns[1] = h->ns2; u.ns[2] = h->ns3;
+  u.dq = h->dq; u.a4 = h->a4; u.cost_terms = h->cost_terms; u.cost_out = h->cost_out; u.cost_accum = h->cost_accum;
+  u.B = h->B; u.A = h->A;
+  u.rho = (float)h->cfg.decay_rate; u.one_minus_rho = (float)(1.0 - h->cfg.decay_rate);
+  u.lr = (float)h->cfg.learning_rate; u.eps = (float)h->cfg.epsilon;
+  u.skip_fc4 = a.fuse_rms;
+  u.opt = h->cfg.optimizer; u.state2 = h->state2;
+  if (h->cfg.datatype == 1) { u.wh = h->wh[0]; u.wht = h->wht[0]; }
+  if (u.opt == 1) {            // Neon Adam [neon-recalled]: t = epoch + 1, l = lr*sqrt(1-b2^t)/(1-b1^t), math in Python floats
+    const double b1 = h->cfg.beta_1, b2 = h->cfg.beta_2, t = (double)h->epoch + 1.0;
+    u.beta1 = (float)b1; u.one_minus_beta1 = (float)(1.0 - b1); u.beta2 = (float)b2; u.one_minus_beta2 = (float)(1.0 - b2);
+    u.lr_t = (float)(h->cfg.learning_rate * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t)));
+  }
+  return u;
 }
 static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const PrepArgs* next = nullptr) {
   int rc = run_forward(h, a, hd); if (rc) return rc;
@@ -536,6 +579,26 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   // on the side stream (fork after the producer of their delta, join before the update).
   hipStream_t ss = h->two_streams ? g_side : g_stream;
   LAUNCH(K_FC4_DGRAD, launch_kernel(K_FC4_DGRAD, a, g_stream));
+  const bool dp_ov = h->comm && h->comm2 && h->dp_overlap && h->fused_launches && !h->two_streams;
+  if (dp_ov) {
+    // data parallel, overlapped: ALL of fc4_wgrad rides the first backward launch, so the 6.4 MB fc4 gradient is
+    // complete two launches before the step ends; its all-reduce and its optimizer update run on g_comm
+    // (second communicator) under K_BWD2, K_BWD1, the conv/fc5 all-reduce + update and the next step's conv1..3.
+    StepArgs b3 = a, b2 = a, b1 = a;
+    b3.f4w_first = 0; b3.f4w_count = (NIN4 / 32) * (NFC / 32); b2.f4w_count = b1.f4w_count = 0;
+    LAUNCH(K_BWD3, launch_kernel(K_BWD3, b3, g_stream));
+    HIPCHK(hipEventRecord(h->ev_g4, g_stream));
+    HIPCHK(hipStreamWaitEvent(g_comm, h->ev_g4, 0));
+    LAUNCH_ON(g_comm, K_ALLREDUCE, (g_rccl.AllReduce(h->g + OFF4, h->g + OFF4, (size_t)NW4, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm2, g_comm) == 0
+                                    ? hipSuccess : hipErrorUnknown));
+    UpdateArgs u4 = make_update_args(h, a);
+    u4.mode = 2; u4.only_fc4 = 1; u4.skip_fc4 = 0; u4.bsz = (float)h->B * (float)h->nranks;
+    LAUNCH_ON(g_comm, K_UPDATE, launch_update(u4, g_comm));
+    HIPCHK(hipEventRecord(h->ev_w4, g_comm));
+    h->w4_pending = true;
+    LAUNCH(K_BWD2, launch_kernel(K_BWD2, b2, g_stream));
+    LAUNCH(K_BWD1, launch_kernel(K_BWD1, b1, g_stream));
+  } else
   if (h->fused_launches && !h->two_streams) {
     // fc4 wgrad (1568 tiles at B <= 32) is spread over the three backward launches as background traffic;
     // for B > 32 (K-split workgroups) it all rides in the first one
@@ -562,23 +625,21 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   LAUNCH(K_CONV1_WGRAD, launch_kernel(K_CONV1_WGRAD, a, g_stream));
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[3], ss)); HIPCHK(hipStreamWaitEvent(g_stream, g_ev[3], 0)); }
   }
-  UpdateArgs u; memset(&u, 0, sizeof u);
-  u.theta = h->theta; u.state = h->state; u.g = h->g;
-  u.slab[0] = h->slab1; u.slab[1] = h->slab2; u.slab[2] = h->slab3; u.ns[0] = h->ns1; u.ns[1] = h->ns2; u.ns[2] = h->ns3;
-  u.dq = h->dq; u.a4 = h->a4; u.cost_terms = h->cost_terms; u.cost_out = h->cost_out; u.cost_accum = h->cost_accum;
-  u.B = h->B; u.A = h->A;
-  u.rho = (float)h->cfg.decay_rate; u.one_minus_rho = (float)(1.0 - h->cfg.decay_rate);
-  u.lr = (float)h->cfg.learning_rate; u.eps = (float)h->cfg.epsilon;
-  u.skip_fc4 = a.fuse_rms;
-  u.opt = h->cfg.optimizer; u.state2 = h->state2;
-  if (h->cfg.datatype == 1) { u.wh = h->wh[0]; u.wht = h->wht[0]; }
-  if (u.opt == 1) {            // Neon Adam [neon-recalled]: t = epoch + 1, l = lr*sqrt(1-b2^t)/(1-b1^t), math in Python floats
-    const double b1 = h->cfg.beta_1, b2 = h->cfg.beta_2, t = (double)h->epoch + 1.0;
-    u.beta1 = (float)b1; u.one_minus_beta1 = (float)(1.0 - b1); u.beta2 = (float)b2; u.one_minus_beta2 = (float)(1.0 - b2);
-    u.lr_t = (float)(h->cfg.learning_rate * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t)));
-  }
+  UpdateArgs u = make_update_args(h, a);
   if (next) u.next = *next;                 // (memset above left next.B = 0 otherwise)
-  if (h->comm) {
+  if (dp_ov) {
+    // conv + fc5 gradients (0.3 MB): reduce the slabs, all-reduce the two ranges as one RCCL group on the library
+    // stream (first communicator), apply; the fc4 part is already on its way on g_comm
+    u.mode = 1; u.bsz = (float)h->B; u.next.B = 0; u.skip_fc4 = 1;
+    LAUNCH(K_UPDATE, launch_update(u, g_stream));
+    if (g_rccl.GroupStart && g_rccl.GroupEnd) NCCLCHK(g_rccl.GroupStart());
+    LAUNCH(K_ALLREDUCE, (g_rccl.AllReduce(h->g, h->g, (size_t)OFF4, 7, 0, h->comm, g_stream) == 0 ? hipSuccess : hipErrorUnknown));
+    LAUNCH(K_ALLREDUCE, (g_rccl.AllReduce(h->g + OFF5, h->g + OFF5, (size_t)(h->NP - OFF5), 7, 0, h->comm, g_stream) == 0 ? hipSuccess : hipErrorUnknown));
+    if (g_rccl.GroupStart && g_rccl.GroupEnd) NCCLCHK(g_rccl.GroupEnd());
+    u.mode = 2; u.bsz = (float)h->B * (float)h->nranks; u.skip_fc4 = 1;
+    if (next) u.next = *next;
+    LAUNCH(K_UPDATE, launch_update(u, g_stream));
+  } else   if (h->comm) {
     // synchronous data parallel: local gradient sums -> one RCCL all-reduce of the flat buffer -> identical RMSProp
     u.mode = 1; u.bsz = (float)h->B; u.next.B = 0;
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
@@ -773,6 +834,7 @@ extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, 
 }
 extern "C" int sdqn_net_update_target(sdqn_net_t h) {
   ARGCHK(h, "NULL handle");
+  { int rc = join_comm(h); if (rc) return rc; }
   if (h->theta_t != h->theta) {
     HIPCHK(hipMemcpyAsync(h->theta_t, h->theta, (size_t)h->NP * 4, hipMemcpyDeviceToDevice, g_stream));   // deepqnetwork.py:102-105
     if (h->cfg.datatype == 1) {
@@ -782,7 +844,10 @@ extern "C" int sdqn_net_update_target(sdqn_net_t h) {
   }
   return SDQN_OK;
 }
-extern "C" int sdqn_net_sync(sdqn_net_t h) { ARGCHK(h, "NULL handle"); HIPCHK(hipStreamSynchronize(g_stream)); return SDQN_OK; }
+extern "C" int sdqn_net_sync(sdqn_net_t h) {
+  ARGCHK(h, "NULL handle"); int rc = join_comm(h); if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(g_stream)); return SDQN_OK;
+}
 extern "C" int sdqn_net_last_q(sdqn_net_t h, float* preq, float* maxpostq) {
   ARGCHK(h, "NULL handle");
   const size_t nq = (size_t)h->B * h->A;
@@ -803,6 +868,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "two_streams")) h->two_streams = value != 0;
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;
+  else if (!strcmp(name, "dp_overlap")) h->dp_overlap = value != 0;     // before dp_init: 0 = single all-reduce on the library stream
   else if (!strcmp(name, "f4_share3")) h->f4_share[0] = value;
   else if (!strcmp(name, "f4_share2")) h->f4_share[1] = value;
   else if (!strncmp(name, "nw:", 3)) {                     // tuning: waves per tile of kernel id
@@ -825,7 +891,7 @@ extern "C" int sdqn_net_debug_read(sdqn_net_t h, const char* name, float* out, i
     {"dq", h->dq, (int64_t)B * h->A}, {"g", h->g, h->NP}, {"theta", h->theta, h->NP}, {"cost_terms", h->cost_terms, B}};
   for (auto& e : tab) if (!strcmp(e.n, name)) {
     ARGCHK(n <= e.len, "buffer %s holds %lld floats", name, (long long)e.len);
-    HIPCHK(hipStreamSynchronize(g_stream));
+    { int rc_ = join_comm(h); if (rc_) return rc_; } HIPCHK(hipStreamSynchronize(g_stream));
     HIPCHK(hipMemcpy(out, e.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return SDQN_OK;
   }
@@ -845,11 +911,26 @@ extern "C" int sdqn_dp_init(sdqn_net_t h, const char* rccl_path, const char id[1
   Id128 u; memcpy(u.b, id, 128);
   NCCLCHK(g_rccl.CommInitRank(&h->comm, nranks, u, rank));
   h->rank = rank; h->nranks = nranks;
+  // second communicator (same ranks) for the overlapped fc4 all-reduce: two collectives may only be in flight at
+  // once on different communicators.  Without ncclCommSplit the step falls back to one all-reduce on the library stream.
+  h->comm2 = nullptr;
+  if (g_rccl.CommSplit && h->dp_overlap) {
+    if (g_rccl.CommSplit(h->comm, 0, rank, &h->comm2, nullptr) != 0) h->comm2 = nullptr;
+  }
+  if (h->comm2) {
+    if (!h->ev_g4) HIPCHK(hipEventCreateWithFlags(&h->ev_g4, hipEventDisableTiming));
+    if (!h->ev_w4) HIPCHK(hipEventCreateWithFlags(&h->ev_w4, hipEventDisableTiming));
+  }
   return SDQN_OK;
 }
 extern "C" int sdqn_dp_shutdown(sdqn_net_t h) {
   ARGCHK(h, "NULL handle");
-  if (h->comm) { HIPCHK(hipStreamSynchronize(g_stream)); NCCLCHK(g_rccl.CommDestroy(h->comm)); h->comm = nullptr; }
+  { int rc = join_comm(h); if (rc) return rc; }
+  if (h->comm) {
+    HIPCHK(hipStreamSynchronize(g_stream)); HIPCHK(hipStreamSynchronize(g_comm));
+    if (h->comm2) { NCCLCHK(g_rccl.CommDestroy(h->comm2)); h->comm2 = nullptr; }
+    NCCLCHK(g_rccl.CommDestroy(h->comm)); h->comm = nullptr;
+  }
   h->rank = 0; h->nranks = 1;
   return SDQN_OK;
 }

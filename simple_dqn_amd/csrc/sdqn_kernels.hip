@@ -297,6 +297,7 @@ constexpr int FC5_BLOCKS_PER_ACTION = NFC / 4 / 32;   // 4 workgroups of 32 floa
 __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
   __shared__ float4 part[8][32];
   const int t = threadIdx.x;
+  if (u.only_fc4 && (int)blockIdx.x < CONV_BLOCKS + u.A * FC5_BLOCKS_PER_ACTION) return;
   if ((int)blockIdx.x < CONV_BLOCKS) {
     const int c4 = t & 31, sg = t >> 5;
     const int64_t e = ((int64_t)blockIdx.x * 32 + c4) * 4;

@@ -343,21 +343,47 @@ def test_batch256_one_step(sd):
         assert np.abs(net.get_layer(i, 3) - g[i]).max() < 2e-4 * max(1e-3, np.abs(g[i]).max()), i
 
 
-def test_dp_single_rank_rccl(sd):
-    """RCCL path with nranks=1 on the 1-GPU box: all-reduce of the flat gradient is the identity, so the
-    reduce -> all-reduce -> apply split must reproduce the fused single-GPU update bit for bit."""
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_dp_single_rank_rccl(sd, overlap):
+    """RCCL path with nranks=1 on the 1-GPU box: the all-reduce of the gradient is the identity, so the
+    reduce -> all-reduce -> apply split must reproduce the fused single-GPU update bit for bit — both as one
+    all-reduce on the library stream (overlap=0) and with the fc4 gradient all-reduced and applied on the
+    communication stream under the rest of the backward pass and the next forward (overlap=1, second communicator)."""
+    import ctypes as C
+    from bench import fill_ring
     from simple_dqn_amd.deepqnetwork import dp_unique_id
     A, B = 4, 32
     n1, _ = _pair(sd, A, B, 71)
     n2, _ = _pair(sd, A, B, 71)
+    n2.set_option("dp_overlap", overlap)
     n2.dp_init(dp_unique_id(), 0, 1)
-    for s in range(3):
+    for s in range(6):
         mb = random_minibatch(B, A, 72 + s)
         n1.train(mb)
         n2.train(mb)
+        if s % 2:                                   # acting between train steps must see the updated W4
+            assert np.array_equal(n1.predict(mb[0]), n2.predict(mb[0]))
+        if s == 3:
+            n1.update_target_network(); n2.update_target_network()
+    for i in range(5):
+        assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
+        assert np.array_equal(n1.get_layer(i, 1), n2.get_layer(i, 1)), i
+        assert np.array_equal(n1.get_layer(i, 2), n2.get_layer(i, 2)), i
+    # the library-driven loop (sample-ahead, prep riding the update launch)
+    args = make_args(batch_size=B)
+    mem = sd.ReplayMemory(3000, args); fill_ring(mem, 5, A)
+    lib = sd.load()
+    costs = []
+    for n in (n1, n2):
+        mt = (C.c_uint32 * 625)(); lib.sdqn_mt_seed(mt, 23)
+        costs.append([n.train_from_memory(mem, 20, mt_state=mt, want_cost=True) for _ in range(3)])
+    assert costs[0] == costs[1]
     for i in range(5):
         assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
     n2.dp_shutdown()
+    n1.train(mb); n2.train(mb)                      # back to the single-GPU path after shutdown
+    for i in range(5):
+        assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
 
 
 def test_agent_loop_plumbing(sd):
