@@ -102,8 +102,15 @@ struct StepArgs {
 };
 
 // A9 + A10 in Neon's operation order (the library is built with -ffp-contract=off: one rounding per op)
+// grad / be.bsz (A9), exactly: for a power-of-two divisor (B = 32, 256, ...; R*B under data parallel) the quotient
+// equals the product with the exactly representable reciprocal, which saves one of the two IEEE divisions per weight
+SDQN_HD float div_bsz(float x, float bsz) {
+  union { float f; uint32_t u; } b, r; b.f = bsz;
+  if ((b.u & 0x007FFFFFu) == 0u && b.u >= 0x00800000u && b.u < 0x7E800000u) { r.u = 0x7F000000u - b.u; return x * r.f; }
+  return x / bsz;
+}
 SDQN_HD float rms_step(float w, float& st, float gsum, float bsz, float rho, float omr, float lr, float eps) {
-  const float g = gsum / bsz;                         // grad / be.bsz
+  const float g = div_bsz(gsum, bsz);                 // grad / be.bsz
   st = rho * st + (g * g) * omr;                      // state = rho*state + g^2*(1-rho)
   return w - (g * lr) / (sqrtf(st + eps) + eps);
 }

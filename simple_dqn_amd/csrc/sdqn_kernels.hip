@@ -252,7 +252,7 @@ hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
 // every one starts with grad = grad / be.bsz
 __device__ inline float opt_apply(float w, float& s1, float& s2, float gsum, const UpdateArgs& u) {
   if (u.opt == 0) return rms_step(w, s1, gsum, u.bsz, u.rho, u.one_minus_rho, u.lr, u.eps);
-  const float g = gsum / u.bsz;
+  const float g = div_bsz(gsum, u.bsz);
   if (u.opt == 1) {                                   // Adam: m, v; bias correction folded into lr_t (t = epoch + 1)
     s1 = s1 * u.beta1 + u.one_minus_beta1 * g;
     s2 = s2 * u.beta2 + (u.one_minus_beta2 * g) * g;

@@ -33,6 +33,7 @@ static void run(const StepArgs& a) {
   }
 }
 
+extern "C" void emul_div_bsz(const float* x, float bsz, float* out, int n) { for (int i = 0; i < n; ++i) out[i] = div_bsz(x[i], bsz); }
 extern "C" void emul_norm_u8(float* out256) { for (int i = 0; i < 256; ++i) out256[i] = norm_u8((uint32_t)i); }
 
 extern "C" int emul_step(int B, int A, const float* const* w_online /*5, Neon*/, const float* const* w_target,

@@ -51,3 +51,18 @@ def test_normalisation_is_exact_division(emul):
     out = np.zeros(256, np.float32)
     emul.emul_norm_u8(out.ctypes.data_as(C.POINTER(C.c_float)))
     assert np.array_equal(out, np.arange(256, dtype=np.float32) / np.float32(255))
+
+
+def test_batch_size_division_is_exact(emul):
+    """A9's grad / be.bsz: the power-of-two shortcut (multiply by the exact reciprocal) must equal IEEE division for
+    every input, and other divisors must take the division path."""
+    rng = np.random.RandomState(5)
+    x = rng.randint(0, 2 ** 32, size=2_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    x = x[np.isfinite(x)]
+    out = np.empty_like(x)
+    emul.emul_div_bsz.argtypes = [C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float), C.c_int]
+    for bsz in (1.0, 2.0, 32.0, 64.0, 256.0, 2048.0, 3.0, 96.0, 0.5):
+        emul.emul_div_bsz(x.ctypes.data_as(C.POINTER(C.c_float)), C.c_float(bsz), out.ctypes.data_as(C.POINTER(C.c_float)), len(x))
+        with np.errstate(all="ignore"):
+            ref = x / np.float32(bsz)
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), bsz
