@@ -87,6 +87,11 @@ constexpr int tile_lds() {
 // operand exactly four 16-byte loads of the lane's own row (j = t >> 2 selects the load, e = t & 3 the component):
 __device__ __forceinline__ constexpr int kslot(int t, int h) { return 8 * (t >> 2) + 4 * h + (t & 3); }
 
+template <class T>
+__device__ __forceinline__ T ld_byte_off(const T* base, uint32_t byte_off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 // One 32x32 output tile (bx, by, bz) of problem P computed by the first NW waves of a workgroup of NT threads
 // (waves >= NW idle through the epilogue barrier).  NW == 1 inside a wider workgroup is handled by the caller
 // (one tile per wave, no barrier): see gemm_multi_kernel.
@@ -119,7 +124,12 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
   const AT* areg = nullptr; const BT* breg = nullptr;
   if constexpr (!P::A_K && P::A_REG) areg = abase + (uint32_t)arow + (hi ? 4 * P::A_LD : 0);
   if constexpr (!P::B_K && P::B_REG) breg = bbase + (uint32_t)bcol + (hi ? 4 * P::B_LD : 0);
-  (void)abase; (void)bbase; (void)areg; (void)breg;
+  // the same per-lane position as a 32-bit BYTE offset from the (uniform) base pointer: `global_load v, v_off, s[base]`
+  // instead of three VALU instructions of 64-bit pointer arithmetic per load (all operand buffers are < 4 GB)
+  uint32_t aoffb = 0, boffb = 0;
+  if constexpr (!P::A_K && P::A_REG) aoffb = (uint32_t)sizeof(AT) * ((uint32_t)arow + (hi ? 4u * P::A_LD : 0u));
+  if constexpr (!P::B_K && P::B_REG) boffb = (uint32_t)sizeof(BT) * ((uint32_t)bcol + (hi ? 4u * P::B_LD : 0u));
+  (void)abase; (void)bbase; (void)areg; (void)breg; (void)aoffb; (void)boffb;
 
   // staged operands: lane -> (k4 = l & 7, rows (l >> 3) + 8j) for the loads, wave-private panels [k][x] (pitch 33)
   float* pan_a = smem + (wave < NW ? wave : 0) * WAVE_LDS;
@@ -153,9 +163,15 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
       }
     } else if constexpr (P::A_REG) {
       if (kc + 32 <= kend) {
-        const AT* p = areg + (size_t)kc * P::A_LD;
+        if constexpr (sizeof(AT) * P::A_LD >= 2048) {          // every row offset beyond the 12-bit immediate: 32-bit offsets
+          const uint32_t kcb = (uint32_t)sizeof(AT) * (uint32_t)kc * (uint32_t)P::A_LD;          // wave-uniform
 #pragma unroll
-        for (int t = 0; t < 16; ++t) dst[t] = (float)p[(size_t)kslot(t, 0) * P::A_LD];
+          for (int t = 0; t < 16; ++t) dst[t] = (float)ld_byte_off(abase, aoffb + kcb + (uint32_t)(sizeof(AT) * kslot(t, 0) * P::A_LD));
+        } else {
+          const AT* p = areg + (size_t)kc * P::A_LD;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) dst[t] = (float)p[(size_t)kslot(t, 0) * P::A_LD];
+        }
       } else {
 #pragma unroll
         for (int t = 0; t < 16; ++t) { const int k = kc + kslot(t, hb); dst[t] = k < kend ? (float)areg[(size_t)(kc + kslot(t, 0)) * P::A_LD] : 0.0f; }
@@ -183,9 +199,15 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
       }
     } else if constexpr (P::B_REG) {
       if (kc + 32 <= kend) {
-        const BT* p = breg + (size_t)kc * P::B_LD;
+        if constexpr (sizeof(BT) * P::B_LD >= 2048) {
+          const uint32_t kcb = (uint32_t)sizeof(BT) * (uint32_t)kc * (uint32_t)P::B_LD;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) dst[t] = (float)p[(size_t)kslot(t, 0) * P::B_LD];
+          for (int t = 0; t < 16; ++t) dst[t] = (float)ld_byte_off(bbase, boffb + kcb + (uint32_t)(sizeof(BT) * kslot(t, 0) * P::B_LD));
+        } else {
+          const BT* p = breg + (size_t)kc * P::B_LD;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) dst[t] = (float)p[(size_t)kslot(t, 0) * P::B_LD];
+        }
       } else {
 #pragma unroll
         for (int t = 0; t < 16; ++t) { const int k = kc + kslot(t, hb); dst[t] = k < kend ? (float)breg[(size_t)(kc + kslot(t, 0)) * P::B_LD] : 0.0f; }

@@ -355,29 +355,33 @@ struct Fc4Wgrad {   // gW4 = delta4 . a3^T (sum over batch, A8) in the W4i layou
   // single-wave epilogue (B <= 32): the read-modify-write's 32 loads (theta, state) are issued at kernel
   // entry (epi_begin) so they fly under the operand loads and the MFMAs
   struct Epi { float w[16], st[16]; };
+  // accumulator register r of lane l is element (m0 + (r&3) + 8(r>>2) + 4(l>>5), n0 + (l&31)): one 32-bit base offset
+  // per lane + compile-time row offsets (uniform base pointer + 32-bit offset addressing, no 64-bit math per element)
+  // BYTE offsets in 32 bits added to the uniform base pointer: the form hipcc turns into `global_load v, v_off32, s[base]`
+  __device__ static uint32_t epi_base(int m0, int n0, int lane) { return 4u * (uint32_t)(OFF4 + (m0 + 4 * (lane >> 5)) * NFC + n0 + (lane & 31)); }
+  __device__ static constexpr uint32_t epi_row(int r) { return 4u * (uint32_t)(((r & 3) + 8 * (r >> 2)) * NFC); }
+  __device__ static float ldb(const float* p, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + byte_off); }
+  __device__ static void stb(float* p, uint32_t byte_off, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(p) + byte_off) = v; }
   __device__ static void epi_begin(const StepArgs& a, int m0, int n0, int lane, Epi& e) {
     if (!a.fuse_rms) return;
+    const float* __restrict__ tw = a.theta_w; const float* __restrict__ sp = a.state;
+    const uint32_t base = epi_base(m0, n0, lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int64_t o = OFF4 + (int64_t)(m0 + ml) * NFC + n0 + (lane & 31);
-      e.w[r] = a.theta_w[o]; e.st[r] = a.state[o];
-    }
+    for (int r = 0; r < 16; ++r) { e.w[r] = ldb(tw, base + epi_row(r)); e.st[r] = ldb(sp, base + epi_row(r)); }
   }
   __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi& e) {
+    const uint32_t base = epi_base(m0, n0, lane);
     if (!a.fuse_rms) {
+      float* __restrict__ gp = a.g;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); a.g[OFF4 + (int64_t)(m0 + ml) * NFC + n0 + (lane & 31)] = v[r]; }
+      for (int r = 0; r < 16; ++r) stb(gp, base + epi_row(r), v[r]);
       return;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) e.w[r] = rms_step(e.w[r], e.st[r], v[r], a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps);
+    float* __restrict__ tw = a.theta_w; float* __restrict__ sp = a.state;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int64_t o = OFF4 + (int64_t)(m0 + ml) * NFC + n0 + (lane & 31);
-      a.theta_w[o] = e.w[r]; a.state[o] = e.st[r];
-    }
+    for (int r = 0; r < 16; ++r) { stb(tw, base + epi_row(r), e.w[r]); stb(sp, base + epi_row(r), e.st[r]); }
   }
 #endif
 };
