@@ -40,6 +40,11 @@ template <class P> struct b_elem<P, decltype((void)sizeof(typename P::BT))> { ty
 template <class P, class = void> struct stages_lds { static constexpr bool value = false; };
 template <class P> struct stages_lds<P, decltype((void)P::STAGE_LDS)> { static constexpr bool value = P::STAGE_LDS; };
 template <class P> struct Staged : P { static constexpr bool STAGE_LDS = true; };      // same problem, staged operands
+// A_GROUP4: the irregular (im2col-row) A operand is affine inside every aligned group of 4 consecutive k
+// (conv1: 20 x 20 output positions, x fastest, stride 4 bytes in the u8 frame; 20 and 400 are multiples of 4), so a
+// lane needs 4 gathered offsets per chunk instead of 16 and fetches its 4 bytes with ONE unaligned 16-byte load
+template <class P, class = void> struct a_group4 { static constexpr bool value = false; };
+template <class P> struct a_group4<P, decltype((void)P::A_GROUP4)> { static constexpr bool value = P::A_GROUP4; };
 template <class P, class = void> struct uses_f16_mfma { static constexpr bool value = false; };
 template <class P> struct uses_f16_mfma<P, decltype((void)P::F16_MFMA)> { static constexpr bool value = P::F16_MFMA; };
 
@@ -175,6 +180,16 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
       } else {
 #pragma unroll
         for (int t = 0; t < 16; ++t) { const int k = kc + kslot(t, hb); dst[t] = k < kend ? (float)areg[(size_t)(kc + kslot(t, 0)) * P::A_LD] : 0.0f; }
+      }
+    } else if constexpr (a_group4<P>::value) {
+      const int kl = kc + (lane & 31);
+      const aoff_t cv = P::a_col(a, z, kl < kend ? kl : kbeg);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                                         // k = kc + 8j + 4h + e, e = 0..3
+        const aoff_t c = pick_half(cv, 8 * j, hi);
+        const bool ok = kc + 8 * j + 4 * hb < kend;                         // Kt is a multiple of 4: whole groups
+        const f4 v = P::a_load_group4(a, z, arow + c);
+        dst[4 * j] = ok ? v.x : 0.0f; dst[4 * j + 1] = ok ? v.y : 0.0f; dst[4 * j + 2] = ok ? v.z : 0.0f; dst[4 * j + 3] = ok ? v.w : 0.0f;
       }
     } else {
       const int kl = kc + (lane & 31);

@@ -135,6 +135,21 @@ SDQN_HD f4 ld4(const float* p) {
   f4 o; o.x = p[0]; o.y = p[1]; o.z = p[2]; o.w = p[3]; return o;
 #endif
 }
+// bytes p[0], p[4], p[8], p[12] (four consecutive conv1 output positions of one patch element), normalised:
+// ONE unaligned 16-byte load on the device (gfx9+ global loads take any byte alignment), v_cvt_f32_ubyte0 per dword.
+// Reads up to 12 bytes past the last byte used: frame buffers are allocated with SRC_PAD bytes of slack.
+constexpr int SRC_PAD = 16;
+SDQN_HD f4 ld4_u8_stride4(const uint8_t* p) {
+  f4 o;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(1)));
+  const u32x4 w = *reinterpret_cast<const u32x4*>(p);
+  o.x = norm_u8(w.x & 255u); o.y = norm_u8(w.y & 255u); o.z = norm_u8(w.z & 255u); o.w = norm_u8(w.w & 255u);
+#else
+  o.x = norm_u8(p[0]); o.y = norm_u8(p[4]); o.z = norm_u8(p[8]); o.w = norm_u8(p[12]);
+#endif
+  return o;
+}
 SDQN_HD f4 ld4_u8(const uint8_t* p) {       // 4 consecutive bytes (4-byte aligned by construction) -> 4 normalised floats
   uint32_t w;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -548,6 +563,8 @@ struct Conv1Wgrad { // re-gathers the normalised u8 patches from the ring (no fp
   SDQN_HD static aoff_t a_col(const StepArgs& a, int, int k) { return row1(a, 0, k); }
   SDQN_HD static float a_load(const StepArgs& a, int, aoff_t o) { return norm_u8(a.src[o]); }
   SDQN_HD static f4 a_load4(const StepArgs& a, int, aoff_t o) { return ld4_u8(a.src + o); }
+  static constexpr bool A_GROUP4 = true;              // k = (n, y, x), x fastest: +4 bytes per k inside aligned groups of 4
+  SDQN_HD static f4 a_load_group4(const StepArgs& a, int, aoff_t o) { return ld4_u8_stride4(a.src + o); }
   SDQN_HD static int b_row(const StepArgs&, int, int k) { return k * K1; }
   SDQN_HD static int b_col(const StepArgs&, int, int n) { return n; }
   SDQN_HD static float b_load(const StepArgs& a, int, int o) { return a.d1[o]; }

@@ -123,7 +123,7 @@ extern "C" int sdqn_replay_create(sdqn_replay_t* out, int64_t size, int H, int W
   r->size = size; r->H = H; r->W = W; r->hist = hist; r->B = batch; r->flags = flags;
   const unsigned hf = hipHostMallocMapped | hipHostMallocPortable;
 #define RCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s -> %s", #x, hipGetErrorString(e_)); replay_free(r); return SDQN_ERR_HIP; } } while (0)
-  RCHK(hipHostMalloc((void**)&r->screens, (size_t)size * FRAME, hf));
+  RCHK(hipHostMalloc((void**)&r->screens, (size_t)size * FRAME + SRC_PAD, hf));     // + slack: conv1_wgrad's 16-byte patch loads (problems.h)
   RCHK(hipHostMalloc((void**)&r->actions, (size_t)size, hf));
   RCHK(hipHostMalloc((void**)&r->rewards, (size_t)size * 8, hf));
   RCHK(hipHostMalloc((void**)&r->terminals, (size_t)size, hf));
@@ -133,7 +133,7 @@ extern "C" int sdqn_replay_create(sdqn_replay_t* out, int64_t size, int H, int W
     RCHK(hipHostGetDevicePointer((void**)&r->d_ring, r->screens, 0));
     RCHK(hipHostGetDevicePointer((void**)&r->d_meta, r->h_meta, 0));
   } else {
-    RCHK(hipMalloc((void**)&r->d_ring, (size_t)size * FRAME));
+    RCHK(hipMalloc((void**)&r->d_ring, (size_t)size * FRAME + SRC_PAD));
     RCHK(hipMalloc((void**)&r->d_meta, (size_t)size * sizeof(MetaRec)));
     RCHK(hipMemsetAsync(r->d_meta, 0, (size_t)size * sizeof(MetaRec), g_stream));
   }
@@ -416,7 +416,7 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->cost_terms, (size_t)B * 4));
   NCHK(dalloc(h, (void**)&h->cost_out, 16));
   NCHK(dalloc(h, (void**)&h->cost_accum, 16));
-  NCHK(dalloc(h, (void**)&h->st_states, (size_t)2 * B * STATE));
+  NCHK(dalloc(h, (void**)&h->st_states, (size_t)2 * B * STATE + SRC_PAD));
   NCHK(dalloc(h, (void**)&h->st_act, B)); NCHK(dalloc(h, (void**)&h->st_term, B));
   NCHK(dalloc(h, (void**)&h->st_rew, (size_t)B * 8));
   NCHK(dalloc(h, (void**)&h->d_idx, (size_t)B * 8));
