@@ -75,9 +75,39 @@ def pmc_traffic(name, B, A):
     return None
 
 
+# substring of the rocprofv3 kernel name -> kernel id (kernels.h order); shared with tools/pmc_traffic.py
+ROCPROF_MATCH = [
+    ("gemm_kernel<sdqn::Conv1Fwd", 0), ("gemm_kernel<sdqn::Conv2Fwd", 1), ("Conv3Fwd", 2), ("Fc4Fwd", 3),
+    ("head_kernel", 4), ("Fc4Dgrad", 5), ("update_kernel", 12), ("gather_kernel", 14), ("prep_kernel", 15),
+    ("gemm_multi_kernel<512, sdqn::Fc4Wgrad", 16), ("Conv2Dgrad", 17), ("Conv1Wgrad", 18),
+]
+
+
+def rocprof_us(kid, B, A):
+    """Average kernel duration (us) of this kernel in the committed `rocprofv3 --kernel-trace --stats` summary of the
+    same command (profiles/r01_final_kernel_stats.csv, B=32 A=4 fp32); None for other shapes."""
+    if (B, A) != (32, 4):
+        return None
+    try:
+        import csv
+        rows = [r for r in csv.reader(l for l in open(os.path.join(ROOT, "profiles", "r01_final_kernel_stats.csv")) if not l.startswith("#"))]
+        for sub, k in ROCPROF_MATCH:
+            if k == kid:
+                for r in rows[1:]:
+                    if sub in r[0]:
+                        return round(float(r[3]) / 1e3, 2)
+    except Exception:
+        pass
+    return None
+
+
 def roofline_entry(kid, name, ms_per_launch, B, A):
+    """`achieved` uses the LIVE HIP-event bracket of each launch (us_per_launch), which also contains the ~2 us
+    dispatch gap of a dependent launch and is therefore conservative; rocprof_us_per_launch is the kernel's own
+    execution time from the committed rocprofv3 summary of the same command."""
     e = _roofline_entry(kid, name, ms_per_launch, B, A)
     e["traffic"] = pmc_traffic(name, B, A)
+    e["rocprof_us_per_launch"] = rocprof_us(kid, B, A)
     return e
 
 
@@ -152,6 +182,47 @@ def cpu_baseline(B, A, seed, budget_s):
     return dict(value=round(n / el, 2), unit="train_steps/sec", cores=int(threads), kind="port",
                 sample="%d steps of oracle ReplayOracle.getMinibatch + OracleDQN.train (numpy fp32, B=%d, A=%d, ring %d frames); "
                        "tried BLAS pools %s" % (n, B, A, ring, [r[0] for r in runs]), ms_per_step=round(el / n * 1e3, 2))
+
+
+def cpu_standin_torch(B, A, seed, budget_s):
+    """a 'strong CPU' stand-in — the same train step (target forward, online forward, clipped
+    TD error, backward, RMSProp) in torch-CPU fp32 (oneDNN convolutions, all host cores), on oracle-gathered minibatches.
+    Not the reference and not a parity oracle: a second, clearly labelled CPU row beside `cpu_baseline`."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from oracle.dqn_numpy import xavier_weights
+    from oracle.replay_numpy import ReplayOracle, synthetic_fill, MT19937
+    ws = xavier_weights(A, seed + 1)                       # Neon layouts: conv (C*R*S, K), fc (nout, nin)
+    shapes = [(32, 4, 8, 8), (64, 32, 4, 4), (64, 64, 3, 3)]
+    P = [torch.tensor(w.T.reshape(sh).copy(), requires_grad=True) for w, sh in zip(ws[:3], shapes)] + \
+        [torch.tensor(ws[3].copy(), requires_grad=True), torch.tensor(ws[4].copy(), requires_grad=True)]
+    T = [p.detach().clone() for p in P]
+    S = [torch.zeros_like(p) for p in P]
+
+    def fwd(x, W):
+        h = F.relu(F.conv2d(x, W[0], stride=4)); h = F.relu(F.conv2d(h, W[1], stride=2)); h = F.relu(F.conv2d(h, W[2]))
+        return F.relu(h.flatten(1) @ W[3].t()) @ W[4].t()
+    mem = ReplayOracle(20000, batch_size=B); synthetic_fill(mem, seed, num_actions=A); rng = MT19937(seed + 2)
+
+    def step():
+        pre, act, rew, post, term = mem.getMinibatch(rng)
+        with torch.no_grad():
+            m = fwd(torch.from_numpy(post).float() / 255, T).max(1).values
+            y = torch.from_numpy(np.clip(rew, -1, 1)).float() + 0.99 * m * (1 - torch.from_numpy(term.astype(np.float32)))
+        q = fwd(torch.from_numpy(pre).float() / 255, P)
+        d = (q.gather(1, torch.from_numpy(act.astype(np.int64))[:, None])[:, 0] - y)
+        q.backward(torch.zeros_like(q).scatter_(1, torch.from_numpy(act.astype(np.int64))[:, None], d.detach().clamp(-1, 1)[:, None]))
+        with torch.no_grad():
+            for p, s_ in zip(P, S):
+                g = p.grad / B; s_.mul_(0.95).add_(0.05 * g * g); p.sub_(2.5e-4 * g / (torch.sqrt(s_ + 1e-6) + 1e-6)); p.grad = None
+    step()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and n < 2000:
+        step(); n += 1
+    el = time.perf_counter() - t0
+    return dict(value=round(n / el, 2), unit="train_steps/sec", cores=int(torch.get_num_threads()), kind="stand-in (torch-CPU fp32, oneDNN; not the reference)",
+                sample="%d steps of oracle getMinibatch + torch-CPU train step (B=%d, A=%d, ring 20000 frames)" % (n, B, A), ms_per_step=round(el / n * 1e3, 2))
 
 
 def q_mae_vs_oracle(sd, B, A, seed):
@@ -320,6 +391,10 @@ def main():
             out["q_mae_vs_cpu_ref"] = {"mae": mae, "max_abs": mx, "after_steps": 1, "tolerance": 1e-4}
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(B, A, a.seed, a.cpu_baseline_seconds)
+                try:
+                    out["cpu_standin_torch"] = cpu_standin_torch(B, A, a.seed, 5.0)
+                except Exception as e:                         # never let the optional row break the bench line
+                    out["cpu_standin_torch"] = {"error": repr(e)[:200]}
     # The JSON line must be the LAST line of the job's stdout.  RCCL prints a version banner through C stdio, which
     # is block-buffered on a pipe and would otherwise be flushed at process exit — after the JSON, from every rank.
     # So: tear the communicators down, flush C stdio on every rank, barrier, and only then let rank 0 print.

@@ -20,13 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernel_work  # noqa: E402
 
-# substring of the rocprof kernel name -> bench.py kernel_work id / display name
-MATCH = [
-    ("gemm_kernel<sdqn::Conv1Fwd", 0), ("gemm_kernel<sdqn::Conv2Fwd", 1), ("Conv3Fwd", 2), ("Fc4Fwd", 3),
-    ("head_kernel", 4), ("Fc4Dgrad", 5), ("update_kernel", 12), ("gather_kernel", 14), ("prep_kernel", 15),
-    ("gemm_multi_kernel<512, sdqn::Fc4Wgrad", 16), ("Conv2Dgrad", 17), ("Conv1Wgrad", 18),
-]
-
+from bench import ROCPROF_MATCH as MATCH  # noqa: E402
 
 NAMES = ["conv1_fwd(gather+norm+conv+relu)", "conv2_fwd", "conv3_fwd", "fc4_fwd(splitK)", "head(fc5+td+delta)",
          "fc4_dgrad", "fc4_wgrad", "conv3_dgrad", "conv3_wgrad", "conv2_dgrad", "conv2_wgrad",
