@@ -217,12 +217,19 @@ def cpu_standin_torch(B, A, seed, budget_s):
             for p, s_ in zip(P, S):
                 g = p.grad / B; s_.mul_(0.95).add_(0.05 * g * g); p.sub_(2.5e-4 * g / (torch.sqrt(s_ + 1e-6) + 1e-6)); p.grad = None
     step()
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s and n < 2000:
-        step(); n += 1
-    el = time.perf_counter() - t0
-    return dict(value=round(n / el, 2), unit="train_steps/sec", cores=int(torch.get_num_threads()), kind="stand-in (torch-CPU fp32, oneDNN; not the reference)",
-                sample="%d steps of oracle getMinibatch + torch-CPU train step (B=%d, A=%d, ring 20000 frames)" % (n, B, A), ms_per_step=round(el / n * 1e3, 2))
+    runs, all_threads = [], torch.get_num_threads()
+    for th in sorted({all_threads, min(16, all_threads)}, reverse=True):   # many-core hosts oversubscribe on these small convs
+        torch.set_num_threads(th)
+        step()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s / 2 and n < 2000:
+            step(); n += 1
+        runs.append((th, n, time.perf_counter() - t0))
+    torch.set_num_threads(all_threads)
+    th, n, el = max(runs, key=lambda r: r[1] / r[2])
+    return dict(value=round(n / el, 2), unit="train_steps/sec", cores=int(th), kind="stand-in (torch-CPU fp32, oneDNN; not the reference)",
+                sample="%d steps of oracle getMinibatch + torch-CPU train step (B=%d, A=%d, ring 20000 frames); tried thread pools %s"
+                       % (n, B, A, [r[0] for r in runs]), ms_per_step=round(el / n * 1e3, 2))
 
 
 def q_mae_vs_oracle(sd, B, A, seed):
