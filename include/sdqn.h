@@ -111,7 +111,7 @@ typedef struct {
   double beta_1;           /* Adam (Neon default 0.9) */
   double beta_2;           /* Adam (Neon default 0.999) */
   double loss_scale;       /* float16 mode: static power-of-two scale of the stored deltas (0 -> 1024) */
-  double reserved1;
+  double batch_norm;       /* args.batch_norm :26 (0 / 1): Neon BatchNorm after conv1..3 and fc4 (float32 only) */
 } sdqn_net_cfg;
 
 /* DeepQNetwork.__init__, deepqnetwork.py:16-75 (weights start at zero: inject with set_weights) */
@@ -119,7 +119,9 @@ int sdqn_net_create(sdqn_net_t* h, const sdqn_net_cfg* cfg);
 int sdqn_net_destroy(sdqn_net_t h);
 /* which: 0 online theta, 1 target theta-, 2 optimizer state (RMSProp s / Adam m / Adadelta E[g^2]),
  * 3 last gradient sum (get only), 4 second optimizer state (Adam v / Adadelta E[dx^2]).
- * layer: 0..4 = conv1, conv2, conv3, fc4, fc5.  Data in Neon layout:
+ * layer: 0..4 = conv1, conv2, conv3, fc4, fc5.  With batch_norm also 5..8 = the BatchNorm layers after conv1, conv2,
+ * conv3, fc4: 2*C floats [beta | gamma] (C = 32, 64, 64, 512); for those layers which = 5 / 6 reads or writes the
+ * running statistics [gmean | gvar] of the online / target net.  Data in Neon layout:
  * conv (C*R*S, K) rows c*R*S+r*S+s; fc4 (512, 3136) nin in (K,P,Q) order; fc5 (A, 512).  */
 int sdqn_net_layer_size(sdqn_net_t h, int layer, int64_t* n);
 int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const float* w, int64_t n);

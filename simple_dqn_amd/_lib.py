@@ -26,7 +26,7 @@ class NetCfg(C.Structure):
                 ("optimizer", C.c_int), ("datatype", C.c_int),
                 ("discount_rate", C.c_double), ("clip_error", C.c_double), ("min_reward", C.c_double),
                 ("max_reward", C.c_double), ("learning_rate", C.c_double), ("decay_rate", C.c_double),
-                ("epsilon", C.c_double), ("beta_1", C.c_double), ("beta_2", C.c_double), ("loss_scale", C.c_double), ("reserved1", C.c_double)]
+                ("epsilon", C.c_double), ("beta_1", C.c_double), ("beta_2", C.c_double), ("loss_scale", C.c_double), ("batch_norm", C.c_double)]
 
 
 _u8p, _i64p, _f32p, _u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_uint32)

@@ -13,6 +13,7 @@ enum KernelId {
   K_BWD3,      // one launch: conv3_dgrad + conv3_wgrad + fc4_wgrad (all depend on fc4_dgrad only)
   K_BWD2,      // one launch: conv2_dgrad + conv2_wgrad (both depend on conv3_dgrad only) + a share of fc4_wgrad
   K_BWD1,      // one launch: conv1_wgrad + the last share of fc4_wgrad
+  K_BN,        // --batch_norm: one BatchNorm layer, forward ([partial +] apply) or backward (partial + apply)
   K_COUNT
 };
 const char* kernel_name(int id);
@@ -64,6 +65,25 @@ struct UpdateArgs {
   float beta1, one_minus_beta1, beta2, one_minus_beta2, lr_t;   // Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), t = epoch+1
   half_t* wh;                   // fp16 mode: half copies of theta refreshed by the update (master layout / transposed)
   half_t* wht;
+  int64_t bn_first;             // --batch_norm: element offset of the [beta|gamma] block (bn_update_kernel); BN_PARAMS elements
+};
+
+struct BnArgs {                  // one BatchNorm layer (bn_kernels.hip); activations NHWC: rows x C, C contiguous
+  int layer;                    // 0..3 = after conv1, conv2, conv3, fc4
+  int C, rows;                  // features; rows per net (B*P*Q, or B for fc4)
+  int nz;                       // nets in this forward pass (2 = online + target, 1 = predict)
+  int train;                    // 1: z = 0 normalises with batch statistics and updates the running ones
+  const float* x;               // raw linear output [nz][rows][C]; fc4: the split-K slabs [S4][2][B][512]
+  int S4, B;                    // fc4 only (S4 > 0)
+  float* a;                     // activated output [nz][rows][C]
+  float* theta[2];              // flat parameter buffers (BatchNorm block at off_bn)
+  int64_t off_bn;
+  double* partial;              // [row blocks][C][2]
+  float* mean; float* rstd;     // [C] batch statistics of z = 0 (kept for the backward pass)
+  float* d;                     // backward: dense delta [rows][C], transformed in place
+  float* dpad;                  // optional zero-padded copy [n][PD][PD][C] (operand of the next dgrad)
+  int PQ, Qw, PD, pad;
+  float* g;                     // flat gradient buffer
 };
 
 struct GatherArgs {
@@ -78,10 +98,32 @@ struct GatherArgs {
   int B;
 };
 
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------------------------------------
+// one parameter of Neon's optimizers [neon-recalled, SURVEY.md A9/A10 + §8a-bis "non-default branches"];
+// every one starts with grad = grad / be.bsz
+__device__ inline float opt_apply(float w, float& s1, float& s2, float gsum, const UpdateArgs& u) {
+  if (u.opt == 0) return rms_step(w, s1, gsum, u.bsz, u.rho, u.one_minus_rho, u.lr, u.eps);
+  const float g = div_bsz(gsum, u.bsz);
+  if (u.opt == 1) {                                   // Adam: m, v; bias correction folded into lr_t (t = epoch + 1)
+    s1 = s1 * u.beta1 + u.one_minus_beta1 * g;
+    s2 = s2 * u.beta2 + (u.one_minus_beta2 * g) * g;
+    return w - (u.lr_t * s1) / (sqrtf(s2) + u.eps);
+  }
+  s1 = s1 * u.rho + (u.one_minus_rho * g) * g;        // Adadelta: E[g^2], E[dx^2]
+  const float upd = sqrtf((s2 + u.eps) / (s1 + u.eps)) * g;
+  s2 = s2 * u.rho + (u.one_minus_rho * upd) * upd;
+  return w - upd;
+}
+#endif
+
 hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s);     // the GEMM-shaped stages (single or multi-problem launches)
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s);
 hipError_t launch_update(const UpdateArgs& u, hipStream_t s);
 hipError_t launch_gather(const GatherArgs& g, hipStream_t s);
+hipError_t launch_bn_forward(const BnArgs& b, hipStream_t s);      // [partial +] apply
+hipError_t launch_bn_backward(const BnArgs& b, hipStream_t s);     // partial + apply
+hipError_t launch_bn_update(const UpdateArgs& u, hipStream_t s);   // optimizer step of the [beta | gamma] block (g already holds the sums)
 hipError_t launch_prep(const PrepArgs& p, hipStream_t s);
 hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s);   // fp16 mode: rebuild both half copies
 

@@ -43,6 +43,12 @@ constexpr int PD3 = 11, PD2 = 11;                   // padded delta planes
 constexpr int NW1 = CRS1 * K1, NW2 = CRS2 * K2, NW3 = CRS3 * K3, NW4 = NIN4 * NFC;
 constexpr int OFF1 = 0, OFF2 = OFF1 + NW1, OFF3 = OFF2 + NW2, OFF4 = OFF3 + NW3, OFF5 = OFF4 + NW4;
 constexpr int MAX_ACTIONS = 18;
+// --batch_norm: BatchNorm after conv1..3 and fc4 (features per layer), parameter block appended to the flat buffers:
+// [beta_l | gamma_l] per layer at BN_OFF(l), then the running statistics [gmean_l | gvar_l] at BN_PARAMS + BN_OFF(l)
+constexpr int BN_LAYERS = 4;
+constexpr int BN_PARAMS = 2 * (32 + 64 + 64 + 512);      // 1344
+SDQN_HD constexpr int bn_features(int l) { return l == 0 ? 32 : (l == 3 ? 512 : 64); }
+SDQN_HD constexpr int bn_off(int l) { return l == 0 ? 0 : (l == 1 ? 64 : (l == 2 ? 192 : 320)); }
 
 #if defined(__HIPCC__)
 typedef _Float16 half_t;                                             // IEEE binary16 storage type of the fp16 mode
@@ -99,6 +105,9 @@ struct StepArgs {
   float* __restrict__ theta_w;   // online parameters, writable alias of theta[0]
   float* __restrict__ state;     // RMSProp state
   float bsz, rho, one_minus_rho, lr, eps;
+  // --batch_norm (deepqnetwork.py:26,83-89): launch_kernel picks the *Raw forward problems (linear output without the
+  // Rectlin: the BatchNorm + Rectlin pass of bn_kernels.hip follows) and the head variant that reads an activated a4
+  int bn;
 };
 
 // A9 + A10 in Neon's operation order (the library is built with -ffp-contract=off: one rounding per op)
@@ -586,6 +595,32 @@ SDQN_STORE16_DEFAULT(Conv3Wgrad)
 SDQN_STORE16_DEFAULT(Conv2Dgrad)
 SDQN_STORE16_DEFAULT(Conv2Wgrad)
 SDQN_STORE16_DEFAULT(Conv1Wgrad)
+#endif
+
+// --batch_norm forward: the same three conv problems storing the raw linear output x_l (no Rectlin) into a.a1/a2/a3,
+// which the orchestration points at the x buffers for that launch
+struct Conv1FwdRaw : Conv1Fwd {
+  SDQN_HD static void store(const StepArgs& a, int z, int, int m, int n, float v) { a.a1[((int64_t)z * M(a) + m) * K1 + n] = v; }
+#if defined(__HIPCC__)
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&);
+#endif
+};
+struct Conv2FwdRaw : Conv2Fwd {
+  SDQN_HD static void store(const StepArgs& a, int z, int, int m, int n, float v) { a.a2[((int64_t)z * M(a) + m) * K2 + n] = v; }
+#if defined(__HIPCC__)
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&);
+#endif
+};
+struct Conv3FwdRaw : Conv3Fwd {
+  SDQN_HD static void store(const StepArgs& a, int z, int, int m, int n, float v) { a.a3[((int64_t)z * M(a) + m) * K3 + n] = v; }
+#if defined(__HIPCC__)
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi&);
+#endif
+};
+#if defined(__HIPCC__)
+SDQN_STORE16_DEFAULT(Conv1FwdRaw)
+SDQN_STORE16_DEFAULT(Conv2FwdRaw)
+SDQN_STORE16_DEFAULT(Conv3FwdRaw)
 #endif
 
 // ---- Neon <-> internal parameter layouts (host side; C ABI boundary) ---------------------------

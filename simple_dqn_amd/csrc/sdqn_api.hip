@@ -297,7 +297,11 @@ static int rccl_load(const char* path) {
 // ---- network -------------------------------------------------------------------------------------------
 struct ProfPair { int id; hipEvent_t a, b; };
 struct sdqn_net_s {
-  sdqn_net_cfg cfg; int B = 0, A = 0; int64_t NP = 0;
+  sdqn_net_cfg cfg; int B = 0, A = 0; int64_t NP = 0;   // NP: floats per flat buffer (weights [+ BatchNorm params + running stats])
+  int64_t NPW = 0;                         // weights only = offset of the BatchNorm block
+  bool bn = false;                         // --batch_norm
+  float *x1 = nullptr, *x2 = nullptr, *x3 = nullptr;          // raw linear outputs [2][B*PIX][K] (BatchNorm input; kept for the backward pass)
+  float *bn_mean = nullptr, *bn_rstd = nullptr; double* bn_partial = nullptr;
   float *theta = nullptr, *theta_t = nullptr, *state = nullptr, *state2 = nullptr, *g = nullptr;
   int epoch = 0;
   float *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *slab4 = nullptr, *a4 = nullptr, *d4 = nullptr;
@@ -359,11 +363,14 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   ARGCHK(c->num_actions > 0 && c->num_actions <= MAX_ACTIONS, "num_actions must be in 1..%d (got %d)", MAX_ACTIONS, c->num_actions);
   ARGCHK(c->optimizer >= 0 && c->optimizer <= 2, "unknown optimizer %d", c->optimizer);
   ARGCHK(c->datatype == 0 || c->datatype == 1, "datatype must be 0 (float32) or 1 (float16)");
+  ARGCHK(!(c->batch_norm != 0.0 && c->datatype != 0), "batch_norm is float32 only");
   ARGCHK(c->screen_height == H0 && c->screen_width == W0 && c->history_length == C0,
          "this build supports 84x84 screens with history_length 4 (got %dx%d, %d)", c->screen_height, c->screen_width, c->history_length);
   STREAMCHK();
   sdqn_net_s* h = new sdqn_net_s();
-  h->cfg = *c; h->B = c->batch_size; h->A = c->num_actions; h->NP = OFF5 + (int64_t)h->A * NFC;
+  h->cfg = *c; h->B = c->batch_size; h->A = c->num_actions; h->NPW = OFF5 + (int64_t)h->A * NFC;
+  h->bn = c->batch_norm != 0.0;
+  h->NP = h->NPW + (h->bn ? 2 * BN_PARAMS : 0);
   memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n);
   const int B = h->B;
   auto pick = [](int T, int target) { int t = (T + target - 1) / target; return t < 1 ? 1 : t; };
@@ -393,6 +400,22 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->slab1, (size_t)h->ns1 * NW1 * 4));
   NCHK(dalloc(h, (void**)&h->slab2, (size_t)h->ns2 * NW2 * 4));
   NCHK(dalloc(h, (void**)&h->slab3, (size_t)h->ns3 * NW3 * 4));
+  if (h->bn) {
+    NCHK(dalloc(h, (void**)&h->x1, (size_t)2 * B * PIX1 * K1 * 4));
+    NCHK(dalloc(h, (void**)&h->x2, (size_t)2 * B * PIX2 * K2 * 4));
+    NCHK(dalloc(h, (void**)&h->x3, (size_t)2 * B * PIX3 * K3 * 4));
+    NCHK(dalloc(h, (void**)&h->bn_mean, (size_t)BN_PARAMS / 2 * 4));
+    NCHK(dalloc(h, (void**)&h->bn_rstd, (size_t)BN_PARAMS / 2 * 4));
+    const int max_rb = (B * PIX1 + 255) / 256;
+    NCHK(dalloc(h, (void**)&h->bn_partial, (size_t)max_rb * 512 * 2 * 8));
+    // BatchNorm init [neon-recalled]: beta = 0, gamma = 1, running mean / variance = 0
+    std::vector<float> blk((size_t)BN_PARAMS, 0.0f);
+    for (int l = 0; l < BN_LAYERS; ++l) for (int cc = 0; cc < bn_features(l); ++cc) blk[(size_t)bn_off(l) + bn_features(l) + cc] = 1.0f;
+    HIPCHK(hipStreamSynchronize(g_stream));
+    { hipError_t e_ = hipMemcpy(h->theta + h->NPW, blk.data(), (size_t)BN_PARAMS * 4, hipMemcpyHostToDevice);
+      if (e_ == hipSuccess && h->theta_t != h->theta) e_ = hipMemcpy(h->theta_t + h->NPW, blk.data(), (size_t)BN_PARAMS * 4, hipMemcpyHostToDevice);
+      if (e_ != hipSuccess) { set_error("hipMemcpy -> %s", hipGetErrorString(e_)); net_free(h); return SDQN_ERR_HIP; } }
+  }
   if (c->datatype == 1) {
     if (h->cfg.loss_scale == 0) h->cfg.loss_scale = 1024.0;
     NCHK(dalloc(h, (void**)&h->h_a1, (size_t)2 * B * PIX1 * K1 * 2));
@@ -429,16 +452,48 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
 }
 extern "C" int sdqn_net_destroy(sdqn_net_t h) { return net_free(h); }
 
-extern "C" int sdqn_net_layer_size(sdqn_net_t h, int layer, int64_t* n) {
-  ARGCHK(h && n && layer >= 0 && layer < 5, "bad arguments");
-  int64_t r, c, o; layer_dims(layer, h->A, r, c, o); *n = r * c; return SDQN_OK;
-}
 static float* which_buf(sdqn_net_s* h, int which) {
   switch (which) { case 0: return h->theta; case 1: return h->theta_t; case 2: return h->state; case 3: return h->g;
                    case 4: return h->state2; default: return nullptr; }
 }
+// BatchNorm pseudo-layers 5..8 (batch_norm only): [beta | gamma] at NPW + bn_off(l); which 5 / 6 = running statistics
+static bool bn_layer_span(sdqn_net_s* h, int which, int layer, float** base, int64_t* n) {
+  if (!h->bn || layer < 5 || layer > 8) return false;
+  const int l = layer - 5;
+  *n = 2 * bn_features(l);
+  float* buf = nullptr; int64_t extra = 0;
+  switch (which) {
+    case 0: buf = h->theta; break;
+    case 1: buf = h->theta_t; break;
+    case 2: buf = h->state; break;
+    case 3: buf = h->g; break;
+    case 4: buf = h->state2; break;
+    case 5: buf = h->theta; extra = BN_PARAMS; break;
+    case 6: buf = h->theta_t; extra = BN_PARAMS; break;
+    default: break;
+  }
+  if (!buf) return false;
+  *base = buf + h->NPW + extra + bn_off(l);
+  return true;
+}
+extern "C" int sdqn_net_layer_size(sdqn_net_t h, int layer, int64_t* n) {
+  ARGCHK(h && n && layer >= 0 && layer < (h->bn ? 9 : 5), "bad arguments");
+  if (layer >= 5) { *n = 2 * bn_features(layer - 5); return SDQN_OK; }
+  int64_t rows, cols, off; layer_dims(layer, h->A, rows, cols, off);
+  *n = rows * cols;
+  return SDQN_OK;
+}
 extern "C" int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const float* w, int64_t n) {
-  ARGCHK(h && w && layer >= 0 && layer < 5 && (which == 0 || which == 1 || which == 2 || which == 4), "bad arguments");
+  ARGCHK(h && w, "NULL argument");
+  if (layer >= 5) {
+    float* base; int64_t cnt;
+    ARGCHK(which != 3 && bn_layer_span(h, which, layer, &base, &cnt), "no such BatchNorm buffer (which %d, layer %d)", which, layer);
+    ARGCHK(n == cnt, "layer %d holds %lld values, got %lld", layer, (long long)cnt, (long long)n);
+    { int rc_ = join_comm(h); if (rc_) return rc_; } HIPCHK(hipStreamSynchronize(g_stream));
+    HIPCHK(hipMemcpy(base, w, (size_t)n * 4, hipMemcpyHostToDevice));
+    return SDQN_OK;
+  }
+  ARGCHK(layer >= 0 && layer < 5 && (which == 0 || which == 1 || which == 2 || which == 4), "bad arguments");
   ARGCHK(which_buf(h, which), "this optimizer has no second state");
   int64_t rows, cols, off; layer_dims(layer, h->A, rows, cols, off);
   ARGCHK(n == rows * cols, "layer %d holds %lld values, got %lld", layer, (long long)(rows * cols), (long long)n);
@@ -454,7 +509,16 @@ extern "C" int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const fl
   return SDQN_OK;
 }
 extern "C" int sdqn_net_get_weights(sdqn_net_t h, int which, int layer, float* w, int64_t n) {
-  ARGCHK(h && w && layer >= 0 && layer < 5 && which >= 0 && which <= 4, "bad arguments");
+  ARGCHK(h && w, "NULL argument");
+  if (layer >= 5) {
+    float* base; int64_t cnt;
+    ARGCHK(bn_layer_span(h, which, layer, &base, &cnt), "no such BatchNorm buffer (which %d, layer %d)", which, layer);
+    ARGCHK(n == cnt, "layer %d holds %lld values, got %lld", layer, (long long)cnt, (long long)n);
+    { int rc_ = join_comm(h); if (rc_) return rc_; } HIPCHK(hipStreamSynchronize(g_stream));
+    HIPCHK(hipMemcpy(w, base, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return SDQN_OK;
+  }
+  ARGCHK(layer >= 0 && layer < 5 && which >= 0 && which <= 4, "bad arguments");
   ARGCHK(which_buf(h, which), "this optimizer has no second state");
   int64_t rows, cols, off; layer_dims(layer, h->A, rows, cols, off);
   ARGCHK(n == rows * cols, "layer %d holds %lld values, got %lld", layer, (long long)(rows * cols), (long long)n);
@@ -545,7 +609,39 @@ static int join_comm(sdqn_net_s* h) {
   if (h->w4_pending) { HIPCHK(hipStreamWaitEvent(g_stream, h->ev_w4, 0)); h->w4_pending = false; }
   return SDQN_OK;
 }
+// --batch_norm: one BatchNorm layer's arguments (bn_kernels.hip)
+static BnArgs bn_args(sdqn_net_s* h, const StepArgs& a, int layer, int train) {
+  BnArgs b; memset(&b, 0, sizeof b);
+  const int pix[4] = {PIX1, PIX2, PIX3, 1};
+  b.layer = layer; b.C = bn_features(layer); b.rows = a.B * pix[layer]; b.nz = a.nz; b.train = train; b.B = a.B;
+  b.theta[0] = h->theta; b.theta[1] = h->theta_t; b.off_bn = h->NPW; b.partial = h->bn_partial;
+  b.mean = h->bn_mean + bn_off(layer) / 2; b.rstd = h->bn_rstd + bn_off(layer) / 2; b.g = h->g;
+  switch (layer) {
+    case 0: b.x = h->x1; b.a = h->a1; b.d = h->d1; break;
+    case 1: b.x = h->x2; b.a = h->a2; b.d = h->d2; b.dpad = h->d2p; b.PQ = PIX2; b.Qw = Q2; b.PD = PD2; b.pad = 1; break;
+    case 2: b.x = h->x3; b.a = h->a3; b.d = h->d3; b.dpad = h->d3p; b.PQ = PIX3; b.Qw = Q3; b.PD = PD3; b.pad = 2; break;
+    default: b.x = h->slab4; b.S4 = a.S4; b.a = h->a4; b.d = h->d4; break;
+  }
+  return b;
+}
 static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
+  if (h->bn) {
+    // deepqnetwork.py:83-89 with batch_norm: [Convolution|Linear] -> BatchNorm -> Rectlin.  The GEMM stage writes the raw
+    // linear output (x_l), the BatchNorm pass turns it into the activation the next stage reads; training-mode
+    // statistics for the online net of a train step (:129), running statistics for the target net (:120) and predict (:180)
+    StepArgs f = a; f.bn = 1;
+    f.a1 = h->x1; LAUNCH(K_CONV1_FWD, launch_kernel(K_CONV1_FWD, f, g_stream)); f.a1 = h->a1;
+    LAUNCH(K_BN, launch_bn_forward(bn_args(h, a, 0, hd.train), g_stream));
+    f.a2 = h->x2; LAUNCH(K_CONV2_FWD, launch_kernel(K_CONV2_FWD, f, g_stream)); f.a2 = h->a2;
+    LAUNCH(K_BN, launch_bn_forward(bn_args(h, a, 1, hd.train), g_stream));
+    f.a3 = h->x3; LAUNCH(K_CONV3_FWD, launch_kernel(K_CONV3_FWD, f, g_stream)); f.a3 = h->a3;
+    LAUNCH(K_BN, launch_bn_forward(bn_args(h, a, 2, hd.train), g_stream));
+    { int rc = join_comm(h); if (rc) return rc; }
+    LAUNCH(K_FC4_FWD, launch_kernel(K_FC4_FWD, f, g_stream));
+    LAUNCH(K_BN, launch_bn_forward(bn_args(h, a, 3, hd.train), g_stream));
+    LAUNCH(K_HEAD, launch_head(f, hd, g_stream));
+    return SDQN_OK;
+  }
   LAUNCH(K_CONV1_FWD, launch_kernel(K_CONV1_FWD, a, g_stream));
   LAUNCH(K_CONV2_FWD, launch_kernel(K_CONV2_FWD, a, g_stream));
   LAUNCH(K_CONV3_FWD, launch_kernel(K_CONV3_FWD, a, g_stream));
@@ -565,6 +661,7 @@ static UpdateArgs make_update_args(sdqn_net_s* h, const StepArgs& a) {
   u.skip_fc4 = a.fuse_rms;
   u.opt = h->cfg.optimizer; u.state2 = h->state2;
   if (h->cfg.datatype == 1) { u.wh = h->wh[0]; u.wht = h->wht[0]; }
+  u.bn_first = h->bn ? h->NPW : 0;
   if (u.opt == 1) {            // Neon Adam [neon-recalled]: t = epoch + 1, l = lr*sqrt(1-b2^t)/(1-b1^t), math in Python floats
     const double b1 = h->cfg.beta_1, b2 = h->cfg.beta_2, t = (double)h->epoch + 1.0;
     u.beta1 = (float)b1; u.one_minus_beta1 = (float)(1.0 - b1); u.beta2 = (float)b2; u.one_minus_beta2 = (float)(1.0 - b2);
@@ -578,7 +675,11 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   // The three other weight-gradient kernels only need the delta of their layer, so they run beside it
   // on the side stream (fork after the producer of their delta, join before the update).
   hipStream_t ss = h->two_streams ? g_side : g_stream;
+  // --batch_norm: the delta arriving at layer l (masked by its Rectlin) first goes back through BatchNorm l, in place
+#define BN_BWD(L) do { if (h->bn) LAUNCH(K_BN, launch_bn_backward(bn_args(h, a, (L), 1), g_stream)); } while (0)
+  BN_BWD(3);
   LAUNCH(K_FC4_DGRAD, launch_kernel(K_FC4_DGRAD, a, g_stream));
+  BN_BWD(2);
   const bool dp_ov = h->comm && h->comm2 && h->dp_overlap && h->fused_launches && !h->two_streams;
   if (dp_ov) {
     // data parallel, overlapped: ALL of fc4_wgrad rides the first backward launch, so the 6.4 MB fc4 gradient is
@@ -596,7 +697,9 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     LAUNCH_ON(g_comm, K_UPDATE, launch_update(u4, g_comm));
     HIPCHK(hipEventRecord(h->ev_w4, g_comm));
     h->w4_pending = true;
+    BN_BWD(1);
     LAUNCH(K_BWD2, launch_kernel(K_BWD2, b2, g_stream));
+    BN_BWD(0);
     LAUNCH(K_BWD1, launch_kernel(K_BWD1, b1, g_stream));
   } else
   if (h->fused_launches && !h->two_streams) {
@@ -611,7 +714,9 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
       b1.f4w_first = s3 + s2; b1.f4w_count = f4_tiles - s3 - s2;
     } else { b3.f4w_first = 0; b3.f4w_count = f4_tiles; b2.f4w_count = b1.f4w_count = 0; }
     LAUNCH(K_BWD3, launch_kernel(K_BWD3, b3, g_stream));
+    BN_BWD(1);
     LAUNCH(K_BWD2, launch_kernel(K_BWD2, b2, g_stream));
+    BN_BWD(0);
     LAUNCH(K_BWD1, launch_kernel(K_BWD1, b1, g_stream));
   } else {
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[1], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[1], 0)); }
@@ -619,9 +724,11 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   LAUNCH_ON(ss, K_FC4_WGRAD, launch_kernel(K_FC4_WGRAD, a, ss));            // needs d4, a3
   LAUNCH_ON(ss, K_CONV3_WGRAD, launch_kernel(K_CONV3_WGRAD, a, ss));        // needs d3p, a2
   LAUNCH(K_CONV3_DGRAD, launch_kernel(K_CONV3_DGRAD, a, g_stream));
+  BN_BWD(1);
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[2], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[2], 0)); }
   LAUNCH_ON(ss, K_CONV2_WGRAD, launch_kernel(K_CONV2_WGRAD, a, ss));        // needs d2p, a1
   LAUNCH(K_CONV2_DGRAD, launch_kernel(K_CONV2_DGRAD, a, g_stream));
+  BN_BWD(0);
   LAUNCH(K_CONV1_WGRAD, launch_kernel(K_CONV1_WGRAD, a, g_stream));
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[3], ss)); HIPCHK(hipStreamWaitEvent(g_stream, g_ev[3], 0)); }
   }
@@ -639,6 +746,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     u.mode = 2; u.bsz = (float)h->B * (float)h->nranks; u.skip_fc4 = 1;
     if (next) u.next = *next;
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
+    if (h->bn) LAUNCH(K_BN, launch_bn_update(u, g_stream));
   } else   if (h->comm) {
     // synchronous data parallel: local gradient sums -> one RCCL all-reduce of the flat buffer -> identical RMSProp
     u.mode = 1; u.bsz = (float)h->B; u.next.B = 0;
@@ -648,9 +756,11 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     u.mode = 2; u.bsz = (float)h->B * (float)h->nranks;
     if (next) u.next = *next;
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
+    if (h->bn) LAUNCH(K_BN, launch_bn_update(u, g_stream));
   } else {
     u.mode = 0; u.bsz = (float)h->B;
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
+    if (h->bn) LAUNCH(K_BN, launch_bn_update(u, g_stream));
   }
   h->train_iterations += 1;                                                   // deepqnetwork.py:168
   return SDQN_OK;
@@ -865,7 +975,7 @@ extern "C" int sdqn_net_set_epoch(sdqn_net_t h, int epoch) { ARGCHK(h && epoch >
 extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   ARGCHK(h && name, "NULL argument");
   if (!strcmp(name, "keep_gradients")) h->keep_grads = value != 0;
-  else if (!strcmp(name, "two_streams")) h->two_streams = value != 0;
+  else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;
   else if (!strcmp(name, "dp_overlap")) h->dp_overlap = value != 0;     // before dp_init: 0 = single all-reduce on the library stream

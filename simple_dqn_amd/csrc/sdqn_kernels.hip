@@ -14,7 +14,8 @@ static const char* k_names[K_COUNT] = {
   "conv1_fwd(gather+norm+conv+relu)", "conv2_fwd", "conv3_fwd", "fc4_fwd(splitK)", "head(fc5+td+delta)",
   "fc4_dgrad", "fc4_wgrad", "conv3_dgrad", "conv3_wgrad", "conv2_dgrad", "conv2_wgrad",
   "conv1_wgrad", "update(reduce+fc5wgrad+rmsprop)", "rccl_allreduce", "replay_gather_u8", "prep(idx+meta)",
-  "bwd3(conv3_dgrad+conv3_wgrad+fc4_wgrad)", "bwd2(conv2_dgrad+conv2_wgrad+fc4_wgrad)", "bwd1(conv1_wgrad+fc4_wgrad)"};
+  "bwd3(conv3_dgrad+conv3_wgrad+fc4_wgrad)", "bwd2(conv2_dgrad+conv2_wgrad+fc4_wgrad)", "bwd1(conv1_wgrad+fc4_wgrad)",
+  "batchnorm(layer fwd/bwd)"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? k_names[id] : "?"; }
 
 template <class P>
@@ -56,6 +57,14 @@ static hipError_t launch_kernel_h16(int id, const StepArgs& a, hipStream_t s) {
 
 hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
   if (a.h16) return launch_kernel_h16(id, a, s);
+  if (a.bn) {                  // --batch_norm forward: raw linear outputs (same tilings as the default problems)
+    switch (id) {
+      case K_CONV1_FWD: return launch_gemm<Conv1FwdRaw, 8>(a, s);
+      case K_CONV2_FWD: return a.B >= 128 ? launch_gemm<Staged<Conv2FwdRaw>, 8>(a, s) : launch_gemm<Conv2FwdRaw, 16>(a, s);
+      case K_CONV3_FWD: return a.B >= 128 ? launch_gemm<Staged<Conv3FwdRaw>, 8>(a, s) : launch_gemm<Staged<Conv3FwdRaw>, 9>(a, s);
+      default: break;
+    }
+  }
   if (id >= 0 && id < 12 && a.nw_override[id] > 0) {          // tuning hook (sdqn_net_set_option "nw:<id>")
     const int nw = a.nw_override[id];
     switch (id) {
@@ -126,7 +135,7 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
 // AMAX = compile-time bound on num_actions (4 / 8 / 18): every load below is unconditional with a clamped index and
 // a select — a conditional load costs hipcc a branch, a scalar pointer re-load and a wait EACH (36 of them measured
 // ~3000 cycles here), and the LDS footprint follows the bucket.
-template <int AMAX>
+template <int AMAX, bool BN>
 __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadArgs h) {
   SDQN_STAMP(0);
   const int n = blockIdx.x, j = threadIdx.x, lane = j & 63, wave = j >> 6;
@@ -142,7 +151,10 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   float a4v[2] = {0.0f, 0.0f};
   const int64_t sstride = (int64_t)2 * a.B * NFC;
   float t[2][7];
-  if (a.S4 == 7) {                                   // the built-in split: 14 independent loads in flight
+  if constexpr (BN) {                                // --batch_norm: a4 was activated by the BatchNorm pass (bn_kernels.hip)
+#pragma unroll
+    for (int z = 0; z < 2; ++z) a4v[z] = a.a4[((int64_t)(z < nz ? z : 0) * a.B + n) * NFC + j];
+  } else if (a.S4 == 7) {                            // the built-in split: 14 independent loads in flight
 #pragma unroll
     for (int z = 0; z < 2; ++z)
 #pragma unroll
@@ -159,7 +171,8 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   // minibatch metadata last: thread 0 only, and nothing above waits behind it
   int m_act = 0, m_term = 0; int64_t m_rew = 0;
   if (h.train && j == 0) { m_act = h.st_actions[n]; m_rew = h.st_rewards[n]; m_term = h.st_terminals[n]; }
-  if (a.S4 == 7) {
+  if constexpr (BN) {
+  } else if (a.S4 == 7) {
 #pragma unroll
     for (int z = 0; z < 2; ++z) { float v = 0.0f;
 #pragma unroll
@@ -184,7 +197,7 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
     if (z >= nz) continue;
     const float v = fmaxf(a4v[z], 0.0f);                                                          // Rectlin, :89
     a4v[z] = v;
-    a.a4[((int64_t)z * a.B + n) * NFC + j] = v;
+    if constexpr (!BN) a.a4[((int64_t)z * a.B + n) * NFC + j] = v;
 #pragma unroll
     for (int act = 0; act < AMAX; ++act)
       if (act < A) prod[z * A + act][j] = w5[z][act] * v;
@@ -241,28 +254,13 @@ hipError_t set_timing_buffer(unsigned long long* p) { return hipMemcpyToSymbol(H
 #endif
 
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
-  if (a.A <= 4) hipLaunchKernelGGL(head_kernel<4>, dim3(a.B), dim3(512), 0, s, a, h);
-  else if (a.A <= 8) hipLaunchKernelGGL(head_kernel<8>, dim3(a.B), dim3(512), 0, s, a, h);
-  else hipLaunchKernelGGL(head_kernel<MAX_ACTIONS>, dim3(a.B), dim3(512), 0, s, a, h);
+  if (a.bn) hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, true>), dim3(a.B), dim3(512), 0, s, a, h);     // --batch_norm (not tuned per bucket)
+  else if (a.A <= 4) hipLaunchKernelGGL((head_kernel<4, false>), dim3(a.B), dim3(512), 0, s, a, h);
+  else if (a.A <= 8) hipLaunchKernelGGL((head_kernel<8, false>), dim3(a.B), dim3(512), 0, s, a, h);
+  else hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, false>), dim3(a.B), dim3(512), 0, s, a, h);
   return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------
-// one parameter of Neon's optimizers [neon-recalled, SURVEY.md A9/A10 + §8a-bis "non-default branches"];
-// every one starts with grad = grad / be.bsz
-__device__ inline float opt_apply(float w, float& s1, float& s2, float gsum, const UpdateArgs& u) {
-  if (u.opt == 0) return rms_step(w, s1, gsum, u.bsz, u.rho, u.one_minus_rho, u.lr, u.eps);
-  const float g = div_bsz(gsum, u.bsz);
-  if (u.opt == 1) {                                   // Adam: m, v; bias correction folded into lr_t (t = epoch + 1)
-    s1 = s1 * u.beta1 + u.one_minus_beta1 * g;
-    s2 = s2 * u.beta2 + (u.one_minus_beta2 * g) * g;
-    return w - (u.lr_t * s1) / (sqrtf(s2) + u.eps);
-  }
-  s1 = s1 * u.rho + (u.one_minus_rho * g) * g;        // Adadelta: E[g^2], E[dx^2]
-  const float upd = sqrtf((s2 + u.eps) / (s1 + u.eps)) * g;
-  s2 = s2 * u.rho + (u.one_minus_rho * upd) * upd;
-  return w - upd;
-}
 __device__ inline void opt_apply4(float* __restrict__ theta, float* __restrict__ st1, float* __restrict__ st2,
                                   int64_t e, const float4& gs, const UpdateArgs& u) {
   float4 w = *reinterpret_cast<float4*>(theta + e);

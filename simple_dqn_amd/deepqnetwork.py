@@ -30,15 +30,15 @@ class DeepQNetwork:
         self.clip_error = args.clip_error
         self.min_reward = args.min_reward
         self.max_reward = args.max_reward
-        self.batch_norm = getattr(args, "batch_norm", False)
-        if self.batch_norm:
-            raise NotImplementedError("batch_norm=True is not on the MI355X hot path yet (SURVEY.md §8f)")
+        self.batch_norm = bool(getattr(args, "batch_norm", False))                      # :26
         if getattr(args, "backend", "hip") == "cpu":
             raise NotImplementedError("there is no CPU backend: libsdqn_hip is MI355X-only")
         dt = str(getattr(args, "datatype", "float32"))
         if dt not in ("float32", "float16"):
             raise NotImplementedError("datatype %s: float32 and float16 (half activations, fp32 master weights) are implemented" % dt)
         self.datatype = dt
+        if self.batch_norm and dt != "float32":
+            raise NotImplementedError("batch_norm is implemented for float32 only")
         optimizer = getattr(args, "optimizer", "rmsprop")
         assert optimizer in ("rmsprop", "adam", "adadelta"), "Unknown optimizer"      # deepqnetwork.py:61
         self.optimizer = optimizer
@@ -55,6 +55,7 @@ class DeepQNetwork:
         cfg.optimizer = ("rmsprop", "adam", "adadelta").index(optimizer)              # :50-59
         cfg.datatype = 1 if dt == "float16" else 0                                   # :33
         cfg.loss_scale = float(getattr(args, "loss_scale", 1024.0))
+        cfg.batch_norm = 1.0 if self.batch_norm else 0.0                              # :83-89 Conv/Affine(batch_norm=...)
         # Neon's defaults (the reference passes none): RMSProp/Adadelta epsilon 1e-6, Adam epsilon 1e-8, betas 0.9/0.999
         cfg.epsilon = float(getattr(args, "optimizer_epsilon", 1e-8 if optimizer == "adam" else 1e-6))
         cfg.beta_1, cfg.beta_2 = float(getattr(args, "beta_1", 0.9)), float(getattr(args, "beta_2", 0.999))
@@ -97,6 +98,21 @@ class DeepQNetwork:
         w = np.empty(layer_shapes(self.num_actions)[layer], dtype=np.float32)
         _lib.check(self._lib.sdqn_net_get_weights(self._h, which, layer, _lib.ptr(w, C.c_float), w.size))
         return w
+
+    # --batch_norm: BatchNorm layer l = 0..3 (after conv1, conv2, conv3, fc4).  which as above for (beta, gamma);
+    # running=True addresses (gmean, gvar) of the online (which=0) or target (which=1) net
+    def get_bn(self, l, which=0, running=False):
+        assert self.batch_norm and 0 <= l < 4
+        c = (32, 64, 64, 512)[l]
+        w = np.empty((2, c), dtype=np.float32)
+        _lib.check(self._lib.sdqn_net_get_weights(self._h, (5 + which) if running else which, 5 + l, _lib.ptr(w, C.c_float), w.size))
+        return w[0].copy(), w[1].copy()
+
+    def set_bn(self, l, first, second, which=0, running=False):
+        assert self.batch_norm and 0 <= l < 4
+        w = np.ascontiguousarray(np.stack([first, second]), dtype=np.float32)
+        assert w.shape == (2, (32, 64, 64, 512)[l])
+        _lib.check(self._lib.sdqn_net_set_weights(self._h, (5 + which) if running else which, 5 + l, _lib.ptr(w, C.c_float), w.size))
 
     def set_weights(self, weights, which=0):
         for i, w in enumerate(weights):
@@ -176,6 +192,15 @@ class DeepQNetwork:
                     name = "%s%d" % (key, i)
                     if name in f:
                         self.set_layer(i, f[name], which)
+                if self.batch_norm:
+                    for l in range(4):
+                        if "%s_bn%d" % (key, l) in f:
+                            self.set_bn(l, *f["%s_bn%d" % (key, l)], which=which)
+            if self.batch_norm:
+                for which, key in ((0, "run"), (1, "run_t")):
+                    for l in range(4):
+                        if "%s_bn%d" % (key, l) in f:
+                            self.set_bn(l, *f["%s_bn%d" % (key, l)], which=which, running=True)
             if "train_iterations" in f:
                 self.train_iterations = int(f["train_iterations"])
 
@@ -191,6 +216,13 @@ class DeepQNetwork:
         for which, key in ((0, "W"), (1, "Wt"), (2, "S")) + ((() if self.optimizer == "rmsprop" else ((4, "S2"),))):
             for i in range(5):
                 d["%s%d" % (key, i)] = self.get_layer(i, which)
+            if self.batch_norm:
+                for l in range(4):
+                    d["%s_bn%d" % (key, l)] = np.stack(self.get_bn(l, which))
+        if self.batch_norm:
+            for which, key in ((0, "run"), (1, "run_t")):
+                for l in range(4):
+                    d["%s_bn%d" % (key, l)] = np.stack(self.get_bn(l, which, running=True))
         d["train_iterations"] = np.int64(self.train_iterations)
         with open(save_path, "wb") as f:
             np.savez(f, **d)

@@ -523,7 +523,7 @@ def test_preconditions_raise_like_the_reference(sd):
     with pytest.raises(AssertionError):
         mem.getState(0)                                              # :38
     with pytest.raises(NotImplementedError):
-        sd.DeepQNetwork(A, make_args(batch_size=B, batch_norm=True))
+        sd.DeepQNetwork(A, make_args(batch_size=B, batch_norm=True, datatype="float16"))    # batch_norm is float32 only
     with pytest.raises(AssertionError):
         sd.DeepQNetwork(A, make_args(batch_size=B, optimizer="sgd"))  # deepqnetwork.py:61
 
