@@ -59,6 +59,9 @@ def kernel_work(B, A):
         16: dict(bytes=(a3 + w3 + 2 * a2) + (a2 + a3 + w3) + (a4 + a3 + 4 * w4), flops=2 * B * 81 * 64 * 576 + 2 * B * 49 * 64 * 576 + 2 * B * 512 * 3136),
         17: dict(bytes=(a2 + w2 + 2 * a1) + (a1 + a2 + w2), flops=2 * B * 400 * 32 * 256 + 2 * B * 81 * 64 * 512),
         18: dict(bytes=B * 5 * 7056 + a1 + w1, flops=2 * B * 400 * 32 * 256),
+        # --batch_norm only: average over the 17 BatchNorm launches of a step (forward: statistics read x once, apply reads x and
+        # writes a for both nets; backward: partial + apply read d and x, apply writes d and its padded copy) = 11 X / 17
+        19: dict(bytes=11 * (a1 + a2 + a3 + a4) // 17, flops=0),
     }
     # (default tile split: the whole fc4 wgrad + fused RMSProp read-modify-write — theta, s read and written — rides in bwd3)
 
@@ -282,6 +285,7 @@ def main():
     ap.add_argument("--dp-overlap", action="store_true",
                     help="data parallel: all-reduce + apply the fc4 gradient on a second communicator / stream under the rest of "
                          "the step (opt-in: validated with a 1-rank communicator only; default = one all-reduce on the library stream)")
+    ap.add_argument("--batch-norm", action="store_true", help="--batch_norm variant of the network (non-default learner option; not the headline)")
     ap.add_argument("--zero-copy", action="store_true", help="gather from the pinned host ring over PCIe (no HBM mirror)")
     a = ap.parse_args()
 
@@ -311,7 +315,7 @@ def main():
     _lib.check(sd.load().sdqn_set_device(dev))
 
     B, A = a.batch_size, a.num_actions
-    args = make_args(batch_size=B, random_seed=a.seed + 1, datatype=a.datatype)   # identical initial weights on every rank
+    args = make_args(batch_size=B, random_seed=a.seed + 1, datatype=a.datatype, batch_norm=a.batch_norm)   # identical initial weights on every rank
     mem = sd.ReplayMemory(a.replay_size, args, flags=2 if a.zero_copy else 1)
     fill_ring(mem, a.seed + 1000 * rank, A)                            # own experience per learner
     net = sd.DeepQNetwork(A, args)
@@ -390,7 +394,9 @@ def main():
         }
         out["roofline"] = roofline_entry(dom["id"], dom["name"], live["total_ms"] / max(live["launches"], 1), B, A)
         out["kernels_us"] = {p["name"]: round(p["total_ms"] / p["launches"] * 1e3, 2) for p in step_kernels}
-        if world == 1 and a.datatype == "float32":
+        if a.batch_norm:
+            out["config"]["workload"] += " [--batch_norm]"
+        if world == 1 and a.datatype == "float32" and not a.batch_norm:
             idx = np.array(mem.sample_indexes())
             g_ms = mem.bench_gather(idx, iters=200)
             out["replay_gather"] = roofline_entry(14, "replay_gather_u8", g_ms, B, A)

@@ -33,6 +33,7 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const BnArgs b) {
   const int c = blockIdx.y * 32 + cl, rb = blockIdx.x;
   const int r0 = rb * BN_ROWS_PER_PART, r1 = min(r0 + BN_ROWS_PER_PART, b.rows);
   double s = 0.0, q = 0.0;
+#pragma unroll 4
   for (int r = r0 + rl; r < r1; r += 8) { const double v = (double)bn_x(b, 0, r, c); s += v; q += v * v; }
   sh[rl][cl][0] = s; sh[rl][cl][1] = q;
   __syncthreads();
@@ -42,28 +43,45 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const BnArgs b) {
   }
 }
 
-// statistics of feature c from the partials (every caller sums them in the same order -> same bits everywhere)
-__device__ inline void bn_finalize(const BnArgs& b, int c, float& mean, float& var) {
+// Totals of the two partial sums of every feature, by the whole 256-thread workgroup: G = 256 / min(C, 256) thread groups
+// each add every G-th row block, then group 0 adds the G group sums in order.  Every workgroup of every kernel that
+// needs the totals runs exactly this (same order -> same bits everywhere).  tot[c] = {sum0, sum1}; sh: 256 x 2 doubles.
+__device__ inline void bn_totals(const BnArgs& b, double (*tot)[2], double (*sh)[2]) {
+  const int t = threadIdx.x;
   const int RB = (b.rows + BN_ROWS_PER_PART - 1) / BN_ROWS_PER_PART;
-  double s = 0.0, q = 0.0;
-  for (int rb = 0; rb < RB; ++rb) { s += b.partial[((int64_t)rb * b.C + c) * 2]; q += b.partial[((int64_t)rb * b.C + c) * 2 + 1]; }
-  const double m = s / (double)b.rows;
-  double v = q / (double)b.rows - m * m;
-  mean = (float)m; var = (float)(v > 0.0 ? v : 0.0);
+  const int Cc = b.C < 256 ? b.C : 256, G = 256 / Cc;
+  const int cl = t % Cc, grp = t / Cc;
+  for (int cb = 0; cb < b.C; cb += Cc) {
+    const int c = cb + cl;
+    double s = 0.0, q = 0.0;
+#pragma unroll 4
+    for (int rb = grp; rb < RB; rb += G) { s += b.partial[((int64_t)rb * b.C + c) * 2]; q += b.partial[((int64_t)rb * b.C + c) * 2 + 1]; }
+    sh[t][0] = s; sh[t][1] = q;
+    __syncthreads();
+    if (grp == 0) {
+      for (int k = 1; k < G; ++k) { s += sh[k * Cc + cl][0]; q += sh[k * Cc + cl][1]; }
+      tot[c][0] = s; tot[c][1] = q;
+    }
+    __syncthreads();
+  }
 }
 
 // grid = ceil(nz * rows * C / 4 / 256) workgroups; every one first builds scale/shift of ALL C features of both nets
 // in LDS (C <= 512), workgroup 0 also publishes mean / rstd for the backward pass and updates the running statistics
 __global__ void __launch_bounds__(256) bn_apply_kernel(const BnArgs b) {
   __shared__ float sc[2][512], sf[2][512];
+  __shared__ double tot[512][2], sh[256][2];
   const int t = threadIdx.x;
   const int off = bn_off(b.layer);
+  if (b.train) bn_totals(b, tot, sh);
   for (int z = 0; z < b.nz; ++z) {
     const float* th = b.theta[z] + b.off_bn;
     for (int c = t; c < b.C; c += 256) {
       float mean, var;
       if (z == 0 && b.train) {
-        bn_finalize(b, c, mean, var);
+        const double m = tot[c][0] / (double)b.rows;
+        const double v = tot[c][1] / (double)b.rows - m * m;                                     // biased variance (be.var)
+        mean = (float)m; var = (float)(v > 0.0 ? v : 0.0);
         if (blockIdx.x == 0) {
           float* run = b.theta[0] + b.off_bn + BN_PARAMS;
           run[off + c] = run[off + c] * BN_RHO + BN_ONE_MINUS_RHO * mean;                          // gmean
@@ -105,6 +123,7 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const BnArgs b) {
   const int r0 = rb * BN_ROWS_PER_PART, r1 = min(r0 + BN_ROWS_PER_PART, b.rows);
   const float mean = b.mean[c], rstd = b.rstd[c];
   double s = 0.0, q = 0.0;
+#pragma unroll 4
   for (int r = r0 + rl; r < r1; r += 8) {
     const float e = b.d[(int64_t)r * b.C + c];
     const float xh = (bn_x(b, 0, r, c) - mean) * rstd;
@@ -120,14 +139,13 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const BnArgs b) {
 
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnArgs b) {
   __shared__ float gb[512], gg[512];
+  __shared__ double tot[512][2], sh[256][2];
   const int t = threadIdx.x;
   const int off = bn_off(b.layer);
-  const int RB = (b.rows + BN_ROWS_PER_PART - 1) / BN_ROWS_PER_PART;
+  bn_totals(b, tot, sh);
   for (int c = t; c < b.C; c += 256) {
-    double s = 0.0, q = 0.0;
-    for (int rb = 0; rb < RB; ++rb) { s += b.partial[((int64_t)rb * b.C + c) * 2]; q += b.partial[((int64_t)rb * b.C + c) * 2 + 1]; }
-    gb[c] = (float)s; gg[c] = (float)q;
-    if (blockIdx.x == 0) { b.g[b.off_bn + off + c] = (float)s; b.g[b.off_bn + off + b.C + c] = (float)q; }    // grad_beta, grad_gamma (sums: A9 divides)
+    gb[c] = (float)tot[c][0]; gg[c] = (float)tot[c][1];
+    if (blockIdx.x == 0) { b.g[b.off_bn + off + c] = gb[c]; b.g[b.off_bn + off + b.C + c] = gg[c]; }    // grad_beta, grad_gamma (sums: A9 divides)
   }
   __syncthreads();
   const int C4 = b.C / 4;
