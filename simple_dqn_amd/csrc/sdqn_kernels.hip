@@ -392,12 +392,19 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
       u.next.actions[n] = rec.action; u.next.rewards[n] = rec.reward; u.next.terminals[n] = rec.terminal;
     }
   }
-  if (u.mode != 2 && (int)blockIdx.x == first_dense + (nb > 1 ? 1 : 0) && t == 0) {   // get_cost: mean over the batch, :154
-    float c = 0.0f;
-    for (int n = 0; n < u.B; ++n) c += u.cost_terms[n];
-    c = c / (float)u.B;
-    u.cost_out[0] = c;
-    u.cost_accum[0] += (double)c;
+  if (u.mode != 2 && (int)blockIdx.x == first_dense + (nb > 1 ? 1 : 0)) {             // get_cost: mean over the batch, :154
+    // all threads fetch (one memory latency for any B), ONE thread adds in index order: same bits as a serial loop,
+    // which at B = 256 was the longest chain of the whole launch (256 dependent L2 round trips = 15 us)
+    __shared__ float cost_sh[4096];
+    for (int n = t; n < u.B; n += 256) cost_sh[n] = u.cost_terms[n];
+    __syncthreads();
+    if (t == 0) {
+      float c = 0.0f;
+      for (int n = 0; n < u.B; ++n) c += cost_sh[n];
+      c = c / (float)u.B;
+      u.cost_out[0] = c;
+      u.cost_accum[0] += (double)c;
+    }
   }
 }
 
