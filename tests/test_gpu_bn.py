@@ -150,3 +150,25 @@ def test_bn_replay_path_and_snapshot(sd, tmp_path):
     net.train(mb); net3.train(mb)
     for i in range(5):
         assert np.array_equal(net.get_layer(i), net3.get_layer(i)), i
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_bn_data_parallel_single_rank(sd, overlap):
+    """the data-parallel split (reduce -> all-reduce -> apply; BatchNorm gradients ride in the flat buffer) with a
+    1-rank RCCL communicator reproduces the single-GPU batch_norm step bit for bit"""
+    from simple_dqn_amd.deepqnetwork import dp_unique_id
+    A, B = 4, 32
+    n1, _ = _pair(sd, A, B, 61)
+    n2, _ = _pair(sd, A, B, 61)
+    n2.set_option("dp_overlap", overlap)
+    n2.dp_init(dp_unique_id(), 0, 1)
+    for s in range(4):
+        mb = random_minibatch(B, A, 62 + s)
+        n1.train(mb); n2.train(mb)
+    for i in range(5):
+        assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
+    for l in range(4):
+        assert all(np.array_equal(a, b) for a, b in zip(n1.get_bn(l), n2.get_bn(l)))
+        assert all(np.array_equal(a, b) for a, b in zip(n1.get_bn(l, running=True), n2.get_bn(l, running=True)))
+        assert all(np.array_equal(a, b) for a, b in zip(n1.get_bn(l, 2), n2.get_bn(l, 2)))
+    n2.dp_shutdown()
