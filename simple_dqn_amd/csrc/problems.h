@@ -124,6 +124,28 @@ SDQN_HD float rms_step(float w, float& st, float gsum, float bsz, float rho, flo
   return w - (g * lr) / (sqrtf(st + eps) + eps);
 }
 
+#if defined(__HIPCC__)
+// two weights at once: the multiplies / adds become packed-fp32 instructions (v_pk_mul_f32, v_pk_add_f32), the square
+// root and the division stay scalar IEEE sequences — operation for operation the same arithmetic as rms_step
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ inline void rms_step2(float& w0, float& w1, float& st0, float& st1, float gs0, float gs1,
+                                 float bsz, float rho, float omr, float lr, float eps) {
+  union { float f; uint32_t u; } b, r; b.f = bsz;
+  f2v gsum = {gs0, gs1}, g;
+  if ((b.u & 0x007FFFFFu) == 0u && b.u >= 0x00800000u && b.u < 0x7E800000u) { r.u = 0x7F000000u - b.u; g = gsum * r.f; }
+  else { g.x = gs0 / bsz; g.y = gs1 / bsz; }
+  f2v st = {st0, st1};
+  const f2v a = rho * st, q = (g * g) * omr;
+  st = a + q;
+  const f2v num = g * lr, rad = st + eps;
+  f2v den; den.x = sqrtf(rad.x); den.y = sqrtf(rad.y);
+  den = den + eps;
+  f2v quo; quo.x = num.x / den.x; quo.y = num.y / den.y;
+  const f2v w = (f2v){w0, w1} - quo;
+  w0 = w.x; w1 = w.y; st0 = st.x; st1 = st.y;
+}
+#endif
+
 SDQN_HD int64_t sbase(const StepArgs& a, int z, int n) {
   // replay_memory.py:71-72: prestate = screens[i-4:i], poststate = screens[i-3:i+1]
   return a.from_ring ? (a.idx[n] - C0 + z) * (int64_t)FRAME : ((int64_t)z * a.B + n) * (int64_t)STATE;
@@ -402,7 +424,7 @@ struct Fc4Wgrad {   // gW4 = delta4 . a3^T (sum over batch, A8) in the W4i layou
       return;
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) e.w[r] = rms_step(e.w[r], e.st[r], v[r], a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps);
+    for (int r = 0; r < 16; r += 2) rms_step2(e.w[r], e.w[r + 1], e.st[r], e.st[r + 1], v[r], v[r + 1], a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps);
     float* __restrict__ tw = a.theta_w; float* __restrict__ sp = a.state;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { stb(tw, base + epi_row(r), e.w[r]); stb(sp, base + epi_row(r), e.st[r]); }
