@@ -87,3 +87,37 @@ def test_gather_properties_large(sd):
     assert not any(i >= m.current and i - 4 < m.current for i in idx)
     ms = m.bench_gather(idx, iters=20)
     assert 0 < ms < 50
+
+
+def test_full_size_ring_64bit_offsets(sd):
+    """BASELINE.json's full ring (1 M frames = 7.06 GB, byte offsets beyond 2^32): states gathered around the 4 GiB
+    boundary and at the very end of the ring are the contiguous windows of the host ring, and the fused
+    gather + train step (ring offsets computed inside conv1 forward and conv1 wgrad) gives exactly the weights of
+    the host-minibatch path fed with the same states."""
+    from bench import fill_ring
+    from oracle.dqn_numpy import xavier_weights
+    size, B, A = 1000000, 32, 4
+    args = make_args(batch_size=B)
+    m = sd.ReplayMemory(size, args)
+    fill_ring(m, 5, A)
+    edge = (1 << 32) // 7056                                          # first frame whose byte offset needs 33 bits
+    idx = np.array([4, 5, edge - 2, edge - 1, edge, edge + 1, edge + 2, edge + 3, edge + 4, edge + 5,
+                    edge + 6, 750000, 900001, size - 1, size - 2, size - 17] +
+                   list(np.random.RandomState(3).randint(edge, size, B - 16)), dtype=np.int64)
+    m.terminals[:] = False                                            # every index is admissible (host master; metadata below)
+    m.sync_mirror()
+    pre, act, rew, post, term = m.gather(idx)
+    for k in range(B):
+        i = int(idx[k])
+        assert np.array_equal(pre[k], m.screens[i - 4:i]) and np.array_equal(post[k], m.screens[i - 3:i + 1]), (k, i)
+    assert np.array_equal(act, m.actions[idx]) and np.array_equal(rew, m.rewards[idx])
+    ws = xavier_weights(A, 7)
+    n1, n2 = sd.DeepQNetwork(A, args), sd.DeepQNetwork(A, args)
+    for n in (n1, n2):
+        n.set_weights(ws, 0); n.update_target_network()
+    mb = (pre.copy(), act.copy(), rew.copy(), post.copy(), term.copy())
+    for _ in range(2):
+        n1.train_indexes(m, idx)                                      # ring offsets on the device
+        n2.train(mb)                                                  # staged host minibatch
+    for i in range(5):
+        assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
