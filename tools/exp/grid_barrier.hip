@@ -49,6 +49,22 @@ int main() {
       CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     }
     const float us_launch = ms * 1000.f / reps / stages;
+    // A2: the same dependent launches captured once into a hipGraph and replayed
+    float us_graph = -1.f;
+    {
+      hipGraph_t graph; hipGraphExec_t exec;
+      CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+      for (int s = 0; s < stages; ++s) hipLaunchKernelGGL(stage, dim3(nb), dim3(512), 0, st, (s & 1) ? b1 : b0, (s & 1) ? b0 : b1, s, per_block);
+      CK(hipStreamEndCapture(st, &graph));
+      CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      for (int w = 0; w < 2; ++w) {
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(exec, st));
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+      }
+      us_graph = ms * 1000.f / reps / stages;
+      CK(hipGraphExecDestroy(exec)); CK(hipGraphDestroy(graph));
+    }
     CK(hipMemset(b0, 0, (size_t)nb * per_block * 4));
     // B: persistent kernel with grid barriers (cooperative launch guarantees co-residency)
     float us_pers = -1.f;
@@ -68,8 +84,8 @@ int main() {
       if (ok) us_pers = ms * 1000.f / reps / stages;
     }
     std::vector<float> h(4); CK(hipMemcpy(h.data(), b0, 16, hipMemcpyDeviceToHost));
-    printf("stages %2d blocks %4d x512 thr, %d KB/block/stage: separate launches %.2f us/stage | persistent+grid barrier %.2f us/stage (incl. 1/%d of a launch+memset) check %.0f\n",
-           stages, nb, per_block * 4 / 1024, us_launch, us_pers, stages, h[0]);
+    printf("stages %2d blocks %4d x512 thr, %d KB/block/stage: separate launches %.2f us/stage | hipGraph replay %.2f us/stage | persistent+grid barrier %.2f us/stage (incl. 1/%d of a launch+memset) check %.0f\n",
+           stages, nb, per_block * 4 / 1024, us_launch, us_graph, us_pers, stages, h[0]);
     CK(hipFree(b0)); CK(hipFree(b1)); CK(hipFree(cnt));
   }
   return 0;
