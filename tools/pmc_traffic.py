@@ -31,6 +31,7 @@ NAMES = ["conv1_fwd(gather+norm+conv+relu)", "conv2_fwd", "conv3_fwd", "fc4_fwd(
 def per_kernel(d, counter):
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     assert f, "no counter_collection.csv under " + d
+    f.sort(key=os.path.getmtime, reverse=True)                  # the most recent capture in that directory
     vals = defaultdict(list)
     for row in csv.DictReader(open(f[0])):
         if row["Counter_Name"] == counter:
