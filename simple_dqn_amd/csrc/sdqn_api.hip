@@ -319,7 +319,8 @@ struct sdqn_net_s {
   int nw_override[12] = {0};               // tuning hook
   int f4_share[2] = {100, 0};               // % of the fc4-wgrad tiles in bwd3 / bwd2 (rest in bwd1)
   int S4_override = 0, tps_override[3] = {0, 0, 0};
-  bool xcd_map = false;                    // XCD-contiguous tile map: less fabric traffic, measured 3-4 % slower
+  bool xcd_map = false;                    // XCD-contiguous tile map for EVERY launch: traffic ~ algorithmic, step ~1 % slower (bwd3);
+                                           // built-in: only where it also wins time (fc4_fwd: the 7 K-slabs of a tile's W4 panel share an L2)
   bool fused_launches = true;              // independent backward stages share one launch (K_BWD3, K_BWD2)
   bool two_streams = false;                // weight-gradient kernels on the side stream (measured slower eagerly: event waits)
   // profiler
@@ -646,7 +647,7 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
   LAUNCH(K_CONV2_FWD, launch_kernel(K_CONV2_FWD, a, g_stream));
   LAUNCH(K_CONV3_FWD, launch_kernel(K_CONV3_FWD, a, g_stream));
   { int rc = join_comm(h); if (rc) return rc; }                // conv1..3 of this step overlap the previous step's fc4 all-reduce
-  LAUNCH(K_FC4_FWD, launch_kernel(K_FC4_FWD, a, g_stream));
+  { StepArgs f4 = a; f4.xcd_map = 1; LAUNCH(K_FC4_FWD, launch_kernel(K_FC4_FWD, f4, g_stream)); }
   LAUNCH(K_HEAD, launch_head(a, hd, g_stream));
   return SDQN_OK;
 }
