@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
   __shared__ float smem[tile_lds_any<P, NW>()];
   const int gx = gridDim.x, gy = gridDim.y;
   const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-  const int t = a.xcd_map ? xcd_tile_id(lin, gx * gy * gridDim.z) : lin;
+  const int t = (a.xcd_map & 1) ? xcd_tile_id(lin, gx * gy * gridDim.z) : lin;
   const int bz = t / (gx * gy), r = t - bz * (gx * gy);
   run_tile<P, NW, NW * 64>(a, r % gx, r / gx, bz, smem);
 }
@@ -466,10 +466,10 @@ __global__ void __launch_bounds__(NT) gemm_multi_kernel(const StepArgs a, const 
   constexpr int L = L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2);
   __shared__ float smem[L];
   const int b = blockIdx.x;                               // problem choice is workgroup-uniform; XCD-contiguous runs per problem
-  const bool xm = a.xcd_map != 0;
-  if (b < d.n[0]) multi_dispatch<P0, NW0, NT>(a, d, 0, xm ? xcd_tile_id_range(b, 0, d.n[0]) : b, smem);
-  else if (b < d.n[0] + d.n[1]) multi_dispatch<P1, NW1, NT>(a, d, 1, xm ? xcd_tile_id_range(b, d.n[0], d.n[1]) : b - d.n[0], smem);
-  else multi_dispatch<P2, NW2, NT>(a, d, 2, xm ? xcd_tile_id_range(b, d.n[0] + d.n[1], d.n[2]) : b - d.n[0] - d.n[1], smem);
+  const int xm = a.xcd_map;                               // bit i: problem i of the launch uses the XCD-contiguous map
+  if (b < d.n[0]) multi_dispatch<P0, NW0, NT>(a, d, 0, (xm & 1) ? xcd_tile_id_range(b, 0, d.n[0]) : b, smem);
+  else if (b < d.n[0] + d.n[1]) multi_dispatch<P1, NW1, NT>(a, d, 1, (xm & 2) ? xcd_tile_id_range(b, d.n[0], d.n[1]) : b - d.n[0], smem);
+  else multi_dispatch<P2, NW2, NT>(a, d, 2, (xm & 4) ? xcd_tile_id_range(b, d.n[0] + d.n[1], d.n[2]) : b - d.n[0] - d.n[1], smem);
 }
 
 struct NoProblem {            // placeholder third problem for two-problem launches (never dispatched: n[2] = 0)

@@ -100,7 +100,7 @@ struct StepArgs {
   half_t *wh_w, *wht_w;            // writable aliases of wh[0] / wht[0] (refreshed by the optimizer epilogues)
   float loss_scale, inv_loss_scale;
   int h16;                         // 1: fp16 mode
-  int xcd_map;              // 1: XCD-contiguous workgroup->tile map (cuts fabric traffic to ~algorithmic, measured 3-4 % slower)
+  int xcd_map;              // XCD-contiguous workgroup->tile map (cuts fabric traffic to ~algorithmic): bit i = problem i of the launch
   int nw_override[12];      // tuning hook: waves per tile for kernel id i (0 = built-in choice)
   float* __restrict__ theta_w;   // online parameters, writable alias of theta[0]
   float* __restrict__ state;     // RMSProp state

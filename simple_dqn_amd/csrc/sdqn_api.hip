@@ -319,12 +319,14 @@ struct sdqn_net_s {
   int nw_override[12] = {0};               // tuning hook
   int f4_share[2] = {100, 0};               // % of the fc4-wgrad tiles in bwd3 / bwd2 (rest in bwd1)
   int S4_override = 0, tps_override[3] = {0, 0, 0};
+  int xcd_mask[K_COUNT] = {0};             // tuning hook "xcd:<kernel id>": per-launch problem mask (-1 = built-in)
   bool xcd_map = false;                    // XCD-contiguous tile map for EVERY launch: traffic ~ algorithmic, step ~1 % slower (bwd3);
                                            // built-in: only where it also wins time (fc4_fwd: the 7 K-slabs of a tile's W4 panel share an L2)
   bool fused_launches = true;              // independent backward stages share one launch (K_BWD3, K_BWD2)
   bool two_streams = false;                // weight-gradient kernels on the side stream (measured slower eagerly: event waits)
   // profiler
   bool prof_on = false; int prof_filter = -1;
+  int prof_every = 1; int64_t prof_seen[K_COUNT] = {0};     // bracket only every prof_every-th launch of a kernel (an event pair costs ~2-3 us of queue time)
   std::vector<ProfPair> prof_pending; std::vector<hipEvent_t> prof_free;
   double prof_ms[K_COUNT]; int64_t prof_n[K_COUNT];
   // data parallel
@@ -549,7 +551,7 @@ static int prof_event(sdqn_net_s* h, hipEvent_t* e) {
   HIPCHK(hipEventCreate(e)); return SDQN_OK;
 }
 #define LAUNCH_ON(STRM, KID, expr) do { \
-  const bool pf_ = h->prof_on && (h->prof_filter < 0 || h->prof_filter == (KID)); ProfPair pp_; \
+  const bool pf_ = h->prof_on && (h->prof_filter < 0 || h->prof_filter == (KID)) && (h->prof_seen[KID]++ % h->prof_every) == 0; ProfPair pp_; \
   if (pf_) { pp_.id = (KID); int r1_ = prof_event(h, &pp_.a); if (r1_) return r1_; r1_ = prof_event(h, &pp_.b); if (r1_) return r1_; \
              HIPCHK(hipEventRecord(pp_.a, (STRM))); } \
   hipError_t le_ = (expr); \
@@ -582,7 +584,7 @@ static StepArgs step_args(sdqn_net_s* h) {
   a.d1 = h->d1; a.g = h->g; a.slab1 = h->slab1; a.slab2 = h->slab2; a.slab3 = h->slab3;
   a.S4 = h->S4; a.tps1 = h->tps1; a.tps2 = h->tps2; a.tps3 = h->tps3;
   for (int i = 0; i < 12; ++i) a.nw_override[i] = h->nw_override[i];
-  a.xcd_map = h->xcd_map ? 1 : 0;
+  a.xcd_map = h->xcd_map ? 7 : 0;
   if (h->cfg.datatype == 1) {
     a.h16 = 1; a.h_a1 = h->h_a1; a.h_a2 = h->h_a2; a.h_a3 = h->h_a3; a.h_d4 = h->h_d4; a.h_d3p = h->h_d3p; a.h_d3 = h->h_d3;
     a.h_d2p = h->h_d2p; a.h_d2 = h->h_d2; a.h_d1 = h->h_d1; a.wh[0] = h->wh[0]; a.wh[1] = h->wh[1]; a.wht[0] = h->wht[0]; a.wht[1] = h->wht[1];
@@ -625,29 +627,32 @@ static BnArgs bn_args(sdqn_net_s* h, const StepArgs& a, int layer, int train) {
   }
   return b;
 }
+// tuning hook: per-launch XCD map mask override (sdqn_net_set_option "xcd:<id>", value = mask + 1; 0 = built-in)
+#define XCD_TUNE(ARGS, KID) do { if (h->xcd_mask[KID] > 0) (ARGS).xcd_map = h->xcd_mask[KID] - 1; } while (0)
+static hipError_t launch_tuned(sdqn_net_s* h, int id, StepArgs a, hipStream_t s) { XCD_TUNE(a, id); return launch_kernel(id, a, s); }
 static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
   if (h->bn) {
     // deepqnetwork.py:83-89 with batch_norm: [Convolution|Linear] -> BatchNorm -> Rectlin.  The GEMM stage writes the raw
     // linear output (x_l), the BatchNorm pass turns it into the activation the next stage reads; training-mode
     // statistics for the online net of a train step (:129), running statistics for the target net (:120) and predict (:180)
     StepArgs f = a; f.bn = 1;
-    f.a1 = h->x1; LAUNCH(K_CONV1_FWD, launch_kernel(K_CONV1_FWD, f, g_stream)); f.a1 = h->a1;
+    f.a1 = h->x1; LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, f, g_stream)); f.a1 = h->a1;
     LAUNCH(K_BN, launch_bn_forward(bn_args(h, a, 0, hd.train), g_stream));
-    f.a2 = h->x2; LAUNCH(K_CONV2_FWD, launch_kernel(K_CONV2_FWD, f, g_stream)); f.a2 = h->a2;
+    f.a2 = h->x2; LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, f, g_stream)); f.a2 = h->a2;
     LAUNCH(K_BN, launch_bn_forward(bn_args(h, a, 1, hd.train), g_stream));
-    f.a3 = h->x3; LAUNCH(K_CONV3_FWD, launch_kernel(K_CONV3_FWD, f, g_stream)); f.a3 = h->a3;
+    f.a3 = h->x3; LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, f, g_stream)); f.a3 = h->a3;
     LAUNCH(K_BN, launch_bn_forward(bn_args(h, a, 2, hd.train), g_stream));
     { int rc = join_comm(h); if (rc) return rc; }
-    LAUNCH(K_FC4_FWD, launch_kernel(K_FC4_FWD, f, g_stream));
+    LAUNCH(K_FC4_FWD, launch_tuned(h, K_FC4_FWD, f, g_stream));
     LAUNCH(K_BN, launch_bn_forward(bn_args(h, a, 3, hd.train), g_stream));
     LAUNCH(K_HEAD, launch_head(f, hd, g_stream));
     return SDQN_OK;
   }
-  LAUNCH(K_CONV1_FWD, launch_kernel(K_CONV1_FWD, a, g_stream));
-  LAUNCH(K_CONV2_FWD, launch_kernel(K_CONV2_FWD, a, g_stream));
-  LAUNCH(K_CONV3_FWD, launch_kernel(K_CONV3_FWD, a, g_stream));
+  LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, a, g_stream));
+  LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, a, g_stream));
+  LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, a, g_stream));
   { int rc = join_comm(h); if (rc) return rc; }                // conv1..3 of this step overlap the previous step's fc4 all-reduce
-  { StepArgs f4 = a; f4.xcd_map = 1; LAUNCH(K_FC4_FWD, launch_kernel(K_FC4_FWD, f4, g_stream)); }
+  { StepArgs f4 = a; f4.xcd_map = 1; XCD_TUNE(f4, K_FC4_FWD); LAUNCH(K_FC4_FWD, launch_tuned(h, K_FC4_FWD, f4, g_stream)); }
   LAUNCH(K_HEAD, launch_head(a, hd, g_stream));
   return SDQN_OK;
 }
@@ -679,7 +684,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   // --batch_norm: the delta arriving at layer l (masked by its Rectlin) first goes back through BatchNorm l, in place
 #define BN_BWD(L) do { if (h->bn) LAUNCH(K_BN, launch_bn_backward(bn_args(h, a, (L), 1), g_stream)); } while (0)
   BN_BWD(3);
-  LAUNCH(K_FC4_DGRAD, launch_kernel(K_FC4_DGRAD, a, g_stream));
+  LAUNCH(K_FC4_DGRAD, launch_tuned(h, K_FC4_DGRAD, a, g_stream));
   BN_BWD(2);
   const bool dp_ov = h->comm && h->comm2 && h->dp_overlap && h->fused_launches && !h->two_streams;
   if (dp_ov) {
@@ -688,7 +693,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     // (second communicator) under K_BWD2, K_BWD1, the conv/fc5 all-reduce + update and the next step's conv1..3.
     StepArgs b3 = a, b2 = a, b1 = a;
     b3.f4w_first = 0; b3.f4w_count = (NIN4 / 32) * (NFC / 32); b2.f4w_count = b1.f4w_count = 0;
-    LAUNCH(K_BWD3, launch_kernel(K_BWD3, b3, g_stream));
+    LAUNCH(K_BWD3, launch_tuned(h, K_BWD3, b3, g_stream));
     HIPCHK(hipEventRecord(h->ev_g4, g_stream));
     HIPCHK(hipStreamWaitEvent(g_comm, h->ev_g4, 0));
     LAUNCH_ON(g_comm, K_ALLREDUCE, (g_rccl.AllReduce(h->g + OFF4, h->g + OFF4, (size_t)NW4, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm2, g_comm) == 0
@@ -699,9 +704,9 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     HIPCHK(hipEventRecord(h->ev_w4, g_comm));
     h->w4_pending = true;
     BN_BWD(1);
-    LAUNCH(K_BWD2, launch_kernel(K_BWD2, b2, g_stream));
+    LAUNCH(K_BWD2, launch_tuned(h, K_BWD2, b2, g_stream));
     BN_BWD(0);
-    LAUNCH(K_BWD1, launch_kernel(K_BWD1, b1, g_stream));
+    LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream));
   } else
   if (h->fused_launches && !h->two_streams) {
     // fc4 wgrad (1568 tiles at B <= 32) is spread over the three backward launches as background traffic;
@@ -714,23 +719,23 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
       b2.f4w_first = s3; b2.f4w_count = s2;
       b1.f4w_first = s3 + s2; b1.f4w_count = f4_tiles - s3 - s2;
     } else { b3.f4w_first = 0; b3.f4w_count = f4_tiles; b2.f4w_count = b1.f4w_count = 0; }
-    LAUNCH(K_BWD3, launch_kernel(K_BWD3, b3, g_stream));
+    LAUNCH(K_BWD3, launch_tuned(h, K_BWD3, b3, g_stream));
     BN_BWD(1);
-    LAUNCH(K_BWD2, launch_kernel(K_BWD2, b2, g_stream));
+    LAUNCH(K_BWD2, launch_tuned(h, K_BWD2, b2, g_stream));
     BN_BWD(0);
-    LAUNCH(K_BWD1, launch_kernel(K_BWD1, b1, g_stream));
+    LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream));
   } else {
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[1], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[1], 0)); }
   // fc4_wgrad may update W4 in place (fused RMSProp): it must not start before fc4_dgrad has read W4
-  LAUNCH_ON(ss, K_FC4_WGRAD, launch_kernel(K_FC4_WGRAD, a, ss));            // needs d4, a3
-  LAUNCH_ON(ss, K_CONV3_WGRAD, launch_kernel(K_CONV3_WGRAD, a, ss));        // needs d3p, a2
-  LAUNCH(K_CONV3_DGRAD, launch_kernel(K_CONV3_DGRAD, a, g_stream));
+  LAUNCH_ON(ss, K_FC4_WGRAD, launch_tuned(h, K_FC4_WGRAD, a, ss));            // needs d4, a3
+  LAUNCH_ON(ss, K_CONV3_WGRAD, launch_tuned(h, K_CONV3_WGRAD, a, ss));        // needs d3p, a2
+  LAUNCH(K_CONV3_DGRAD, launch_tuned(h, K_CONV3_DGRAD, a, g_stream));
   BN_BWD(1);
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[2], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[2], 0)); }
-  LAUNCH_ON(ss, K_CONV2_WGRAD, launch_kernel(K_CONV2_WGRAD, a, ss));        // needs d2p, a1
-  LAUNCH(K_CONV2_DGRAD, launch_kernel(K_CONV2_DGRAD, a, g_stream));
+  LAUNCH_ON(ss, K_CONV2_WGRAD, launch_tuned(h, K_CONV2_WGRAD, a, ss));        // needs d2p, a1
+  LAUNCH(K_CONV2_DGRAD, launch_tuned(h, K_CONV2_DGRAD, a, g_stream));
   BN_BWD(0);
-  LAUNCH(K_CONV1_WGRAD, launch_kernel(K_CONV1_WGRAD, a, g_stream));
+  LAUNCH(K_CONV1_WGRAD, launch_tuned(h, K_CONV1_WGRAD, a, g_stream));
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[3], ss)); HIPCHK(hipStreamWaitEvent(g_stream, g_ev[3], 0)); }
   }
   UpdateArgs u = make_update_args(h, a);
@@ -982,6 +987,12 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "dp_overlap")) h->dp_overlap = value != 0;     // before dp_init: 0 = single all-reduce on the library stream
   else if (!strcmp(name, "f4_share3")) h->f4_share[0] = value;
   else if (!strcmp(name, "f4_share2")) h->f4_share[1] = value;
+  else if (!strcmp(name, "profile_every")) { ARGCHK(value >= 1, "profile_every must be >= 1"); h->prof_every = value; }
+  else if (!strncmp(name, "xcd:", 4)) {                    // tuning: XCD-map problem mask of kernel id (value = mask + 1, 0 = built-in)
+    int id = atoi(name + 4);
+    if (id < 0 || id >= K_COUNT || value < 0 || value > 8) { set_error("bad xcd override"); return SDQN_ERR_ARG; }
+    h->xcd_mask[id] = value;
+  }
   else if (!strncmp(name, "nw:", 3)) {                     // tuning: waves per tile of kernel id
     int id = atoi(name + 3);
     if (id < 0 || id >= 12 || !(value == 0 || value == 2 || value == 4 || value == 8 || value == 16)) { set_error("bad nw override"); return SDQN_ERR_ARG; }
