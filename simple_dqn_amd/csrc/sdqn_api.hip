@@ -648,11 +648,14 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
     LAUNCH(K_HEAD, launch_head(f, hd, g_stream));
     return SDQN_OK;
   }
-  LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, a, g_stream));
-  LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, a, g_stream));
+  // XCD-contiguous tile map where it wins time (tools/sweep_xcd.py, tools/ab_options.py): conv1_fwd +0.5 %, conv2_fwd
+  // +0.2 %, fc4_fwd +0.6 % of the step rate; slower for conv3_fwd, fc4_dgrad and every backward launch
+  StepArgs fm = a; fm.xcd_map = 1;
+  LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, fm, g_stream));
+  LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, fm, g_stream));
   LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, a, g_stream));
   { int rc = join_comm(h); if (rc) return rc; }                // conv1..3 of this step overlap the previous step's fc4 all-reduce
-  { StepArgs f4 = a; f4.xcd_map = 1; XCD_TUNE(f4, K_FC4_FWD); LAUNCH(K_FC4_FWD, launch_tuned(h, K_FC4_FWD, f4, g_stream)); }
+  LAUNCH(K_FC4_FWD, launch_tuned(h, K_FC4_FWD, fm, g_stream));
   LAUNCH(K_HEAD, launch_head(a, hd, g_stream));
   return SDQN_OK;
 }

@@ -1,0 +1,24 @@
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ctypes as C
+import simple_dqn_amd as sd
+from util import make_args
+from bench import fill_ring
+B, A = 32, 4
+args = make_args(batch_size=B)
+mem = sd.ReplayMemory(100000, args); fill_ring(mem, 1, A)
+net = sd.DeepQNetwork(A, args); net.update_target_network()
+mt = (C.c_uint32 * 625)(); sd.load().sdqn_mt_seed(mt, 5)
+def rate(N=6000):
+    net.train_from_memory(mem, 300, mt_state=mt, want_cost=False); net.sync()
+    r = []
+    for _ in range(3):
+        t = time.perf_counter(); net.train_from_memory(mem, N, mt_state=mt, want_cost=False); net.sync()
+        r.append(N / (time.perf_counter() - t))
+    return max(r)
+print("base", round(rate()))
+for opts in ([("xcd:0", 2)], [("xcd:1", 2)], [("xcd:0", 2), ("xcd:1", 2)], [("nw:0", 4)], [("nw:1", 8)], [("nw:11", 8)]):
+    for k, v in opts: net.set_option(k, v)
+    print(opts, round(rate()))
+    for k, v in opts: net.set_option(k, 0)
+print("base", round(rate()))
