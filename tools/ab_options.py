@@ -1,3 +1,5 @@
+"""Tuning helper (not product): end-to-end step rate (no event brackets) with sdqn_net_set_option switches.
+OPTS='[[("nw:1", 8)], [("xcd:16", 3)]]' python tools/ab_options.py"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ctypes as C
@@ -17,8 +19,9 @@ def rate(N=6000):
         r.append(N / (time.perf_counter() - t))
     return max(r)
 print("base", round(rate()))
-for opts in ([("xcd:0", 2)], [("xcd:1", 2)], [("xcd:0", 2), ("xcd:1", 2)], [("nw:0", 4)], [("nw:1", 8)], [("nw:11", 8)]):
+OPTS = eval(os.environ.get("OPTS", "[]")) or ([("two_streams", 1)], [("f4_share3", 70), ("f4_share2", 15)], [("xcd_map", 1)])
+for opts in OPTS:
     for k, v in opts: net.set_option(k, v)
     print(opts, round(rate()))
-    for k, v in opts: net.set_option(k, 0)
+    for k, v in opts: net.set_option(k, 100 if k == "f4_share3" else 0)
 print("base", round(rate()))
