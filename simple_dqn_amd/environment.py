@@ -60,3 +60,75 @@ class SyntheticEnvironment(Environment):
 
     def setMode(self, mode):
         self.mode = mode
+
+
+def _to_gray_resized(obs, height, width):
+    """cv2.resize(cv2.cvtColor(obs, COLOR_RGB2GRAY), (w, h)) of environment.py:139 without cv2: ITU-R 601 luma,
+    then bilinear interpolation with half-pixel centres (cv2.INTER_LINEAR's sampling grid)."""
+    obs = np.asarray(obs)
+    if obs.ndim == 3:
+        g = obs[..., 0] * 0.299 + obs[..., 1] * 0.587 + obs[..., 2] * 0.114
+    else:
+        g = obs.astype(np.float64)
+    H, W = g.shape
+    if (H, W) == (height, width):
+        return np.clip(np.rint(g), 0, 255).astype(np.uint8)
+    ys = (np.arange(height) + 0.5) * H / height - 0.5
+    xs = (np.arange(width) + 0.5) * W / width - 0.5
+    y0 = np.clip(np.floor(ys).astype(int), 0, H - 1); y1 = np.clip(y0 + 1, 0, H - 1); fy = np.clip(ys - np.floor(ys), 0, 1)
+    x0 = np.clip(np.floor(xs).astype(int), 0, W - 1); x1 = np.clip(x0 + 1, 0, W - 1); fx = np.clip(xs - np.floor(xs), 0, 1)
+    fy = np.where(ys < 0, 0.0, fy)[:, None]; fx = np.where(xs < 0, 0.0, fx)[None, :]
+    top = g[y0][:, x0] * (1 - fx) + g[y0][:, x1] * fx
+    bot = g[y1][:, x0] * (1 - fx) + g[y1][:, x1] * fx
+    return np.clip(np.rint(top * (1 - fy) + bot * fy), 0, 255).astype(np.uint8)
+
+
+class GymEnvironment(Environment):
+    """py3 restatement of /root/reference/src/environment.py:112-144 for `gymnasium` (or classic `gym`) when one of
+    them is installed — neither is in this image, so this adapter is exercised against a stand-in module only
+    (tests/test_environment.py).  Emulator I/O is outside the hot path (optional part)."""
+
+    def __init__(self, env_id, args, make=None):
+        if make is None:
+            try:
+                import gymnasium as gym
+            except ImportError:
+                import gym
+            make = gym.make
+        self.gym = make(env_id)
+        self.obs = None
+        self.terminal = None
+        self.screen_width = args.screen_width
+        self.screen_height = args.screen_height
+        self.mode = "train"
+
+    def numActions(self):
+        n = getattr(self.gym.action_space, "n", None)
+        assert n is not None, "a Discrete action space is required"          # environment.py:127
+        return int(n)
+
+    def restart(self):
+        r = self.gym.reset()
+        self.obs = r[0] if isinstance(r, tuple) else r                         # gymnasium returns (obs, info)
+        self.terminal = False
+
+    def act(self, action):
+        r = self.gym.step(action)
+        if len(r) == 5:                                                       # gymnasium: terminated, truncated
+            self.obs, reward, terminated, truncated, _ = r
+            self.terminal = bool(terminated or truncated)
+        else:                                                                 # classic gym, environment.py:135
+            self.obs, reward, self.terminal, _ = r
+            self.terminal = bool(self.terminal)
+        return reward
+
+    def getScreen(self):
+        assert self.obs is not None
+        return _to_gray_resized(self.obs, self.screen_height, self.screen_width)
+
+    def isTerminal(self):
+        assert self.terminal is not None
+        return self.terminal
+
+    def setMode(self, mode):
+        self.mode = mode

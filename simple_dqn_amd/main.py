@@ -69,12 +69,14 @@ def run(args):
     logger.setLevel(args.log_level)
     if args.random_seed:                                             # main.py:89-90
         random.seed(args.random_seed)
-    if args.environment != "synthetic":
-        raise NotImplementedError("the ALE / gym wrappers (src/environment.py:35-144) are emulator I/O outside the hot "
-                                  "path; plug any object with the six Environment methods into Agent instead")
-    if args.device_id:
-        _lib.check(load().sdqn_set_device(args.device_id))
-    env = SyntheticEnvironment(args, num_actions=args.num_actions, seed=args.random_seed or 0)
+    if args.environment == "ale":
+        raise NotImplementedError("the ALE wrapper (src/environment.py:35-110) is emulator I/O outside the hot path; "
+                                  "use --environment gym with gymnasium[atari] installed, or the synthetic environment")
+    if args.environment == "gym":
+        from .environment import GymEnvironment                    # needs gymnasium (or gym); not part of this image
+        env = GymEnvironment(args.game, args)
+    else:
+        env = SyntheticEnvironment(args, num_actions=args.num_actions, seed=args.random_seed or 0)
     mem = ReplayMemory(args.replay_size, args)                       # main.py:103-106
     net = DeepQNetwork(env.numActions(), args)
     agent = Agent(env, mem, net, args)
