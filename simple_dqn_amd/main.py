@@ -69,6 +69,8 @@ def run(args):
     logger.setLevel(args.log_level)
     if args.random_seed:                                             # main.py:89-90
         random.seed(args.random_seed)
+    if args.device_id:
+        _lib.check(load().sdqn_set_device(args.device_id))
     if args.environment == "ale":
         raise NotImplementedError("the ALE wrapper (src/environment.py:35-110) is emulator I/O outside the hot path; "
                                   "use --environment gym with gymnasium[atari] installed, or the synthetic environment")
