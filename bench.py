@@ -111,6 +111,13 @@ def roofline_entry(kid, name, ms_per_launch, B, A):
     e = _roofline_entry(kid, name, ms_per_launch, B, A)
     e["traffic"] = pmc_traffic(name, B, A)
     e["rocprof_us_per_launch"] = rocprof_us(kid, B, A)
+    try:                                       # the peak this box actually sustains (tools/exp/box_probe.hip)
+        m = json.load(open(os.path.join(ROOT, "profiles", "r01_box.json")))["measured"]
+        pm = m["triad_GBps"] if e["bound"] == "hbm" else m["fp32_mfma_32x32x2_TFLOPs"]
+        e["peak_measured"] = pm
+        e["frac_of_measured_peak"] = round(e["achieved"] / pm, 4)
+    except Exception:
+        pass
     return e
 
 
