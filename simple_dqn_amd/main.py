@@ -7,58 +7,55 @@ import random
 import sys
 
 
-def str2bool(v):
-    return v.lower() in ("yes", "true", "t", "1")
+def _flag(text):
+    return text.lower() in ("yes", "true", "t", "1")
+
+
+# The command line of the reference (same flag names, defaults and grouping: src/main.py:16-84), as data.
+# (flag, type, default[, extra argparse keywords])
+_OPTIONS = {
+    "Environment": [
+        ("--environment", str, "synthetic", dict(choices=["synthetic", "ale", "gym"])),
+        ("--num_actions", int, 4, dict(help="Action-set size of the synthetic environment.")),
+        ("--screen_width", int, 84), ("--screen_height", int, 84),
+    ],
+    "Replay memory": [("--replay_size", int, 1000000), ("--history_length", int, 4)],
+    "Deep Q-learning network": [
+        ("--learning_rate", float, 0.00025), ("--discount_rate", float, 0.99), ("--batch_size", int, 32),
+        ("--optimizer", str, "rmsprop", dict(choices=["rmsprop", "adam", "adadelta"])),
+        ("--decay_rate", float, 0.95), ("--clip_error", float, 1), ("--min_reward", float, -1), ("--max_reward", float, 1),
+        ("--batch_norm", _flag, False),
+    ],
+    "Backend": [
+        ("--backend", str, "hip", dict(choices=["hip", "gpu", "cpu"])), ("--device_id", int, 0),
+        ("--datatype", str, "float32", dict(choices=["float16", "float32", "float64"])),
+        ("--stochastic_round", int, False, dict(const=True, nargs="?")),
+    ],
+    "Agent": [
+        ("--exploration_rate_start", float, 1), ("--exploration_rate_end", float, 0.1),
+        ("--exploration_decay_steps", float, 1000000), ("--exploration_rate_test", float, 0.05),
+        ("--train_frequency", int, 4), ("--train_repeat", int, 1), ("--target_steps", int, 10000), ("--random_starts", int, 30),
+    ],
+    "Main loop": [
+        ("--random_steps", int, 50000), ("--train_steps", int, 250000), ("--test_steps", int, 125000), ("--epochs", int, 200),
+        ("--start_epoch", int, 0), ("--play_games", int, 0),
+        ("--load_weights", str, None), ("--save_weights_prefix", str, None), ("--csv_file", str, None),
+    ],
+    "Common": [
+        ("--random_seed", int, None),
+        ("--log_level", str, "INFO", dict(choices=["DEBUG", "INFO", "WARNING", "ERROR", "CRITICAL"])),
+    ],
+}
 
 
 def build_parser():
-    parser = argparse.ArgumentParser()
-    envarg = parser.add_argument_group('Environment')
-    envarg.add_argument("game", nargs="?", default="synthetic", help="Ignored by the synthetic environment.")
-    envarg.add_argument("--environment", choices=["synthetic", "ale", "gym"], default="synthetic")
-    envarg.add_argument("--num_actions", type=int, default=4, help="Action-set size of the synthetic environment.")
-    envarg.add_argument("--screen_width", type=int, default=84)
-    envarg.add_argument("--screen_height", type=int, default=84)
-    memarg = parser.add_argument_group('Replay memory')
-    memarg.add_argument("--replay_size", type=int, default=1000000)
-    memarg.add_argument("--history_length", type=int, default=4)
-    netarg = parser.add_argument_group('Deep Q-learning network')
-    netarg.add_argument("--learning_rate", type=float, default=0.00025)
-    netarg.add_argument("--discount_rate", type=float, default=0.99)
-    netarg.add_argument("--batch_size", type=int, default=32)
-    netarg.add_argument('--optimizer', choices=['rmsprop', 'adam', 'adadelta'], default='rmsprop')
-    netarg.add_argument("--decay_rate", type=float, default=0.95)
-    netarg.add_argument("--clip_error", type=float, default=1)
-    netarg.add_argument("--min_reward", type=float, default=-1)
-    netarg.add_argument("--max_reward", type=float, default=1)
-    netarg.add_argument("--batch_norm", type=str2bool, default=False)
-    neonarg = parser.add_argument_group('Backend')
-    neonarg.add_argument('--backend', choices=['hip', 'gpu', 'cpu'], default='hip')
-    neonarg.add_argument('--device_id', type=int, default=0)
-    neonarg.add_argument('--datatype', choices=['float16', 'float32', 'float64'], default='float32')
-    neonarg.add_argument('--stochastic_round', const=True, type=int, nargs='?', default=False)
-    antarg = parser.add_argument_group('Agent')
-    antarg.add_argument("--exploration_rate_start", type=float, default=1)
-    antarg.add_argument("--exploration_rate_end", type=float, default=0.1)
-    antarg.add_argument("--exploration_decay_steps", type=float, default=1000000)
-    antarg.add_argument("--exploration_rate_test", type=float, default=0.05)
-    antarg.add_argument("--train_frequency", type=int, default=4)
-    antarg.add_argument("--train_repeat", type=int, default=1)
-    antarg.add_argument("--target_steps", type=int, default=10000)
-    antarg.add_argument("--random_starts", type=int, default=30)
-    mainarg = parser.add_argument_group('Main loop')
-    mainarg.add_argument("--random_steps", type=int, default=50000)
-    mainarg.add_argument("--train_steps", type=int, default=250000)
-    mainarg.add_argument("--test_steps", type=int, default=125000)
-    mainarg.add_argument("--epochs", type=int, default=200)
-    mainarg.add_argument("--start_epoch", type=int, default=0)
-    mainarg.add_argument("--play_games", type=int, default=0)
-    mainarg.add_argument("--load_weights")
-    mainarg.add_argument("--save_weights_prefix")
-    mainarg.add_argument("--csv_file")
-    comarg = parser.add_argument_group('Common')
-    comarg.add_argument("--random_seed", type=int)
-    comarg.add_argument("--log_level", choices=["DEBUG", "INFO", "WARNING", "ERROR", "CRITICAL"], default="INFO")
+    parser = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    for title, options in _OPTIONS.items():
+        group = parser.add_argument_group(title)
+        if title == "Environment":
+            group.add_argument("game", nargs="?", default="synthetic", help="gym environment id (ignored by the synthetic environment)")
+        for flag, typ, default, *extra in options:
+            group.add_argument(flag, type=typ, default=default, **(extra[0] if extra else {}))
     return parser
 
 
