@@ -47,17 +47,17 @@ def kernel_work(B, A):
         4: dict(bytes=2 * a4 * 2 + 2 * 512 * A * f, flops=2 * 2 * B * 512 * A),
         5: dict(bytes=a4 + w4 + 2 * a3, flops=2 * B * 512 * 3136),                             # fc4 dgrad
         6: dict(bytes=a4 + a3 + w4, flops=2 * B * 512 * 3136),                                 # fc4 wgrad (writes g4)
-        7: dict(bytes=a3 + w3 + 2 * a2, flops=2 * B * 81 * 64 * 576),
+        7: dict(bytes=a3 + w3 + 2 * a2, flops=2 * B * 49 * 64 * 576),                               # conv3 dgrad: ALGORITHMIC MACs (the padded full-correlation form executes 81/49 of them)
         8: dict(bytes=a2 + a3 + w3, flops=2 * B * 49 * 64 * 576),
-        9: dict(bytes=a2 + w2 + 2 * a1, flops=2 * B * 400 * 32 * 256),
+        9: dict(bytes=a2 + w2 + 2 * a1, flops=2 * B * 81 * 64 * 512),                               # conv2 dgrad: algorithmic (executed: 400*32*256 per sample)
         10: dict(bytes=a1 + a2 + w2, flops=2 * B * 81 * 64 * 512),
         11: dict(bytes=B * 5 * 7056 + a1 + w1, flops=2 * B * 400 * 32 * 256),
         12: dict(bytes=(npar - 1605632) * f * 5 + (25 * w1 + 6 * w2 + 4 * w3), flops=8 * (npar - 1605632)),   # conv+fc5 params (fc4 is fused into bwd3) + slabs
         13: dict(bytes=npar * f, flops=0),
         14: dict(bytes=B * 13 * 7056, flops=0),
         15: dict(bytes=1024, flops=0),
-        16: dict(bytes=(a3 + w3 + 2 * a2) + (a2 + a3 + w3) + (a4 + a3 + 4 * w4), flops=2 * B * 81 * 64 * 576 + 2 * B * 49 * 64 * 576 + 2 * B * 512 * 3136),
-        17: dict(bytes=(a2 + w2 + 2 * a1) + (a1 + a2 + w2), flops=2 * B * 400 * 32 * 256 + 2 * B * 81 * 64 * 512),
+        16: dict(bytes=(a3 + w3 + 2 * a2) + (a2 + a3 + w3) + (a4 + a3 + 4 * w4), flops=2 * B * 49 * 64 * 576 + 2 * B * 49 * 64 * 576 + 2 * B * 512 * 3136),
+        17: dict(bytes=(a2 + w2 + 2 * a1) + (a1 + a2 + w2), flops=2 * B * 81 * 64 * 512 + 2 * B * 81 * 64 * 512),
         18: dict(bytes=B * 5 * 7056 + a1 + w1, flops=2 * B * 400 * 32 * 256),
         # --batch_norm only: average over the 17 BatchNorm launches of a step (forward: statistics read x once, apply reads x and
         # writes a for both nets; backward: partial + apply read d and x, apply writes d and its padded copy) = 11 X / 17
