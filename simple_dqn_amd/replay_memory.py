@@ -114,6 +114,32 @@ class ReplayMemory:
         assert self.count > self.history_length
         return self.gather(self.sample_indexes())
 
+    # ---- checkpoint of the ring (additive: the reference never persists its replay memory, README.md:132) -----------
+    _MAGIC = b"SDQNRING1\n"
+
+    def save(self, path):
+        """Raw dump of the filled part of the ring (header + actions, rewards, terminals, screens), streamed straight
+        from the pinned master copy: 7 GB at 1 M frames, no extra host copy."""
+        count, current = self._state()
+        with open(path, "wb") as f:
+            f.write(self._MAGIC)
+            np.array([self.size, count, current, self.dims[0], self.dims[1], self.history_length], dtype=np.int64).tofile(f)
+            self.actions[:count].tofile(f); self.rewards[:count].tofile(f)
+            self.terminals[:count].view(np.uint8).tofile(f); self.screens[:count].tofile(f)
+
+    def load(self, path):
+        """Restores a ring written by save() into THIS memory (same size and geometry) and refreshes the HBM mirror."""
+        with open(path, "rb") as f:
+            assert f.read(len(self._MAGIC)) == self._MAGIC, "not a replay-memory checkpoint"
+            size, count, current, h, w, hist = np.fromfile(f, dtype=np.int64, count=6)
+            assert (size, h, w, hist) == (self.size, self.dims[0], self.dims[1], self.history_length), "geometry mismatch"
+            self.actions[:count] = np.fromfile(f, dtype=np.uint8, count=count)
+            self.rewards[:count] = np.fromfile(f, dtype=np.int64, count=count)
+            self.terminals[:count] = np.fromfile(f, dtype=np.uint8, count=count).view(np.bool_)
+            f.readinto(memoryview(self.screens[:count]).cast("B"))
+        _lib.check(self._lib.sdqn_replay_set_state(self._h, int(count), int(current)))
+        self.sync_mirror(0, int(count))
+
     def bench_gather(self, indexes, iters=100):
         idx = np.ascontiguousarray(indexes, dtype=np.int64)
         ms = C.c_float()

@@ -121,3 +121,26 @@ def test_full_size_ring_64bit_offsets(sd):
         n2.train(mb)                                                  # staged host minibatch
     for i in range(5):
         assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
+
+
+def test_ring_checkpoint_roundtrip(sd, tmp_path):
+    """save() / load() of the replay ring (additive): a restored memory samples and gathers exactly like the original."""
+    size, B = 500, 16
+    args = make_args(batch_size=B)
+    m = sd.ReplayMemory(size, args)
+    rng = np.random.RandomState(4)
+    for i in range(730):                                              # wraps: count = size, current = 230
+        m.add(int(rng.randint(0, 4)), int(rng.randint(-1, 2)), rng.randint(0, 256, (84, 84), dtype=np.uint8), bool(rng.rand() < 0.02))
+    p = str(tmp_path / "ring.bin")
+    m.save(p)
+    m2 = sd.ReplayMemory(size, args)
+    m2.load(p)
+    assert (m2.count, m2.current) == (m.count, m.current) == (500, 230)
+    assert np.array_equal(m2.screens, m.screens) and np.array_equal(m2.rewards, m.rewards)
+    assert np.array_equal(m2.actions, m.actions) and np.array_equal(m2.terminals, m.terminals)
+    random.seed(9); a = [x.copy() for x in m.getMinibatch()]
+    random.seed(9); b = [x.copy() for x in m2.getMinibatch()]
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    with pytest.raises(AssertionError):
+        sd.ReplayMemory(size + 1, args).load(p)
