@@ -37,6 +37,8 @@ class DeepQNetwork:
         if dt not in ("float32", "float16"):
             raise NotImplementedError("datatype %s: float32 and float16 (half activations, fp32 master weights) are implemented" % dt)
         self.datatype = dt
+        if getattr(args, "stochastic_round", False):                                    # main.py:54 -> gen_backend(stochastic_round=...)
+            raise NotImplementedError("stochastic rounding (a Neon fp16 GPU-backend feature) is not implemented")
         if self.batch_norm and dt != "float32":
             raise NotImplementedError("batch_norm is implemented for float32 only")
         optimizer = getattr(args, "optimizer", "rmsprop")

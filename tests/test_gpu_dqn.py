@@ -524,6 +524,8 @@ def test_preconditions_raise_like_the_reference(sd):
         mem.getState(0)                                              # :38
     with pytest.raises(NotImplementedError):
         sd.DeepQNetwork(A, make_args(batch_size=B, batch_norm=True, datatype="float16"))    # batch_norm is float32 only
+    with pytest.raises(NotImplementedError):
+        sd.DeepQNetwork(A, make_args(batch_size=B, stochastic_round=True))                   # not silently ignored
     with pytest.raises(AssertionError):
         sd.DeepQNetwork(A, make_args(batch_size=B, optimizer="sgd"))  # deepqnetwork.py:61
 
