@@ -124,27 +124,29 @@ struct Fc4WgradH : Fc4Wgrad {
   struct Epi { float w[16], st[16]; };
   __device__ static void epi_begin(const StepArgs& a, int m0, int n0, int lane, Epi& e) {
     if (!a.fuse_rms) return;
+    const float* __restrict__ tw = a.theta_w; const float* __restrict__ sp = a.state;
+    const uint32_t base = epi_base(m0, n0, lane);                 // 32-bit byte offsets from the uniform base (Fc4Wgrad)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int64_t o = OFF4 + (int64_t)(m0 + ml) * NFC + n0 + (lane & 31);
-      e.w[r] = a.theta_w[o]; e.st[r] = a.state[o];
-    }
+    for (int r = 0; r < 16; ++r) { e.w[r] = ldb(tw, base + epi_row(r)); e.st[r] = ldb(sp, base + epi_row(r)); }
   }
   __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi& e) {
     const int n = n0 + (lane & 31);
+    const uint32_t base = epi_base(m0, n0, lane);
     if (!a.fuse_rms) {
+      float* __restrict__ gp = a.g;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); a.g[OFF4 + (int64_t)(m0 + ml) * NFC + n] = v[r] * a.inv_loss_scale; }
+      for (int r = 0; r < 16; ++r) stb(gp, base + epi_row(r), v[r] * a.inv_loss_scale);
       return;
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) e.w[r] = rms_step(e.w[r], e.st[r], v[r] * a.inv_loss_scale, a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps);
+    for (int r = 0; r < 16; r += 2)
+      rms_step2(e.w[r], e.w[r + 1], e.st[r], e.st[r + 1], v[r] * a.inv_loss_scale, v[r + 1] * a.inv_loss_scale, a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps);
+    float* __restrict__ tw = a.theta_w; float* __restrict__ sp = a.state;
+    half_t* __restrict__ whp = a.wh_w;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int64_t o = OFF4 + (int64_t)(m0 + ml) * NFC + n;
-      a.theta_w[o] = e.w[r]; a.state[o] = e.st[r]; a.wh_w[o] = (half_t)e.w[r];
+      stb(tw, base + epi_row(r), e.w[r]); stb(sp, base + epi_row(r), e.st[r]);
+      *reinterpret_cast<half_t*>(reinterpret_cast<char*>(whp) + (base + epi_row(r)) / 2) = (half_t)e.w[r];
     }
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #pragma unroll
