@@ -104,6 +104,18 @@ def rocprof_us(kid, B, A):
     return None
 
 
+def fc_mfma_util(B, A):
+    """north_star: 'MFMA utilisation on the FC layers against gfx950 peak' — the committed rocprofv3 `--pmc MfmaUtil` pass
+    (profiles/r01_pmc_mfma_util.json; fc4_wgrad runs inside bwd3, fc5 is 0.5 MFLOP and lives in the head kernel)."""
+    if (B, A) != (32, 4):
+        return None
+    try:
+        k = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_util.json")))["kernels"]
+        return {n: k[n] for n in ("fc4_fwd(splitK)", "fc4_dgrad", "bwd3(conv3_dgrad+conv3_wgrad+fc4_wgrad)") if n in k}
+    except Exception:
+        return None
+
+
 def roofline_entry(kid, name, ms_per_launch, B, A):
     """`achieved` uses the LIVE HIP-event bracket of each launch (us_per_launch), which also contains the ~2 us
     dispatch gap of a dependent launch and is therefore conservative; rocprof_us_per_launch is the kernel's own
@@ -405,6 +417,7 @@ def main():
         }
         out["roofline"] = roofline_entry(dom["id"], dom["name"], live["total_ms"] / max(live["launches"], 1), B, A)
         out["kernels_us"] = {p["name"]: round(p["total_ms"] / p["launches"] * 1e3, 2) for p in step_kernels}
+        out["fc_mfma_utilisation"] = fc_mfma_util(B, A)
         if a.batch_norm:
             out["config"]["workload"] += " [--batch_norm]"
         if world == 1 and a.datatype == "float32" and not a.batch_norm:
