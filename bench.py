@@ -371,14 +371,16 @@ def main():
         net.sync()
 
     # ---- warmup (untimed): includes a pass with every kernel bracketed to find the dominant one
-    run(max(a.warmup - 60, 0))
+    n_prof = min(60, max(a.warmup // 2, 1)) if a.warmup else 20      # W = 0 still needs a pass to find the dominant kernel
+    run(max(a.warmup - n_prof, 0))                                   # (first launches also load the code objects)
     net.profile(True, -1)
     net.profile_reset()
-    run(min(60, a.warmup) or 20)
+    run(n_prof)
     prof = net.profile_read()
     net.profile(False)
     step_kernels = [p for p in prof if p["launches"] > 0]
-    dom = max(step_kernels, key=lambda p: p["total_ms"])
+    per_step = [p for p in step_kernels if p["launches"] >= n_prof] or step_kernels    # not the one-off prep / gather launches
+    dom = max(per_step, key=lambda p: p["total_ms"])
     # timed region: the dominant kernel stays bracketed with HIP events, but only every 16th launch — an event pair costs
     # 2-3 us of queue time, and bracketing every launch took 7 % off the step rate it is supposed to observe
     net.set_option("profile_every", 16)
@@ -396,6 +398,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t[0])
     live = [p for p in net.profile_read() if p["id"] == dom["id"]][0]
+    if live["launches"] == 0:                                        # fewer than 16 steps timed: fall back to the warm-up pass
+        live = dom
     net.profile(False)
     net.set_option("profile_every", 1)
 
@@ -442,11 +446,14 @@ def main():
     flush_c_stdio()
     if world > 1:
         dist.barrier()
+        flush_c_stdio()                                    # gloo logs "[Gloo] Rank r is connected ..." through C stdio too
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        # nothing may follow the JSON line on the job's merged stdout: no further collective (gloo logs when it sets up
+        # connections), no interpreter teardown (buffered C stdio of any rank would be flushed then)
+        sys.stdout.flush()
+        os._exit(0)
 
 
 def flush_c_stdio():
