@@ -372,7 +372,7 @@ def main():
 
     # ---- warmup (untimed): includes a pass with every kernel bracketed to find the dominant one
     n_prof = min(60, max(a.warmup // 2, 1)) if a.warmup else 20      # W = 0 still needs a pass to find the dominant kernel
-    run(max(a.warmup - n_prof, 0))                                   # (first launches also load the code objects)
+    run(max(a.warmup - n_prof, 3))                                   # at least 3: the first launches also load the code objects
     net.profile(True, -1)
     net.profile_reset()
     run(n_prof)
