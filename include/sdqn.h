@@ -166,8 +166,10 @@ int sdqn_net_set_epoch(sdqn_net_t h, int epoch);
 
 /* options: "keep_gradients" (1: the fc4 gradient is materialised and readable with which=3; 0 (default): on one
  * GPU RMSProp of fc4 is fused into the wgrad epilogue), "two_streams" (0 default; 1: wgrad kernels overlap the dgrad chain on a side stream), "fused_launches" (1 default:
- * independent backward stages share one grid), "xcd_map" (0 default; 1: XCD-contiguous workgroup->tile map),
- * "nw:<kernel id>" / "f4_share3" / "f4_share2" (tuning hooks) */
+ * independent backward stages share one grid), "xcd_map" (0 default = only where it wins time: conv1/conv2/fc4 forward; 1: the
+ * XCD-contiguous workgroup->tile map for every launch), "dp_overlap" (0 default; 1 BEFORE sdqn_dp_init: fc4 gradient
+ * all-reduced and applied on a second communicator + stream), "profile_every" (N: sdqn_net_profile brackets every N-th
+ * launch), "nw:<kernel id>" / "xcd:<kernel id>" / "f4_share3" / "f4_share2" (tuning hooks) */
 int sdqn_net_set_option(sdqn_net_t h, const char* name, int value);
 
 /* test hook: raw read-back of an internal device buffer ("a1","a2","a3","a4","d4","d3p","d2p","d1","q",
