@@ -99,7 +99,7 @@ class ReplayMemory:
         st = random.getstate()
         self._mt[:] = st[1]
         _lib.check(self._lib.sdqn_replay_sample(self._h, self._mt, _lib.ptr(self._idx, C.c_int64), None))
-        random.setstate((st[0], tuple(self._mt), st[2]))
+        random.setstate((st[0], tuple(self._mt[:]), st[2]))
         return self._idx
 
     def gather(self, indexes):
