@@ -45,7 +45,11 @@ typedef struct sdqn_net_s* sdqn_net_t;
 const char* sdqn_last_error(void);
 int sdqn_version(void);
 int sdqn_device_count(int* n);
-int sdqn_set_device(int dev);                 /* replaces --device_id, src/main.py:52, deepqnetwork.py:32 */
+/* replaces --device_id (src/main.py:52 -> gen_backend(device_id=...), deepqnetwork.py:29-34).  One device per process:
+ * the first device call binds the library; asking for the bound device again is a no-op, any other device afterwards
+ * is SDQN_ERR_STATE (never a silent run on the wrong GPU). */
+int sdqn_set_device(int dev);
+int sdqn_get_device(int* dev);                /* the device the library is bound to (binds the current one if none yet) */
 int sdqn_device_sync(void);
 
 /* ---- index sampler: pure host, no device needed ---------------------------
@@ -158,13 +162,18 @@ int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t mt[SDQN_MT_WORDS
 /* DeepQNetwork.update_target_network, deepqnetwork.py:102-105 */
 int sdqn_net_update_target(sdqn_net_t h);
 int sdqn_net_sync(sdqn_net_t h);
+/* The two halves of a data-parallel step without a communicator (the arithmetic every rank performs
+ * around the all-reduce).  With option "grad_only" = 1 a train step ends after the local gradient SUMS are in the flat
+ * gradient buffer (readable / writable per layer with which = 3); sdqn_net_apply_update then runs the optimizer on
+ * whatever that buffer holds with divisor bsz (A9: grad / be.bsz, deepqnetwork.py:165 — nranks * batch_size under DP). */
+int sdqn_net_apply_update(sdqn_net_t h, double bsz);
 /* q-values of the last train step: preq float[B,A] (online, prestates), maxpostq float[B] (sync) */
 int sdqn_net_last_q(sdqn_net_t h, float* preq, float* maxpostq);
 int sdqn_net_train_iterations(sdqn_net_t h, int64_t* n);     /* deepqnetwork.py:168 */
 /* the `epoch` argument of DeepQNetwork.train (deepqnetwork.py:107,165): Neon's Adam bias-corrects with t = epoch + 1 */
 int sdqn_net_set_epoch(sdqn_net_t h, int epoch);
 
-/* options: "keep_gradients" (1: the fc4 gradient is materialised and readable with which=3; 0 (default): on one
+/* options: "grad_only" (see sdqn_net_apply_update), "keep_gradients" (1: the fc4 gradient is materialised and readable with which=3; 0 (default): on one
  * GPU RMSProp of fc4 is fused into the wgrad epilogue), "two_streams" (0 default; 1: wgrad kernels overlap the dgrad chain on a side stream), "fused_launches" (1 default:
  * independent backward stages share one grid), "xcd_map" (0 default = only where it wins time: conv1/conv2/fc4 forward; 1: the
  * XCD-contiguous workgroup->tile map for every launch), "dp_overlap" (0 default; 1 BEFORE sdqn_dp_init: fc4 gradient
@@ -188,6 +197,9 @@ int sdqn_net_profile_reset(sdqn_net_t h);
 int sdqn_dp_unique_id(const char* rccl_path, char id[128]);
 int sdqn_dp_init(sdqn_net_t h, const char* rccl_path, const char id[128], int rank, int nranks);
 int sdqn_dp_shutdown(sdqn_net_t h);
+/* what RCCL reports about the live communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice; -1 without one)
+ * and the device the library is bound to: lets a multi-GPU record prove that RCCL spanned N ranks on N devices */
+int sdqn_dp_info(sdqn_net_t h, int* comm_ranks, int* comm_rank, int* comm_device, int* bound_device);
 
 #ifdef __cplusplus
 }

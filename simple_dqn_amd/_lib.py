@@ -38,6 +38,7 @@ SIGNATURES = {
     "sdqn_version": (C.c_int, []),
     "sdqn_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "sdqn_set_device": (C.c_int, [C.c_int]),
+    "sdqn_get_device": (C.c_int, [C.POINTER(C.c_int)]),
     "sdqn_device_sync": (C.c_int, []),
     "sdqn_mt_seed": (C.c_int, [_u32p, C.c_uint64]),
     "sdqn_mt_randint": (C.c_int, [_u32p, C.c_int64, C.c_int64, _i64p]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     "sdqn_net_train_many": (C.c_int, [_vp, _vp, _u32p, C.c_int, _f32p]),
     "sdqn_net_update_target": (C.c_int, [_vp]),
     "sdqn_net_sync": (C.c_int, [_vp]),
+    "sdqn_net_apply_update": (C.c_int, [_vp, C.c_double]),
     "sdqn_net_last_q": (C.c_int, [_vp, _f32p, _f32p]),
     "sdqn_net_train_iterations": (C.c_int, [_vp, _i64p]),
     "sdqn_net_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
@@ -86,6 +88,7 @@ SIGNATURES = {
     "sdqn_dp_unique_id": (C.c_int, [C.c_char_p, C.c_char_p]),
     "sdqn_dp_init": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
     "sdqn_dp_shutdown": (C.c_int, [_vp]),
+    "sdqn_dp_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 
 _lib = None
@@ -111,6 +114,15 @@ def load():
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def bind_device(args):
+    """--device_id of the reference (src/main.py:52, deepqnetwork.py:29-34): the drop-in classes bind the library to
+    args.device_id before their first device call; a second object asking for a different device raises."""
+    dev = getattr(args, "device_id", None)
+    if dev is None:
+        return
+    check(load().sdqn_set_device(int(dev)))
 
 
 def check(rc):

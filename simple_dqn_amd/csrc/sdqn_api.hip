@@ -31,11 +31,13 @@ static hipStream_t g_stream = nullptr;      // the library stream: everything is
 static hipStream_t g_side = nullptr;        // side stream: weight-gradient kernels run beside the dgrad chain
 static hipStream_t g_comm = nullptr;        // data parallel: the fc4 gradient all-reduce + fc4 update run here, beside the compute stream
 static hipEvent_t g_ev[5];                  // fork/join events between the two (timing disabled)
+static int g_dev = -1;                      // device the library streams live on (bound by the first device call)
 static int ensure_stream() {
   if (g_stream) return SDQN_OK;
   int n = 0;
   HIPCHK(hipGetDeviceCount(&n));
   if (n <= 0) { set_error("no HIP device visible (libsdqn_hip has no CPU path)"); return SDQN_ERR_HIP; }
+  HIPCHK(hipGetDevice(&g_dev));
   HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&g_comm, hipStreamNonBlocking));
@@ -48,9 +50,21 @@ extern "C" const char* sdqn_last_error(void) { return g_err.c_str(); }
 extern "C" int sdqn_version(void) { return 100; }
 extern "C" int sdqn_device_count(int* n) { ARGCHK(n, "n is NULL"); HIPCHK(hipGetDeviceCount(n)); return SDQN_OK; }
 extern "C" int sdqn_set_device(int dev) {
-  if (g_stream) { set_error("sdqn_set_device must precede any other device call"); return SDQN_ERR_STATE; }
+  // one device per process (one process per GPU): the first device call binds the library streams; asking for the
+  // bound device again is a no-op, asking for another one is an error instead of a silent run on the wrong GPU
+  if (g_stream) {
+    if (dev == g_dev) return SDQN_OK;
+    set_error("libsdqn_hip is already bound to device %d (asked for %d): one device per process", g_dev, dev);
+    return SDQN_ERR_STATE;
+  }
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n));
+  ARGCHK(dev >= 0 && dev < n, "device_id %d out of range (%d visible)", dev, n);
   HIPCHK(hipSetDevice(dev));
   return SDQN_OK;
+}
+extern "C" int sdqn_get_device(int* dev) {
+  ARGCHK(dev, "dev is NULL"); STREAMCHK(); *dev = g_dev; return SDQN_OK;
 }
 extern "C" int sdqn_device_sync(void) { STREAMCHK(); HIPCHK(hipStreamSynchronize(g_stream)); return SDQN_OK; }
 
@@ -212,7 +226,7 @@ static int replay_push_idx(sdqn_replay_s* r, const int64_t* idx, int* slot_out, 
   if (r->slot_busy[s]) { HIPCHK(hipEventSynchronize(r->slot_ev[s])); r->slot_busy[s] = false; }
   int64_t* dst = r->h_idx + (size_t)s * r->B;
   for (int i = 0; i < r->B; ++i) {
-    ARGCHK(idx[i] >= r->hist && idx[i] < r->size, "index %lld out of range", (long long)idx[i]);
+    ARGCHK(idx[i] >= r->hist && idx[i] < r->count, "index %lld out of range (count %lld)", (long long)idx[i], (long long)r->count);
     dst[i] = idx[i];
   }
   *slot_out = s; *dev = r->d_idx_view + (size_t)s * r->B;
@@ -271,6 +285,9 @@ struct Rccl {
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
+  int (*CommUserRank)(void*, int*) = nullptr;
+  int (*CommCuDevice)(void*, int*) = nullptr;
 };
 static Rccl g_rccl;
 static int rccl_load(const char* path) {
@@ -286,6 +303,9 @@ static int rccl_load(const char* path) {
   g_rccl.CommSplit = (int (*)(void*, int, int, void**, void*))dlsym(lib, "ncclCommSplit");
   g_rccl.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
   g_rccl.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
+  g_rccl.CommCount = (int (*)(void*, int*))dlsym(lib, "ncclCommCount");
+  g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(lib, "ncclCommUserRank");
+  g_rccl.CommCuDevice = (int (*)(void*, int*))dlsym(lib, "ncclCommCuDevice");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
     set_error("%s lacks the nccl* entry points", p); dlclose(lib); return SDQN_ERR_RCCL;
   }
@@ -316,6 +336,8 @@ struct sdqn_net_s {
   int S4 = 7, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
   int64_t train_iterations = 0;
   bool keep_grads = false;                 // true: fc4 gradient materialised in g (readable with which=3), no fused RMSProp
+  bool grad_only = false;                  // true: a train step stops after the local gradient sums (update mode 1): what a
+                                           // data-parallel rank has before the all-reduce; sdqn_net_apply_update finishes it
   int nw_override[12] = {0};               // tuning hook
   int f4_share[2] = {100, 0};               // % of the fc4-wgrad tiles in bwd3 / bwd2 (rest in bwd1)
   int S4_override = 0, tps_override[3] = {0, 0, 0};
@@ -330,7 +352,7 @@ struct sdqn_net_s {
   std::vector<ProfPair> prof_pending; std::vector<hipEvent_t> prof_free;
   double prof_ms[K_COUNT]; int64_t prof_n[K_COUNT];
   // data parallel
-  void* comm = nullptr; int rank = 0, nranks = 1;
+  void* comm = nullptr; int rank = 0, nranks = 1; int nccl_rc = 0;
   // overlapped data parallel (run_train): comm2 carries the fc4 gradient (95 % of the bytes) on g_comm while the
   // compute stream finishes the backward pass and starts the next forward; ev_w4 = "W4 of the last step is updated"
   void* comm2 = nullptr; hipEvent_t ev_g4 = nullptr, ev_w4 = nullptr; bool w4_pending = false;
@@ -496,7 +518,7 @@ extern "C" int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const fl
     HIPCHK(hipMemcpy(base, w, (size_t)n * 4, hipMemcpyHostToDevice));
     return SDQN_OK;
   }
-  ARGCHK(layer >= 0 && layer < 5 && (which == 0 || which == 1 || which == 2 || which == 4), "bad arguments");
+  ARGCHK(layer >= 0 && layer < 5 && which >= 0 && which <= 4, "bad arguments");
   ARGCHK(which_buf(h, which), "this optimizer has no second state");
   int64_t rows, cols, off; layer_dims(layer, h->A, rows, cols, off);
   ARGCHK(n == rows * cols, "layer %d holds %lld values, got %lld", layer, (long long)(rows * cols), (long long)n);
@@ -555,7 +577,11 @@ static int prof_event(sdqn_net_s* h, hipEvent_t* e) {
   if (pf_) { pp_.id = (KID); int r1_ = prof_event(h, &pp_.a); if (r1_) return r1_; r1_ = prof_event(h, &pp_.b); if (r1_) return r1_; \
              HIPCHK(hipEventRecord(pp_.a, (STRM))); } \
   hipError_t le_ = (expr); \
-  if (le_ != hipSuccess) { set_error("launch %s -> %s", kernel_name(KID), hipGetErrorString(le_)); return SDQN_ERR_HIP; } \
+  if (le_ != hipSuccess) { \
+    if ((KID) == K_ALLREDUCE && h->nccl_rc != 0) { \
+      set_error("ncclAllReduce (rank %d of %d) -> %s", h->rank, h->nranks, g_rccl.GetErrorString ? g_rccl.GetErrorString(h->nccl_rc) : "rccl error"); \
+      return SDQN_ERR_RCCL; } \
+    set_error("launch %s -> %s", kernel_name(KID), hipGetErrorString(le_)); return SDQN_ERR_HIP; } \
   if (pf_) { HIPCHK(hipEventRecord(pp_.b, (STRM))); h->prof_pending.push_back(pp_); \
              if (h->prof_pending.size() > 16384) { int r2_ = prof_collect(h); if (r2_) return r2_; } } \
 } while (0)
@@ -576,6 +602,13 @@ extern "C" int sdqn_net_profile_reset(sdqn_net_t h) {
   memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n); return SDQN_OK;
 }
 
+// RCCL all-reduce on behalf of LAUNCH_ON: a failure keeps RCCL's own message (h->nccl_rc / sdqn_last_error) and is
+// reported as SDQN_ERR_RCCL by the macro instead of an anonymous hipErrorUnknown
+static hipError_t dp_allreduce(sdqn_net_s* h, void* buf, size_t count, int dtype, void* comm, hipStream_t s) {
+  h->nccl_rc = g_rccl.AllReduce(buf, buf, count, dtype, /*ncclSum*/ 0, comm, s);
+  return h->nccl_rc == 0 ? hipSuccess : hipErrorUnknown;
+}
+
 // ---- the step ---------------------------------------------------------------------------------------------
 static StepArgs step_args(sdqn_net_s* h) {
   StepArgs a; memset(&a, 0, sizeof a);
@@ -592,7 +625,7 @@ static StepArgs step_args(sdqn_net_s* h) {
     a.loss_scale = (float)h->cfg.loss_scale; a.inv_loss_scale = (float)(1.0 / h->cfg.loss_scale);
   }
   a.f4w_first = 0; a.f4w_count = (NIN4 / 32) * (NFC / 32);
-  a.fuse_rms = (!h->comm && !h->keep_grads && h->cfg.optimizer == 0) ? 1 : 0;
+  a.fuse_rms = (!h->comm && !h->keep_grads && !h->grad_only && h->cfg.optimizer == 0) ? 1 : 0;
   a.theta_w = h->theta; a.state = h->state; a.bsz = (float)h->B;
   a.rho = (float)h->cfg.decay_rate; a.one_minus_rho = (float)(1.0 - h->cfg.decay_rate);
   a.lr = (float)h->cfg.learning_rate; a.eps = (float)h->cfg.epsilon;
@@ -699,8 +732,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     LAUNCH(K_BWD3, launch_tuned(h, K_BWD3, b3, g_stream));
     HIPCHK(hipEventRecord(h->ev_g4, g_stream));
     HIPCHK(hipStreamWaitEvent(g_comm, h->ev_g4, 0));
-    LAUNCH_ON(g_comm, K_ALLREDUCE, (g_rccl.AllReduce(h->g + OFF4, h->g + OFF4, (size_t)NW4, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm2, g_comm) == 0
-                                    ? hipSuccess : hipErrorUnknown));
+    LAUNCH_ON(g_comm, K_ALLREDUCE, dp_allreduce(h, h->g + OFF4, (size_t)NW4, /*ncclFloat32*/ 7, h->comm2, g_comm));
     UpdateArgs u4 = make_update_args(h, a);
     u4.mode = 2; u4.only_fc4 = 1; u4.skip_fc4 = 0; u4.bsz = (float)h->B * (float)h->nranks;
     LAUNCH_ON(g_comm, K_UPDATE, launch_update(u4, g_comm));
@@ -749,8 +781,8 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     u.mode = 1; u.bsz = (float)h->B; u.next.B = 0; u.skip_fc4 = 1;
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
     if (g_rccl.GroupStart && g_rccl.GroupEnd) NCCLCHK(g_rccl.GroupStart());
-    LAUNCH(K_ALLREDUCE, (g_rccl.AllReduce(h->g, h->g, (size_t)OFF4, 7, 0, h->comm, g_stream) == 0 ? hipSuccess : hipErrorUnknown));
-    LAUNCH(K_ALLREDUCE, (g_rccl.AllReduce(h->g + OFF5, h->g + OFF5, (size_t)(h->NP - OFF5), 7, 0, h->comm, g_stream) == 0 ? hipSuccess : hipErrorUnknown));
+    LAUNCH(K_ALLREDUCE, dp_allreduce(h, h->g, (size_t)OFF4, 7, h->comm, g_stream));
+    LAUNCH(K_ALLREDUCE, dp_allreduce(h, h->g + OFF5, (size_t)(h->NP - OFF5), 7, h->comm, g_stream));
     if (g_rccl.GroupStart && g_rccl.GroupEnd) NCCLCHK(g_rccl.GroupEnd());
     u.mode = 2; u.bsz = (float)h->B * (float)h->nranks; u.skip_fc4 = 1;
     if (next) u.next = *next;
@@ -760,12 +792,14 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     // synchronous data parallel: local gradient sums -> one RCCL all-reduce of the flat buffer -> identical RMSProp
     u.mode = 1; u.bsz = (float)h->B; u.next.B = 0;
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
-    LAUNCH(K_ALLREDUCE, (g_rccl.AllReduce(h->g, h->g, (size_t)h->NP, /*ncclFloat32*/ 7, /*ncclSum*/ 0, h->comm, g_stream) == 0
-                         ? hipSuccess : hipErrorUnknown));
+    LAUNCH(K_ALLREDUCE, dp_allreduce(h, h->g, (size_t)h->NP, /*ncclFloat32*/ 7, h->comm, g_stream));
     u.mode = 2; u.bsz = (float)h->B * (float)h->nranks;
     if (next) u.next = *next;
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
     if (h->bn) LAUNCH(K_BN, launch_bn_update(u, g_stream));
+  } else if (h->grad_only) {
+    u.mode = 1; u.bsz = (float)h->B;                                            // local sums -> g, nothing applied
+    LAUNCH(K_UPDATE, launch_update(u, g_stream));
   } else {
     u.mode = 0; u.bsz = (float)h->B;
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
@@ -905,6 +939,14 @@ static PrepArgs prep_args(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pinned
   p.rewards = h->st_rew; p.terminals = h->st_term; p.B = h->B;
   return p;
 }
+// ring paths take (a, r, t) from the ring: an action the network has no output for would index past the Q row in the
+// head kernel (which clamps) and train garbage silently; the tuple API checks the same thing (sdqn_net_train_host)
+static int check_ring_actions(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* idx) {
+  for (int i = 0; i < r->B; ++i)
+    ARGCHK(idx[i] >= 0 && idx[i] < r->size && r->actions[idx[i]] < h->A,
+           "ring slot %lld holds action %d but the network has %d actions", (long long)idx[i], (int)r->actions[idx[i]], h->A);
+  return SDQN_OK;
+}
 // do_prep: launch the standalone prep for THIS step; next_pinned: fold the NEXT step's prep into the update
 static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pinned_idx, bool do_prep = true,
                              const int64_t* next_pinned = nullptr) {
@@ -917,7 +959,8 @@ static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pin
 extern "C" int sdqn_net_train_replay(sdqn_net_t h, sdqn_replay_t r, const int64_t* idx_host, float* cost_out) {
   ARGCHK(h && r && idx_host, "NULL argument");
   ARGCHK(r->B == h->B, "replay batch_size %d != network batch_size %d", r->B, h->B);
-  int slot; const int64_t* didx; int rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
+  int slot; const int64_t* didx; int rc = check_ring_actions(h, r, idx_host); if (rc) return rc;
+  rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
   rc = train_replay_slot(h, r, didx); if (rc) return rc;
   rc = replay_release_idx(r, slot); if (rc) return rc;
   if (cost_out) return read_cost(h, cost_out);
@@ -932,12 +975,14 @@ extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, 
   int slot = -1, next_slot = -1; const int64_t *pinned = nullptr, *next_pinned = nullptr;
   if (n_steps > 0) {
     int rc = sample_checked(mt, r->terminals, r->count, r->current, r->hist, r->B, idx.data(), nullptr); if (rc) return rc;
+    rc = check_ring_actions(h, r, idx.data()); if (rc) return rc;
     rc = replay_push_idx(r, idx.data(), &slot, &pinned); if (rc) return rc;
   }
   for (int i = 0; i < n_steps; ++i) {
     next_pinned = nullptr;
     if (i + 1 < n_steps) {
       int rc = sample_checked(mt, r->terminals, r->count, r->current, r->hist, r->B, idx.data(), nullptr); if (rc) return rc;
+      rc = check_ring_actions(h, r, idx.data()); if (rc) return rc;
       rc = replay_push_idx(r, idx.data(), &next_slot, &next_pinned); if (rc) return rc;
     }
     int rc = train_replay_slot(h, r, pinned, /*do_prep=*/i == 0, next_pinned); if (rc) return rc;
@@ -963,6 +1008,19 @@ extern "C" int sdqn_net_update_target(sdqn_net_t h) {
   }
   return SDQN_OK;
 }
+// The second half of a data-parallel step without a communicator: the gradient sums currently in the flat buffer g
+// (written by a grad_only step and/or sdqn_net_set_weights(which = 3)) are applied with divisor bsz — exactly what every
+// rank does after the all-reduce with bsz = nranks * batch_size (A9: grad / be.bsz, deepqnetwork.py:165).
+extern "C" int sdqn_net_apply_update(sdqn_net_t h, double bsz) {
+  ARGCHK(h && bsz > 0, "bad arguments");
+  { int rc = join_comm(h); if (rc) return rc; }
+  StepArgs a = step_args(h);
+  UpdateArgs u = make_update_args(h, a);
+  u.mode = 2; u.bsz = (float)bsz; u.skip_fc4 = 0;
+  LAUNCH(K_UPDATE, launch_update(u, g_stream));
+  if (h->bn) LAUNCH(K_BN, launch_bn_update(u, g_stream));
+  return SDQN_OK;
+}
 extern "C" int sdqn_net_sync(sdqn_net_t h) {
   ARGCHK(h, "NULL handle"); int rc = join_comm(h); if (rc) return rc;
   HIPCHK(hipStreamSynchronize(g_stream)); return SDQN_OK;
@@ -984,6 +1042,7 @@ extern "C" int sdqn_net_set_epoch(sdqn_net_t h, int epoch) { ARGCHK(h && epoch >
 extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   ARGCHK(h && name, "NULL argument");
   if (!strcmp(name, "keep_gradients")) h->keep_grads = value != 0;
+  else if (!strcmp(name, "grad_only")) h->grad_only = value != 0;
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;
@@ -1046,6 +1105,20 @@ extern "C" int sdqn_dp_init(sdqn_net_t h, const char* rccl_path, const char id[1
     if (!h->ev_g4) HIPCHK(hipEventCreateWithFlags(&h->ev_g4, hipEventDisableTiming));
     if (!h->ev_w4) HIPCHK(hipEventCreateWithFlags(&h->ev_w4, hipEventDisableTiming));
   }
+  return SDQN_OK;
+}
+// What RCCL itself reports about the communicator (not what the caller passed in): ranks it spans, this rank, its device.
+// All -1 without a communicator.  bench.py gathers these so a multi-GPU record can show "RCCL saw N ranks".
+extern "C" int sdqn_dp_info(sdqn_net_t h, int* comm_ranks, int* comm_rank, int* comm_device, int* bound_device) {
+  ARGCHK(h, "NULL handle");
+  int n = -1, r = -1, d = -1;
+  if (h->comm) {
+    if (g_rccl.CommCount) NCCLCHK(g_rccl.CommCount(h->comm, &n));
+    if (g_rccl.CommUserRank) NCCLCHK(g_rccl.CommUserRank(h->comm, &r));
+    if (g_rccl.CommCuDevice) NCCLCHK(g_rccl.CommCuDevice(h->comm, &d));
+  }
+  if (comm_ranks) *comm_ranks = n; if (comm_rank) *comm_rank = r; if (comm_device) *comm_device = d;
+  if (bound_device) *bound_device = g_dev;
   return SDQN_OK;
 }
 extern "C" int sdqn_dp_shutdown(sdqn_net_t h) {

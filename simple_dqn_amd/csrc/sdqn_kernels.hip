@@ -171,6 +171,7 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
   // minibatch metadata last: thread 0 only, and nothing above waits behind it
   int m_act = 0, m_term = 0; int64_t m_rew = 0;
   if (h.train && j == 0) { m_act = h.st_actions[n]; m_rew = h.st_rewards[n]; m_term = h.st_terminals[n]; }
+  m_act = m_act < A ? m_act : A - 1;                 // memory safety only: the host rejects out-of-range actions before launching
   if constexpr (BN) {
   } else if (a.S4 == 7) {
 #pragma unroll

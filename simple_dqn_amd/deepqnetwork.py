@@ -44,7 +44,7 @@ class DeepQNetwork:
         optimizer = getattr(args, "optimizer", "rmsprop")
         assert optimizer in ("rmsprop", "adam", "adadelta"), "Unknown optimizer"      # deepqnetwork.py:61
         self.optimizer = optimizer
-        dev = getattr(args, "device_id", None)
+        _lib.bind_device(args)                                                        # :29-34 gen_backend(device_id=args.device_id)
         cfg = _lib.NetCfg()
         cfg.batch_size, cfg.history_length = self.batch_size, self.history_length
         cfg.screen_height, cfg.screen_width = self.screen_dim
@@ -61,7 +61,6 @@ class DeepQNetwork:
         # Neon's defaults (the reference passes none): RMSProp/Adadelta epsilon 1e-6, Adam epsilon 1e-8, betas 0.9/0.999
         cfg.epsilon = float(getattr(args, "optimizer_epsilon", 1e-8 if optimizer == "adam" else 1e-6))
         cfg.beta_1, cfg.beta_2 = float(getattr(args, "beta_1", 0.9)), float(getattr(args, "beta_2", 0.999))
-        self._dev = dev
         h = C.c_void_p()
         _lib.check(self._lib.sdqn_net_create(C.byref(h), C.byref(cfg)))
         self._h = h
@@ -79,7 +78,8 @@ class DeepQNetwork:
         self.callback = None
         self.save_weights_prefix = getattr(args, "save_weights_prefix", None)
         # Xavier init (A4): online layers first, then the target model's own draw (:65-70)
-        rng = np.random.RandomState(getattr(args, "random_seed", None) or None)
+        # (gen_backend(rng_seed=args.random_seed), :31: seed 0 is a seed here, unlike main.py:89's `if args.random_seed`)
+        rng = np.random.RandomState(getattr(args, "random_seed", None))
         for which in ((0, 1) if cfg.target_enabled else (0,)):
             for i, shp in enumerate(layer_shapes(num_actions)):
                 fan_in = shp[0] if i < 3 else shp[1]
@@ -247,6 +247,18 @@ class DeepQNetwork:
             mt = mt_state
         want = (self.callback is not None) if want_cost is None else want_cost
         cost = C.c_float()
+        if self.callback is not None and n_steps > 1:
+            # the reference reports every step to the callback (deepqnetwork.py:168-172: train_iterations, then
+            # on_train(cost)): step by step, so Statistics' running mean sees the same sequence; no callback -> one call
+            total = 0.0
+            for _ in range(int(n_steps)):
+                _lib.check(self._lib.sdqn_net_train_many(self._h, mem._h, mt, 1, C.byref(cost)))
+                self.train_iterations += 1
+                self.callback.on_train(cost.value)
+                total += cost.value
+            if mt_state is None:
+                random.setstate((st[0], tuple(mt[:]), st[2]))
+            return total / n_steps if want else None
         _lib.check(self._lib.sdqn_net_train_many(self._h, mem._h, mt, int(n_steps), C.byref(cost) if want else None))
         if mt_state is None:
             random.setstate((st[0], tuple(mt[:]), st[2]))
@@ -301,6 +313,17 @@ class DeepQNetwork:
     def dp_init(self, unique_id, rank, nranks, rccl=None):
         path = (rccl or _lib.rccl_path()).encode()
         _lib.check(self._lib.sdqn_dp_init(self._h, path, unique_id, rank, nranks))
+
+    def dp_info(self):
+        """What RCCL reports about the communicator + the bound device (all -1 without a communicator)."""
+        v = [C.c_int(-1) for _ in range(4)]
+        _lib.check(self._lib.sdqn_dp_info(self._h, *[C.byref(x) for x in v]))
+        return dict(comm_ranks=v[0].value, comm_rank=v[1].value, comm_device=v[2].value, bound_device=v[3].value)
+
+    def apply_update(self, bsz):
+        """Optimizer step on the gradient sums currently in the flat buffer (which=3) with divisor bsz: the second half of
+        a data-parallel step (see option 'grad_only')."""
+        _lib.check(self._lib.sdqn_net_apply_update(self._h, float(bsz)))
 
     def dp_shutdown(self):
         _lib.check(self._lib.sdqn_dp_shutdown(self._h))

@@ -20,6 +20,7 @@ HBM_MIRROR, ZERO_COPY = 1, 2
 class ReplayMemory:
     def __init__(self, size, args, flags=HBM_MIRROR):
         self._lib = _lib.load()
+        _lib.bind_device(args)              # main.py builds the memory first: --device_id must be bound before its allocations
         self.size = size
         self.history_length = args.history_length
         self.dims = (args.screen_height, args.screen_width)
@@ -108,7 +109,9 @@ class ReplayMemory:
         _lib.check(self._lib.sdqn_replay_gather(self._h, _lib.ptr(idx, C.c_int64)))
         _lib.check(self._lib.sdqn_replay_minibatch_to_host(self._h))
         self.last_indexes = idx.copy()
-        return self.prestates, self._mb_actions, self._mb_rewards, self.poststates, self._mb_terminals
+        # replay_memory.py:76-79: prestates/poststates are the preallocated (aliased) buffers, the three small arrays are
+        # fresh fancy-index copies in the reference — a caller may keep them across calls
+        return self.prestates, self._mb_actions.copy(), self._mb_rewards.copy(), self.poststates, self._mb_terminals.copy()
 
     def getMinibatch(self):                                        # :50-79
         assert self.count > self.history_length

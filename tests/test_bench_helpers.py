@@ -6,6 +6,42 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_profiles_still_match_the_kernel_names():
+    """The replayed numbers are looked up by substrings of the rocprofv3 kernel names (bench.ROCPROF_MATCH).  If a kernel
+    is renamed / re-templated and profiles/ is not regenerated, the look-up must fail HERE instead of going stale silently:
+    every per-step kernel id of the B=32 step resolves to a row of the newest committed kernel-stats capture, and every
+    GEMM-engine row of that capture is claimed by exactly one id."""
+    import csv
+    rows = [r for r in csv.reader(l for l in open(os.path.join(ROOT, bench.STATS_FILE)) if not l.startswith("#"))][1:]
+    names = [r[0] for r in rows]
+    per_step = {0, 1, 2, 3, 4, 5, 12, 16, 17, 18}
+    for sub, kid in bench.ROCPROF_MATCH:
+        hits = [n for n in names if sub in n]
+        if kid in per_step:
+            assert len(hits) >= 1, "no row of %s matches %r (kernel id %d): regenerate profiles/ (tools/final_capture.sh)" % (bench.STATS_FILE, sub, kid)
+        assert bench.rocprof_us(kid, 32, 4) is not None or kid not in per_step
+    engine_rows = [n for n in names if "sdqn::gemm_" in n]
+    for n in engine_rows:
+        claimed = [kid for sub, kid in bench.ROCPROF_MATCH if sub in n]
+        assert len(claimed) == 1, "capture row %r is claimed by kernel ids %s" % (n, claimed)
+    pmc = json.load(open(os.path.join(ROOT, bench.PMC_FILE)))["kernels"]
+    import ctypes as C, simple_dqn_amd as sd
+    lib = sd.load()                                          # kernel display names come from the library itself
+    n = C.c_int(); assert lib.sdqn_net_profile_count(C.byref(n)) == 0
+    for key in pmc:
+        assert any(key == k for k in KERNEL_NAMES), "PMC capture row %r is not a kernel name of this build" % key
+
+
+KERNEL_NAMES = [
+    "conv1_fwd(gather+norm+conv+relu)", "conv2_fwd", "conv3_fwd", "fc4_fwd(splitK)", "head(fc5+td+delta)",
+    "fc4_dgrad", "fc4_wgrad", "conv3_dgrad", "conv3_wgrad", "conv2_dgrad", "conv2_wgrad",
+    "conv1_wgrad", "update(reduce+fc5wgrad+rmsprop)", "rccl_allreduce", "replay_gather_u8", "prep(idx+meta)",
+    "bwd3(conv3_dgrad+conv3_wgrad+fc4_wgrad)", "bwd2(conv2_dgrad+conv2_wgrad+fc4_wgrad)", "bwd1(conv1_wgrad+fc4_wgrad)",
+    "batchnorm(layer fwd/bwd)"]
+
 
 def test_kernel_work_matches_survey_figures():
     w = bench.kernel_work(32, 4)
@@ -21,8 +57,11 @@ def test_roofline_entry_bounds_and_committed_profiles():
     e = bench.roofline_entry(16, "bwd3(conv3_dgrad+conv3_wgrad+fc4_wgrad)", 0.0156, 32, 4)
     assert e["bound"] == "hbm" and abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-3
     assert e["traffic"] and e["traffic"] > e["algorithmic_bytes"]           # PMC bytes >= compulsory bytes
-    assert e["rocprof_us_per_launch"] and 5 < e["rocprof_us_per_launch"] < 30
-    assert 0 < e["frac_of_measured_peak"] < 1 and e["peak_measured"] < e["peak"]
+    fp = e["from_profiles"]                                                  # replayed (committed) numbers are labelled as such
+    assert fp["traffic"] == e["traffic"] and "NOT measured in this run" in fp["note"] and all(os.path.exists(os.path.join(ROOT, f)) for f in fp["files"])
+    assert fp["rocprof_us_per_launch"] and 5 < fp["rocprof_us_per_launch"] < 30
+    assert 0 < fp["frac_of_measured_peak"] < 1 and fp["peak_measured"] < e["peak"]
+    assert "rocprof_us_per_launch" not in e and "peak_measured" not in e     # nothing replayed sits beside the live fields
     c = bench.roofline_entry(0, "conv1_fwd(gather+norm+conv+relu)", 0.012, 32, 4)
     assert c["bound"] == "mfma" and c["unit"] == "TFLOP/s"                  # AI ~ 94 FLOP/B: compute-bound in fp32
     assert bench.rocprof_us(16, 256, 3) is None                             # other shapes: no committed profile

@@ -171,7 +171,8 @@ def test_100_step_q_parity_teacher_forced(sd):
     fp32 round-off of its threshold flips the mask in one implementation only, which is a finite
     gradient difference that RMSProp's sign-like early steps turn into ~1e-3 weight moves.  The oracle
     in fp32 vs fp64 shows the same rare events (parity); so: median at round-off level,
-    >= 90 % of the steps within 1e-4, and no step beyond 5e-2."""
+    >= 95 % of the steps within 1e-4 and no step beyond 2e-3 (measured on MI355X: 98 %, worst 4.4e-4 — the bounds sit
+    ~2x / ~4x above that so that a real regression fails)."""
     A, B = 4, 32
     net, o = _pair(sd, A, B, 21)
     hold = random_minibatch(B, A, 99)[0]
@@ -190,8 +191,8 @@ def test_100_step_q_parity_teacher_forced(sd):
     print("teacher-forced 100 steps: Q max-abs err median %.3e, p90 %.3e, worst %.3e, steps > 1e-4: %d"
           % (np.median(errs), np.percentile(errs, 90), errs.max(), int((errs >= Q_TOL).sum())))
     assert np.median(errs) < 1e-5
-    assert (errs < Q_TOL).mean() >= 0.90
-    assert errs.max() < 5e-2
+    assert (errs < Q_TOL).mean() >= 0.95
+    assert errs.max() < 2e-3
 
 
 def test_100_step_free_running_chaos_budget(sd):
@@ -215,7 +216,7 @@ def test_100_step_free_running_chaos_budget(sd):
     print("free-running 100 steps: MAE hip-vs-fp64 %.3e, oracle fp32-vs-fp64 %.3e, hip-vs-fp32 %.3e"
           % (e_hip, e_ora, np.abs(q - q32).mean()))
     assert np.isfinite(q).all()
-    assert e_hip < 3.0 * e_ora + 1e-3
+    assert e_hip < 1.5 * e_ora + 1e-3           # measured: 0.5-0.9x the oracle's own fp32-vs-fp64 drift
 
 
 def test_train_replay_equals_train_host(sd):

@@ -1,0 +1,276 @@
+"""Round-2 parity additions (VERDICT r1 "next round" item 1): the BASELINE.json configs that round 1 only touched at
+other shapes — fp16 at A=6 (configs[4]), B=256 at A=6 and in the fused train_from_memory loop (configs[2]) — and the
+data-parallel arithmetic on ONE GPU in a form that is not the identity (two learners' gradient sums added on the host,
+applied through the library's apply-only update with divisor 2B, against the oracle on the concatenated batch).
+Tolerances are stated next to each assert; fp32 Q-values are held to BASELINE.json's 1e-4."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from oracle.dqn_numpy import OracleDQN, xavier_weights
+from oracle.replay_numpy import ReplayOracle, synthetic_fill
+from util import make_args, random_minibatch
+
+pytestmark = pytest.mark.gpu
+Q_TOL = 1e-4
+H_TOL = 3e-3          # fp16 mode vs its own (half-rounding) oracle: a few half ulps through 5 layers
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import simple_dqn_amd
+    return simple_dqn_amd
+
+
+def _net(sd, A, B, seed, **kw):
+    args = make_args(batch_size=B, **kw)
+    net = sd.DeepQNetwork(A, args)
+    ws, wt = xavier_weights(A, seed), xavier_weights(A, seed + 1)
+    net.set_weights(wt, 1)
+    net.set_weights(ws, 0)
+    return net, ws, wt
+
+
+# ---- configs[4]: float16 activations at A = 6, B = 32 ---------------------------------------------------------------
+def test_fp16_a6_one_step_and_five_step_tracking(sd):
+    A, B = 6, 32
+    net, ws, wt = _net(sd, A, B, 611, datatype="float16")
+    o = OracleDQN(A, batch_size=B, weights=ws, half_activations=True)
+    o.Wt = [w.copy() for w in wt]
+    net.set_option("keep_gradients", 1)
+    mb = random_minibatch(B, A, 612, reward_range=(-2, 3))
+    g, cost, _, preq = o.gradients(mb)
+    costs = []
+    net.callback = type("CB", (), {"on_train": lambda self, c: costs.append(c)})()
+    net.train(mb)
+    q, _ = net.last_q()
+    assert np.abs(q - preq).max() < H_TOL
+    assert abs(costs[0] - float(cost)) < 5e-3 * max(1.0, float(cost))
+    for i in range(5):
+        rel = np.abs(net.get_layer(i, which=3) - g[i]).max() / max(1e-6, np.abs(g[i]).max())
+        print("fp16 A=6 grad layer %d: max rel err %.3e" % (i, rel))
+        assert rel < 2e-2, i                                   # half rounding of activations/deltas under fp32 accumulation
+    # 5 free-running steps (fused fc4 update) against the half oracle; fused == unfused bit for bit
+    n1, _, _ = _net(sd, A, B, 621, datatype="float16")
+    n2, ws2, wt2 = _net(sd, A, B, 621, datatype="float16")
+    n2.set_option("keep_gradients", 1)
+    o2 = OracleDQN(A, batch_size=B, weights=ws2, half_activations=True)
+    o2.Wt = [w.copy() for w in wt2]
+    hold = random_minibatch(B, A, 622)[0]
+    for s in range(5):
+        mb = random_minibatch(B, A, 623 + s, p_term=0.05, reward_range=(-1, 2))
+        n1.train(mb); n2.train(mb); o2.train(mb)
+    q1, q2, qo = n1.predict(hold), n2.predict(hold), o2.predict(hold)
+    print("fp16 A=6, 5 steps: Q max abs err vs half oracle %.3e" % np.abs(q1 - qo).max())
+    assert np.array_equal(q1, q2)
+    assert np.abs(q1 - qo).max() < 2e-2
+
+
+# ---- configs[2]: B = 256 --------------------------------------------------------------------------------------------
+def test_batch256_a6_one_step(sd):
+    A, B = 6, 256
+    net, ws, wt = _net(sd, A, B, 631)
+    o = OracleDQN(A, batch_size=B, weights=ws)
+    o.Wt = [w.copy() for w in wt]
+    net.set_option("keep_gradients", 1)
+    mb = random_minibatch(B, A, 632, reward_range=(-2, 3))
+    g, cost, _, preq = o.gradients(mb)
+    costs = []
+    net.callback = type("CB", (), {"on_train": lambda self, c: costs.append(c)})()
+    net.train(mb)
+    q, _ = net.last_q()
+    assert np.abs(q - preq).max() < Q_TOL
+    assert abs(costs[0] - float(cost)) < 1e-5 * max(1.0, float(cost))
+    for i in range(5):
+        rel = np.abs(net.get_layer(i, 3) - g[i]).max() / max(1e-3, np.abs(g[i]).max())
+        assert rel < 2e-4, (i, rel)                            # K = B*400 = 102400-long fp32 sums in conv1 wgrad
+
+
+def test_batch256_train_from_memory_five_steps(sd):
+    """The fused loop (native sampler -> gather fused into conv1 -> step) at B = 256, A = 3, 5 free-running steps from a
+    ring: indexes bit-exact (same MT stream as the oracle's sampler), Q of a held-out batch within 1e-4."""
+    A, B, size = 3, 256, 6000
+    args = make_args(batch_size=B)
+    mem, omem = sd.ReplayMemory(size, args), ReplayOracle(size, batch_size=B)
+    synthetic_fill(mem, 641, num_actions=A)
+    synthetic_fill(omem, 641, num_actions=A)
+    mem.sync_mirror()
+    net, ws, wt = _net(sd, A, B, 642)
+    o = OracleDQN(A, batch_size=B, weights=ws)
+    o.Wt = [w.copy() for w in wt]
+    random.seed(643)
+    st = random.getstate()
+    net.train_from_memory(mem, 5)
+    after = random.getstate()
+    random.setstate(st)
+    for _ in range(5):
+        o.train(omem.getMinibatch())
+    assert random.getstate() == after                          # the native sampler consumed exactly the reference's draws
+    hold = omem.getMinibatch()[0]
+    err = np.abs(net.predict(hold) - o.predict(hold))
+    print("B=256 train_from_memory x5: Q MAE %.3e max %.3e" % (err.mean(), err.max()))
+    assert err.max() < Q_TOL
+
+
+# ---- data-parallel arithmetic, not the identity ---------------------------------------------------------------------
+@pytest.mark.parametrize("datatype", ["float32"])
+def test_dp_arithmetic_two_learners_one_gpu(sd, datatype):
+    """What two data-parallel ranks compute, on one GPU without RCCL: each learner stops after its LOCAL gradient sums
+    (option grad_only = update mode 1), the host adds the two flat gradients (the all-reduce), and the library's
+    apply-only update (mode 2) runs with divisor R*B = 2B on both — the result must equal the oracle trained on the
+    concatenated 2B batch (Neon semantics: gradient SUM over the batch, then grad / be.bsz, deepqnetwork.py:162-165),
+    and both learners must end bit-identical."""
+    A, B = 4, 32
+    n1, ws, wt = _net(sd, A, B, 651, datatype=datatype)
+    n2, _, _ = _net(sd, A, B, 651, datatype=datatype)
+    o = OracleDQN(A, batch_size=2 * B, weights=ws)
+    o.Wt = [w.copy() for w in wt]
+    for n in (n1, n2):
+        n.set_option("grad_only", 1)
+    for s in range(3):
+        mb1 = random_minibatch(B, A, 652 + 2 * s, reward_range=(-2, 3))
+        mb2 = random_minibatch(B, A, 653 + 2 * s, reward_range=(-2, 3))
+        w_before = n1.get_weights(0)
+        n1.train(mb1); n2.train(mb2)
+        for a, b in zip(n1.get_weights(0), w_before):
+            assert np.array_equal(a, b)                        # grad_only really applied nothing
+        gsum = [n1.get_layer(i, 3) + n2.get_layer(i, 3) for i in range(5)]      # the all-reduce (sum), on the host
+        both = tuple(np.concatenate([x, y]) for x, y in zip(mb1, mb2))
+        g, _, _, _ = o.gradients(both)
+        for i in range(5):
+            assert np.abs(gsum[i] - g[i]).max() < 1e-4 * max(1e-3, np.abs(g[i]).max()), ("grad", s, i)
+        for n in (n1, n2):
+            for i in range(5):
+                n.set_layer(i, gsum[i], 3)
+            n.apply_update(2 * B)
+        o.rmsprop(g, 2 * B)
+        for i in range(5):
+            assert np.array_equal(n1.get_layer(i, 0), n2.get_layer(i, 0)), i
+            assert np.array_equal(n1.get_layer(i, 2), n2.get_layer(i, 2)), i
+            big = np.abs(g[i]) / (2 * B) > 1e-6
+            assert np.abs(n1.get_layer(i, 0) - o.W[i])[big].max() < 2e-5, ("weights", s, i)
+            assert np.abs(n1.get_layer(i, 2) - o.S[i]).max() < 1e-6 + 1e-3 * np.abs(o.S[i]).max(), ("state", s, i)
+        # keep the three in lock-step for the next round (the comparison above is per step, not free-running)
+        for n in (n1, n2):
+            n.set_weights(o.W, 0); n.set_weights(o.S, 2)
+    hold = random_minibatch(B, A, 660)[0]
+    assert np.abs(n1.predict(hold) - o.predict(np.concatenate([hold, hold]))[:B]).max() < Q_TOL
+
+
+def test_dp_divisor_is_ranks_times_batch(sd):
+    """apply_update(bsz) with bsz = B reproduces the ordinary single-learner step bit for bit; with 2B it does not."""
+    A, B = 4, 32
+    ref, _, _ = _net(sd, A, B, 671)
+    ref.set_option("keep_gradients", 1)
+    n, _, _ = _net(sd, A, B, 671)
+    n.set_option("grad_only", 1)
+    mb = random_minibatch(B, A, 672)
+    ref.train(mb); n.train(mb)
+    n.apply_update(B)
+    for i in range(5):
+        assert np.array_equal(ref.get_layer(i, 0), n.get_layer(i, 0)), i
+        assert np.array_equal(ref.get_layer(i, 2), n.get_layer(i, 2)), i
+    n2, _, _ = _net(sd, A, B, 671)
+    n2.set_option("grad_only", 1)
+    n2.train(mb); n2.apply_update(2 * B)
+    assert not np.array_equal(ref.get_layer(3, 2), n2.get_layer(3, 2))
+
+
+# ---- boundary: --device_id, ring-action validation, error text ------------------------------------------------------
+def test_device_id_is_honoured_or_refused(sd):
+    """src/deepqnetwork.py:29-34 passes args.device_id to the backend.  Here: the drop-in classes bind it; the bound
+    device is reported; a second object asking for ANOTHER device is refused instead of silently running on this one."""
+    lib = sd.load()
+    dev = C.c_int(-1)
+    assert lib.sdqn_get_device(C.byref(dev)) == 0
+    assert dev.value == 0
+    net = sd.DeepQNetwork(4, make_args(batch_size=8, device_id=0))       # same device again: fine
+    assert net.dp_info()["bound_device"] == 0 and net.dp_info()["comm_ranks"] == -1
+    n = C.c_int(0)
+    assert lib.sdqn_device_count(C.byref(n)) == 0
+    other = 1 if n.value > 1 else 7
+    with pytest.raises(RuntimeError) as ei:
+        sd.DeepQNetwork(4, make_args(batch_size=8, device_id=other))
+    assert "already bound to device 0" in str(ei.value)
+    with pytest.raises(RuntimeError):
+        sd.ReplayMemory(100, make_args(batch_size=8, device_id=other))
+    assert lib.sdqn_set_device(0) == 0                                    # C ABI: re-asking for the bound device is a no-op
+    assert lib.sdqn_set_device(other) == -4                               # SDQN_ERR_STATE
+
+
+def test_ring_action_out_of_range_is_rejected(sd):
+    """the ring paths took actions unchecked (the tuple API checks them, sdqn_api.hip train_host)."""
+    A, B, size = 4, 8, 300
+    args = make_args(batch_size=B)
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 3, num_actions=A)
+    mem.actions[:] = A                                                    # every slot holds an action the net lacks
+    mem.sync_mirror()
+    net = sd.DeepQNetwork(A, args)
+    random.seed(1)
+    with pytest.raises(AssertionError) as ei:
+        net.train_from_memory(mem, 2)
+    assert "actions" in str(ei.value)
+    idx = np.arange(10, 10 + B)
+    with pytest.raises(AssertionError):
+        net.train_indexes(mem, idx)
+    mem.count = 100
+    with pytest.raises(AssertionError):
+        mem.gather(np.full(B, 150))                                       # beyond count (was: only beyond size)
+
+
+def test_minibatch_small_arrays_are_copies(sd):
+    """replay_memory.py:76-79: prestates/poststates alias the preallocated buffers, actions/rewards/terminals are fresh."""
+    B, size = 8, 400
+    mem = sd.ReplayMemory(size, make_args(batch_size=B))
+    synthetic_fill(mem, 5, num_actions=4)
+    mem.sync_mirror()
+    random.seed(2)
+    p1, a1, r1, q1, t1 = mem.getMinibatch()
+    a1c, r1c, t1c = a1.copy(), r1.copy(), t1.copy()
+    p2, a2, r2, q2, t2 = mem.getMinibatch()
+    assert p1 is p2 and q1 is q2
+    assert np.array_equal(a1, a1c) and np.array_equal(r1, r1c) and np.array_equal(t1, t1c)
+    assert a1.dtype == np.uint8 and r1.dtype == np.int64 and t1.dtype == np.bool_
+
+
+def test_on_train_called_per_step_with_callback(sd):
+    """deepqnetwork.py:168-172: every step reports its cost; the fused n-step loop keeps that when a callback is set."""
+    A, B, size = 4, 16, 800
+    args = make_args(batch_size=B)
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 7, num_actions=A)
+    mem.sync_mirror()
+    n1, _, _ = _net(sd, A, B, 681)
+    n2, _, _ = _net(sd, A, B, 681)
+    c1, c2 = [], []
+    n1.callback = type("CB", (), {"on_train": lambda self, c: c1.append(c)})()
+    n2.callback = type("CB", (), {"on_train": lambda self, c: c2.append(c)})()
+    random.seed(4); st = random.getstate()
+    n1.train_from_memory(mem, 4)
+    random.setstate(st)
+    for _ in range(4):
+        n2.train(mem.getMinibatch())
+    assert len(c1) == 4 and c1 == c2 and n1.train_iterations == 4
+    for i in range(5):
+        assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
+
+
+# ---- multi-GPU readiness that a 1-GPU box can check --------------------------------------------------------------------
+def test_bench_dry_run_dp_two_ranks(sd):
+    """bench.py under torch.distributed.run with 2 ranks sharing the one GPU (control plane only: gloo id exchange,
+    barriers, max-reduce of the time; no RCCL communicator): the JSON line is the LAST stdout line and says n_gpus = 2."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "10",
+           "--replay-size", "20000", "--no-cpu-baseline", "--dry-run-dp"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 2 and out["steps"] == 30 and out["value"] > 0
+    assert out["dp"]["ranks"] == 2 and len(out["dp"]["per_rank"]) == 2
