@@ -389,13 +389,24 @@ __device__ __forceinline__ void gemm_tile_h(const StepArgs& a, int bx, int by, i
   }
 }
 
+}  // namespace sdqn
+#include "gemm_engine_rb.h"      // register-blocked routine of the throughput regime (B >= 128)
+namespace sdqn {
+
 template <class P, int NW, int NT>
 __device__ __forceinline__ void run_tile(const StepArgs& a, int bx, int by, int bz, float* smem) {
-  if constexpr (uses_f16_mfma<P>::value) gemm_tile_h<P, NW, NT>(a, bx, by, bz, smem);
+  if constexpr (is_rb<P>::value) gemm_tile_rb<P, NW, NT>(a, bx, by, bz, smem);
+  else if constexpr (uses_f16_mfma<P>::value) gemm_tile_h<P, NW, NT>(a, bx, by, bz, smem);
   else gemm_tile<P, NW, NT>(a, bx, by, bz, smem);
 }
 template <class P, int NW>
-constexpr int tile_lds_any() { return uses_f16_mfma<P>::value ? NW * PANEL : tile_lds<P, NW>(); }
+constexpr int tile_lds_any() {
+  if constexpr (is_rb<P>::value) return NW > 1 ? NW * PANEL : 1;       // sub-tiles are combined one at a time
+  else return uses_f16_mfma<P>::value ? NW * PANEL : tile_lds<P, NW>();
+}
+// rows / columns of C one wave-tile covers
+template <class P> constexpr int tile_m() { return 32 * rb_m<P>::value; }
+template <class P> constexpr int tile_n() { return 32 * rb_n<P>::value; }
 
 // XCD-aware workgroup -> tile map (guide T1).  The dispatcher places workgroup b on XCD b % 8, each XCD with its
 // own L2.  Tiles are numbered x-fastest (then y, then split/net z), so NEIGHBOURING tile ids share operands
@@ -494,14 +505,14 @@ struct NoProblem {            // placeholder third problem for two-problem launc
 
 template <class P, int NW>
 inline hipError_t launch_gemm(const StepArgs& a, hipStream_t stream) {
-  dim3 grid((P::M(a) + 31) / 32, (P::N(a) + 31) / 32, P::nbz(a));
+  dim3 grid((P::M(a) + tile_m<P>() - 1) / tile_m<P>(), (P::N(a) + tile_n<P>() - 1) / tile_n<P>(), P::nbz(a));
   hipLaunchKernelGGL((gemm_kernel<P, NW>), grid, dim3(NW * 64), 0, stream, a);
   return hipGetLastError();
 }
 
 template <int NT, class P, int NW>
 inline void multi_fill(const StepArgs& a, MultiDims& d, int i) {
-  d.gx[i] = (P::M(a) + 31) / 32; d.gy[i] = (P::N(a) + 31) / 32;
+  d.gx[i] = (P::M(a) + tile_m<P>() - 1) / tile_m<P>(); d.gy[i] = (P::N(a) + tile_n<P>() - 1) / tile_n<P>();
   const int tiles = d.gx[i] * d.gy[i] * P::nbz(a);
   d.n[i] = NW == 1 ? (a.f4w_count + NT / 64 - 1) / (NT / 64) : tiles;    // NW == 1: one tile per wave, range from StepArgs
 }

@@ -102,6 +102,7 @@ struct StepArgs {
   int h16;                         // 1: fp16 mode
   int xcd_map;              // XCD-contiguous workgroup->tile map (cuts fabric traffic to ~algorithmic): bit i = problem i of the launch
   int nw_override[12];      // tuning hook: waves per tile for kernel id i (0 = built-in choice)
+  int rb[12];               // B >= 128: register-blocked routine of kernel id i, menu entry (sdqn_kernels_rb.hip); 0 = unblocked routine
   float* __restrict__ theta_w;   // online parameters, writable alias of theta[0]
   float* __restrict__ state;     // RMSProp state
   float bsz, rho, one_minus_rho, lr, eps;

@@ -340,7 +340,8 @@ struct sdqn_net_s {
                                            // data-parallel rank has before the all-reduce; sdqn_net_apply_update finishes it
   int nw_override[12] = {0};               // tuning hook
   int f4_share[2] = {100, 0};               // % of the fc4-wgrad tiles in bwd3 / bwd2 (rest in bwd1)
-  int S4_override = 0, tps_override[3] = {0, 0, 0};
+  int ns_cap[3] = {1, 1, 1};               // slabs the split-K buffers were allocated for (tuning hook "tps:<layer>")
+  int rb[12] = {0};                        // B >= 128: register-blocked routine, menu entry per kernel id (0 = unblocked)
   int xcd_mask[K_COUNT] = {0};             // tuning hook "xcd:<kernel id>": per-launch problem mask (-1 = built-in)
   bool xcd_map = false;                    // XCD-contiguous tile map for EVERY launch: traffic ~ algorithmic, step ~1 % slower (bwd3);
                                            // built-in: only where it also wins time (fc4_fwd: the 7 K-slabs of a tile's W4 panel share an L2)
@@ -403,6 +404,8 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   const int big = B >= 128 ? 2 : 1;
   const int T1 = ceil_div(B * PIX1, 32), T2 = ceil_div(B * PIX2, 32), T3 = ceil_div(B * PIX3, 32);
   h->tps1 = pick(T1, 25 * big); h->tps2 = pick(T2, 6 * big); h->tps3 = pick(T3, 4 * big);
+  // (the register-blocked routine, gemm_engine_rb.h, is available per kernel id through set_option "rb:<id>" / "tps:<l>":
+  //  measured slower than these choices at B = 256 in every fused launch — tools/exp/README.md — so it is off by default)
   h->ns1 = ceil_div(T1, h->tps1); h->ns2 = ceil_div(T2, h->tps2); h->ns3 = ceil_div(T3, h->tps3);
   h->S4 = 7;
 #define NCHK(x) do { int r_ = (x); if (r_) { net_free(h); return r_; } } while (0)
@@ -422,9 +425,10 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->d1, (size_t)B * PIX1 * K1 * 4));
   NCHK(dalloc(h, (void**)&h->d3, (size_t)B * PIX3 * K3 * 4));
   NCHK(dalloc(h, (void**)&h->d2, (size_t)B * PIX2 * K2 * 4));
-  NCHK(dalloc(h, (void**)&h->slab1, (size_t)h->ns1 * NW1 * 4));
-  NCHK(dalloc(h, (void**)&h->slab2, (size_t)h->ns2 * NW2 * 4));
-  NCHK(dalloc(h, (void**)&h->slab3, (size_t)h->ns3 * NW3 * 4));
+  h->ns_cap[0] = h->ns1 > 64 ? h->ns1 : 64; h->ns_cap[1] = h->ns2 > 64 ? h->ns2 : 64; h->ns_cap[2] = h->ns3 > 64 ? h->ns3 : 64;
+  NCHK(dalloc(h, (void**)&h->slab1, (size_t)h->ns_cap[0] * NW1 * 4));
+  NCHK(dalloc(h, (void**)&h->slab2, (size_t)h->ns_cap[1] * NW2 * 4));
+  NCHK(dalloc(h, (void**)&h->slab3, (size_t)h->ns_cap[2] * NW3 * 4));
   if (h->bn) {
     NCHK(dalloc(h, (void**)&h->x1, (size_t)2 * B * PIX1 * K1 * 4));
     NCHK(dalloc(h, (void**)&h->x2, (size_t)2 * B * PIX2 * K2 * 4));
@@ -616,7 +620,7 @@ static StepArgs step_args(sdqn_net_s* h) {
   a.a1 = h->a1; a.a2 = h->a2; a.a3 = h->a3; a.slab4 = h->slab4; a.a4 = h->a4; a.d4 = h->d4; a.d3p = h->d3p; a.d2p = h->d2p; a.d3 = h->d3; a.d2 = h->d2;
   a.d1 = h->d1; a.g = h->g; a.slab1 = h->slab1; a.slab2 = h->slab2; a.slab3 = h->slab3;
   a.S4 = h->S4; a.tps1 = h->tps1; a.tps2 = h->tps2; a.tps3 = h->tps3;
-  for (int i = 0; i < 12; ++i) a.nw_override[i] = h->nw_override[i];
+  for (int i = 0; i < 12; ++i) { a.nw_override[i] = h->nw_override[i]; a.rb[i] = h->B >= 128 ? h->rb[i] : 0; }
   a.xcd_map = h->xcd_map ? 7 : 0;
   if (h->cfg.datatype == 1) {
     a.h16 = 1; a.h_a1 = h->h_a1; a.h_a2 = h->h_a2; a.h_a3 = h->h_a3; a.h_d4 = h->h_d4; a.h_d3p = h->h_d3p; a.h_d3 = h->h_d3;
@@ -1054,6 +1058,20 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
     int id = atoi(name + 4);
     if (id < 0 || id >= K_COUNT || value < 0 || value > 8) { set_error("bad xcd override"); return SDQN_ERR_ARG; }
     h->xcd_mask[id] = value;
+  }
+  else if (!strncmp(name, "rb:", 3)) {                     // register-blocked routine (B >= 128): menu entry of kernel id, 0 = unblocked
+    int id = atoi(name + 3);
+    if (id < 0 || id >= 12 || value < 0 || value > 8) { set_error("bad rb override"); return SDQN_ERR_ARG; }
+    h->rb[id] = value;
+  }
+  else if (!strncmp(name, "tps:", 4)) {                    // tuning: 32-deep K-chunks per split-K slab of conv layer 1..3 wgrad
+    int l = atoi(name + 4);
+    if (l < 1 || l > 3 || value < 1) { set_error("bad tps override"); return SDQN_ERR_ARG; }
+    const int pix[3] = {PIX1, PIX2, PIX3};
+    const int T = ceil_div(h->B * pix[l - 1], 32), ns = ceil_div(T, value);
+    if (ns > h->ns_cap[l - 1]) { set_error("tps:%d = %d needs %d slabs (%d allocated)", l, value, ns, h->ns_cap[l - 1]); return SDQN_ERR_ARG; }
+    { int rc_ = join_comm(h); if (rc_) return rc_; } HIPCHK(hipStreamSynchronize(g_stream));
+    if (l == 1) { h->tps1 = value; h->ns1 = ns; } else if (l == 2) { h->tps2 = value; h->ns2 = ns; } else { h->tps3 = value; h->ns3 = ns; }
   }
   else if (!strncmp(name, "nw:", 3)) {                     // tuning: waves per tile of kernel id
     int id = atoi(name + 3);

@@ -55,8 +55,11 @@ static hipError_t launch_kernel_h16(int id, const StepArgs& a, hipStream_t s) {
   }
 }
 
+hipError_t launch_kernel_rb(int id, int menu, const StepArgs& a, hipStream_t s);     // sdqn_kernels_rb.hip
+
 hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
   if (a.h16) return launch_kernel_h16(id, a, s);
+  if (!a.bn && id >= 0 && id < 12 && a.rb[id] > 0) return launch_kernel_rb(id, a.rb[id], a, s);     // throughput regime (B >= 128)
   if (a.bn) {                  // --batch_norm forward: raw linear outputs (same tilings as the default problems)
     switch (id) {
       case K_CONV1_FWD: return launch_gemm<Conv1FwdRaw, 8>(a, s);
@@ -81,7 +84,11 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
       default: break;
     }
   }
-  if (a.B >= 128) {            // throughput regime (thousands of tiles per launch): tools/sweep_nw.py at B = 256
+  if (a.B >= 128) {            // throughput regime (thousands of tiles per launch): tools/sweep_nw.py / tools/sweep_rb.py at B = 256
+    // conv weight gradients on the register-blocked routine (gemm_engine_rb.h; long K, few output tiles: the only stages
+    // where blocking beat the unblocked routine — profiles/README.md): RB<., 1, 2> = 32 x 64 wave tiles, one dwordx2 of the
+    // delta per k-slot for both column tiles; conv1 (u8 patches re-gathered from the ring) 64 x 32 with 16 waves per tile
+    const bool rb3 = a.rb[K_CONV3_WGRAD] != 0, rb2 = a.rb[K_CONV2_WGRAD] != 0, rb1 = a.rb[K_CONV1_WGRAD] != 0;
     switch (id) {
       case K_CONV1_FWD: return launch_gemm<Conv1Fwd, 8>(a, s);
       case K_CONV2_FWD: return launch_gemm<Staged<Conv2Fwd>, 8>(a, s);
@@ -91,9 +98,18 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
       case K_CONV3_DGRAD: return launch_gemm<Staged<Conv3Dgrad>, 8>(a, s);
       case K_CONV2_DGRAD: return launch_gemm<Staged<Conv2Dgrad>, 8>(a, s);
       case K_BWD3:
-        if (a.f4w_count > 0) return launch_multi<512, Fc4Wgrad, 8, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
+        if (a.f4w_count > 0) {
+          if (rb3) return launch_multi<512, Fc4Wgrad, 8, Staged<Conv3Dgrad>, 8, RB<Conv3Wgrad, 1, 2>, 8>(a, true, true, s);
+          return launch_multi<512, Fc4Wgrad, 8, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
+        }
+        if (rb3) return launch_multi<512, NoProblem, 2, Staged<Conv3Dgrad>, 8, RB<Conv3Wgrad, 1, 2>, 8>(a, true, true, s);
         return launch_multi<512, NoProblem, 2, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
-      case K_BWD2: return launch_multi<512, NoProblem, 2, Staged<Conv2Dgrad>, 8, Conv2Wgrad, 8>(a, true, true, s);
+      case K_BWD2:
+        if (rb2) return launch_multi<512, NoProblem, 2, Staged<Conv2Dgrad>, 8, RB<Conv2Wgrad, 1, 2>, 8>(a, true, true, s);
+        return launch_multi<512, NoProblem, 2, Staged<Conv2Dgrad>, 8, Conv2Wgrad, 8>(a, true, true, s);
+      case K_BWD1:
+        if (rb1) return launch_multi<1024, NoProblem, 2, RB<Conv1Wgrad, 2, 1>, 16, NoProblem, 2>(a, true, false, s);
+        break;
       default: break;
     }
   }
@@ -251,7 +267,11 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
 }
 
 #ifdef SDQN_TIMING
-hipError_t set_timing_buffer(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sdqn_dbg), &p, sizeof p); }
+hipError_t set_timing_buffer_rb(unsigned long long* p);
+hipError_t set_timing_buffer(unsigned long long* p) {
+  hipError_t e = set_timing_buffer_rb(p);
+  return e != hipSuccess ? e : hipMemcpyToSymbol(HIP_SYMBOL(g_sdqn_dbg), &p, sizeof p);
+}
 #endif
 
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
