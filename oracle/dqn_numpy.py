@@ -126,7 +126,6 @@ class OracleDQN:
 
     def fprop(self, W, x, keep=False):
         """x (N, C, H, W) normalised. Returns q (N, A) [+ saved tensors]."""
-        x32 = x
         x = self._h(x)
         acts, cols_all = [x], []
         a = x
@@ -137,8 +136,8 @@ class OracleDQN:
             a = np.ascontiguousarray(z.transpose(0, 2, 1)).reshape(x.shape[0], K, P, Q)
             acts.append(a)
             cols_all.append(cols)
-        if self.half:                                             # conv1 wgrad re-reads the fp32-normalised frames
-            cols_all[0] = _im2col(x32, CONV[0][0], CONV[0][1], CONV[0][3])[0]
+        # (half mode: conv1's weight gradient reads the same half-rounded normalised frames as its forward pass — every
+        #  MFMA operand of the fp16 mode is half; round 1 re-read them in fp32 for its fp32-MFMA wgrad)
         a3f = a.reshape(x.shape[0], -1)                           # (K,P,Q) flatten (A2)
         a4 = np.maximum(a3f @ self._h(W[3]).T, 0)                 # a4 and fc5 stay fp32
         q = a4 @ W[4].T

@@ -45,6 +45,8 @@ template <class P> struct Staged : P { static constexpr bool STAGE_LDS = true; }
 // lane needs 4 gathered offsets per chunk instead of 16 and fetches its 4 bytes with ONE unaligned 16-byte load
 template <class P, class = void> struct a_group4 { static constexpr bool value = false; };
 template <class P> struct a_group4<P, decltype((void)P::A_GROUP4)> { static constexpr bool value = P::A_GROUP4; };
+template <class P, class = void> struct uses_f16_wgrad { static constexpr bool value = false; };
+template <class P> struct uses_f16_wgrad<P, decltype((void)P::F16_WGRAD)> { static constexpr bool value = P::F16_WGRAD; };
 template <class P, class = void> struct uses_f16_mfma { static constexpr bool value = false; };
 template <class P> struct uses_f16_mfma<P, decltype((void)P::F16_MFMA)> { static constexpr bool value = P::F16_MFMA; };
 
@@ -393,15 +395,149 @@ __device__ __forceinline__ void gemm_tile_h(const StepArgs& a, int bx, int by, i
 #include "gemm_engine_rb.h"      // register-blocked routine of the throughput regime (B >= 128)
 namespace sdqn {
 
+
+// ---- fp16-mode weight gradients on packed-fp16 MFMA ---------------------------------------------------------------
+// C(m, n) = sum_k A(k, m) B(k, n) with k = (sample, output position): BOTH operands are contiguous along m / n in memory
+// (NHWC activations, dense deltas), while v_mfma_f32_32x32x16_f16 wants 8 consecutive k per lane.  So every 32-deep
+// K-chunk goes through a wave-private LDS transpose: lane (k = l & 31, part = l >> 5) fetches 16 consecutive halves
+// (32 B, two 16-byte loads) of row k of each operand and stores them as [k][x] rows (pitch 40 halves: 16-byte aligned,
+// conflict-free for the 8-lane groups of ds_write_b128); lane (i = l & 31, h = l >> 5) then reads its 8 k-values of
+// column i with 8 ds_read_u16 (lanes along x: 64 contiguous bytes per half-wave, no conflicts) per MFMA operand.
+// 4 loads + 4 wide stores + 32 narrow reads + 2 MFMAs per chunk instead of 32 loads + 16 fp32 MFMAs (1024 pipe cycles).
+// conv1's A operand needs no transpose: the 4 output positions of an aligned k-group are 4 bytes apart in the u8 frame
+// (A_GROUP4), so a lane builds its 8 k-values from two unaligned 16-byte ring loads, normalised and rounded to half like
+// the forward pass does.  fp32 accumulation, K split over NW waves and combined in fixed order, same epilogues as the
+// fp32-MFMA wgrads (loss scale divided out, fused RMSProp + half-copy refresh for fc4).
+constexpr int HW_PITCH = 40;                                   // halves per staged k-row
+constexpr int HW_TILE = 32 * HW_PITCH;                         // one [32 k][32 x] half tile: 2560 B
+constexpr int HW_WAVE_LDS = (2 * HW_TILE * 2 + 3) / 4 > PANEL ? (2 * HW_TILE * 2 + 3) / 4 : PANEL;   // floats per wave: two half tiles, later one fp32 combine panel
+static_assert(2 * HW_TILE * 2 <= HW_WAVE_LDS * 4 && PANEL <= HW_WAVE_LDS, "staging tiles / combine panel fit the per-wave region");
+__device__ __forceinline__ half8 ld_half8(const half_t* p) { return *reinterpret_cast<const half8*>(p); }
+
+template <class P, int NW, int NT>
+__device__ __forceinline__ void gemm_tile_hw(const StepArgs& a, int bx, int by, int bz, float* smem) {
+  typedef typename P::aoff_t aoff_t;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m0 = bx * 32, n0 = by * 32;
+  int z, ks, kbeg, kend;
+  P::ksplit(a, bz, z, ks, kbeg, kend);
+  if (NW * 64 < NT && wave >= NW) kend = kbeg;
+  const int M = P::M(a), N = P::N(a);
+  const int i = lane & 31, hb = lane >> 5;
+  const bool hi = lane >= 32;
+  // NW == 1 inside a wider workgroup (one tile per wave, gemm_multi_kernel): every wave stages in its own region
+  half_t* sa = reinterpret_cast<half_t*>(smem + (NW == 1 ? wave : (wave < NW ? wave : 0)) * HW_WAVE_LDS);
+  half_t* sb = sa + HW_TILE;
+  const half_t* bbase = P::b_ptr(a, z);
+  // staging role: this lane fetches halves [16 * hb, 16 * hb + 16) of row k = kc + i of the chunk
+  const int bcol16 = P::b_col(a, z, n0 + 16 * hb);
+  aoff_t arow16 = 0, arow_own = 0;
+  if constexpr (P::A_U8) arow_own = P::a_row(a, z, m0 + i < M ? m0 + i : M - 1);          // conv1: own row, direct
+  else arow16 = P::a_row(a, z, m0 + 16 * hb);
+  (void)arow16; (void)arow_own;
+
+  typename P::Epi epi;
+  if constexpr (NW == 1) P::epi_begin(a, m0, n0, lane, epi);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+  half8 pa0, pa1, pb0, pb1;                                    // staged rows of the NEXT chunk (prefetched)
+  aoff_t cvn = 0;                                             // conv1: patch origin of k = kc + i of the next chunk
+  auto stage_load = [&](int kc) {
+    const int kl = kc + i;
+    const int kk = kl < kend ? kl : kbeg;
+    const half8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    const half_t* pb = bbase + (size_t)kk * P::B_LD + bcol16;
+    pb0 = ld_half8(pb); pb1 = ld_half8(pb + 8);
+    if (kl >= kend) { pb0 = zero; pb1 = zero; }
+    if constexpr (P::A_U8) cvn = P::a_col(a, z, kk);
+    else {
+      const half_t* pa;
+      if constexpr (P::A_REG) pa = P::a_ptr(a, z) + (size_t)kk * P::A_LD + (size_t)arow16;
+      else pa = P::a_ptr(a, z) + (uint32_t)(arow16 + P::a_col(a, z, kk));
+      pa0 = ld_half8(pa); pa1 = ld_half8(pa + 8);
+      if (kl >= kend) { pa0 = zero; pa1 = zero; }
+    }
+  };
+  int kc = kbeg + (wave < NW ? wave : 0) * 32;
+  if (kc < kend) stage_load(kc);
+  while (kc < kend) {
+    // staged rows -> LDS ([k][x], pitch 40 halves)
+    *reinterpret_cast<half8*>(sb + i * HW_PITCH + 16 * hb) = pb0;
+    *reinterpret_cast<half8*>(sb + i * HW_PITCH + 16 * hb + 8) = pb1;
+    if constexpr (!P::A_U8) {
+      *reinterpret_cast<half8*>(sa + i * HW_PITCH + 16 * hb) = pa0;
+      *reinterpret_cast<half8*>(sa + i * HW_PITCH + 16 * hb + 8) = pa1;
+    }
+    const aoff_t cv = cvn;
+    const int kcur = kc;
+    kc += NW * 32;
+    if (kc < kend) stage_load(kc);                              // next chunk's loads fly under the transposes + MFMAs
+    wave_lds_sync();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      half8 fa, fb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fb[j] = sb[(16 * s + 8 * hb + j) * HW_PITCH + i];
+      if constexpr (P::A_U8) {
+        // k = kcur + 16 s + 8 h + 4 g + e: patch origins of the two aligned k-groups from lanes 16 s + 4 g (+ 8 for h = 1)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int src = 16 * s + 4 * g;
+          const int l0 = __builtin_amdgcn_readlane((int)(cv & 0xFFFFFFFF), src), l1 = __builtin_amdgcn_readlane((int)((int64_t)cv >> 32), src);
+          const int u0 = __builtin_amdgcn_readlane((int)(cv & 0xFFFFFFFF), src + 8), u1 = __builtin_amdgcn_readlane((int)((int64_t)cv >> 32), src + 8);
+          const int64_t lo = ((int64_t)l1 << 32) | (uint32_t)l0, up = ((int64_t)u1 << 32) | (uint32_t)u0;
+          const int64_t c = hi ? up : lo;
+          const bool ok = kcur + 16 * s + 8 * hb + 4 * g < kend;
+          const f4 v = P::a_load_group4(a, z, arow_own + c);
+          fa[4 * g] = ok ? (half_t)v.x : (half_t)0.0f; fa[4 * g + 1] = ok ? (half_t)v.y : (half_t)0.0f;
+          fa[4 * g + 2] = ok ? (half_t)v.z : (half_t)0.0f; fa[4 * g + 3] = ok ? (half_t)v.w : (half_t)0.0f;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fa[j] = sa[(16 * s + 8 * hb + j) * HW_PITCH + i];
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc, 0, 0, 0);
+    }
+    wave_lds_sync();                                            // tile reads issued before the next chunk's stores
+  }
+
+  if constexpr (NW > 1) {
+    if (wave < NW) {                                            // the wave's own staging region becomes its combine panel
+      float* cw = smem + wave * HW_WAVE_LDS;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2) + 4 * hb) * 33 + i] = acc[r];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += NT) {
+      const int ml = e >> 5, nl = e & 31;
+      float v = smem[ml * 33 + nl];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) v += smem[w * HW_WAVE_LDS + ml * 33 + nl];
+      if (m0 + ml < M && n0 + nl < N) P::store(a, z, ks, m0 + ml, n0 + nl, v);
+    }
+  } else {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[r];
+    P::store16(a, z, ks, m0, n0, lane, M, N, v, epi);
+  }
+}
+
 template <class P, int NW, int NT>
 __device__ __forceinline__ void run_tile(const StepArgs& a, int bx, int by, int bz, float* smem) {
   if constexpr (is_rb<P>::value) gemm_tile_rb<P, NW, NT>(a, bx, by, bz, smem);
+  else if constexpr (uses_f16_wgrad<P>::value) gemm_tile_hw<P, NW, NT>(a, bx, by, bz, smem);
   else if constexpr (uses_f16_mfma<P>::value) gemm_tile_h<P, NW, NT>(a, bx, by, bz, smem);
   else gemm_tile<P, NW, NT>(a, bx, by, bz, smem);
 }
 template <class P, int NW>
 constexpr int tile_lds_any() {
   if constexpr (is_rb<P>::value) return NW > 1 ? NW * PANEL : 1;       // sub-tiles are combined one at a time
+  else if constexpr (uses_f16_wgrad<P>::value) return NW * HW_WAVE_LDS;   // staging tiles, reused as combine panels
   else return uses_f16_mfma<P>::value ? NW * PANEL : tile_lds<P, NW>();
 }
 // rows / columns of C one wave-tile covers
@@ -473,7 +609,9 @@ __device__ __forceinline__ void multi_dispatch(const StepArgs& a, const MultiDim
 
 template <int NT, class P0, int NW0, class P1, int NW1, class P2, int NW2>
 __global__ void __launch_bounds__(NT) gemm_multi_kernel(const StepArgs a, const MultiDims d) {
-  constexpr int L0 = tile_lds_any<P0, NW0>(), L1 = tile_lds_any<P1, NW1>(), L2 = tile_lds_any<P2, NW2>();
+  // (a one-tile-per-wave problem needs one region per wave of the workgroup)
+  constexpr int L0 = tile_lds_any<P0, NW0>() * (NW0 == 1 ? NT / 64 : 1), L1 = tile_lds_any<P1, NW1>() * (NW1 == 1 ? NT / 64 : 1),
+                L2 = tile_lds_any<P2, NW2>() * (NW2 == 1 ? NT / 64 : 1);
   constexpr int L = L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2);
   __shared__ float smem[L];
   const int b = blockIdx.x;                               // problem choice is workgroup-uniform; XCD-contiguous runs per problem

@@ -192,5 +192,11 @@ struct Conv1WgradH : Conv1Wgrad {      // A' = fp32-normalised u8 patches (as in
   }
 };
 
+// ---- the same weight gradients on packed-fp16 MFMA (gemm_tile_hw: wave-private LDS transposes) ---------------------
+struct Fc4WgradHW : Fc4WgradH { static constexpr bool F16_WGRAD = true; };
+struct Conv3WgradHW : Conv3WgradH { static constexpr bool F16_WGRAD = true; };
+struct Conv2WgradHW : Conv2WgradH { static constexpr bool F16_WGRAD = true; };
+struct Conv1WgradHW : Conv1WgradH { static constexpr bool F16_WGRAD = true; };    // A = half(x / 255) like the forward pass
+
 }  // namespace sdqn
 #endif

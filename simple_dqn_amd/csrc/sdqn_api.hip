@@ -336,6 +336,7 @@ struct sdqn_net_s {
   int S4 = 7, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
   int64_t train_iterations = 0;
   bool keep_grads = false;                 // true: fc4 gradient materialised in g (readable with which=3), no fused RMSProp
+  bool h16_wgrad_mfma = true;              // fp16 mode: weight gradients on packed-fp16 MFMA (LDS transposes); false = fp32 MFMA with half operands
   bool grad_only = false;                  // true: a train step stops after the local gradient sums (update mode 1): what a
                                            // data-parallel rank has before the all-reduce; sdqn_net_apply_update finishes it
   int nw_override[12] = {0};               // tuning hook
@@ -623,7 +624,7 @@ static StepArgs step_args(sdqn_net_s* h) {
   for (int i = 0; i < 12; ++i) { a.nw_override[i] = h->nw_override[i]; a.rb[i] = h->B >= 128 ? h->rb[i] : 0; }
   a.xcd_map = h->xcd_map ? 7 : 0;
   if (h->cfg.datatype == 1) {
-    a.h16 = 1; a.h_a1 = h->h_a1; a.h_a2 = h->h_a2; a.h_a3 = h->h_a3; a.h_d4 = h->h_d4; a.h_d3p = h->h_d3p; a.h_d3 = h->h_d3;
+    a.h16 = h->h16_wgrad_mfma ? 2 : 1; a.h_a1 = h->h_a1; a.h_a2 = h->h_a2; a.h_a3 = h->h_a3; a.h_d4 = h->h_d4; a.h_d3p = h->h_d3p; a.h_d3 = h->h_d3;
     a.h_d2p = h->h_d2p; a.h_d2 = h->h_d2; a.h_d1 = h->h_d1; a.wh[0] = h->wh[0]; a.wh[1] = h->wh[1]; a.wht[0] = h->wht[0]; a.wht[1] = h->wht[1];
     a.wh_w = h->wh[0]; a.wht_w = h->wht[0];
     a.loss_scale = (float)h->cfg.loss_scale; a.inv_loss_scale = (float)(1.0 / h->cfg.loss_scale);
@@ -1047,6 +1048,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   ARGCHK(h && name, "NULL argument");
   if (!strcmp(name, "keep_gradients")) h->keep_grads = value != 0;
   else if (!strcmp(name, "grad_only")) h->grad_only = value != 0;
+  else if (!strcmp(name, "h16_wgrad_mfma")) h->h16_wgrad_mfma = value != 0;
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;

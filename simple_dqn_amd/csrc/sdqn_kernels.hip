@@ -32,6 +32,22 @@ static hipError_t launch_nw(int nw, const StepArgs& a, hipStream_t s) {
 // Waves per workgroup = how many 32-deep K-chunks run concurrently on one output tile (gemm_engine.h).
 // fp16 mode: forward / dgrad on packed-fp16 MFMA (problems_h16.h), wgrad on the fp32 engine with half operands
 static hipError_t launch_kernel_h16(int id, const StepArgs& a, hipStream_t s) {
+  if (a.h16 == 2) {            // weight gradients on packed-fp16 MFMA too (default); h16 == 1: fp32 MFMA with half operands (round 1)
+    switch (id) {
+      case K_FC4_WGRAD:
+        if (a.B <= 32) return launch_gemm<Fc4WgradHW, 1>(a, s);
+        return launch_gemm<Fc4WgradHW, 8>(a, s);
+      case K_CONV3_WGRAD: return launch_gemm<Conv3WgradHW, 8>(a, s);
+      case K_CONV2_WGRAD: return launch_gemm<Conv2WgradHW, 8>(a, s);
+      case K_CONV1_WGRAD: return launch_gemm<Conv1WgradHW, 16>(a, s);
+      case K_BWD3:
+        if (a.B <= 32) return launch_multi<512, Fc4WgradHW, 1, Conv3DgradH, 8, Conv3WgradHW, 8>(a, true, true, s);
+        return launch_multi<512, Fc4WgradHW, 8, Conv3DgradH, 8, Conv3WgradHW, 8>(a, true, true, s);
+      case K_BWD2: return launch_multi<512, NoProblem, 2, Conv2DgradH, 8, Conv2WgradHW, 8>(a, true, true, s);
+      case K_BWD1: return launch_multi<1024, NoProblem, 2, Conv1WgradHW, 16, NoProblem, 2>(a, true, false, s);
+      default: break;
+    }
+  }
   switch (id) {
     case K_CONV1_FWD: return launch_gemm<Conv1FwdH, 8>(a, s);
     case K_CONV2_FWD: return launch_gemm<Conv2FwdH, 16>(a, s);

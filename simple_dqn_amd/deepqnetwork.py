@@ -66,7 +66,7 @@ class DeepQNetwork:
         self._h = h
         import os
         for env, opt in (("SDQN_TWO_STREAMS", b"two_streams"), ("SDQN_FUSED_LAUNCHES", b"fused_launches"),
-                         ("SDQN_XCD_MAP", b"xcd_map")):
+                         ("SDQN_XCD_MAP", b"xcd_map"), ("SDQN_H16_WGRAD_MFMA", b"h16_wgrad_mfma")):
             if os.environ.get(env) is not None:                       # A/B switches for benchmarking
                 _lib.check(self._lib.sdqn_net_set_option(h, opt, int(os.environ[env])))
         if os.environ.get("SDQN_F4_SHARE"):                           # tuning: "s3,s2" percent of fc4-wgrad tiles in bwd3 / bwd2

@@ -591,7 +591,8 @@ def test_fp16_training_tracks_oracle_and_fused_path(sd):
     q, q2, qo = net.predict(hold), net2.predict(hold), o.predict(hold)
     print("fp16 5 steps: Q max abs err vs half oracle %.3e" % np.abs(q - qo).max())
     assert np.array_equal(q, q2)
-    assert np.abs(q - qo).max() < 2e-2                               # 5 free-running steps of a half-precision net
+    assert np.abs(q - qo).max() < 5e-2                               # 5 free-running steps of a half-precision net (measured 1.4e-2 r1, 2.0e-2 r2:
+                                                                     # conv1's wgrad input is half(x/255) now; gate flips make this seed-dependent)
     net.update_target_network()
     assert np.isfinite(net.predict(hold)).all()
 
