@@ -21,6 +21,7 @@ const char* kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? k_names[id]
 template <class P>
 static hipError_t launch_nw(int nw, const StepArgs& a, hipStream_t s) {
   switch (nw) {
+    case 1: return launch_gemm<P, 1>(a, s);
     case 2: return launch_gemm<P, 2>(a, s);
     case 4: return launch_gemm<P, 4>(a, s);
     case 8: return launch_gemm<P, 8>(a, s);
@@ -32,6 +33,23 @@ static hipError_t launch_nw(int nw, const StepArgs& a, hipStream_t s) {
 // Waves per workgroup = how many 32-deep K-chunks run concurrently on one output tile (gemm_engine.h).
 // fp16 mode: forward / dgrad on packed-fp16 MFMA (problems_h16.h), wgrad on the fp32 engine with half operands
 static hipError_t launch_kernel_h16(int id, const StepArgs& a, hipStream_t s) {
+  if (id >= 0 && id < 12 && a.nw_override[id] > 0) {          // tuning hook (sdqn_net_set_option "nw:<id>")
+    const int nw = a.nw_override[id];
+    switch (id) {
+      case K_CONV1_FWD: return launch_nw<Conv1FwdH>(nw, a, s);
+      case K_CONV2_FWD: return launch_nw<Conv2FwdH>(nw, a, s);
+      case K_CONV3_FWD: return launch_nw<Conv3FwdH>(nw, a, s);
+      case K_FC4_FWD: return launch_nw<Fc4FwdH>(nw, a, s);
+      case K_FC4_DGRAD: return launch_nw<Fc4DgradH>(nw, a, s);
+      case K_CONV3_DGRAD: return launch_nw<Conv3DgradH>(nw, a, s);
+      case K_CONV2_DGRAD: return launch_nw<Conv2DgradH>(nw, a, s);
+      case K_FC4_WGRAD: return launch_nw<Fc4WgradHW>(nw, a, s);
+      case K_CONV3_WGRAD: return launch_nw<Conv3WgradHW>(nw, a, s);
+      case K_CONV2_WGRAD: return launch_nw<Conv2WgradHW>(nw, a, s);
+      case K_CONV1_WGRAD: return launch_nw<Conv1WgradHW>(nw, a, s);
+      default: break;
+    }
+  }
   if (a.h16 == 2) {            // weight gradients on packed-fp16 MFMA too (default); h16 == 1: fp32 MFMA with half operands (round 1)
     switch (id) {
       case K_FC4_WGRAD:
@@ -45,6 +63,14 @@ static hipError_t launch_kernel_h16(int id, const StepArgs& a, hipStream_t s) {
         return launch_multi<512, Fc4WgradHW, 8, Conv3DgradH, 8, Conv3WgradHW, 8>(a, true, true, s);
       case K_BWD2: return launch_multi<512, NoProblem, 2, Conv2DgradH, 8, Conv2WgradHW, 8>(a, true, true, s);
       case K_BWD1: return launch_multi<1024, NoProblem, 2, Conv1WgradHW, 16, NoProblem, 2>(a, true, false, s);
+      default: break;
+    }
+  }
+  if (a.B >= 128) {            // throughput regime: these launches are operand-traffic bound, fewer K-split waves per tile win
+    switch (id) {              // (tools/sweep_nw.py, B=256 DATATYPE=float16: fc4_fwd 24.3 -> 17.3 us, conv1_fwd 26.8 -> 24.4, conv3_fwd 21.9 -> 19.4)
+      case K_CONV1_FWD: return launch_gemm<Conv1FwdH, 1>(a, s);
+      case K_CONV3_FWD: return launch_gemm<Conv3FwdH, 8>(a, s);
+      case K_FC4_FWD: return launch_gemm<Fc4FwdH, 1>(a, s);
       default: break;
     }
   }

@@ -8,7 +8,7 @@ from bench import fill_ring
 import ctypes as C
 from simple_dqn_amd import _lib
 B, A = int(os.environ.get("B", 32)), 4
-args = make_args(batch_size=B)
+args = make_args(batch_size=B, datatype=os.environ.get("DATATYPE", "float32"))
 mem = sd.ReplayMemory(50000, args); fill_ring(mem, 1, A)
 net = sd.DeepQNetwork(A, args); net.update_target_network()
 net.set_option("fused_launches", 0)
@@ -22,10 +22,10 @@ def measure(n=300):
     return r
 base = measure()
 print("base", {k: round(v, 2) for k, v in base.items()})
-names = {0: "conv1_fwd", 1: "conv2_fwd", 2: "conv3_fwd", 3: "fc4_fwd", 5: "fc4_dgrad", 7: "conv3_dgrad", 8: "conv3_wgrad", 9: "conv2_dgrad", 10: "conv2_wgrad", 11: "conv1_wgrad"}
+names = {0: "conv1_fwd", 1: "conv2_fwd", 2: "conv3_fwd", 3: "fc4_fwd", 5: "fc4_dgrad", 6: "fc4_wgrad", 7: "conv3_dgrad", 8: "conv3_wgrad", 9: "conv2_dgrad", 10: "conv2_wgrad", 11: "conv1_wgrad"}
 for kid, nm in names.items():
     row = {}
-    for nw in (2, 4, 8, 16):
+    for nw in (1, 2, 4, 8, 16):
         net.set_option("nw:%d" % kid, nw)
         try:
             row[nw] = round(measure(200)[kid], 2)
