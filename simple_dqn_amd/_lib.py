@@ -78,6 +78,7 @@ SIGNATURES = {
     "sdqn_net_apply_update": (C.c_int, [_vp, C.c_double]),
     "sdqn_net_last_q": (C.c_int, [_vp, _f32p, _f32p]),
     "sdqn_net_train_iterations": (C.c_int, [_vp, _i64p]),
+    "sdqn_net_overflow_steps": (C.c_int, [_vp, _i64p]),
     "sdqn_net_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "sdqn_net_set_epoch": (C.c_int, [_vp, C.c_int]),
     "sdqn_net_debug_read": (C.c_int, [_vp, C.c_char_p, _f32p, C.c_int64]),

@@ -65,6 +65,8 @@ struct UpdateArgs {
   float beta1, one_minus_beta1, beta2, one_minus_beta2, lr_t;   // Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), t = epoch+1
   half_t* wh;                   // fp16 mode: half copies of theta refreshed by the update (master layout / transposed)
   half_t* wht;
+  const int* ovf_flag;          // fp16 data parallel: != 0 -> the all-reduced half gradient overflowed, leave theta / state untouched
+  int64_t* ovf_count;           //   ... and count the skipped step
   int64_t bn_first;             // --batch_norm: element offset of the [beta|gamma] block (bn_update_kernel); BN_PARAMS elements
 };
 
@@ -125,6 +127,8 @@ hipError_t launch_bn_forward(const BnArgs& b, hipStream_t s);      // [partial +
 hipError_t launch_bn_backward(const BnArgs& b, hipStream_t s);     // partial + apply
 hipError_t launch_bn_update(const UpdateArgs& u, hipStream_t s);   // optimizer step of the [beta | gamma] block (g already holds the sums)
 hipError_t launch_prep(const PrepArgs& p, hipStream_t s);
+hipError_t launch_grad_to_half(const float* g, half_t* gh, int64_t n, float scale, int* flag, hipStream_t s);       // fp16 DP payload
+hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, float inv_scale, int* flag, hipStream_t s);
 hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s);   // fp16 mode: rebuild both half copies
 
 }  // namespace sdqn

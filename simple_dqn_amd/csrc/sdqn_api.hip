@@ -336,6 +336,8 @@ struct sdqn_net_s {
   int S4 = 7, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
   int64_t train_iterations = 0;
   bool keep_grads = false;                 // true: fc4 gradient materialised in g (readable with which=3), no fused RMSProp
+  half_t* gh = nullptr; int* ovf_flag = nullptr; int64_t* ovf_count = nullptr;    // fp16 data parallel: half gradient payload, overflow flag / skipped steps
+  int dp_half = 1, dp_half_scale_log2 = 6;   // fp16 mode: all-reduce the gradient as half (x 2^6: 8 summed ranks stay inside the half range for |g| < 127)
   bool h16_wgrad_mfma = true;              // fp16 mode: weight gradients on packed-fp16 MFMA (LDS transposes); false = fp32 MFMA with half operands
   bool grad_only = false;                  // true: a train step stops after the local gradient sums (update mode 1): what a
                                            // data-parallel rank has before the all-reduce; sdqn_net_apply_update finishes it
@@ -462,6 +464,9 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
       NCHK(dalloc(h, (void**)&h->wht[zz], (size_t)OFF5 * 2));
     }
     if (!c->target_enabled) { h->wh[1] = h->wh[0]; h->wht[1] = h->wht[0]; }
+    NCHK(dalloc(h, (void**)&h->gh, (size_t)h->NP * 2));
+    NCHK(dalloc(h, (void**)&h->ovf_flag, 16));
+    NCHK(dalloc(h, (void**)&h->ovf_count, 16));
   }
   NCHK(dalloc(h, (void**)&h->q, (size_t)2 * B * h->A * 4));
   NCHK(dalloc(h, (void**)&h->maxq, (size_t)B * 4));
@@ -797,6 +802,14 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     // synchronous data parallel: local gradient sums -> one RCCL all-reduce of the flat buffer -> identical RMSProp
     u.mode = 1; u.bsz = (float)h->B; u.next.B = 0;
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
+    if (h->cfg.datatype == 1 && h->dp_half && h->gh) {
+      // fp16 mode: half payload, fp32 accumulation in the optimizer, overflow -> the step is skipped on all ranks
+      const float sc = ldexpf(1.0f, h->dp_half_scale_log2);
+      LAUNCH(K_UPDATE, launch_grad_to_half(h->g, h->gh, h->NP, sc, h->ovf_flag, g_stream));
+      LAUNCH(K_ALLREDUCE, dp_allreduce(h, h->gh, (size_t)h->NP, /*ncclFloat16*/ 6, h->comm, g_stream));
+      LAUNCH(K_UPDATE, launch_grad_from_half(h->gh, h->g, h->NP, 1.0f / sc, h->ovf_flag, g_stream));
+      u.ovf_flag = h->ovf_flag; u.ovf_count = h->ovf_count;
+    } else
     LAUNCH(K_ALLREDUCE, dp_allreduce(h, h->g, (size_t)h->NP, /*ncclFloat32*/ 7, h->comm, g_stream));
     u.mode = 2; u.bsz = (float)h->B * (float)h->nranks;
     if (next) u.next = *next;
@@ -1040,6 +1053,15 @@ extern "C" int sdqn_net_last_q(sdqn_net_t h, float* preq, float* maxpostq) {
   if (maxpostq) memcpy(maxpostq, h->h_f + nq, (size_t)h->B * 4);
   return SDQN_OK;
 }
+// fp16 data parallel: train steps whose all-reduced half gradient overflowed and were therefore skipped (sync)
+extern "C" int sdqn_net_overflow_steps(sdqn_net_t h, int64_t* n) {
+  ARGCHK(h && n, "NULL argument");
+  *n = 0;
+  if (!h->ovf_count) return SDQN_OK;
+  { int rc = join_comm(h); if (rc) return rc; } HIPCHK(hipStreamSynchronize(g_stream));
+  HIPCHK(hipMemcpy(n, h->ovf_count, 8, hipMemcpyDeviceToHost));
+  return SDQN_OK;
+}
 extern "C" int sdqn_net_train_iterations(sdqn_net_t h, int64_t* n) { ARGCHK(h && n, "NULL"); *n = h->train_iterations; return SDQN_OK; }
 
 extern "C" int sdqn_net_set_epoch(sdqn_net_t h, int epoch) { ARGCHK(h && epoch >= 0, "bad epoch"); h->epoch = epoch; return SDQN_OK; }
@@ -1049,6 +1071,8 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   if (!strcmp(name, "keep_gradients")) h->keep_grads = value != 0;
   else if (!strcmp(name, "grad_only")) h->grad_only = value != 0;
   else if (!strcmp(name, "h16_wgrad_mfma")) h->h16_wgrad_mfma = value != 0;
+  else if (!strcmp(name, "dp_half")) h->dp_half = value != 0;              // fp16 mode: half (1, default) or fp32 (0) all-reduce payload
+  else if (!strcmp(name, "dp_half_scale_log2")) { ARGCHK(value >= 0 && value <= 40, "bad scale"); h->dp_half_scale_log2 = value; }
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;

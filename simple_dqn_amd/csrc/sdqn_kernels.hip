@@ -358,6 +358,9 @@ constexpr int FC5_BLOCKS_PER_ACTION = NFC / 4 / 32;   // 4 workgroups of 32 floa
 __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
   __shared__ float4 part[8][32];
   const int t = threadIdx.x;
+  // fp16 data parallel: a half overflow in the all-reduced gradient skips the whole apply step on every rank
+  const bool skip_apply = u.ovf_flag != nullptr && *u.ovf_flag != 0;
+  if (skip_apply && blockIdx.x == 0 && t == 0) u.ovf_count[0] += 1;
   if (u.only_fc4 && (int)blockIdx.x < CONV_BLOCKS + u.A * FC5_BLOCKS_PER_ACTION) return;
   if ((int)blockIdx.x < CONV_BLOCKS) {
     const int c4 = t & 31, sg = t >> 5;
@@ -394,7 +397,7 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
         *reinterpret_cast<float4*>(u.g + e) = gs;
       }
     }
-    if (sg == 0 && u.mode != 1) opt_apply4(u.theta, u.state, u.state2, e, gs, u);
+    if (sg == 0 && u.mode != 1 && !skip_apply) opt_apply4(u.theta, u.state, u.state2, e, gs, u);
     return;
   }
   const int fc5_blocks = u.A * FC5_BLOCKS_PER_ACTION;
@@ -434,7 +437,7 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
         *reinterpret_cast<float4*>(u.g + e) = gs;
       }
     }
-    if (sg == 0 && u.mode != 1) opt_apply4(u.theta, u.state, u.state2, e, gs, u);
+    if (sg == 0 && u.mode != 1 && !skip_apply) opt_apply4(u.theta, u.state, u.state2, e, gs, u);
     return;
   }
   // fc4: g written by fc4_wgrad (or all-reduced), elementwise; skipped when fused into fc4_wgrad's epilogue
@@ -444,7 +447,7 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
     for (int64_t i4 = CONV_F4 + (int64_t)(blockIdx.x - first_dense) * 256 + t; i4 < OFF5 / 4; i4 += (int64_t)nb * 256) {
       const int64_t e = i4 * 4;
       const float4 gs = *reinterpret_cast<const float4*>(u.g + e);
-      if (u.mode != 1) opt_apply4(u.theta, u.state, u.state2, e, gs, u);
+      if (u.mode != 1 && !skip_apply) opt_apply4(u.theta, u.state, u.state2, e, gs, u);
     }
   }
   if (u.next.B > 0 && (int)blockIdx.x == first_dense) {             // next step's prep rides along (every reader of idx is done)
@@ -493,6 +496,41 @@ __global__ void __launch_bounds__(256) refresh16_kernel(const float* theta, half
 }
 hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s) {
   hipLaunchKernelGGL(refresh16_kernel, dim3(2048), dim3(256), 0, s, theta, wh, wht);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp16 mode, data parallel: the gradient crosses xGMI as IEEE half (3.37 MB instead of 6.74 MB per rank and
+// step).  g * scale -> half before the all-reduce (scale = a power of two that keeps R summed ranks inside the half
+// range), half -> fp32 / scale after it; accumulation in the optimizer stays fp32.  A non-finite value after the
+// all-reduce (a half overflow on any rank becomes inf on EVERY rank through the sum) raises the step's overflow flag:
+// the apply-only update then leaves parameters and optimizer state untouched on all ranks alike (the usual
+// mixed-precision "skip the step" rule) and the skipped-step counter goes up.
+__global__ void __launch_bounds__(256) grad_to_half_kernel(const float* __restrict__ g, half_t* __restrict__ gh, int64_t n, float scale, int* flag) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;                    // this step's flag (only the from-half pass, a later launch, sets it)
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 4 <= n) {
+      const float4 v = *reinterpret_cast<const float4*>(g + i);
+      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+      half4 h; h[0] = (half_t)(v.x * scale); h[1] = (half_t)(v.y * scale); h[2] = (half_t)(v.z * scale); h[3] = (half_t)(v.w * scale);
+      *reinterpret_cast<half4*>(gh + i) = h;
+    } else for (int64_t k = i; k < n; ++k) gh[k] = (half_t)(g[k] * scale);
+  }
+}
+__global__ void __launch_bounds__(256) grad_from_half_kernel(const half_t* __restrict__ gh, float* __restrict__ g, int64_t n, float inv_scale, int* flag) {
+  bool bad = false;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    const int64_t e = i + 4 <= n ? i + 4 : n;
+    for (int64_t k = i; k < e; ++k) { const float v = (float)gh[k]; bad |= !(fabsf(v) <= 65504.0f); g[k] = v * inv_scale; }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+hipError_t launch_grad_to_half(const float* g, half_t* gh, int64_t n, float scale, int* flag, hipStream_t s) {
+  hipLaunchKernelGGL(grad_to_half_kernel, dim3(512), dim3(256), 0, s, g, gh, n, scale, flag);
+  return hipGetLastError();
+}
+hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, float inv_scale, int* flag, hipStream_t s) {
+  hipLaunchKernelGGL(grad_from_half_kernel, dim3(512), dim3(256), 0, s, gh, g, n, inv_scale, flag);
   return hipGetLastError();
 }
 

@@ -314,6 +314,12 @@ class DeepQNetwork:
         path = (rccl or _lib.rccl_path()).encode()
         _lib.check(self._lib.sdqn_dp_init(self._h, path, unique_id, rank, nranks))
 
+    def overflow_steps(self):
+        """float16 mode under data parallel: steps skipped because the all-reduced half gradient overflowed."""
+        n = C.c_int64()
+        _lib.check(self._lib.sdqn_net_overflow_steps(self._h, C.byref(n)))
+        return n.value
+
     def dp_info(self):
         """What RCCL reports about the communicator + the bound device (all -1 without a communicator)."""
         v = [C.c_int(-1) for _ in range(4)]

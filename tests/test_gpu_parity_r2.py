@@ -213,6 +213,55 @@ def test_dp_divisor_is_ranks_times_batch(sd):
     assert not np.array_equal(ref.get_layer(3, 2), n2.get_layer(3, 2))
 
 
+def test_fp16_dp_half_payload_and_overflow_skip(sd):
+    """SURVEY.md §8e, configs[4]: under data parallel the float16 mode all-reduces the gradient as IEEE half (x 2^6) and
+    accumulates in fp32.  1-rank RCCL communicator on the one GPU (the all-reduce is the identity, the half round trip is
+    not): (a) weights track the single-GPU float16 path to half-rounding of the gradient; the fp32-payload option
+    reproduces the single-GPU path exactly like the float32 test does; (b) a payload scale that overflows half makes
+    every value inf -> the step is skipped: parameters and optimizer state untouched, skipped-step counter counts."""
+    from simple_dqn_amd.deepqnetwork import dp_unique_id
+    A, B = 4, 32
+    ref, _, _ = _net(sd, A, B, 691, datatype="float16")
+    ref.set_option("keep_gradients", 1)
+    nh, _, _ = _net(sd, A, B, 691, datatype="float16")
+    nh.dp_init(dp_unique_id(), 0, 1)
+    mbs = [random_minibatch(B, A, 692 + s) for s in range(3)]
+    for mb in mbs:
+        ref.train(mb); nh.train(mb)
+    assert nh.overflow_steps() == 0
+    for i in range(5):
+        dw = np.abs(nh.get_layer(i, 0) - ref.get_layer(i, 0)).max()
+        ds = np.abs(nh.get_layer(i, 2) - ref.get_layer(i, 2)).max() / max(1e-12, np.abs(ref.get_layer(i, 2)).max())
+        print("fp16 DP half payload layer %d: max |dW| %.2e, rel dS %.2e" % (i, dw, ds))
+        assert dw < 1e-4 and ds < 5e-3, i                       # half rounding of g (2^-11) through RMSProp's normalised steps
+    nh.dp_shutdown()
+    # fp32 payload option: bit-identical to the single-GPU (materialised-gradient) float16 path
+    nf, _, _ = _net(sd, A, B, 691, datatype="float16")
+    nf.set_option("dp_half", 0)
+    nf.dp_init(dp_unique_id(), 0, 1)
+    for mb in mbs:
+        nf.train(mb)
+    for i in range(5):
+        assert np.array_equal(nf.get_layer(i, 0), ref.get_layer(i, 0)), i
+    nf.dp_shutdown()
+    # overflow: 2^30 x gradient does not fit half -> inf after the all-reduce -> skipped
+    no, _, _ = _net(sd, A, B, 691, datatype="float16")
+    no.set_option("dp_half_scale_log2", 30)
+    no.dp_init(dp_unique_id(), 0, 1)
+    w0, s0 = no.get_weights(0), no.get_weights(2)
+    for mb in mbs[:2]:
+        no.train(mb)
+    assert no.overflow_steps() == 2
+    for a, b in zip(no.get_weights(0), w0):
+        assert np.array_equal(a, b)
+    for a, b in zip(no.get_weights(2), s0):
+        assert np.array_equal(a, b)
+    no.set_option("dp_half_scale_log2", 6)
+    no.train(mbs[0])                                            # and training resumes once the scale fits again
+    assert no.overflow_steps() == 2 and not np.array_equal(no.get_layer(3, 0), w0[3])
+    no.dp_shutdown()
+
+
 # ---- boundary: --device_id, ring-action validation, error text ------------------------------------------------------
 def test_device_id_is_honoured_or_refused(sd):
     """src/deepqnetwork.py:29-34 passes args.device_id to the backend.  Here: the drop-in classes bind it; the bound
