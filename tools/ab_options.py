@@ -23,5 +23,6 @@ OPTS = eval(os.environ.get("OPTS", "[]")) or ([("two_streams", 1)], [("f4_share3
 for opts in OPTS:
     for k, v in opts: net.set_option(k, v)
     print(opts, round(rate()))
-    for k, v in opts: net.set_option(k, 100 if k == "f4_share3" else 0)
+    for k, v in opts:
+        if not k.startswith("tps:"): net.set_option(k, 100 if k == "f4_share3" else 0)
 print("base", round(rate()))
