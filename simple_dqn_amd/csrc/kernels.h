@@ -30,6 +30,9 @@ struct HeadArgs {
   double discount, min_reward, max_reward;
   float clip_error;
   int train;                    // 0: predict only (z = 0)
+  // hoist: one extra workgroup copies the NEXT step's sampled indexes from their pinned slot into device memory, so that
+  // the target conv1 riding in this step's K_BWD2 launch reads them from HBM (next_B = 0: nothing to copy)
+  const int64_t* next_idx_pinned; int64_t* next_idx_dev; int next_B;
 };
 
 struct PrepArgs {                // pinned index slot + ring metadata -> device-resident (idx, a, r, t) of this step

@@ -332,6 +332,9 @@ struct sdqn_net_s {
   float *d3p = nullptr, *d2p = nullptr, *d1 = nullptr, *slab1 = nullptr, *slab2 = nullptr, *slab3 = nullptr;
   float *q = nullptr, *maxq = nullptr, *dq = nullptr, *cost_terms = nullptr, *cost_out = nullptr; double* cost_accum = nullptr;
   uint8_t *st_states = nullptr, *st_act = nullptr, *st_term = nullptr; int64_t* st_rew = nullptr; int64_t* d_idx = nullptr;
+  int64_t* d_idx_t = nullptr;              // hoist: the NEXT step's indexes (copied from their pinned slot by an extra workgroup of the head launch)
+  bool hoist = false;                      // train_many: the next step's target-net forward rides in this step's launches (B <= 32, fp32).
+                                           // Built, bit-identical, measured 1.8 % SLOWER (tools/exp/README.md) -> off; set_option "hoist"
   float* h_f = nullptr;                    // pinned scratch for small read-backs
   int S4 = 7, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
   int64_t train_iterations = 0;
@@ -478,6 +481,7 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->st_act, B)); NCHK(dalloc(h, (void**)&h->st_term, B));
   NCHK(dalloc(h, (void**)&h->st_rew, (size_t)B * 8));
   NCHK(dalloc(h, (void**)&h->d_idx, (size_t)B * 8));
+  NCHK(dalloc(h, (void**)&h->d_idx_t, (size_t)B * 8));
   { hipError_t e = hipHostMalloc((void**)&h->h_f, (size_t)(2 * B * MAX_ACTIONS + B + 64) * 8, hipHostMallocMapped);
     if (e != hipSuccess) { set_error("hipHostMalloc -> %s", hipGetErrorString(e)); net_free(h); return SDQN_ERR_HIP; } }
 #undef NCHK
@@ -691,12 +695,30 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
     LAUNCH(K_HEAD, launch_head(f, hd, g_stream));
     return SDQN_OK;
   }
+  if (a.hoist & 2) {
+    // hoist, second half: target conv1 / conv2 of THIS step ran inside the previous step's K_BWD2 / K_BWD1; its conv3 and fc4
+    // ride in this step's conv1 / conv2 launches, whose own tiles are the online net's only (nz = 1).  The head then finds
+    // the split-K slabs of both nets as usual.
+    StepArgs f1 = a; f1.nz = 1; f1.idx_t = nullptr; f1.hoist = 2;
+    StepArgs c1 = f1; c1.xcd_map = 1;                           // problem 0 (online conv1 / conv2) on the XCD-contiguous map, as below
+    StepArgs c2 = f1; c2.xcd_map = 3;                           // + the riding target fc4 (the K-slabs of a W4 panel share an L2)
+    LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, c1, g_stream));
+    LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, c2, g_stream));
+    f1.hoist = 0;
+    LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, f1, g_stream));
+    { int rc = join_comm(h); if (rc) return rc; }
+    StepArgs f4 = f1; f4.xcd_map = 1;
+    LAUNCH(K_FC4_FWD, launch_tuned(h, K_FC4_FWD, f4, g_stream));
+    StepArgs ah = a; ah.hoist = 0;
+    LAUNCH(K_HEAD, launch_head(ah, hd, g_stream));
+    return SDQN_OK;
+  }
   // XCD-contiguous tile map where it wins time (tools/sweep_xcd.py, tools/ab_options.py): conv1_fwd +0.5 %, conv2_fwd
   // +0.2 %, fc4_fwd +0.6 % of the step rate; slower for conv3_fwd, fc4_dgrad and every backward launch
-  StepArgs fm = a; fm.xcd_map = 1;
+  StepArgs fm = a; fm.xcd_map = 1; fm.idx_t = nullptr; fm.hoist = 0;
   LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, fm, g_stream));
   LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, fm, g_stream));
-  LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, a, g_stream));
+  { StepArgs f3 = fm; f3.xcd_map = a.xcd_map; LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, f3, g_stream)); }
   { int rc = join_comm(h); if (rc) return rc; }                // conv1..3 of this step overlap the previous step's fc4 all-reduce
   LAUNCH(K_FC4_FWD, launch_tuned(h, K_FC4_FWD, fm, g_stream));
   LAUNCH(K_HEAD, launch_head(a, hd, g_stream));
@@ -721,8 +743,9 @@ static UpdateArgs make_update_args(sdqn_net_s* h, const StepArgs& a) {
   }
   return u;
 }
-static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const PrepArgs* next = nullptr) {
-  int rc = run_forward(h, a, hd); if (rc) return rc;
+static int run_train(sdqn_net_s* h, const StepArgs& a_in, const HeadArgs& hd, const PrepArgs* next = nullptr) {
+  int rc = run_forward(h, a_in, hd); if (rc) return rc;
+  StepArgs a = a_in; a.hoist &= 1;                                            // bit 1 concerned the forward launches only
   // Backward.  Critical path on the library stream: fc4_dgrad -> conv3_dgrad -> conv2_dgrad -> conv1_wgrad.
   // The three other weight-gradient kernels only need the delta of their layer, so they run beside it
   // on the side stream (fork after the producer of their delta, join before the update).
@@ -966,11 +989,18 @@ static int check_ring_actions(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* id
   return SDQN_OK;
 }
 // do_prep: launch the standalone prep for THIS step; next_pinned: fold the NEXT step's prep into the update
+// hoist_in: this step's target conv1 / conv2 already ran inside the previous step; hoist_out: this step carries the next one's
+static bool hoist_possible(sdqn_net_s* h) {
+  return h->hoist && h->B <= 32 && !h->bn && h->cfg.datatype == 0 && h->fused_launches && !h->two_streams &&
+         !(h->comm && h->comm2 && h->dp_overlap) && h->f4_share[0] == 100 && h->f4_share[1] == 0 && h->theta_t != h->theta;
+}
 static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pinned_idx, bool do_prep = true,
-                             const int64_t* next_pinned = nullptr) {
+                             const int64_t* next_pinned = nullptr, bool hoist_in = false, bool hoist_out = false) {
   if (do_prep) { PrepArgs p = prep_args(h, r, pinned_idx); LAUNCH(K_PREP, launch_prep(p, g_stream)); }
   StepArgs a = step_args(h); a.from_ring = 1; a.src = r->d_ring; a.idx = h->d_idx;
   HeadArgs hd = head_args(h, 1);
+  a.hoist = (hoist_out ? 1 : 0) | (hoist_in ? 2 : 0);
+  if (hoist_out) { a.idx_t = h->d_idx_t; hd.next_idx_pinned = next_pinned; hd.next_idx_dev = h->d_idx_t; hd.next_B = h->B; }
   if (next_pinned) { PrepArgs np = prep_args(h, r, next_pinned); return run_train(h, a, hd, &np); }
   return run_train(h, a, hd);
 }
@@ -996,6 +1026,7 @@ extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, 
     rc = check_ring_actions(h, r, idx.data()); if (rc) return rc;
     rc = replay_push_idx(r, idx.data(), &slot, &pinned); if (rc) return rc;
   }
+  bool hoisted = false;                      // step i's target conv1 / conv2 were computed during step i - 1
   for (int i = 0; i < n_steps; ++i) {
     next_pinned = nullptr;
     if (i + 1 < n_steps) {
@@ -1003,7 +1034,10 @@ extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, 
       rc = check_ring_actions(h, r, idx.data()); if (rc) return rc;
       rc = replay_push_idx(r, idx.data(), &next_slot, &next_pinned); if (rc) return rc;
     }
-    int rc = train_replay_slot(h, r, pinned, /*do_prep=*/i == 0, next_pinned); if (rc) return rc;
+    // the target-net forward of step i+1 (theta- and the next indexes only) rides in step i's launches: run_forward / launch_kernel
+    const bool hoist_out = next_pinned != nullptr && hoist_possible(h);
+    int rc = train_replay_slot(h, r, pinned, /*do_prep=*/i == 0, next_pinned, hoisted, hoist_out); if (rc) return rc;
+    hoisted = hoist_out;
     rc = replay_release_idx(r, slot); if (rc) return rc;
     slot = next_slot; pinned = next_pinned;
   }
@@ -1071,6 +1105,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   if (!strcmp(name, "keep_gradients")) h->keep_grads = value != 0;
   else if (!strcmp(name, "grad_only")) h->grad_only = value != 0;
   else if (!strcmp(name, "h16_wgrad_mfma")) h->h16_wgrad_mfma = value != 0;
+  else if (!strcmp(name, "hoist")) h->hoist = value != 0;
   else if (!strcmp(name, "dp_half")) h->dp_half = value != 0;              // fp16 mode: half (1, default) or fp32 (0) all-reduce payload
   else if (!strcmp(name, "dp_half_scale_log2")) { ARGCHK(value >= 0 && value <= 40, "bad scale"); h->dp_half_scale_log2 = value; }
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }

@@ -155,6 +155,28 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
       default: break;
     }
   }
+  if (a.B <= 32 && a.hoist) {
+    // hoist (B <= 32): the target-net forward of the NEXT step rides in launches of this step that have room for it in the
+    // same round of workgroups (bwd2: 592 of 1024 slots, bwd1: 200 of 512; conv1/conv2 online-only: 400 / 162 workgroups):
+    //   K_BWD2(i)   + target conv1(i+1)      K_BWD1(i)   + target conv2(i+1)
+    //   K_CONV1(i+1) + target conv3(i+1)     K_CONV2(i+1) + target fc4(i+1)      -> the head of step i+1 finds both slab sets
+    // same tiles / waves per tile as the plain launches: bit-identical values.  StepArgs::nz = 1 in the two forward launches.
+    switch (id) {
+      case K_BWD2:
+        if ((a.hoist & 1) && a.f4w_count == 0) return launch_multi<512, TargetOnly<Conv1Fwd>, 8, Conv2Dgrad, 8, Conv2Wgrad, 8>(a, true, true, s);
+        break;
+      case K_BWD1:
+        if ((a.hoist & 1) && a.f4w_count == 0) return launch_multi<1024, TargetOnly<Conv2Fwd>, 16, Conv1Wgrad, 16, NoProblem, 2>(a, true, false, s);
+        break;
+      case K_CONV1_FWD:
+        if (a.hoist & 2) return launch_multi<576, Conv1Fwd, 8, TargetOnly<Staged<Conv3Fwd> >, 9, NoProblem, 2>(a, true, false, s);
+        break;
+      case K_CONV2_FWD:
+        if (a.hoist & 2) return launch_multi<1024, Conv2Fwd, 16, Staged<Fc4FwdTarget>, 14, NoProblem, 2>(a, true, false, s);
+        break;
+      default: break;
+    }
+  }
   switch (id) {
     case K_CONV1_FWD: return launch_gemm<Conv1Fwd, 8>(a, s);        // K = 256  -> 8 chunks
     case K_CONV2_FWD: return launch_gemm<Conv2Fwd, 16>(a, s);       // K = 512  -> 16 chunks
@@ -196,6 +218,10 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
 template <int AMAX, bool BN>
 __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadArgs h) {
   SDQN_STAMP(0);
+  if ((int)blockIdx.x >= a.B) {                      // hoist: the extra workgroup fetches the next step's indexes (pinned host slot -> HBM)
+    for (int k = threadIdx.x; k < h.next_B; k += 512) h.next_idx_dev[k] = h.next_idx_pinned[k];
+    return;
+  }
   const int n = blockIdx.x, j = threadIdx.x, lane = j & 63, wave = j >> 6;
   __shared__ float prod[2 * AMAX][NFC];               // 16 KB (A <= 4) .. 72 KB (A <= 18)
   __shared__ float sh_q[2][AMAX];
@@ -317,10 +343,11 @@ hipError_t set_timing_buffer(unsigned long long* p) {
 #endif
 
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
-  if (a.bn) hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, true>), dim3(a.B), dim3(512), 0, s, a, h);     // --batch_norm (not tuned per bucket)
-  else if (a.A <= 4) hipLaunchKernelGGL((head_kernel<4, false>), dim3(a.B), dim3(512), 0, s, a, h);
-  else if (a.A <= 8) hipLaunchKernelGGL((head_kernel<8, false>), dim3(a.B), dim3(512), 0, s, a, h);
-  else hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, false>), dim3(a.B), dim3(512), 0, s, a, h);
+  const int nb = a.B + (h.next_B > 0 ? 1 : 0);
+  if (a.bn) hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, true>), dim3(nb), dim3(512), 0, s, a, h);     // --batch_norm (not tuned per bucket)
+  else if (a.A <= 4) hipLaunchKernelGGL((head_kernel<4, false>), dim3(nb), dim3(512), 0, s, a, h);
+  else if (a.A <= 8) hipLaunchKernelGGL((head_kernel<8, false>), dim3(nb), dim3(512), 0, s, a, h);
+  else hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, false>), dim3(nb), dim3(512), 0, s, a, h);
   return hipGetLastError();
 }
 
