@@ -434,6 +434,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="for rocprofv3 captures: skip the side rows that launch step kernels at other shapes (B=4096 gather, "
+                         "oracle comparison steps) so that per-kernel statistics describe the timed configuration only")
     ap.add_argument("--datatype", choices=["float32", "float16"], default="float32",
                     help="float16 = BASELINE.json configs[4] precision (half activations, fp32 master weights); NOT the headline")
     ap.add_argument("--dry-run-dp", action="store_true",
@@ -541,7 +544,10 @@ def main():
     dom = max(per_step, key=lambda p: p["total_ms"])
     # timed region: the dominant kernel stays bracketed with HIP events, but only every 16th launch — an event pair costs
     # 2-3 us of queue time, and bracketing every launch took 7 % off the step rate it is supposed to observe
-    every = 16 if a.steps >= 64 else 1                      # short runs: every launch, so `roofline` is always live
+    # short runs still get >= 1 live bracket inside the timed region (launch 0 is always bracketed) without paying an event
+    # pair on every step: every 16th launch from 64 steps up, otherwise ~5 samples (measured: bracketing EVERY launch of a
+    # 20-step run cost 7 % of its step rate)
+    every = 16 if a.steps >= 64 else max(2, a.steps // 5)
     net.set_option("profile_every", every)
     net.profile(True, dom["id"])
     net.profile_reset()
@@ -557,7 +563,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t[0])
     live = [p for p in net.profile_read() if p["id"] == dom["id"]][0]
-    live_src = "timed region, every %s launch bracketed" % ("16th" if every == 16 else "single")
+    live_src = "timed region, every %d%s launch bracketed" % (every, "th" if every > 3 else ("nd" if every == 2 else "rd"))
     if live["launches"] == 0:                                        # (K = 0)
         live, live_src = dom, "warm-up pass (no timed launches)"
     net.profile(False)
@@ -597,11 +603,12 @@ def main():
             idx = np.array(mem.sample_indexes())
             g_ms = mem.bench_gather(idx, iters=200)
             out["replay_gather"] = roofline_entry(14, "replay_gather_u8", g_ms, B, A)
-            try:
-                out["replay_gather_large"] = gather_large(sd, make_args, fill_ring, A)
-            except Exception as e:
-                out["replay_gather_large"] = {"error": repr(e)[:200]}
-            out["q_mae_vs_cpu_ref"] = q_mae_on_timed_ring(net, mem, B, A, mt, steps=10 if B <= 64 else 3)
+            if not a.profile_run:
+                try:
+                    out["replay_gather_large"] = gather_large(sd, make_args, fill_ring, A)
+                except Exception as e:
+                    out["replay_gather_large"] = {"error": repr(e)[:200]}
+                out["q_mae_vs_cpu_ref"] = q_mae_on_timed_ring(net, mem, B, A, mt, steps=10 if B <= 64 else 3)
             out["north_star_target"] = north_star_target(out, sd, B, A)
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(B, A, a.seed, a.cpu_baseline_seconds)

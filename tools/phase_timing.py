@@ -15,6 +15,7 @@ args = make_args(batch_size=B)
 mem = sd.ReplayMemory(50000, args); fill_ring(mem, 1, A)
 net = sd.DeepQNetwork(A, args); net.update_target_network()
 net.set_option("fused_launches", 0)
+if os.environ.get("XCD"): net.set_option("xcd_map", int(os.environ["XCD"]))
 mt = (C.c_uint32 * 625)(); lib.sdqn_mt_seed(mt, 5)
 net.train_from_memory(mem, 20, mt_state=mt, want_cost=False); net.sync()
 random.seed(1); idx = np.array(mem.sample_indexes())

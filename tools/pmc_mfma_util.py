@@ -11,11 +11,14 @@ from pmc_traffic import NAMES  # noqa: E402
 def main():
     d, prefix = sys.argv[1:3]
     f = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1]
-    vals, dur = defaultdict(list), defaultdict(list)
+    by_grid = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == "MfmaUtil":
-            vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-            dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            by_grid[r["Kernel_Name"]][r.get("Grid_Size", "")].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    vals, dur = defaultdict(list), defaultdict(list)
+    for k, g in by_grid.items():                      # the most frequent grid of a kernel name = its per-step shape
+        best = max(g.values(), key=len)
+        vals[k] = [x[0] for x in best]; dur[k] = [x[1] for x in best]
     out = {"_method": "rocprofv3 --pmc MfmaUtil --kernel-trace (one pass), bench.py --steps 60 --warmup 70, B=32 A=4 fp32; MfmaUtil = "
                       "sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE * SIMD_NUM) * 100 (rocprofv3's derived counter), mean over the last 2/3 of a "
                       "kernel's launches; flop_util = algorithmic FLOP / (kernel duration under the counter pass * 157.3 TFLOP/s)", "kernels": {}}

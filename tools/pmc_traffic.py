@@ -32,10 +32,15 @@ def per_kernel(d, counter):
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     assert f, "no counter_collection.csv under " + d
     f.sort(key=os.path.getmtime, reverse=True)                  # the most recent capture in that directory
-    vals = defaultdict(list)
+    # one kernel name can run at several grid sizes in a bench run (the standalone gather: B = 32 and the B = 4096
+    # replay_gather_large row): keep the launches of the most frequent grid = the per-step shape
+    by_grid = defaultdict(lambda: defaultdict(list))
     for row in csv.DictReader(open(f[0])):
         if row["Counter_Name"] == counter:
-            vals[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+            by_grid[row["Kernel_Name"]][row.get("Grid_Size", "")].append(float(row["Counter_Value"]))
+    vals = defaultdict(list)
+    for k, g in by_grid.items():
+        vals[k] = max(g.values(), key=len)
     return vals
 
 
