@@ -170,8 +170,9 @@ int sdqn_net_apply_update(sdqn_net_t h, double bsz);
 /* q-values of the last train step: preq float[B,A] (online, prestates), maxpostq float[B] (sync) */
 int sdqn_net_last_q(sdqn_net_t h, float* preq, float* maxpostq);
 int sdqn_net_train_iterations(sdqn_net_t h, int64_t* n);     /* deepqnetwork.py:168 */
-/* float16 mode under data parallel: the gradient is all-reduced as IEEE half (x 2^6, fp32 accumulation in the optimizer;
- * options "dp_half", "dp_half_scale_log2").  A step whose summed half gradient is not finite is skipped on every rank;
+/* float16 mode under data parallel: the gradient is all-reduced as IEEE half with a dynamic power-of-two payload scale
+ * (device-side: halved on overflow, doubled after 200 clean steps; fp32 accumulation in the optimizer; options "dp_half",
+ * "dp_half_scale_log2" = fixed scale).  A step whose summed half gradient is not finite is skipped on every rank;
  * this returns how many were (sync).  Always 0 in float32 mode. */
 int sdqn_net_overflow_steps(sdqn_net_t h, int64_t* n);
 /* the `epoch` argument of DeepQNetwork.train (deepqnetwork.py:107,165): Neon's Adam bias-corrects with t = epoch + 1 */

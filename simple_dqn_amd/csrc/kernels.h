@@ -68,9 +68,10 @@ struct UpdateArgs {
   float beta1, one_minus_beta1, beta2, one_minus_beta2, lr_t;   // Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), t = epoch+1
   half_t* wh;                   // fp16 mode: half copies of theta refreshed by the update (master layout / transposed)
   half_t* wht;
-  const int* ovf_flag;          // fp16 data parallel: != 0 -> the all-reduced half gradient overflowed, leave theta / state untouched
-  int64_t* ovf_count;           //   ... and count the skipped step
   int64_t bn_first;             // --batch_norm: element offset of the [beta|gamma] block (bn_update_kernel); BN_PARAMS elements
+  const int* ovf_flag;          // fp16 data parallel (update_kernel<true>): != 0 -> the all-reduced half gradient overflowed, leave theta / state untouched
+  int64_t* ovf_count;           //   ... and count the skipped step
+  int ovf_dynamic;              //   1: block 0 also moves the payload scale (state[1]) — halve on overflow, double after 200 clean steps
 };
 
 struct BnArgs {                  // one BatchNorm layer (bn_kernels.hip); activations NHWC: rows x C, C contiguous
@@ -122,7 +123,14 @@ __device__ inline float opt_apply(float w, float& s1, float& s2, float gsum, con
 }
 #endif
 
-hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s);     // the GEMM-shaped stages (single or multi-problem launches)
+// host-side launch choices that never reach a kernel (kept out of StepArgs: kernel-argument bytes are not free)
+struct LaunchTune {
+  int nw_override[12];      // tuning hook: waves per tile for kernel id i (0 = built-in choice)
+  int rb[12];               // B >= 128: register-blocked routine of kernel id i, menu entry (sdqn_kernels_rb.hip); 0 = unblocked routine
+  int hoist;                // bit 0: K_BWD2 / K_BWD1 carry the NEXT step's target conv1 / conv2; bit 1: K_CONV1_FWD / K_CONV2_FWD carry
+                            // this step's target conv3 / fc4 and compute the online net only (StepArgs::nz = 1)
+};
+hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s);     // the GEMM-shaped stages (single or multi-problem launches)
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s);
 hipError_t launch_update(const UpdateArgs& u, hipStream_t s);
 hipError_t launch_gather(const GatherArgs& g, hipStream_t s);
@@ -130,8 +138,8 @@ hipError_t launch_bn_forward(const BnArgs& b, hipStream_t s);      // [partial +
 hipError_t launch_bn_backward(const BnArgs& b, hipStream_t s);     // partial + apply
 hipError_t launch_bn_update(const UpdateArgs& u, hipStream_t s);   // optimizer step of the [beta | gamma] block (g already holds the sums)
 hipError_t launch_prep(const PrepArgs& p, hipStream_t s);
-hipError_t launch_grad_to_half(const float* g, half_t* gh, int64_t n, float scale, int* flag, hipStream_t s);       // fp16 DP payload
-hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, float inv_scale, int* flag, hipStream_t s);
+hipError_t launch_grad_to_half(const float* g, half_t* gh, int64_t n, int* state, hipStream_t s);       // fp16 DP payload; state = {flag, log2 scale, good steps}
+hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, int* state, hipStream_t s);
 hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s);   // fp16 mode: rebuild both half copies
 
 }  // namespace sdqn

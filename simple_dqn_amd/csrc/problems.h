@@ -67,8 +67,6 @@ struct MetaRec {            // device mirror of (rewards, actions, terminals) of
 struct StepArgs {
   const uint8_t* src;       // ring mirror (from_ring) or staging states [2][B][STATE]
   const int64_t* idx;       // sampled indexes [B] in DEVICE memory (copied from the pinned slot by prep_kernel)
-  const int64_t* idx_t;     // indexes the TARGET net (z = 1) gathers with; nullptr = idx.  Differs only when the target forward of the
-                            // NEXT step rides in this step's launches (hoist): then these are the next step's indexes
   int from_ring;
   int B, A, nz;
   const float* theta[2];    // flat parameter buffers: [0] online, [1] target
@@ -102,17 +100,16 @@ struct StepArgs {
   half_t *wh_w, *wht_w;            // writable aliases of wh[0] / wht[0] (refreshed by the optimizer epilogues)
   float loss_scale, inv_loss_scale;
   int h16;                         // 1: fp16 mode
-  int hoist;                // bit 0: this step's backward launches carry the NEXT step's target conv1 / conv2 (K_BWD2, K_BWD1);
-                            // bit 1: this step's conv1 / conv2 launches carry the rest of its own target forward (conv3, fc4), online net z = 0 only
   int xcd_map;              // XCD-contiguous workgroup->tile map (cuts fabric traffic to ~algorithmic): bit i = problem i of the launch
-  int nw_override[12];      // tuning hook: waves per tile for kernel id i (0 = built-in choice)
-  int rb[12];               // B >= 128: register-blocked routine of kernel id i, menu entry (sdqn_kernels_rb.hip); 0 = unblocked routine
+  int reserved_[12];        // (keeps the field offsets of the round-1 layout: the scalar-load schedule hipcc derives from them is part of
+                            //  the tuned kernels — a re-packed struct measured 1 % slower; host-only tuning lives in LaunchTune, kernels.h)
   float* __restrict__ theta_w;   // online parameters, writable alias of theta[0]
   float* __restrict__ state;     // RMSProp state
   float bsz, rho, one_minus_rho, lr, eps;
   // --batch_norm (deepqnetwork.py:26,83-89): launch_kernel picks the *Raw forward problems (linear output without the
   // Rectlin: the BatchNorm + Rectlin pass of bn_kernels.hip follows) and the head variant that reads an activated a4
   int bn;
+  const int64_t* idx_t;     // hoist option only (Conv1FwdTarget): the NEXT step's indexes, whose target conv1 rides in this step's K_BWD2
 };
 
 // A9 + A10 in Neon's operation order (the library is built with -ffp-contract=off: one rounding per op)
@@ -153,7 +150,7 @@ __device__ inline void rms_step2(float& w0, float& w1, float& st0, float& st1, f
 
 SDQN_HD int64_t sbase(const StepArgs& a, int z, int n) {
   // replay_memory.py:71-72: prestate = screens[i-4:i], poststate = screens[i-3:i+1]
-  return a.from_ring ? ((z != 0 && a.idx_t != nullptr ? a.idx_t : a.idx)[n] - C0 + z) * (int64_t)FRAME : ((int64_t)z * a.B + n) * (int64_t)STATE;
+  return a.from_ring ? (a.idx[n] - C0 + z) * (int64_t)FRAME : ((int64_t)z * a.B + n) * (int64_t)STATE;
 }
 // deepqnetwork.py:100 be.divide(input, 255): correctly-rounded x/255 without a divide — q = x*r, one fma
 // Newton correction (bit-identical to IEEE x/255.0f for all 256 byte values: tests/test_emul.py checks).
@@ -350,6 +347,14 @@ struct Fc4Fwd {     // deepqnetwork.py:89, split-K over S4 slabs; bias-free, ReL
 template <class P> struct TargetOnly : P {
   SDQN_HD static int nbz(const StepArgs&) { return 1; }
   SDQN_HD static void ksplit(const StepArgs& a, int, int& z, int& ks, int& kb, int& ke) { P::ksplit(a, 1, z, ks, kb, ke); }
+};
+struct Conv1FwdTarget : Conv1Fwd {       // target conv1 of the NEXT step: gathers with StepArgs::idx_t (poststates = screens[i-3 : i+1])
+  SDQN_HD static int nbz(const StepArgs&) { return 1; }
+  SDQN_HD static void ksplit(const StepArgs& a, int, int& z, int& ks, int& kb, int& ke) { Conv1Fwd::ksplit(a, 1, z, ks, kb, ke); }
+  SDQN_HD static aoff_t a_row(const StepArgs& a, int, int m) {
+    int n = m / PIX1, pix = m - n * PIX1, p = pix / Q1, q = pix - p * Q1;
+    return (a.idx_t[n] - C0 + 1) * (int64_t)FRAME + (int64_t)(p * ST1) * W0 + q * ST1;
+  }
 };
 struct Fc4FwdTarget : Fc4Fwd {
   SDQN_HD static int nbz(const StepArgs& a) { return a.S4; }

@@ -340,7 +340,7 @@ struct sdqn_net_s {
   int64_t train_iterations = 0;
   bool keep_grads = false;                 // true: fc4 gradient materialised in g (readable with which=3), no fused RMSProp
   half_t* gh = nullptr; int* ovf_flag = nullptr; int64_t* ovf_count = nullptr;    // fp16 data parallel: half gradient payload, overflow flag / skipped steps
-  int dp_half = 1, dp_half_scale_log2 = 6;   // fp16 mode: all-reduce the gradient as half (x 2^6: 8 summed ranks stay inside the half range for |g| < 127)
+  int dp_half = 1, dp_half_scale_log2 = -1;  // fp16 mode: all-reduce the gradient as half; -1 = dynamic payload scale (starts at 2^10, device-side), >= 0 = fixed 2^n
   bool h16_wgrad_mfma = true;              // fp16 mode: weight gradients on packed-fp16 MFMA (LDS transposes); false = fp32 MFMA with half operands
   bool grad_only = false;                  // true: a train step stops after the local gradient sums (update mode 1): what a
                                            // data-parallel rank has before the all-reduce; sdqn_net_apply_update finishes it
@@ -469,6 +469,7 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
     if (!c->target_enabled) { h->wh[1] = h->wh[0]; h->wht[1] = h->wht[0]; }
     NCHK(dalloc(h, (void**)&h->gh, (size_t)h->NP * 2));
     NCHK(dalloc(h, (void**)&h->ovf_flag, 16));
+    { const int st0[4] = {0, 10, 0, 0}; HIPCHK(hipMemcpyAsync(h->ovf_flag, st0, 16, hipMemcpyHostToDevice, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); }
     NCHK(dalloc(h, (void**)&h->ovf_count, 16));
   }
   NCHK(dalloc(h, (void**)&h->q, (size_t)2 * B * h->A * 4));
@@ -630,7 +631,7 @@ static StepArgs step_args(sdqn_net_s* h) {
   a.a1 = h->a1; a.a2 = h->a2; a.a3 = h->a3; a.slab4 = h->slab4; a.a4 = h->a4; a.d4 = h->d4; a.d3p = h->d3p; a.d2p = h->d2p; a.d3 = h->d3; a.d2 = h->d2;
   a.d1 = h->d1; a.g = h->g; a.slab1 = h->slab1; a.slab2 = h->slab2; a.slab3 = h->slab3;
   a.S4 = h->S4; a.tps1 = h->tps1; a.tps2 = h->tps2; a.tps3 = h->tps3;
-  for (int i = 0; i < 12; ++i) { a.nw_override[i] = h->nw_override[i]; a.rb[i] = h->B >= 128 ? h->rb[i] : 0; }
+
   a.xcd_map = h->xcd_map ? 7 : 0;
   if (h->cfg.datatype == 1) {
     a.h16 = h->h16_wgrad_mfma ? 2 : 1; a.h_a1 = h->h_a1; a.h_a2 = h->h_a2; a.h_a3 = h->h_a3; a.h_d4 = h->h_d4; a.h_d3p = h->h_d3p; a.h_d3 = h->h_d3;
@@ -676,8 +677,14 @@ static BnArgs bn_args(sdqn_net_s* h, const StepArgs& a, int layer, int train) {
 }
 // tuning hook: per-launch XCD map mask override (sdqn_net_set_option "xcd:<id>", value = mask + 1; 0 = built-in)
 #define XCD_TUNE(ARGS, KID) do { if (h->xcd_mask[KID] > 0) (ARGS).xcd_map = h->xcd_mask[KID] - 1; } while (0)
-static hipError_t launch_tuned(sdqn_net_s* h, int id, StepArgs a, hipStream_t s) { XCD_TUNE(a, id); return launch_kernel(id, a, s); }
-static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
+static hipError_t launch_tuned(sdqn_net_s* h, int id, StepArgs a, hipStream_t s, int hoist = 0) {
+  XCD_TUNE(a, id);
+  LaunchTune t;
+  for (int i = 0; i < 12; ++i) { t.nw_override[i] = h->nw_override[i]; t.rb[i] = h->rb[i]; }
+  t.hoist = hoist;
+  return launch_kernel(id, a, t, s);
+}
+static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int hoist = 0) {
   if (h->bn) {
     // deepqnetwork.py:83-89 with batch_norm: [Convolution|Linear] -> BatchNorm -> Rectlin.  The GEMM stage writes the raw
     // linear output (x_l), the BatchNorm pass turns it into the activation the next stage reads; training-mode
@@ -695,27 +702,25 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd) {
     LAUNCH(K_HEAD, launch_head(f, hd, g_stream));
     return SDQN_OK;
   }
-  if (a.hoist & 2) {
+  if (hoist & 2) {
     // hoist, second half: target conv1 / conv2 of THIS step ran inside the previous step's K_BWD2 / K_BWD1; its conv3 and fc4
     // ride in this step's conv1 / conv2 launches, whose own tiles are the online net's only (nz = 1).  The head then finds
     // the split-K slabs of both nets as usual.
-    StepArgs f1 = a; f1.nz = 1; f1.idx_t = nullptr; f1.hoist = 2;
+    StepArgs f1 = a; f1.nz = 1; f1.idx_t = nullptr;
     StepArgs c1 = f1; c1.xcd_map = 1;                           // problem 0 (online conv1 / conv2) on the XCD-contiguous map, as below
     StepArgs c2 = f1; c2.xcd_map = 3;                           // + the riding target fc4 (the K-slabs of a W4 panel share an L2)
-    LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, c1, g_stream));
-    LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, c2, g_stream));
-    f1.hoist = 0;
+    LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, c1, g_stream, 2));
+    LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, c2, g_stream, 2));
     LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, f1, g_stream));
     { int rc = join_comm(h); if (rc) return rc; }
     StepArgs f4 = f1; f4.xcd_map = 1;
     LAUNCH(K_FC4_FWD, launch_tuned(h, K_FC4_FWD, f4, g_stream));
-    StepArgs ah = a; ah.hoist = 0;
-    LAUNCH(K_HEAD, launch_head(ah, hd, g_stream));
+    LAUNCH(K_HEAD, launch_head(a, hd, g_stream));
     return SDQN_OK;
   }
   // XCD-contiguous tile map where it wins time (tools/sweep_xcd.py, tools/ab_options.py): conv1_fwd +0.5 %, conv2_fwd
   // +0.2 %, fc4_fwd +0.6 % of the step rate; slower for conv3_fwd, fc4_dgrad and every backward launch
-  StepArgs fm = a; fm.xcd_map = 1; fm.idx_t = nullptr; fm.hoist = 0;
+  StepArgs fm = a; fm.xcd_map = 1; fm.idx_t = nullptr;
   LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, fm, g_stream));
   LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, fm, g_stream));
   { StepArgs f3 = fm; f3.xcd_map = a.xcd_map; LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, f3, g_stream)); }
@@ -743,9 +748,8 @@ static UpdateArgs make_update_args(sdqn_net_s* h, const StepArgs& a) {
   }
   return u;
 }
-static int run_train(sdqn_net_s* h, const StepArgs& a_in, const HeadArgs& hd, const PrepArgs* next = nullptr) {
-  int rc = run_forward(h, a_in, hd); if (rc) return rc;
-  StepArgs a = a_in; a.hoist &= 1;                                            // bit 1 concerned the forward launches only
+static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const PrepArgs* next = nullptr, int hoist = 0) {
+  int rc = run_forward(h, a, hd, hoist); if (rc) return rc;
   // Backward.  Critical path on the library stream: fc4_dgrad -> conv3_dgrad -> conv2_dgrad -> conv1_wgrad.
   // The three other weight-gradient kernels only need the delta of their layer, so they run beside it
   // on the side stream (fork after the producer of their delta, join before the update).
@@ -789,9 +793,9 @@ static int run_train(sdqn_net_s* h, const StepArgs& a_in, const HeadArgs& hd, co
     } else { b3.f4w_first = 0; b3.f4w_count = f4_tiles; b2.f4w_count = b1.f4w_count = 0; }
     LAUNCH(K_BWD3, launch_tuned(h, K_BWD3, b3, g_stream));
     BN_BWD(1);
-    LAUNCH(K_BWD2, launch_tuned(h, K_BWD2, b2, g_stream));
+    LAUNCH(K_BWD2, launch_tuned(h, K_BWD2, b2, g_stream, hoist & 1));
     BN_BWD(0);
-    LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream));
+    LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream, hoist & 1));
   } else {
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[1], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[1], 0)); }
   // fc4_wgrad may update W4 in place (fused RMSProp): it must not start before fc4_dgrad has read W4
@@ -827,11 +831,10 @@ static int run_train(sdqn_net_s* h, const StepArgs& a_in, const HeadArgs& hd, co
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
     if (h->cfg.datatype == 1 && h->dp_half && h->gh) {
       // fp16 mode: half payload, fp32 accumulation in the optimizer, overflow -> the step is skipped on all ranks
-      const float sc = ldexpf(1.0f, h->dp_half_scale_log2);
-      LAUNCH(K_UPDATE, launch_grad_to_half(h->g, h->gh, h->NP, sc, h->ovf_flag, g_stream));
+      LAUNCH(K_UPDATE, launch_grad_to_half(h->g, h->gh, h->NP, h->ovf_flag, g_stream));
       LAUNCH(K_ALLREDUCE, dp_allreduce(h, h->gh, (size_t)h->NP, /*ncclFloat16*/ 6, h->comm, g_stream));
-      LAUNCH(K_UPDATE, launch_grad_from_half(h->gh, h->g, h->NP, 1.0f / sc, h->ovf_flag, g_stream));
-      u.ovf_flag = h->ovf_flag; u.ovf_count = h->ovf_count;
+      LAUNCH(K_UPDATE, launch_grad_from_half(h->gh, h->g, h->NP, h->ovf_flag, g_stream));
+      u.ovf_flag = h->ovf_flag; u.ovf_count = h->ovf_count; u.ovf_dynamic = h->dp_half_scale_log2 < 0 ? 1 : 0;
     } else
     LAUNCH(K_ALLREDUCE, dp_allreduce(h, h->g, (size_t)h->NP, /*ncclFloat32*/ 7, h->comm, g_stream));
     u.mode = 2; u.bsz = (float)h->B * (float)h->nranks;
@@ -999,10 +1002,10 @@ static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pin
   if (do_prep) { PrepArgs p = prep_args(h, r, pinned_idx); LAUNCH(K_PREP, launch_prep(p, g_stream)); }
   StepArgs a = step_args(h); a.from_ring = 1; a.src = r->d_ring; a.idx = h->d_idx;
   HeadArgs hd = head_args(h, 1);
-  a.hoist = (hoist_out ? 1 : 0) | (hoist_in ? 2 : 0);
+  const int hoist = (hoist_out ? 1 : 0) | (hoist_in ? 2 : 0);
   if (hoist_out) { a.idx_t = h->d_idx_t; hd.next_idx_pinned = next_pinned; hd.next_idx_dev = h->d_idx_t; hd.next_B = h->B; }
-  if (next_pinned) { PrepArgs np = prep_args(h, r, next_pinned); return run_train(h, a, hd, &np); }
-  return run_train(h, a, hd);
+  if (next_pinned) { PrepArgs np = prep_args(h, r, next_pinned); return run_train(h, a, hd, &np, hoist); }
+  return run_train(h, a, hd, nullptr, hoist);
 }
 extern "C" int sdqn_net_train_replay(sdqn_net_t h, sdqn_replay_t r, const int64_t* idx_host, float* cost_out) {
   ARGCHK(h && r && idx_host, "NULL argument");
@@ -1107,7 +1110,13 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "h16_wgrad_mfma")) h->h16_wgrad_mfma = value != 0;
   else if (!strcmp(name, "hoist")) h->hoist = value != 0;
   else if (!strcmp(name, "dp_half")) h->dp_half = value != 0;              // fp16 mode: half (1, default) or fp32 (0) all-reduce payload
-  else if (!strcmp(name, "dp_half_scale_log2")) { ARGCHK(value >= 0 && value <= 40, "bad scale"); h->dp_half_scale_log2 = value; }
+  else if (!strcmp(name, "dp_half_scale_log2")) {          // -1: dynamic (default); n >= 0: fixed payload scale 2^n
+    ARGCHK(value >= -1 && value <= 40 && h->ovf_flag, "bad scale (or not a float16 network)");
+    { int rc_ = join_comm(h); if (rc_) return rc_; } HIPCHK(hipStreamSynchronize(g_stream));
+    h->dp_half_scale_log2 = value;
+    const int st0[4] = {0, value < 0 ? 10 : value, 0, 0};
+    HIPCHK(hipMemcpy(h->ovf_flag, st0, 16, hipMemcpyHostToDevice));
+  }
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;
@@ -1227,7 +1236,7 @@ extern "C" int sdqn_debug_time_kernel(sdqn_net_t h, sdqn_replay_t r, const int64
   HIPCHK(set_timing_buffer(d));
   for (int rep = 0; rep < 3; ++rep) {                                               // last launch's stamps survive
     if (kernel == K_HEAD) { HeadArgs hd = head_args(h, 1); HIPCHK(launch_head(a, hd, g_stream)); }
-    else HIPCHK(launch_kernel(kernel, a, g_stream));
+    else HIPCHK(launch_tuned(h, kernel, a, g_stream));
   }
   HIPCHK(hipStreamSynchronize(g_stream));
   HIPCHK(set_timing_buffer(nullptr));

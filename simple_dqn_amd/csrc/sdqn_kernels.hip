@@ -21,7 +21,6 @@ const char* kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? k_names[id]
 template <class P>
 static hipError_t launch_nw(int nw, const StepArgs& a, hipStream_t s) {
   switch (nw) {
-    case 1: return launch_gemm<P, 1>(a, s);
     case 2: return launch_gemm<P, 2>(a, s);
     case 4: return launch_gemm<P, 4>(a, s);
     case 8: return launch_gemm<P, 8>(a, s);
@@ -31,77 +30,17 @@ static hipError_t launch_nw(int nw, const StepArgs& a, hipStream_t s) {
 }
 
 // Waves per workgroup = how many 32-deep K-chunks run concurrently on one output tile (gemm_engine.h).
-// fp16 mode: forward / dgrad on packed-fp16 MFMA (problems_h16.h), wgrad on the fp32 engine with half operands
-static hipError_t launch_kernel_h16(int id, const StepArgs& a, hipStream_t s) {
-  if (id >= 0 && id < 12 && a.nw_override[id] > 0) {          // tuning hook (sdqn_net_set_option "nw:<id>")
-    const int nw = a.nw_override[id];
-    switch (id) {
-      case K_CONV1_FWD: return launch_nw<Conv1FwdH>(nw, a, s);
-      case K_CONV2_FWD: return launch_nw<Conv2FwdH>(nw, a, s);
-      case K_CONV3_FWD: return launch_nw<Conv3FwdH>(nw, a, s);
-      case K_FC4_FWD: return launch_nw<Fc4FwdH>(nw, a, s);
-      case K_FC4_DGRAD: return launch_nw<Fc4DgradH>(nw, a, s);
-      case K_CONV3_DGRAD: return launch_nw<Conv3DgradH>(nw, a, s);
-      case K_CONV2_DGRAD: return launch_nw<Conv2DgradH>(nw, a, s);
-      case K_FC4_WGRAD: return launch_nw<Fc4WgradHW>(nw, a, s);
-      case K_CONV3_WGRAD: return launch_nw<Conv3WgradHW>(nw, a, s);
-      case K_CONV2_WGRAD: return launch_nw<Conv2WgradHW>(nw, a, s);
-      case K_CONV1_WGRAD: return launch_nw<Conv1WgradHW>(nw, a, s);
-      default: break;
-    }
-  }
-  if (a.h16 == 2) {            // weight gradients on packed-fp16 MFMA too (default); h16 == 1: fp32 MFMA with half operands (round 1)
-    switch (id) {
-      case K_FC4_WGRAD:
-        if (a.B <= 32) return launch_gemm<Fc4WgradHW, 1>(a, s);
-        return launch_gemm<Fc4WgradHW, 8>(a, s);
-      case K_CONV3_WGRAD: return launch_gemm<Conv3WgradHW, 8>(a, s);
-      case K_CONV2_WGRAD: return launch_gemm<Conv2WgradHW, 8>(a, s);
-      case K_CONV1_WGRAD: return launch_gemm<Conv1WgradHW, 16>(a, s);
-      case K_BWD3:
-        if (a.B <= 32) return launch_multi<512, Fc4WgradHW, 1, Conv3DgradH, 8, Conv3WgradHW, 8>(a, true, true, s);
-        return launch_multi<512, Fc4WgradHW, 8, Conv3DgradH, 8, Conv3WgradHW, 8>(a, true, true, s);
-      case K_BWD2: return launch_multi<512, NoProblem, 2, Conv2DgradH, 8, Conv2WgradHW, 8>(a, true, true, s);
-      case K_BWD1: return launch_multi<1024, NoProblem, 2, Conv1WgradHW, 16, NoProblem, 2>(a, true, false, s);
-      default: break;
-    }
-  }
-  if (a.B >= 128) {            // throughput regime: these launches are operand-traffic bound, fewer K-split waves per tile win
-    switch (id) {              // (tools/sweep_nw.py, B=256 DATATYPE=float16: fc4_fwd 24.3 -> 17.3 us, conv1_fwd 26.8 -> 24.4, conv3_fwd 21.9 -> 19.4)
-      case K_CONV1_FWD: return launch_gemm<Conv1FwdH, 1>(a, s);
-      case K_CONV3_FWD: return launch_gemm<Conv3FwdH, 8>(a, s);
-      case K_FC4_FWD: return launch_gemm<Fc4FwdH, 1>(a, s);
-      default: break;
-    }
-  }
-  switch (id) {
-    case K_CONV1_FWD: return launch_gemm<Conv1FwdH, 8>(a, s);
-    case K_CONV2_FWD: return launch_gemm<Conv2FwdH, 16>(a, s);
-    case K_CONV3_FWD: return launch_gemm<Conv3FwdH, 9>(a, s);
-    case K_FC4_FWD: return launch_gemm<Fc4FwdH, 14>(a, s);
-    case K_FC4_DGRAD: return launch_gemm<Fc4DgradH, 16>(a, s);
-    case K_FC4_WGRAD:
-      if (a.B <= 32) return launch_gemm<Fc4WgradH, 1>(a, s);
-      return launch_gemm<Fc4WgradH, 8>(a, s);
-    case K_CONV3_DGRAD: return launch_gemm<Conv3DgradH, 8>(a, s);
-    case K_CONV3_WGRAD: return launch_gemm<Conv3WgradH, 8>(a, s);
-    case K_CONV2_DGRAD: return launch_gemm<Conv2DgradH, 8>(a, s);
-    case K_CONV2_WGRAD: return launch_gemm<Conv2WgradH, 8>(a, s);
-    case K_CONV1_WGRAD: return launch_gemm<Conv1WgradH, 16>(a, s);
-    case K_BWD3:
-      if (a.B <= 32) return launch_multi<512, Fc4WgradH, 1, Conv3DgradH, 8, Conv3WgradH, 8>(a, true, true, s);
-      return launch_multi<512, Fc4WgradH, 8, Conv3DgradH, 8, Conv3WgradH, 8>(a, true, true, s);
-    case K_BWD2: return launch_multi<512, NoProblem, 2, Conv2DgradH, 8, Conv2WgradH, 8>(a, true, true, s);
-    case K_BWD1: return launch_multi<1024, NoProblem, 2, Conv1WgradH, 16, NoProblem, 2>(a, true, false, s);
-    default: return hipErrorInvalidValue;
-  }
-}
+// Everything that is NOT the default fp32 step lives in sdqn_kernels_ext.hip (fp16 mode, option "hoist", the register-blocked
+// experiments): hipcc's schedule of the default kernels depends on what else is instantiated in their translation unit
+// (measured: -1 % step rate when the new variants shared this file), so this file stays what round 1 tuned.
+hipError_t launch_kernel_ext(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled);
 
-hipError_t launch_kernel_rb(int id, int menu, const StepArgs& a, hipStream_t s);     // sdqn_kernels_rb.hip
-
-hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
-  if (a.h16) return launch_kernel_h16(id, a, s);
-  if (!a.bn && id >= 0 && id < 12 && a.rb[id] > 0) return launch_kernel_rb(id, a.rb[id], a, s);     // throughput regime (B >= 128)
+hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s) {
+  if (a.h16 || t.hoist || (a.B >= 128 && id >= 0 && id < 12 && t.rb[id] > 0)) {
+    bool handled = false;
+    const hipError_t e = launch_kernel_ext(id, a, t, s, &handled);
+    if (handled) return e;
+  }
   if (a.bn) {                  // --batch_norm forward: raw linear outputs (same tilings as the default problems)
     switch (id) {
       case K_CONV1_FWD: return launch_gemm<Conv1FwdRaw, 8>(a, s);
@@ -110,8 +49,8 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
       default: break;
     }
   }
-  if (id >= 0 && id < 12 && a.nw_override[id] > 0) {          // tuning hook (sdqn_net_set_option "nw:<id>")
-    const int nw = a.nw_override[id];
+  if (id >= 0 && id < 12 && t.nw_override[id] > 0) {          // tuning hook (sdqn_net_set_option "nw:<id>")
+    const int nw = t.nw_override[id];
     switch (id) {
       case K_CONV1_FWD: return launch_nw<Conv1Fwd>(nw, a, s);
       case K_CONV2_FWD: return launch_nw<Conv2Fwd>(nw, a, s);
@@ -127,10 +66,6 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
     }
   }
   if (a.B >= 128) {            // throughput regime (thousands of tiles per launch): tools/sweep_nw.py / tools/sweep_rb.py at B = 256
-    // conv weight gradients on the register-blocked routine (gemm_engine_rb.h; long K, few output tiles: the only stages
-    // where blocking beat the unblocked routine — profiles/README.md): RB<., 1, 2> = 32 x 64 wave tiles, one dwordx2 of the
-    // delta per k-slot for both column tiles; conv1 (u8 patches re-gathered from the ring) 64 x 32 with 16 waves per tile
-    const bool rb3 = a.rb[K_CONV3_WGRAD] != 0, rb2 = a.rb[K_CONV2_WGRAD] != 0, rb1 = a.rb[K_CONV1_WGRAD] != 0;
     switch (id) {
       case K_CONV1_FWD: return launch_gemm<Conv1Fwd, 8>(a, s);
       case K_CONV2_FWD: return launch_gemm<Staged<Conv2Fwd>, 8>(a, s);
@@ -140,40 +75,9 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
       case K_CONV3_DGRAD: return launch_gemm<Staged<Conv3Dgrad>, 8>(a, s);
       case K_CONV2_DGRAD: return launch_gemm<Staged<Conv2Dgrad>, 8>(a, s);
       case K_BWD3:
-        if (a.f4w_count > 0) {
-          if (rb3) return launch_multi<512, Fc4Wgrad, 8, Staged<Conv3Dgrad>, 8, RB<Conv3Wgrad, 1, 2>, 8>(a, true, true, s);
-          return launch_multi<512, Fc4Wgrad, 8, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
-        }
-        if (rb3) return launch_multi<512, NoProblem, 2, Staged<Conv3Dgrad>, 8, RB<Conv3Wgrad, 1, 2>, 8>(a, true, true, s);
+        if (a.f4w_count > 0) return launch_multi<512, Fc4Wgrad, 8, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
         return launch_multi<512, NoProblem, 2, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
-      case K_BWD2:
-        if (rb2) return launch_multi<512, NoProblem, 2, Staged<Conv2Dgrad>, 8, RB<Conv2Wgrad, 1, 2>, 8>(a, true, true, s);
-        return launch_multi<512, NoProblem, 2, Staged<Conv2Dgrad>, 8, Conv2Wgrad, 8>(a, true, true, s);
-      case K_BWD1:
-        if (rb1) return launch_multi<1024, NoProblem, 2, RB<Conv1Wgrad, 2, 1>, 16, NoProblem, 2>(a, true, false, s);
-        break;
-      default: break;
-    }
-  }
-  if (a.B <= 32 && a.hoist) {
-    // hoist (B <= 32): the target-net forward of the NEXT step rides in launches of this step that have room for it in the
-    // same round of workgroups (bwd2: 592 of 1024 slots, bwd1: 200 of 512; conv1/conv2 online-only: 400 / 162 workgroups):
-    //   K_BWD2(i)   + target conv1(i+1)      K_BWD1(i)   + target conv2(i+1)
-    //   K_CONV1(i+1) + target conv3(i+1)     K_CONV2(i+1) + target fc4(i+1)      -> the head of step i+1 finds both slab sets
-    // same tiles / waves per tile as the plain launches: bit-identical values.  StepArgs::nz = 1 in the two forward launches.
-    switch (id) {
-      case K_BWD2:
-        if ((a.hoist & 1) && a.f4w_count == 0) return launch_multi<512, TargetOnly<Conv1Fwd>, 8, Conv2Dgrad, 8, Conv2Wgrad, 8>(a, true, true, s);
-        break;
-      case K_BWD1:
-        if ((a.hoist & 1) && a.f4w_count == 0) return launch_multi<1024, TargetOnly<Conv2Fwd>, 16, Conv1Wgrad, 16, NoProblem, 2>(a, true, false, s);
-        break;
-      case K_CONV1_FWD:
-        if (a.hoist & 2) return launch_multi<576, Conv1Fwd, 8, TargetOnly<Staged<Conv3Fwd> >, 9, NoProblem, 2>(a, true, false, s);
-        break;
-      case K_CONV2_FWD:
-        if (a.hoist & 2) return launch_multi<1024, Conv2Fwd, 16, Staged<Fc4FwdTarget>, 14, NoProblem, 2>(a, true, false, s);
-        break;
+      case K_BWD2: return launch_multi<512, NoProblem, 2, Staged<Conv2Dgrad>, 8, Conv2Wgrad, 8>(a, true, true, s);
       default: break;
     }
   }
@@ -215,12 +119,16 @@ hipError_t launch_kernel(int id, const StepArgs& a, hipStream_t s) {
 // AMAX = compile-time bound on num_actions (4 / 8 / 18): every load below is unconditional with a clamped index and
 // a select — a conditional load costs hipcc a branch, a scalar pointer re-load and a wait EACH (36 of them measured
 // ~3000 cycles here), and the LDS footprint follows the bucket.
-template <int AMAX, bool BN>
+// HOIST (option "hoist" only; compiled out of the default kernel — even this one branch was measurable): one extra workgroup
+// fetches the next step's indexes from their pinned host slot into HBM.
+template <int AMAX, bool BN, bool HOIST = false>
 __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadArgs h) {
   SDQN_STAMP(0);
-  if ((int)blockIdx.x >= a.B) {                      // hoist: the extra workgroup fetches the next step's indexes (pinned host slot -> HBM)
-    for (int k = threadIdx.x; k < h.next_B; k += 512) h.next_idx_dev[k] = h.next_idx_pinned[k];
-    return;
+  if constexpr (HOIST) {
+    if ((int)blockIdx.x >= a.B) {
+      for (int k = threadIdx.x; k < h.next_B; k += 512) h.next_idx_dev[k] = h.next_idx_pinned[k];
+      return;
+    }
   }
   const int n = blockIdx.x, j = threadIdx.x, lane = j & 63, wave = j >> 6;
   __shared__ float prod[2 * AMAX][NFC];               // 16 KB (A <= 4) .. 72 KB (A <= 18)
@@ -343,11 +251,16 @@ hipError_t set_timing_buffer(unsigned long long* p) {
 #endif
 
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
-  const int nb = a.B + (h.next_B > 0 ? 1 : 0);
-  if (a.bn) hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, true>), dim3(nb), dim3(512), 0, s, a, h);     // --batch_norm (not tuned per bucket)
-  else if (a.A <= 4) hipLaunchKernelGGL((head_kernel<4, false>), dim3(nb), dim3(512), 0, s, a, h);
-  else if (a.A <= 8) hipLaunchKernelGGL((head_kernel<8, false>), dim3(nb), dim3(512), 0, s, a, h);
-  else hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, false>), dim3(nb), dim3(512), 0, s, a, h);
+  if (h.next_B > 0 && !a.bn) {                       // option "hoist": + one workgroup fetching the next step's indexes
+    if (a.A <= 4) hipLaunchKernelGGL((head_kernel<4, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
+    else if (a.A <= 8) hipLaunchKernelGGL((head_kernel<8, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
+    else hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
+    return hipGetLastError();
+  }
+  if (a.bn) hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, true>), dim3(a.B), dim3(512), 0, s, a, h);     // --batch_norm (not tuned per bucket)
+  else if (a.A <= 4) hipLaunchKernelGGL((head_kernel<4, false>), dim3(a.B), dim3(512), 0, s, a, h);
+  else if (a.A <= 8) hipLaunchKernelGGL((head_kernel<8, false>), dim3(a.B), dim3(512), 0, s, a, h);
+  else hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, false>), dim3(a.B), dim3(512), 0, s, a, h);
   return hipGetLastError();
 }
 
@@ -382,12 +295,21 @@ constexpr int CONV_F4 = OFF4 / 4;                 // 19456 float4 of conv parame
 constexpr int CONV_BLOCKS = CONV_F4 / 32;         // 608
 constexpr int FC5_BLOCKS_PER_ACTION = NFC / 4 / 32;   // 4 workgroups of 32 float4 columns per action row
 
+// OVF (fp16 data parallel only; compiled out of the default kernel): a half overflow in the all-reduced gradient skips the
+// whole apply step on every rank
+template <bool OVF>
 __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
   __shared__ float4 part[8][32];
   const int t = threadIdx.x;
-  // fp16 data parallel: a half overflow in the all-reduced gradient skips the whole apply step on every rank
-  const bool skip_apply = u.ovf_flag != nullptr && *u.ovf_flag != 0;
-  if (skip_apply && blockIdx.x == 0 && t == 0) u.ovf_count[0] += 1;
+  bool skip_apply = false;
+  if constexpr (OVF) {
+    skip_apply = u.ovf_flag[0] != 0;
+    if (blockIdx.x == 0 && t == 0) {                                 // (every block has read the flag and the scale by its own first lines;
+      int* st = const_cast<int*>(u.ovf_flag);                       //  the two half passes of the NEXT step are later launches)
+      if (skip_apply) { u.ovf_count[0] += 1; st[2] = 0; if (u.ovf_dynamic && st[1] > 0) st[1] -= 1; }
+      else if (u.ovf_dynamic && ++st[2] >= 200) { st[2] = 0; if (st[1] < 15) st[1] += 1; }
+    }
+  }
   if (u.only_fc4 && (int)blockIdx.x < CONV_BLOCKS + u.A * FC5_BLOCKS_PER_ACTION) return;
   if ((int)blockIdx.x < CONV_BLOCKS) {
     const int c4 = t & 31, sg = t >> 5;
@@ -504,7 +426,9 @@ __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
 hipError_t launch_update(const UpdateArgs& u, hipStream_t s) {
   int dense = 2;                                                   // hosts the ride-along prep and the cost mean
   if (!u.skip_fc4) { dense = (NW4 / 4 + 255) / 256; if (dense > 1792) dense = 1792; }
-  hipLaunchKernelGGL(update_kernel, dim3(CONV_BLOCKS + u.A * FC5_BLOCKS_PER_ACTION + dense), dim3(256), 0, s, u);
+  const dim3 grid(CONV_BLOCKS + u.A * FC5_BLOCKS_PER_ACTION + dense);
+  if (u.ovf_flag) hipLaunchKernelGGL(update_kernel<true>, grid, dim3(256), 0, s, u);
+  else hipLaunchKernelGGL(update_kernel<false>, grid, dim3(256), 0, s, u);
   return hipGetLastError();
 }
 
@@ -533,8 +457,13 @@ hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStre
 // all-reduce (a half overflow on any rank becomes inf on EVERY rank through the sum) raises the step's overflow flag:
 // the apply-only update then leaves parameters and optimizer state untouched on all ranks alike (the usual
 // mixed-precision "skip the step" rule) and the skipped-step counter goes up.
-__global__ void __launch_bounds__(256) grad_to_half_kernel(const float* __restrict__ g, half_t* __restrict__ gh, int64_t n, float scale, int* flag) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *flag = 0;                    // this step's flag (only the from-half pass, a later launch, sets it)
+// Dynamic payload scale, kept on the device (state = {flag, log2 scale, good steps}; identical on every rank because every
+// rank sees the same all-reduced values): halved after an overflow, doubled after 200 clean steps, 2^0 .. 2^15 — RMSProp
+// turns a gradient that was flushed to zero into a missing +-lr/sqrt(1-rho) step, so the scale should sit as high as the
+// summed gradient allows.  The update launch (update_kernel<true>, block 0) moves it; these two passes only read it.
+__global__ void __launch_bounds__(256) grad_to_half_kernel(const float* __restrict__ g, half_t* __restrict__ gh, int64_t n, int* state) {
+  const float scale = ldexpf(1.0f, state[1]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) state[0] = 0;                 // this step's flag (only the from-half pass, a later launch, sets it)
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
     if (i + 4 <= n) {
       const float4 v = *reinterpret_cast<const float4*>(g + i);
@@ -544,7 +473,9 @@ __global__ void __launch_bounds__(256) grad_to_half_kernel(const float* __restri
     } else for (int64_t k = i; k < n; ++k) gh[k] = (half_t)(g[k] * scale);
   }
 }
-__global__ void __launch_bounds__(256) grad_from_half_kernel(const half_t* __restrict__ gh, float* __restrict__ g, int64_t n, float inv_scale, int* flag) {
+__global__ void __launch_bounds__(256) grad_from_half_kernel(const half_t* __restrict__ gh, float* __restrict__ g, int64_t n, int* state) {
+  const float inv_scale = ldexpf(1.0f, -state[1]);
+  int* flag = state;
   bool bad = false;
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
     const int64_t e = i + 4 <= n ? i + 4 : n;
@@ -552,12 +483,12 @@ __global__ void __launch_bounds__(256) grad_from_half_kernel(const half_t* __res
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
-hipError_t launch_grad_to_half(const float* g, half_t* gh, int64_t n, float scale, int* flag, hipStream_t s) {
-  hipLaunchKernelGGL(grad_to_half_kernel, dim3(512), dim3(256), 0, s, g, gh, n, scale, flag);
+hipError_t launch_grad_to_half(const float* g, half_t* gh, int64_t n, int* state, hipStream_t s) {
+  hipLaunchKernelGGL(grad_to_half_kernel, dim3(512), dim3(256), 0, s, g, gh, n, state);
   return hipGetLastError();
 }
-hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, float inv_scale, int* flag, hipStream_t s) {
-  hipLaunchKernelGGL(grad_from_half_kernel, dim3(512), dim3(256), 0, s, gh, g, n, inv_scale, flag);
+hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, int* state, hipStream_t s) {
+  hipLaunchKernelGGL(grad_from_half_kernel, dim3(512), dim3(256), 0, s, gh, g, n, state);
   return hipGetLastError();
 }
 
