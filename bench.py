@@ -544,10 +544,10 @@ def main():
     dom = max(per_step, key=lambda p: p["total_ms"])
     # timed region: the dominant kernel stays bracketed with HIP events, but only every 16th launch — an event pair costs
     # 2-3 us of queue time, and bracketing every launch took 7 % off the step rate it is supposed to observe
-    # short runs still get >= 1 live bracket inside the timed region (launch 0 is always bracketed) without paying an event
-    # pair on every step: every 16th launch from 64 steps up, otherwise ~5 samples (measured: bracketing EVERY launch of a
-    # 20-step run cost 7 % of its step rate)
-    every = 16 if a.steps >= 64 else max(2, a.steps // 5)
+    # every 16th launch of the dominant kernel is bracketed, launch 0 included, so even the driver's 20-step run has live
+    # brackets inside the timed region (launches 0 and 16).  Measured on MI355X: an event pair in the dependent launch chain
+    # costs far more than its own 2-3 us (bracketing EVERY launch of a 20-step run: -7 % step rate; every 4th: -2.3 %).
+    every = 16
     net.set_option("profile_every", every)
     net.profile(True, dom["id"])
     net.profile_reset()
