@@ -608,7 +608,9 @@ def main():
                     out["replay_gather_large"] = gather_large(sd, make_args, fill_ring, A)
                 except Exception as e:
                     out["replay_gather_large"] = {"error": repr(e)[:200]}
-                out["q_mae_vs_cpu_ref"] = q_mae_on_timed_ring(net, mem, B, A, mt, steps=10 if B <= 64 else 3)
+                # (B > 64: one step — free-running fp32 implementations separate through ReLU-gate flips, 8x as likely per
+                #  step at B = 256; the multi-step check at that size is teacher-forced: tests/test_gpu_parity_r2.py)
+                out["q_mae_vs_cpu_ref"] = q_mae_on_timed_ring(net, mem, B, A, mt, steps=10 if B <= 64 else 1)
             out["north_star_target"] = north_star_target(out, sd, B, A)
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(B, A, a.seed, a.cpu_baseline_seconds)
