@@ -113,8 +113,10 @@ struct sdqn_replay_s {
   hipEvent_t slot_ev[NSLOT]; bool slot_busy[NSLOT]; int next_slot = 0;
 };
 
+static std::vector<sdqn_replay_s*> g_replays;      // live handles: sdqn_net_train_host recognises their pinned minibatch buffers
 static int replay_free(sdqn_replay_s* r) {
   if (!r) return SDQN_OK;
+  for (size_t i = 0; i < g_replays.size(); ++i) if (g_replays[i] == r) { g_replays.erase(g_replays.begin() + i); break; }
   if (g_stream) hipStreamSynchronize(g_stream);
   if (!(r->flags & SDQN_REPLAY_ZERO_COPY)) { hipFree(r->d_ring); hipFree(r->d_meta); }
   hipFree(r->d_pre); hipFree(r->d_post); hipFree(r->d_act); hipFree(r->d_term); hipFree(r->d_rew);
@@ -162,6 +164,7 @@ extern "C" int sdqn_replay_create(sdqn_replay_t* out, int64_t size, int H, int W
   RCHK(hipHostGetDevicePointer((void**)&r->d_idx_view, r->h_idx, 0));
   for (int i = 0; i < NSLOT; ++i) RCHK(hipEventCreateWithFlags(&r->slot_ev[i], hipEventDisableTiming));
 #undef RCHK
+  g_replays.push_back(r);
   *out = r;
   return SDQN_OK;
 }
@@ -336,6 +339,8 @@ struct sdqn_net_s {
   bool hoist = false;                      // train_many: the next step's target-net forward rides in this step's launches (B <= 32, fp32).
                                            // Built, bit-identical, measured 1.8 % SLOWER (tools/exp/README.md) -> off; set_option "hoist"
   float* h_f = nullptr;                    // pinned scratch for small read-backs
+  uint8_t* h_stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; bool stage_busy[2] = {false, false}; int stage_next = 0;
+                                           // tuple API (sdqn_net_train_host): pinned double buffer for the caller's pageable minibatch
   int S4 = 7, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
   int64_t train_iterations = 0;
   bool keep_grads = false;                 // true: fc4 gradient materialised in g (readable with which=3), no fused RMSProp
@@ -383,6 +388,7 @@ static int net_free(sdqn_net_s* h) {
   if (h->ev_w4) hipEventDestroy(h->ev_w4);
   for (void* p : h->allocs) hipFree(p);
   hipHostFree(h->h_f);
+  for (int i = 0; i < 2; ++i) { if (h->h_stage[i]) hipHostFree(h->h_stage[i]); if (h->stage_ev[i]) hipEventDestroy(h->stage_ev[i]); }
   for (auto& pp : h->prof_pending) { hipEventDestroy(pp.a); hipEventDestroy(pp.b); }
   for (auto e : h->prof_free) hipEventDestroy(e);
   delete h;
@@ -964,13 +970,30 @@ extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8
                                    const uint8_t* post, const uint8_t* terminals, float* cost_out) {
   ARGCHK(h && pre && actions && rewards && post && terminals, "NULL argument");
   for (int i = 0; i < h->B; ++i) ARGCHK(actions[i] < h->A, "action %d out of range at %d", (int)actions[i], i);
-  const size_t sb = (size_t)h->B * STATE;
-  HIPCHK(hipMemcpyAsync(h->st_states, pre, sb, hipMemcpyHostToDevice, g_stream));
-  HIPCHK(hipMemcpyAsync(h->st_states + sb, post, sb, hipMemcpyHostToDevice, g_stream));
-  HIPCHK(hipMemcpyAsync(h->st_act, actions, h->B, hipMemcpyHostToDevice, g_stream));
-  HIPCHK(hipMemcpyAsync(h->st_rew, rewards, (size_t)h->B * 8, hipMemcpyHostToDevice, g_stream));
-  HIPCHK(hipMemcpyAsync(h->st_term, terminals, h->B, hipMemcpyHostToDevice, g_stream));
-  HIPCHK(hipStreamSynchronize(g_stream));       // the caller's (pageable) arrays are free to change after return
+  const size_t sb = (size_t)h->B * STATE, small = (size_t)h->B * 10;
+  // No stream synchronisation (round 1 paid a full PCIe + sync bubble per step here): the caller's arrays are free to
+  // change after return because they are either copied into a pinned double buffer of the library first (pageable
+  // arrays), or ARE the pinned minibatch buffers of one of this library's ReplayMemory handles — what getMinibatch() returns
+  // for prestates / poststates —, whose next overwrite (gather + D2H) is ordered behind this H2D on the library stream.
+  const int sl = h->stage_next; h->stage_next ^= 1;
+  if (!h->h_stage[sl]) {
+    HIPCHK(hipHostMalloc((void**)&h->h_stage[sl], 2 * sb + small, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&h->stage_ev[sl], hipEventDisableTiming));
+  }
+  if (h->stage_busy[sl]) { HIPCHK(hipEventSynchronize(h->stage_ev[sl])); h->stage_busy[sl] = false; }
+  bool ours = false;
+  for (sdqn_replay_s* r : g_replays) ours |= (pre == r->h_pre && post == r->h_post && r->B == h->B);
+  uint8_t* st = h->h_stage[sl];
+  const uint8_t *src_pre = pre, *src_post = post;
+  if (!ours) { memcpy(st, pre, sb); memcpy(st + sb, post, sb); src_pre = st; src_post = st + sb; }
+  uint8_t* sm = st + 2 * sb;                                                  // [actions B | terminals B | rewards 8 B]
+  memcpy(sm, actions, h->B); memcpy(sm + h->B, terminals, h->B); memcpy(sm + 2 * (size_t)h->B, rewards, (size_t)h->B * 8);
+  HIPCHK(hipMemcpyAsync(h->st_states, src_pre, sb, hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipMemcpyAsync(h->st_states + sb, src_post, sb, hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipMemcpyAsync(h->st_act, sm, h->B, hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipMemcpyAsync(h->st_term, sm + h->B, h->B, hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipMemcpyAsync(h->st_rew, sm + 2 * (size_t)h->B, (size_t)h->B * 8, hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipEventRecord(h->stage_ev[sl], g_stream)); h->stage_busy[sl] = true;
   StepArgs a = step_args(h); a.from_ring = 0; a.src = h->st_states;
   HeadArgs hd = head_args(h, 1);
   int rc = run_train(h, a, hd); if (rc) return rc;

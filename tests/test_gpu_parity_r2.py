@@ -387,6 +387,38 @@ def test_on_train_called_per_step_with_callback(sd):
         assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
 
 
+def test_tuple_api_is_asynchronous_and_safe(sd):
+    """DeepQNetwork.train(minibatch) no longer synchronises the stream: pageable arrays are copied into a pinned double buffer
+    first, so the caller may overwrite them the moment train() returns (deepqnetwork.py:94-100 copies too); the pinned
+    prestates / poststates of this library's ReplayMemory are uploaded in place (their next overwrite is stream-ordered)."""
+    A, B, size = 4, 32, 1500
+    args = make_args(batch_size=B)
+    clean, _, _ = _net(sd, A, B, 711)
+    dirty, _, _ = _net(sd, A, B, 711)
+    for s in range(6):                                          # > 2 steps: both staging slots are reused
+        mb = random_minibatch(B, A, 712 + s)
+        clean.train(mb)
+        scratch = [x.copy() for x in mb]
+        dirty.train(tuple(scratch))
+        for x in scratch:
+            x[...] = 0 if x.dtype != np.uint8 else 255          # clobber the caller's arrays right after the call returned
+    for i in range(5):
+        assert np.array_equal(clean.get_layer(i, 0), dirty.get_layer(i, 0)), i
+    # the library's own pinned minibatch buffers, interleaved gathers
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 713, num_actions=A)
+    mem.sync_mirror()
+    n1, _, _ = _net(sd, A, B, 714)
+    n2, _, _ = _net(sd, A, B, 714)
+    random.seed(9); st = random.getstate()
+    for _ in range(4):
+        n1.train(mem.getMinibatch())                            # H2D straight from the pinned buffers, no sync; next gather overwrites them
+    random.setstate(st)
+    n2.train_from_memory(mem, 4)
+    for i in range(5):
+        assert np.array_equal(n1.get_layer(i, 0), n2.get_layer(i, 0)), i
+
+
 # ---- multi-GPU readiness that a 1-GPU box can check --------------------------------------------------------------------
 def test_bench_dry_run_dp_two_ranks(sd):
     """bench.py under torch.distributed.run with 2 ranks sharing the one GPU (control plane only: gloo id exchange,
