@@ -239,6 +239,7 @@ class DeepQNetwork:
         loop body).  Consumes Python's global random stream unless an explicit 625-word mt_state
         (ctypes uint32 array) is given."""
         import random
+        mem._check_mirror()
         if mt_state is None:
             st = random.getstate()
             mt = self._mt_buf                                     # persistent buffer + slice copies: 25 us instead of 78 us
@@ -269,6 +270,7 @@ class DeepQNetwork:
 
     def train_indexes(self, mem, indexes, want_cost=False):
         idx = np.ascontiguousarray(indexes, dtype=np.int64)
+        mem._check_mirror()
         cost = C.c_float()
         _lib.check(self._lib.sdqn_net_train_replay(self._h, mem._h, _lib.ptr(idx, C.c_int64), C.byref(cost) if want_cost else None))
         self.train_iterations += 1

@@ -44,6 +44,8 @@ class ReplayMemory:
         self._mb_actions = np.ctypeslib.as_array(ma, shape=(self.batch_size,))
         self._mb_rewards = np.ctypeslib.as_array(mr, shape=(self.batch_size,))
         self._mb_terminals = np.ctypeslib.as_array(mt, shape=(self.batch_size,)).view(np.bool_)
+        self._flags = flags
+        self._mirror_stale = False      # set when count / current are assigned directly: the tell-tale of a bulk fill through the numpy views
         self._idx = np.empty(self.batch_size, dtype=np.int64)
         self._mt = (C.c_uint32 * _lib.MT_WORDS)()
         self.last_indexes = None
@@ -67,6 +69,7 @@ class ReplayMemory:
     @count.setter
     def count(self, v):
         _lib.check(self._lib.sdqn_replay_set_state(self._h, int(v), self._state()[1]))
+        self._mirror_stale = self._flags != ZERO_COPY
 
     @property
     def current(self):
@@ -75,6 +78,15 @@ class ReplayMemory:
     @current.setter
     def current(self, v):
         _lib.check(self._lib.sdqn_replay_set_state(self._h, self._state()[0], int(v)))
+        self._mirror_stale = self._flags != ZERO_COPY
+
+    def _check_mirror(self):
+        """The reference has one copy of the ring; here the numpy attributes are the pinned master copy and kernels read an
+        HBM mirror that add() keeps current.  Writing the views directly (a bulk fill: `mem.screens[:] = ...; mem.count = n`)
+        leaves the mirror behind — detected through the direct count / current assignment that such a fill needs, and
+        refused loudly instead of training on stale frames."""
+        assert not self._mirror_stale, ("the replay ring was filled through its numpy views (count / current were assigned "
+                                        "directly): call mem.sync_mirror() before sampling or training from it")
 
     def add(self, action, reward, screen, terminal):               # :26-34
         assert screen.shape == self.dims
@@ -94,6 +106,7 @@ class ReplayMemory:
         """After writing the numpy views directly (bulk fills), copy slots into the HBM mirror."""
         n = self.size - first if n is None else n
         _lib.check(self._lib.sdqn_replay_upload(self._h, first, n))
+        self._mirror_stale = False
 
     def sample_indexes(self):
         """replay_memory.py:54-68 on Python's GLOBAL random stream (shared with agent.py:32,50-51)."""
@@ -106,6 +119,7 @@ class ReplayMemory:
     def gather(self, indexes):
         idx = np.ascontiguousarray(indexes, dtype=np.int64)
         assert idx.shape == (self.batch_size,)
+        self._check_mirror()
         _lib.check(self._lib.sdqn_replay_gather(self._h, _lib.ptr(idx, C.c_int64)))
         _lib.check(self._lib.sdqn_replay_minibatch_to_host(self._h))
         self.last_indexes = idx.copy()

@@ -350,6 +350,30 @@ def test_ring_action_out_of_range_is_rejected(sd):
         mem.gather(np.full(B, 150))                                       # beyond count (was: only beyond size)
 
 
+def test_stale_mirror_is_refused(sd):
+    """a bulk fill through the numpy views leaves the HBM mirror behind; the direct count / current
+    assignment such a fill needs marks the ring, and sampling / training refuses until sync_mirror()."""
+    B, size = 8, 300
+    args = make_args(batch_size=B)
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 5, num_actions=4)                                 # writes the views, assigns count / current
+    net = sd.DeepQNetwork(4, args)
+    random.seed(1)
+    with pytest.raises(AssertionError) as ei:
+        mem.getMinibatch()
+    assert "sync_mirror" in str(ei.value)
+    with pytest.raises(AssertionError):
+        net.train_from_memory(mem, 1)
+    mem.sync_mirror()
+    mem.getMinibatch(); net.train_from_memory(mem, 1)
+    scr = np.full((84, 84), 3, np.uint8)
+    mem.add(1, 0, scr, False)                                             # add() keeps the mirror current by itself
+    mem.getMinibatch()
+    zc = sd.ReplayMemory(size, args, flags=2)                             # zero-copy ring: kernels read the views themselves
+    synthetic_fill(zc, 5, num_actions=4)
+    zc.getMinibatch()
+
+
 def test_minibatch_small_arrays_are_copies(sd):
     """replay_memory.py:76-79: prestates/poststates alias the preallocated buffers, actions/rewards/terminals are fresh."""
     B, size = 8, 400
