@@ -87,6 +87,35 @@ def test_fp16_a6_one_step_and_five_step_tracking(sd):
     assert np.abs(q1 - qo).max() < 5e-2                        # 5 free-running steps of a half-precision net (measured 1.4e-2 ... 2.7e-2)
 
 
+def test_fp16_batch256_one_step(sd):
+    """float16 mode in the throughput regime (B = 256: other waves-per-tile choices for conv1 / conv3 / fc4 forward, 8-wave
+    K-split packed-fp16 weight gradients): Q and cost vs the half oracle, gradients in relative Frobenius norm, and the
+    packed-fp16 wgrad routine against the fp32-MFMA one on the same half operands."""
+    A, B = 3, 256
+    mb = random_minibatch(B, A, 732, reward_range=(-2, 3))
+    grads = {}
+    for mode in (0, 1):
+        net, ws, wt = _net(sd, A, B, 731, datatype="float16")
+        net.set_option("keep_gradients", 1)
+        net.set_option("h16_wgrad_mfma", mode)
+        costs = []
+        net.callback = type("CB", (), {"on_train": lambda self, c: costs.append(c)})()
+        net.train(mb)
+        grads[mode] = [net.get_layer(i, which=3) for i in range(5)]
+        q, _ = net.last_q()
+    o = OracleDQN(A, batch_size=B, weights=ws, half_activations=True)
+    o.Wt = [w.copy() for w in wt]
+    g, cost, _, preq = o.gradients(mb)
+    assert np.abs(q - preq).max() < H_TOL
+    assert abs(costs[0] - float(cost)) < 5e-3 * max(1.0, float(cost))
+    for i in range(5):
+        sc = max(1e-6, np.abs(g[i]).max())
+        d = np.abs(grads[1][i] - grads[0][i]).max() / sc
+        print("fp16 B=256 grad layer %d: f16-MFMA vs fp32-MFMA routine %.2e of max|g|; vs half oracle rel Frobenius %.2e" % (i, d, _rel_fro(grads[1][i], g[i])))
+        assert d < (1e-3 if i == 0 else 1e-5), i
+        assert _rel_fro(grads[1][i], g[i]) < 5e-2, i
+
+
 # ---- configs[2]: B = 256 --------------------------------------------------------------------------------------------
 def test_batch256_a6_one_step(sd):
     A, B = 6, 256
