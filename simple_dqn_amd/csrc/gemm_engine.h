@@ -529,7 +529,8 @@ __device__ __forceinline__ void gemm_tile_hw(const StepArgs& a, int bx, int by, 
 
 template <class P, int NW, int NT>
 __device__ __forceinline__ void run_tile(const StepArgs& a, int bx, int by, int bz, float* smem) {
-  if constexpr (is_rb<P>::value) gemm_tile_rb<P, NW, NT>(a, bx, by, bz, smem);
+  if constexpr (is_rb<P>::value && uses_f16_mfma<P>::value) gemm_tile_hb<P, NW, NT>(a, bx, by, bz, smem);
+  else if constexpr (is_rb<P>::value) gemm_tile_rb<P, NW, NT>(a, bx, by, bz, smem);
   else if constexpr (uses_f16_wgrad<P>::value) gemm_tile_hw<P, NW, NT>(a, bx, by, bz, smem);
   else if constexpr (uses_f16_mfma<P>::value) gemm_tile_h<P, NW, NT>(a, bx, by, bz, smem);
   else gemm_tile<P, NW, NT>(a, bx, by, bz, smem);

@@ -65,7 +65,27 @@ static hipError_t launch_kernel_rb(int id, int menu, const StepArgs& a, hipStrea
 
 
 // fp16 mode: forward / dgrad on packed-fp16 MFMA (problems_h16.h), wgrad on the fp32 engine with half operands
+// register-blocked packed-fp16 forward / dgrad (gemm_tile_hb) for B >= 128: menu per kernel id (tools/sweep_rb.py DATATYPE=float16)
+#define HB_CASE(N, P, RM, RN, NW) case N: return launch_gemm<RB<P, RM, RN>, NW>(a, s)
+static hipError_t launch_kernel_hb(int id, int menu, const StepArgs& a, hipStream_t s) {
+  switch (id) {
+    case K_CONV1_FWD: switch (menu) { HB_CASE(1, Conv1FwdH, 2, 1, 1); HB_CASE(2, Conv1FwdH, 4, 1, 1); HB_CASE(3, Conv1FwdH, 2, 1, 2); default: break; } break;
+    case K_CONV2_FWD: switch (menu) { HB_CASE(1, Conv2FwdH, 2, 2, 1); HB_CASE(2, Conv2FwdH, 2, 2, 2); HB_CASE(3, Conv2FwdH, 1, 2, 1); HB_CASE(4, Conv2FwdH, 2, 2, 4); HB_CASE(5, Conv2FwdH, 4, 2, 1); default: break; } break;
+    case K_CONV3_FWD: switch (menu) { HB_CASE(1, Conv3FwdH, 2, 2, 1); HB_CASE(2, Conv3FwdH, 2, 2, 2); HB_CASE(3, Conv3FwdH, 1, 2, 1); HB_CASE(4, Conv3FwdH, 2, 2, 4); HB_CASE(5, Conv3FwdH, 4, 2, 1); default: break; } break;
+    case K_FC4_FWD: switch (menu) { HB_CASE(1, Fc4FwdH, 2, 2, 1); HB_CASE(2, Fc4FwdH, 2, 2, 2); HB_CASE(3, Fc4FwdH, 4, 2, 1); HB_CASE(4, Fc4FwdH, 2, 4, 1); default: break; } break;
+    case K_FC4_DGRAD: switch (menu) { HB_CASE(1, Fc4DgradH, 2, 2, 1); HB_CASE(2, Fc4DgradH, 2, 2, 2); HB_CASE(3, Fc4DgradH, 4, 2, 1); HB_CASE(4, Fc4DgradH, 2, 4, 1); default: break; } break;
+    case K_CONV3_DGRAD: switch (menu) { HB_CASE(1, Conv3DgradH, 2, 2, 1); HB_CASE(2, Conv3DgradH, 2, 2, 2); HB_CASE(3, Conv3DgradH, 1, 2, 1); HB_CASE(4, Conv3DgradH, 4, 2, 1); default: break; } break;
+    case K_CONV2_DGRAD: switch (menu) { HB_CASE(1, Conv2DgradH, 2, 1, 1); HB_CASE(2, Conv2DgradH, 4, 1, 1); HB_CASE(3, Conv2DgradH, 2, 1, 2); default: break; } break;
+    default: break;
+  }
+  return hipErrorInvalidValue;
+}
+
 static hipError_t launch_kernel_h16(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s) {
+  if (a.B >= 128 && id >= 0 && id < 12 && t.rb[id] > 0) {
+    const hipError_t e = launch_kernel_hb(id, t.rb[id], a, s);
+    if (e != hipErrorInvalidValue) return e;
+  }
   if (id >= 0 && id < 12 && t.nw_override[id] > 0) {          // tuning hook (sdqn_net_set_option "nw:<id>")
     const int nw = t.nw_override[id];
     switch (id) {
@@ -99,11 +119,16 @@ static hipError_t launch_kernel_h16(int id, const StepArgs& a, const LaunchTune&
       default: break;
     }
   }
-  if (a.B >= 128) {            // throughput regime: these launches are operand-traffic bound, fewer K-split waves per tile win
-    switch (id) {              // (tools/sweep_nw.py, B=256 DATATYPE=float16: fc4_fwd 24.3 -> 17.3 us, conv1_fwd 26.8 -> 24.4, conv3_fwd 21.9 -> 19.4)
-      case K_CONV1_FWD: return launch_gemm<Conv1FwdH, 1>(a, s);
-      case K_CONV3_FWD: return launch_gemm<Conv3FwdH, 8>(a, s);
-      case K_FC4_FWD: return launch_gemm<Fc4FwdH, 1>(a, s);
+  if (a.B >= 128) {
+    // throughput regime: the forward launches are operand-traffic bound (their time is flat in the number of K-split waves,
+    // tools/sweep_nw.py), so they run on the register-blocked routine (gemm_tile_hb: each half8 fragment feeds 2 MFMAs) —
+    // DATATYPE=float16 tools/sweep_rb.py at B = 256: conv1_fwd 24.8 -> 20.8 us, conv2_fwd 27.5 -> 20.4, conv3_fwd 19.8 -> 16.5,
+    // fc4_fwd 17.3 -> 14.9.  The dgrads (M = B or few tiles per N) lose parallelism when blocked and stay unblocked.
+    switch (id) {
+      case K_CONV1_FWD: return launch_gemm<RB<Conv1FwdH, 2, 1>, 1>(a, s);
+      case K_CONV2_FWD: return launch_gemm<RB<Conv2FwdH, 2, 2>, 4>(a, s);
+      case K_CONV3_FWD: return launch_gemm<RB<Conv3FwdH, 2, 2>, 4>(a, s);
+      case K_FC4_FWD: return launch_gemm<RB<Fc4FwdH, 2, 2>, 1>(a, s);
       default: break;
     }
   }
