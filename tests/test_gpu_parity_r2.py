@@ -116,6 +116,32 @@ def test_fp16_batch256_one_step(sd):
         assert _rel_fro(grads[1][i], g[i]) < 5e-2, i
 
 
+@pytest.mark.parametrize("B", [128, 160])
+def test_fp16_blocked_forward_ragged_batches(sd, B):
+    """float16, B >= 128: the forward stages run on the register-blocked packed-fp16 routine (64-row blocks per wave).  B = 160 leaves
+    half-filled blocks in every stage (fc4: 160 = 2.5 blocks per net); online Q of a train step and `predict` vs the half oracle, and
+    vs the unblocked routine forced through the `nw:<kernel id>` tuning hook (other K-split, so not bit-identical)."""
+    A = 4
+    mb = random_minibatch(B, A, 742, reward_range=(-2, 3))
+    qs, ps = [], []
+    for unblocked in (0, 1):
+        net, ws, wt = _net(sd, A, B, 741, datatype="float16")
+        if unblocked:
+            for kid in (0, 1, 2, 3):
+                net.set_option("nw:%d" % kid, 8)
+        ps.append(net.predict(mb[0]).copy())
+        net.train(mb)
+        qs.append(net.last_q()[0].copy())
+    o = OracleDQN(A, batch_size=B, weights=ws, half_activations=True)
+    o.Wt = [w.copy() for w in wt]
+    _, _, _, preq = o.gradients(mb)
+    print("fp16 B=%d: blocked vs oracle %.2e, unblocked vs oracle %.2e, blocked vs unblocked %.2e" % (
+        B, np.abs(qs[0] - preq).max(), np.abs(qs[1] - preq).max(), np.abs(qs[0] - qs[1]).max()))
+    for q in qs + ps:
+        assert np.abs(q - preq).max() < H_TOL
+    assert np.abs(qs[0] - qs[1]).max() < H_TOL
+
+
 # ---- configs[2]: B = 256 --------------------------------------------------------------------------------------------
 def test_batch256_a6_one_step(sd):
     A, B = 6, 256
