@@ -109,6 +109,9 @@ def load():
     if not os.path.exists(path):
         raise SdqnError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    # the host driver only supports dmabuf IPC: without this RCCL's cross-process buffer registration fails with
+    # "hipIpcGetMemHandle: invalid argument" (must be in the environment before the HSA runtime initialises)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = C.CDLL(path, mode=os.RTLD_NOW | os.RTLD_LOCAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError here == header/library mismatch
