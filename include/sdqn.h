@@ -182,7 +182,8 @@ int sdqn_net_set_epoch(sdqn_net_t h, int epoch);
  * GPU RMSProp of fc4 is fused into the wgrad epilogue), "two_streams" (0 default; 1: wgrad kernels overlap the dgrad chain on a side stream), "fused_launches" (1 default:
  * independent backward stages share one grid), "xcd_map" (0 default = only where it wins time: conv1/conv2/fc4 forward; 1: the
  * XCD-contiguous workgroup->tile map for every launch), "dp_overlap" (0 default; 1 BEFORE sdqn_dp_init: fc4 gradient
- * all-reduced and applied on a second communicator + stream), "profile_every" (N: sdqn_net_profile brackets every N-th
+ * all-reduced and applied on a second communicator + stream), "dp_sync_replicas" (1 default: sdqn_dp_init broadcasts rank 0's online net,
+ * target net and optimizer state so every learner starts from — and keeps — the same network; 0 BEFORE sdqn_dp_init: keep own), "profile_every" (N: sdqn_net_profile brackets every N-th
  * launch), "nw:<kernel id>" / "xcd:<kernel id>" / "f4_share3" / "f4_share2" (tuning hooks) */
 int sdqn_net_set_option(sdqn_net_t h, const char* name, int value);
 

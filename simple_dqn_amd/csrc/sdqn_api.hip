@@ -283,6 +283,7 @@ struct Rccl {
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, Id128, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;   // optional (replica sync at dp_init)
   int (*CommDestroy)(void*) = nullptr;
   int (*CommSplit)(void*, int, int, void**, void*) = nullptr;      // optional (second communicator for the overlapped all-reduce)
   int (*GroupStart)() = nullptr;
@@ -301,6 +302,7 @@ static int rccl_load(const char* path) {
   g_rccl.GetUniqueId = (int (*)(void*))dlsym(lib, "ncclGetUniqueId");
   g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(lib, "ncclCommInitRank");
   g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
+  g_rccl.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclBroadcast");
   g_rccl.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
   g_rccl.CommSplit = (int (*)(void*, int, int, void**, void*))dlsym(lib, "ncclCommSplit");
@@ -368,6 +370,7 @@ struct sdqn_net_s {
   // overlapped data parallel (run_train): comm2 carries the fc4 gradient (95 % of the bytes) on g_comm while the
   // compute stream finishes the backward pass and starts the next forward; ev_w4 = "W4 of the last step is updated"
   void* comm2 = nullptr; hipEvent_t ev_g4 = nullptr, ev_w4 = nullptr; bool w4_pending = false;
+  bool dp_sync_replicas = true;   // dp_init broadcasts rank 0's theta / theta_t / optimizer state (set_option "dp_sync_replicas" 0: keep own)
   bool dp_overlap = false;        // opt-in (set_option "dp_overlap" before dp_init): multi-rank behaviour is unvalidated on 1-GPU boxes
   std::vector<void*> allocs;
 };
@@ -1143,6 +1146,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;
+  else if (!strcmp(name, "dp_sync_replicas")) h->dp_sync_replicas = value != 0;   // before dp_init
   else if (!strcmp(name, "dp_overlap")) h->dp_overlap = value != 0;     // before dp_init: 0 = single all-reduce on the library stream
   else if (!strcmp(name, "f4_share3")) h->f4_share[0] = value;
   else if (!strcmp(name, "f4_share2")) h->f4_share[1] = value;
@@ -1215,6 +1219,21 @@ extern "C" int sdqn_dp_init(sdqn_net_t h, const char* rccl_path, const char id[1
   if (h->comm2) {
     if (!h->ev_g4) HIPCHK(hipEventCreateWithFlags(&h->ev_g4, hipEventDisableTiming));
     if (!h->ev_w4) HIPCHK(hipEventCreateWithFlags(&h->ev_w4, hipEventDisableTiming));
+  }
+  // Replicas start identical BY CONSTRUCTION: rank 0's online net, target net and optimizer state are broadcast, so learners
+  // created with different seeds (random_seed unset: main.py:89) still share one network and one target-net sync
+  // (BASELINE configs[3]: "shared target-net sync" — afterwards every rank applies the same all-reduced gradient).
+  if (g_rccl.Broadcast && h->dp_sync_replicas) {
+    HIPCHK(hipStreamSynchronize(g_stream));
+    NCCLCHK(g_rccl.Broadcast(h->theta, h->theta, (size_t)h->NP, 7 /* ncclFloat32 */, 0, h->comm, g_stream));
+    if (h->theta_t != h->theta) NCCLCHK(g_rccl.Broadcast(h->theta_t, h->theta_t, (size_t)h->NP, 7, 0, h->comm, g_stream));
+    NCCLCHK(g_rccl.Broadcast(h->state, h->state, (size_t)h->NP, 7, 0, h->comm, g_stream));
+    if (h->state2) NCCLCHK(g_rccl.Broadcast(h->state2, h->state2, (size_t)h->NP, 7, 0, h->comm, g_stream));
+    if (h->cfg.datatype == 1) {
+      HIPCHK(launch_refresh16(h->theta, h->wh[0], h->wht[0], g_stream));
+      if (h->theta_t != h->theta) HIPCHK(launch_refresh16(h->theta_t, h->wh[1], h->wht[1], g_stream));
+    }
+    HIPCHK(hipStreamSynchronize(g_stream));
   }
   return SDQN_OK;
 }
