@@ -25,6 +25,7 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL across processes (before torch / HIP initialise)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")           # this stack's default; with 0 every launch fetches its arguments over PCIe (-23 %)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
