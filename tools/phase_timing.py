@@ -10,7 +10,7 @@ from bench import fill_ring
 lib = sd.load()
 lib.sdqn_debug_time_kernel.restype = C.c_int
 lib.sdqn_debug_time_kernel.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_uint64), C.c_int]
-B, A = 32, 4
+B, A = int(os.environ.get("B", 32)), 4
 args = make_args(batch_size=B)
 mem = sd.ReplayMemory(50000, args); fill_ring(mem, 1, A)
 net = sd.DeepQNetwork(A, args); net.update_target_network()
