@@ -416,9 +416,14 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   const int B = h->B;
   auto pick = [](int T, int target) { int t = (T + target - 1) / target; return t < 1 ? 1 : t; };
   // wgrad split-K: 16 waves per workgroup take one 32-deep chunk each at B = 32 (more per wave for larger B)
-  const int big = B >= 128 ? 2 : 1;
   const int T1 = ceil_div(B * PIX1, 32), T2 = ceil_div(B * PIX2, 32), T3 = ceil_div(B * PIX3, 32);
-  h->tps1 = pick(T1, 25 * big); h->tps2 = pick(T2, 6 * big); h->tps3 = pick(T3, 4 * big);
+  h->tps1 = pick(T1, 25); h->tps2 = pick(T2, 6); h->tps3 = pick(T3, 4);       // B = 32: 16 / 14 / 13 chunks per slab
+  if (B >= 128) {
+    // throughput regime: the chunks per slab stay about what they are at B = 32 and the NUMBER of slabs grows with B
+    // (tools/sweep_tps.py at B = 256, steps/s: 64/54/49 chunks per slab 3 430 -> 50/18/20 3 620; float16 5 380 -> 100/18/20 5 790)
+    h->tps1 = c->datatype == 1 ? 100 : 50; h->tps2 = 18; h->tps3 = 20;
+    if (h->tps1 > T1) h->tps1 = T1; if (h->tps2 > T2) h->tps2 = T2; if (h->tps3 > T3) h->tps3 = T3;
+  }
   // (the register-blocked routine, gemm_engine_rb.h, is available per kernel id through set_option "rb:<id>" / "tps:<l>":
   //  measured slower than these choices at B = 256 in every fused launch — tools/exp/README.md — so it is off by default)
   h->ns1 = ceil_div(T1, h->tps1); h->ns2 = ceil_div(T2, h->tps2); h->ns3 = ceil_div(T3, h->tps3);
@@ -440,7 +445,9 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->d1, (size_t)B * PIX1 * K1 * 4));
   NCHK(dalloc(h, (void**)&h->d3, (size_t)B * PIX3 * K3 * 4));
   NCHK(dalloc(h, (void**)&h->d2, (size_t)B * PIX2 * K2 * 4));
-  h->ns_cap[0] = h->ns1 > 64 ? h->ns1 : 64; h->ns_cap[1] = h->ns2 > 64 ? h->ns2 : 64; h->ns_cap[2] = h->ns3 > 64 ? h->ns3 : 64;
+  // room for the "tps:<layer>" tuning hook down to 8 chunks per slab (at least 64 slabs)
+  { const int Ts[3] = {T1, T2, T3}; const int ns[3] = {h->ns1, h->ns2, h->ns3};
+    for (int l = 0; l < 3; ++l) { int c = ceil_div(Ts[l], 8); if (c < 64) c = 64; if (c < ns[l]) c = ns[l]; h->ns_cap[l] = c; } }
   NCHK(dalloc(h, (void**)&h->slab1, (size_t)h->ns_cap[0] * NW1 * 4));
   NCHK(dalloc(h, (void**)&h->slab2, (size_t)h->ns_cap[1] * NW2 * 4));
   NCHK(dalloc(h, (void**)&h->slab3, (size_t)h->ns_cap[2] * NW3 * 4));

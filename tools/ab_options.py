@@ -6,12 +6,12 @@ import ctypes as C
 import simple_dqn_amd as sd
 from util import make_args
 from bench import fill_ring
-B, A = 32, 4
+B, A = int(os.environ.get("B", 32)), 4
 args = make_args(batch_size=B)
 mem = sd.ReplayMemory(100000, args); fill_ring(mem, 1, A)
 net = sd.DeepQNetwork(A, args); net.update_target_network()
 mt = (C.c_uint32 * 625)(); sd.load().sdqn_mt_seed(mt, 5)
-def rate(N=6000):
+def rate(N=int(os.environ.get("N", 6000))):
     net.train_from_memory(mem, 300, mt_state=mt, want_cost=False); net.sync()
     r = []
     for _ in range(3):
