@@ -343,7 +343,7 @@ struct sdqn_net_s {
   float* h_f = nullptr;                    // pinned scratch for small read-backs
   uint8_t* h_stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; bool stage_busy[2] = {false, false}; int stage_next = 0;
                                            // tuple API (sdqn_net_train_host): pinned double buffer for the caller's pageable minibatch
-  int S4 = 7, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
+  int S4 = 7, S4_cap = 7, tps1 = 1, tps2 = 1, tps3 = 1, ns1 = 1, ns2 = 1, ns3 = 1;
   int64_t train_iterations = 0;
   bool keep_grads = false;                 // true: fc4 gradient materialised in g (readable with which=3), no fused RMSProp
   half_t* gh = nullptr; int* ovf_flag = nullptr; int64_t* ovf_count = nullptr;    // fp16 data parallel: half gradient payload, overflow flag / skipped steps
@@ -427,7 +427,9 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   // (the register-blocked routine, gemm_engine_rb.h, is available per kernel id through set_option "rb:<id>" / "tps:<l>":
   //  measured slower than these choices at B = 256 in every fused launch — tools/exp/README.md — so it is off by default)
   h->ns1 = ceil_div(T1, h->tps1); h->ns2 = ceil_div(T2, h->tps2); h->ns3 = ceil_div(T3, h->tps3);
-  h->S4 = 7;
+  // fc4 forward K-splits: parallelism at B = 32; at B >= 128 the M x N tiles fill the chip in fp32 (3 620 -> 3 650 steps/s at B = 256),
+  // not in float16 where a wave owns a 64 x 64 block (S4 = 1: 4 850 steps/s, 7: 5 770)
+  h->S4 = (B >= 128 && c->datatype == 0) ? 1 : 7;
 #define NCHK(x) do { int r_ = (x); if (r_) { net_free(h); return r_; } } while (0)
   NCHK(dalloc(h, (void**)&h->theta, h->NP * 4));
   if (c->target_enabled) NCHK(dalloc(h, (void**)&h->theta_t, h->NP * 4)); else h->theta_t = h->theta;   // deepqnetwork.py:64-73
@@ -437,7 +439,8 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->a1, (size_t)2 * B * PIX1 * K1 * 4));
   NCHK(dalloc(h, (void**)&h->a2, (size_t)2 * B * PIX2 * K2 * 4));
   NCHK(dalloc(h, (void**)&h->a3, (size_t)2 * B * PIX3 * K3 * 4));
-  NCHK(dalloc(h, (void**)&h->slab4, (size_t)h->S4 * 2 * B * NFC * 4));
+  h->S4_cap = 7;
+  NCHK(dalloc(h, (void**)&h->slab4, (size_t)h->S4_cap * 2 * B * NFC * 4));
   NCHK(dalloc(h, (void**)&h->a4, (size_t)2 * B * NFC * 4));
   NCHK(dalloc(h, (void**)&h->d4, (size_t)B * NFC * 4));
   NCHK(dalloc(h, (void**)&h->d3p, (size_t)B * PD3 * PD3 * K3 * 4));    // borders stay zero for ever
@@ -1167,6 +1170,11 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
     int id = atoi(name + 3);
     if (id < 0 || id >= 12 || value < 0 || value > 8) { set_error("bad rb override"); return SDQN_ERR_ARG; }
     h->rb[id] = value;
+  }
+  else if (!strcmp(name, "s4")) {                          // tuning: split-K slabs of the fc4 forward (1..7; 7 allocated)
+    if (value < 1 || value > h->S4_cap) { set_error("bad s4 (1..%d)", h->S4_cap); return SDQN_ERR_ARG; }
+    { int rc_ = join_comm(h); if (rc_) return rc_; } HIPCHK(hipStreamSynchronize(g_stream));
+    h->S4 = value;
   }
   else if (!strncmp(name, "tps:", 4)) {                    // tuning: 32-deep K-chunks per split-K slab of conv layer 1..3 wgrad
     int l = atoi(name + 4);

@@ -7,7 +7,7 @@ import simple_dqn_amd as sd
 from util import make_args
 from bench import fill_ring
 B, A = int(os.environ.get("B", 32)), 4
-args = make_args(batch_size=B)
+args = make_args(batch_size=B, datatype=os.environ.get("DATATYPE", "float32"))
 mem = sd.ReplayMemory(100000, args); fill_ring(mem, 1, A)
 net = sd.DeepQNetwork(A, args); net.update_target_network()
 mt = (C.c_uint32 * 625)(); sd.load().sdqn_mt_seed(mt, 5)
@@ -24,5 +24,5 @@ for opts in OPTS:
     for k, v in opts: net.set_option(k, v)
     print(opts, round(rate()))
     for k, v in opts:
-        if not k.startswith("tps:"): net.set_option(k, 100 if k == "f4_share3" else 0)
+        if not k.startswith("tps:") and k != "s4": net.set_option(k, 100 if k == "f4_share3" else 0)
 print("base", round(rate()))
