@@ -417,7 +417,9 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   auto pick = [](int T, int target) { int t = (T + target - 1) / target; return t < 1 ? 1 : t; };
   // wgrad split-K: 16 waves per workgroup take one 32-deep chunk each at B = 32 (more per wave for larger B)
   const int T1 = ceil_div(B * PIX1, 32), T2 = ceil_div(B * PIX2, 32), T3 = ceil_div(B * PIX3, 32);
-  h->tps1 = pick(T1, 25); h->tps2 = pick(T2, 6); h->tps3 = pick(T3, 4);       // B = 32: 16 / 14 / 13 chunks per slab
+  // B = 32: 16 / 8 / 13 chunks per slab.  conv1 / conv2 wgrad: one chunk per wave of the 16- / 8-wave workgroup (tools/sweep_tps.py: conv2
+  // with 8 instead of 14 chunks per slab 12 570 -> 12 840 steps/s); conv3's slabs ride under the fc4 RMSProp stream: fewer, longer ones
+  h->tps1 = pick(T1, 25); h->tps2 = T2 < 8 ? T2 : 8; h->tps3 = pick(T3, 4);
   if (B >= 128) {
     // throughput regime: the chunks per slab stay about what they are at B = 32 and the NUMBER of slabs grows with B
     // (tools/sweep_tps.py at B = 256, steps/s: 64/54/49 chunks per slab 3 430 -> 50/18/20 3 620; float16 5 380 -> 100/18/20 5 790)

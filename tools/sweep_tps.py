@@ -22,7 +22,7 @@ def rate():
     return max(r)
 PIX = {1: 400, 2: 81, 3: 49}
 T = {l: -(-B * PIX[l] // 32) for l in PIX}
-dflt = {1: -(-T[1] // 25), 2: -(-T[2] // 6), 3: -(-T[3] // 4)}                  # as sdqn_net_create picks them
+dflt = {1: -(-T[1] // 25), 2: min(T[2], 8), 3: -(-T[3] // 4)}                  # as sdqn_net_create picks them
 if B >= 128: dflt = {1: min(T[1], 100 if DT == "float16" else 50), 2: min(T[2], 18), 3: min(T[3], 20)}
 print("B", B, DT, "chunks", T, "default tps", dflt, "base", round(rate()), flush=True)
 cand = eval(os.environ.get("CAND", "{}")) or {1: [50, 56, 80, 100], 2: [11, 14, 18, 24, 36], 3: [7, 10, 13, 16, 20, 25, 33]}
