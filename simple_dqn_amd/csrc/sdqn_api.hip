@@ -352,6 +352,7 @@ struct sdqn_net_s {
   bool grad_only = false;                  // true: a train step stops after the local gradient sums (update mode 1): what a
                                            // data-parallel rank has before the all-reduce; sdqn_net_apply_update finishes it
   int nw_override[12] = {0};               // tuning hook
+  int bwd_order = 0;                       // experiment: problem order inside the fused backward launches (sdqn_kernels_ext.hip)
   int f4_share[2] = {100, 0};               // % of the fc4-wgrad tiles in bwd3 / bwd2 (rest in bwd1)
   int ns_cap[3] = {1, 1, 1};               // slabs the split-K buffers were allocated for (tuning hook "tps:<layer>")
   int rb[12] = {0};                        // B >= 128: register-blocked routine, menu entry per kernel id (0 = unblocked)
@@ -702,7 +703,7 @@ static hipError_t launch_tuned(sdqn_net_s* h, int id, StepArgs a, hipStream_t s,
   XCD_TUNE(a, id);
   LaunchTune t;
   for (int i = 0; i < 12; ++i) { t.nw_override[i] = h->nw_override[i]; t.rb[i] = h->rb[i]; }
-  t.hoist = hoist;
+  t.hoist = hoist; t.order = h->bwd_order;
   return launch_kernel(id, a, t, s);
 }
 static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int hoist = 0) {
@@ -1173,6 +1174,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
     if (id < 0 || id >= 12 || value < 0 || value > 8) { set_error("bad rb override"); return SDQN_ERR_ARG; }
     h->rb[id] = value;
   }
+  else if (!strcmp(name, "bwd_order")) h->bwd_order = value;
   else if (!strcmp(name, "s4")) {                          // tuning: split-K slabs of the fc4 forward (1..7; 7 allocated)
     if (value < 1 || value > h->S4_cap) { set_error("bad s4 (1..%d)", h->S4_cap); return SDQN_ERR_ARG; }
     { int rc_ = join_comm(h); if (rc_) return rc_; } HIPCHK(hipStreamSynchronize(g_stream));

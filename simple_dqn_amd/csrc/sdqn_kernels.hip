@@ -36,7 +36,7 @@ static hipError_t launch_nw(int nw, const StepArgs& a, hipStream_t s) {
 hipError_t launch_kernel_ext(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled);
 
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s) {
-  if (a.h16 || t.hoist || (a.B >= 128 && id >= 0 && id < 12 && t.rb[id] > 0)) {
+  if (a.h16 || t.hoist || t.order || (a.B >= 128 && id >= 0 && id < 12 && t.rb[id] > 0)) {
     bool handled = false;
     const hipError_t e = launch_kernel_ext(id, a, t, s, &handled);
     if (handled) return e;
@@ -101,7 +101,8 @@ hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStre
     // so every tile of the launch is resident at once and the problems' latency chains overlap.  Fc4Wgrad is the
     // first problem so its memory-bound read-modify-write stream starts earliest (one tile per wave at B <= 32).
     case K_BWD3:
-      if (a.B <= 32 && a.f4w_count > 0) return launch_multi<512, Fc4Wgrad, 1, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
+      // (problem order = dispatch order: the long conv3 tiles first, the streaming fc4 tiles fill in behind them: +1 % step rate)
+      if (a.B <= 32 && a.f4w_count > 0) return launch_multi<512, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8, Fc4Wgrad, 1>(a, true, true, s);
       if (a.f4w_count > 0) return launch_multi<512, Fc4Wgrad, 8, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
       return launch_multi<512, NoProblem, 2, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
     case K_BWD2:

@@ -112,8 +112,12 @@ static hipError_t launch_kernel_h16(int id, const StepArgs& a, const LaunchTune&
       case K_CONV2_WGRAD: return launch_gemm<Conv2WgradHW, 8>(a, s);
       case K_CONV1_WGRAD: return launch_gemm<Conv1WgradHW, 16>(a, s);
       case K_BWD3:
-        if (a.B <= 32) return launch_multi<512, Fc4WgradHW, 1, Conv3DgradH, 8, Conv3WgradHW, 8>(a, true, true, s);
-        return launch_multi<512, Fc4WgradHW, 8, Conv3DgradH, 8, Conv3WgradHW, 8>(a, true, true, s);
+        if (t.order == 1) {        // round 1's dispatch order (experiment)
+          if (a.B <= 32) return launch_multi<512, Fc4WgradHW, 1, Conv3DgradH, 8, Conv3WgradHW, 8>(a, true, true, s);
+          return launch_multi<512, Fc4WgradHW, 8, Conv3DgradH, 8, Conv3WgradHW, 8>(a, true, true, s);
+        }
+        if (a.B <= 32) return launch_multi<512, Conv3DgradH, 8, Conv3WgradHW, 8, Fc4WgradHW, 1>(a, true, true, s);
+        return launch_multi<512, Conv3DgradH, 8, Conv3WgradHW, 8, Fc4WgradHW, 8>(a, true, true, s);
       case K_BWD2: return launch_multi<512, NoProblem, 2, Conv2DgradH, 8, Conv2WgradHW, 8>(a, true, true, s);
       case K_BWD1: return launch_multi<1024, NoProblem, 2, Conv1WgradHW, 16, NoProblem, 2>(a, true, false, s);
       default: break;
@@ -189,6 +193,14 @@ hipError_t launch_kernel_ext(int id, const StepArgs& a, const LaunchTune& t, hip
   if (a.h16) return launch_kernel_h16(id, a, t, s);
   if (!a.bn && a.B >= 128 && id >= 0 && id < 12 && t.rb[id] > 0) return launch_kernel_rb(id, t.rb[id], a, s);     // experiments (tools/sweep_rb.py)
   if (a.B <= 32 && t.hoist && !a.bn) return launch_kernel_hoist(id, a, t, s, handled);
+  if (a.B >= 128 && t.order == 3 && !a.bn && a.f4w_count > 0 && id == K_BWD3)       // experiment: the new order in the throughput regime
+    return launch_multi<512, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8, Fc4Wgrad, 8>(a, true, true, s);
+  if (a.B <= 32 && t.order && !a.bn && a.f4w_count > 0 && id == K_BWD3) {
+    // experiment (option "bwd_order"): which problem's workgroups are dispatched first inside bwd3.  Built-in: conv3_dgrad, conv3_wgrad,
+    // fc4_wgrad (12 950 steps/s); 1 = round 1's order fc4_wgrad, conv3_dgrad, conv3_wgrad (12 810); 2 = conv3_dgrad, fc4_wgrad, conv3_wgrad (12 900)
+    if (t.order == 1) return launch_multi<512, Fc4Wgrad, 1, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
+    if (t.order == 2) return launch_multi<512, Staged<Conv3Dgrad>, 8, Fc4Wgrad, 1, Conv3Wgrad, 8>(a, true, true, s);
+  }
   *handled = false;
   return hipSuccess;
 }
