@@ -599,7 +599,7 @@ __device__ __forceinline__ void multi_dispatch(const StepArgs& a, const MultiDim
     if (t < a.f4w_count) {
       const int tile = a.f4w_first + t;
       const int bz = tile / per_z, r = tile - bz * per_z;
-      run_tile<P, 1, 64>(a, r % d.gx[which], r / d.gx[which], bz, smem);
+      run_tile<P, 1, 64>(a, r % d.gx[which], r / d.gx[which], bz, smem);    // (n-fastest tile order measured: -0.4 %)
     }
   } else {
     const int per_z = d.gx[which] * d.gy[which];

@@ -1,5 +1,7 @@
 import sys, os, time, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import simple_dqn_amd._lib as _L
+if os.environ.get("SDQN_LIB"): _L.lib_path = lambda: os.path.join(os.path.dirname(os.path.abspath(_L.__file__)), os.environ["SDQN_LIB"])   # A/B of two builds
 import simple_dqn_amd as sd
 from util import make_args
 from bench import fill_ring
