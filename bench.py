@@ -444,10 +444,11 @@ def gather_large(sd, args_factory, mem_small_fill, A, Bbig=4096):
     mem = sd.ReplayMemory(size, args)
     mem_small_fill(mem, 77, A)
     rng = np.random.RandomState(5)
-    idx = rng.randint(8, size - 8, size=Bbig).astype(np.int64)
-    ms = mem.bench_gather(idx, iters=50)
+    idx = rng.randint(8, size - 8, size=(4, Bbig)).astype(np.int64)           # 4 index sets, cycled (each launch reads 145 MB of frames)
+    ms = mem.bench_gather(idx, iters=48)
     e = _roofline_entry(14, "replay_gather_u8", ms, Bbig, A)
     e["batch"] = Bbig
+    e["index_sets"] = 4
     return e
 
 
@@ -564,9 +565,11 @@ def main():
     # the ring upload otherwise starts the timed region on a device that is still ramping: tools/exp/short_run_rate.sh)
     pre = {}
     if rank == 0 and world == 1 and a.datatype == "float32" and not a.batch_norm:
-        idx = np.array(mem.sample_indexes())
-        g_ms = mem.bench_gather(idx, iters=200)
+        # a fresh index set per launch, like consecutive getMinibatch() calls (one repeated set would be read from L2 / MALL, not HBM)
+        idx = np.array([mem.sample_indexes().copy() for _ in range(256)])
+        g_ms = mem.bench_gather(idx, iters=512)
         pre["replay_gather"] = roofline_entry(14, "replay_gather_u8", g_ms, B, A)
+        pre["replay_gather"]["index_sets"] = 256
         if not a.profile_run:
             try:
                 pre["replay_gather_large"] = gather_large(sd, make_args, fill_ring, A)

@@ -90,6 +90,9 @@ int sdqn_replay_gather(sdqn_replay_t h, const int64_t* idx_host /*[batch]*/);
 int sdqn_replay_minibatch_to_host(sdqn_replay_t h);
 /* device-side timing of the last n gather launches, for bench.py (HIP events on the library stream) */
 int sdqn_replay_bench_gather(sdqn_replay_t h, const int64_t* idx_host, int iters, float* ms_per_launch);
+/* the same with a different index set per launch (idx_host = nsets x batch_size, cycled): a repeated set is served from L2 / MALL
+ * after its first launch, getMinibatch() (replay_memory.py:54-79) never gathers the same states twice in a row */
+int sdqn_replay_bench_gather_sets(sdqn_replay_t h, const int64_t* idx_host, int nsets, int iters, float* ms_per_launch);
 
 /* ---- Q-network: src/deepqnetwork.py ---------------------------------------- */
 typedef struct {

@@ -56,6 +56,7 @@ SIGNATURES = {
     "sdqn_replay_gather": (C.c_int, [_vp, _i64p]),
     "sdqn_replay_minibatch_to_host": (C.c_int, [_vp]),
     "sdqn_replay_bench_gather": (C.c_int, [_vp, _i64p, C.c_int, _f32p]),
+    "sdqn_replay_bench_gather_sets": (C.c_int, [_vp, _i64p, C.c_int, C.c_int, _f32p]),
     "sdqn_net_create": (C.c_int, [C.POINTER(_vp), C.POINTER(NetCfg)]),
     "sdqn_net_destroy": (C.c_int, [_vp]),
     "sdqn_net_layer_size": (C.c_int, [_vp, C.c_int, _i64p]),

@@ -275,6 +275,29 @@ extern "C" int sdqn_replay_bench_gather(sdqn_replay_t r, const int64_t* idx_host
   hipEventDestroy(e0); hipEventDestroy(e1);
   return replay_release_idx(r, slot);
 }
+// As above with a DIFFERENT index set per launch (idx_host = nsets x batch_size indexes, cycled): getMinibatch() never gathers the
+// same states twice in a row, and a repeated set is served from L2 / MALL after its first launch instead of HBM.
+extern "C" int sdqn_replay_bench_gather_sets(sdqn_replay_t r, const int64_t* idx_host, int nsets, int iters, float* ms_per_launch) {
+  ARGCHK(r && idx_host && nsets > 0 && iters > 0 && ms_per_launch, "bad arguments");
+  const int B = r->B;
+  for (int64_t i = 0; i < (int64_t)nsets * B; ++i)
+    ARGCHK(idx_host[i] >= r->hist && idx_host[i] < r->count, "index %lld out of range (count %lld)", (long long)idx_host[i], (long long)r->count);
+  int64_t* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, (size_t)nsets * B * sizeof(int64_t)));
+  HIPCHK(hipMemcpy(d, idx_host, (size_t)nsets * B * sizeof(int64_t), hipMemcpyHostToDevice));
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  GatherArgs g = gather_args(r, d);
+  HIPCHK(launch_gather(g, g_stream));                                        // warm (code object, not data: set 0 comes round last)
+  HIPCHK(hipEventRecord(e0, g_stream));
+  for (int i = 0; i < iters; ++i) { g.idx = d + (size_t)((i + 1) % nsets) * B; HIPCHK(launch_gather(g, g_stream)); }
+  HIPCHK(hipEventRecord(e1, g_stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_per_launch = ms / iters;
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  HIPCHK(hipFree(d));
+  return SDQN_OK;
+}
 
 // ---- RCCL (resolved at run time from the library the process already uses) ------------------------------
 struct Id128 { char b[128]; };   // ncclUniqueId is passed BY VALUE to ncclCommInitRank

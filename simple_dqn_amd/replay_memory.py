@@ -158,7 +158,13 @@ class ReplayMemory:
         self.sync_mirror(0, int(count))
 
     def bench_gather(self, indexes, iters=100):
+        """ms per launch of the standalone gather kernel.  `indexes`: one index set [B] (repeated: cache-resident after the first
+        launch) or several [nsets, B] (cycled, one set per launch — what consecutive getMinibatch() calls look like to the memory system)."""
         idx = np.ascontiguousarray(indexes, dtype=np.int64)
         ms = C.c_float()
-        _lib.check(self._lib.sdqn_replay_bench_gather(self._h, _lib.ptr(idx, C.c_int64), iters, C.byref(ms)))
+        if idx.ndim == 2:
+            assert idx.shape[1] == self.batch_size
+            _lib.check(self._lib.sdqn_replay_bench_gather_sets(self._h, _lib.ptr(idx, C.c_int64), idx.shape[0], iters, C.byref(ms)))
+        else:
+            _lib.check(self._lib.sdqn_replay_bench_gather(self._h, _lib.ptr(idx, C.c_int64), iters, C.byref(ms)))
         return ms.value
