@@ -97,7 +97,7 @@ def pmc_traffic(name, B, A):
 ROCPROF_MATCH = [
     ("gemm_kernel<sdqn::Conv1Fwd", 0), ("gemm_kernel<sdqn::Conv2Fwd", 1), ("Conv3Fwd", 2), ("Fc4Fwd", 3),
     ("head_kernel", 4), ("Fc4Dgrad", 5), ("update_kernel", 12), ("gather_kernel", 14), ("prep_kernel", 15),
-    ("gemm_multi_kernel<512, sdqn::Fc4Wgrad", 16), ("Conv2Dgrad", 17), ("Conv1Wgrad", 18),
+    ("gemm_multi_kernel<512, sdqn::Staged<sdqn::Conv3Dgrad>", 16), ("Conv2Dgrad", 17), ("Conv1Wgrad", 18),
 ]
 
 
