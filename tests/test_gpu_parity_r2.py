@@ -514,3 +514,59 @@ def test_bench_dry_run_dp_two_ranks(sd):
     out = json.loads(lines[-1])
     assert out["n_gpus"] == 2 and out["steps"] == 30 and out["value"] > 0
     assert out["dp"]["ranks"] == 2 and len(out["dp"]["per_rank"]) == 2
+
+
+# ---- tuning hooks must not change the arithmetic ----------------------------------------------------------------------
+@pytest.mark.parametrize("datatype", ["float32", "float16"])
+def test_dispatch_order_and_slab_options_keep_the_numbers(sd, datatype):
+    """`bwd_order` (which problem's workgroups of the fused bwd3 launch are dispatched first) must be bit-neutral: same tiles, same
+    K split, other block indexes.  `tps:<layer>` (split-K slab size of a conv weight gradient) and `s4` (fc4 forward K-splits) change
+    the summation order only: weights after 3 steps agree to fp32 round-off (float16: to the half oracle's own tolerance)."""
+    A, B, size = 4, 32, 4000
+    args = make_args(batch_size=B, datatype=datatype)
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 801, num_actions=A)
+    mem.sync_mirror()
+    lib = sd.load()
+
+    def run(opts):
+        n, _, _ = _net(sd, A, B, 802, datatype=datatype)
+        for k, v in opts: n.set_option(k, v)
+        mt = (C.c_uint32 * 625)(); lib.sdqn_mt_seed(mt, 803)
+        cost = [n.train_from_memory(mem, s, mt_state=mt, want_cost=True) for s in (1, 2)]
+        return n, cost
+    base, cb = run([])
+    for order in (1, 2) if datatype == "float32" else (1,):
+        n, c = run([("bwd_order", order)])
+        assert c == cb, order
+        for which in (0, 2):
+            for i in range(5):
+                assert np.array_equal(base.get_layer(i, which), n.get_layer(i, which)), (order, which, i)
+    tol = 2e-6 if datatype == "float32" else 2e-3
+    for opts in ([("tps:2", 14)], [("tps:1", 10), ("tps:3", 7)], [("s4", 4)]):
+        n, c = run(opts)
+        assert abs(c[-1] - cb[-1]) <= 1e-5 * max(1.0, abs(cb[-1])) if datatype == "float32" else True
+        for i in range(5):
+            d = np.abs(base.get_layer(i) - n.get_layer(i)).max()
+            assert d < tol, (opts, i, d)
+
+
+def test_bench_gather_with_index_sets(sd):
+    """sdqn_replay_bench_gather_sets: a different index set per launch; the last launch's minibatch is the last set's, bit for bit;
+    an index outside [history_length, count) is refused."""
+    A, B, size = 4, 32, 3000
+    args = make_args(batch_size=B)
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 811, num_actions=A)
+    mem.sync_mirror()
+    o = ReplayOracle(size, batch_size=B); synthetic_fill(o, 811, num_actions=A)
+    rng = np.random.RandomState(3)
+    sets = rng.randint(4, mem.count, size=(5, B)).astype(np.int64)
+    ms = mem.bench_gather(sets, iters=9)                      # launches: warm(set 0), then sets 1,2,3,4,0,1,2,3,4
+    assert ms > 0
+    assert sd.load().sdqn_replay_minibatch_to_host(mem._h) == 0          # (synchronises the library stream)
+    pre = np.stack([o.getState(int(i) - 1) for i in sets[4]])
+    assert np.array_equal(mem.prestates, pre)
+    bad = sets.copy(); bad[2, 7] = mem.count
+    with pytest.raises(AssertionError):
+        mem.bench_gather(bad, iters=2)
