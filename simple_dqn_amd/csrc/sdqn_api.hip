@@ -1214,7 +1214,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   }
   else if (!strncmp(name, "nw:", 3)) {                     // tuning: waves per tile of kernel id
     int id = atoi(name + 3);
-    if (id < 0 || id >= 12 || !(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) { set_error("bad nw override"); return SDQN_ERR_ARG; }
+    if (id < 0 || id >= 12 || !(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16 || (value == 9 && id == 2))) { set_error("bad nw override"); return SDQN_ERR_ARG; }
     h->nw_override[id] = value;
   }
   else { set_error("unknown option %s", name); return SDQN_ERR_ARG; }

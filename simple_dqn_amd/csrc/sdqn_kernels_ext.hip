@@ -176,7 +176,7 @@ static hipError_t launch_kernel_hoist(int id, const StepArgs& a, const LaunchTun
         if ((t.hoist & 1) && a.f4w_count == 0) return launch_multi<1024, TargetOnly<Conv2Fwd>, 16, Conv1Wgrad, 16, NoProblem, 2>(a, true, false, s);
         break;
       case K_CONV1_FWD:
-        if (t.hoist & 2) return launch_multi<576, Conv1Fwd, 8, TargetOnly<Staged<Conv3Fwd> >, 9, NoProblem, 2>(a, true, false, s);
+        if (t.hoist & 2) return launch_multi<1024, Conv1Fwd, 8, TargetOnly<Conv3Fwd>, 16, NoProblem, 2>(a, true, false, s);   // (same tiling as the plain conv3_fwd launch)
         break;
       case K_CONV2_FWD:
         if (t.hoist & 2) return launch_multi<1024, Conv2Fwd, 16, Staged<Fc4FwdTarget>, 14, NoProblem, 2>(a, true, false, s);
