@@ -330,7 +330,8 @@ def q_mae_on_timed_ring(net, mem, B, A, mt, steps=10):
         e = np.abs(q - forced.predict(hold)); tf_mae.append(float(e.mean())); tf_max.append(float(e.max()))
         ef = np.abs(q - free.predict(hold)); fr_max.append(float(ef.max()))
     first = next((i + 1 for i, v in enumerate(fr_max) if v > 1e-5), None)
-    return {"mae": float(np.mean(tf_mae)), "max_abs": float(max(tf_max)), "after_steps": steps, "tolerance": 1e-4,
+    return {"mae": float(np.mean(tf_mae)), "max_abs": float(max(tf_max)), "after_steps": steps, "tolerance": 1e-4, "tolerance_on": "mae",
+            "steps_with_gate_flip": int(sum(v > 1e-6 for v in tf_max)),   # tools/exp/qmae_diag.py: 6-8 of 80 steps on a young network, old and new kernels alike
             "mode": "teacher-forced: oracle re-loaded with the library's (theta, theta-, s) before each of the steps; mean MAE / worst element",
             "per_step_max_abs": [float("%.3g" % v) for v in tf_max],
             "free_running": {"mae": float(ef.mean()), "max_abs": float(ef.max()), "after_steps": steps, "first_step_over_1e-5": first,

@@ -17,6 +17,8 @@ args = make_args(batch_size=B, random_seed=seed + 1)
 mem = sd.ReplayMemory(int(os.environ.get("RING", 1000000)), args); fill_ring(mem, seed, A)
 net = sd.DeepQNetwork(A, args); net.update_target_network()
 if os.environ.get("TPS2"): net.set_option("tps:2", int(os.environ["TPS2"]))
+if os.environ.get("R1"):                     # round 1's summation orders / dispatch order
+    net.set_option("tps:2", 14); net.set_option("nw:2", 9); net.set_option("bwd_order", 1)
 mt = (C.c_uint32 * 625)(); _lib.check(sd.load().sdqn_mt_seed(mt, seed + 2))
 net.train_from_memory(mem, max(W - 2, 3) + 2 + K, mt_state=mt, want_cost=False); net.sync()
 
@@ -31,7 +33,7 @@ omem = oracle_view(mem, B)
 rng = MT19937(); rng.setstate(tuple(mt[:]))
 hold_rng = MT19937(); hold_rng.setstate(tuple(mt[:]))
 for _ in range(40): hold = omem.getMinibatch(hold_rng)[0].copy()
-for s in range(10):
+for s in range(int(os.environ.get("STEPS", 10))):
     mb = [x.copy() for x in omem.getMinibatch(rng)]
     load(tf)
     net.train_from_memory(mem, 1, mt_state=mt, want_cost=False); net.sync()
