@@ -515,6 +515,8 @@ def main():
     net = sd.DeepQNetwork(A, args)
     net.update_target_network()
     net.set_option("dp_overlap", 1 if a.dp_overlap else 0)
+    for kv in filter(None, os.environ.get("SDQN_BENCH_OPTS", "").split(",")):      # experiments only, e.g. "xcd:18=3,xcd:17=7"
+        k, v = kv.split("="); net.set_option(k, int(v))
     if world == 1 and a.single_rank_dp:
         net.dp_init(dp_unique_id(), 0, 1)
         flush_c_stdio()

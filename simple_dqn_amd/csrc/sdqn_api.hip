@@ -840,6 +840,9 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     BN_BWD(1);
     LAUNCH(K_BWD2, launch_tuned(h, K_BWD2, b2, g_stream, hoist & 1));
     BN_BWD(0);
+    // conv1_wgrad on the XCD-contiguous tile map: the 8 m-tiles of a K-slab read the same frames, so a slab's tiles belong on ONE XCD's L2
+    // (L2 <-> fabric traffic of the launch 15.8 -> 4.0 MB = 1.4x algorithmic, rocprofv3 PMC; step rate -0.1 %: the re-reads were MALL hits)
+    b1.xcd_map |= 2;
     LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream, hoist & 1));
   } else {
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[1], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[1], 0)); }
