@@ -138,7 +138,7 @@ hipError_t launch_gather(const GatherArgs& g, hipStream_t s);
 hipError_t launch_bn_forward(const BnArgs& b, hipStream_t s);      // [partial +] apply
 hipError_t launch_bn_backward(const BnArgs& b, hipStream_t s);     // partial + apply
 hipError_t launch_bn_update(const UpdateArgs& u, hipStream_t s);   // optimizer step of the [beta | gamma] block (g already holds the sums)
-hipError_t launch_prep(const PrepArgs& p, hipStream_t s);
+hipError_t launch_prep(const PrepArgs& p, hipStream_t s, double* zero8 = nullptr);   // zero8: an 8-byte accumulator the launch also clears
 hipError_t launch_grad_to_half(const float* g, half_t* gh, int64_t n, int* state, hipStream_t s);       // fp16 DP payload; state = {flag, log2 scale, good steps}
 hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, int* state, hipStream_t s);
 hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s);   // fp16 mode: rebuild both half copies

@@ -1084,8 +1084,8 @@ static bool hoist_possible(sdqn_net_s* h) {
          !(h->comm && h->comm2 && h->dp_overlap) && h->f4_share[0] == 100 && h->f4_share[1] == 0 && h->theta_t != h->theta;
 }
 static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pinned_idx, bool do_prep = true,
-                             const int64_t* next_pinned = nullptr, bool hoist_in = false, bool hoist_out = false) {
-  if (do_prep) { PrepArgs p = prep_args(h, r, pinned_idx); LAUNCH(K_PREP, launch_prep(p, g_stream)); }
+                             const int64_t* next_pinned = nullptr, bool hoist_in = false, bool hoist_out = false, double* zero8 = nullptr) {
+  if (do_prep) { PrepArgs p = prep_args(h, r, pinned_idx); LAUNCH(K_PREP, launch_prep(p, g_stream, zero8)); }
   StepArgs a = step_args(h); a.from_ring = 1; a.src = r->d_ring; a.idx = h->d_idx;
   HeadArgs hd = head_args(h, 1);
   const int hoist = (hoist_out ? 1 : 0) | (hoist_in ? 2 : 0);
@@ -1107,7 +1107,7 @@ extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, 
   ARGCHK(h && r && mt && n_steps >= 0, "bad arguments");
   ARGCHK(r->B == h->B, "replay batch_size %d != network batch_size %d", r->B, h->B);
   std::vector<int64_t> idx((size_t)r->B);
-  HIPCHK(hipMemsetAsync(h->cost_accum, 0, 8, g_stream));
+  if (n_steps == 0) HIPCHK(hipMemsetAsync(h->cost_accum, 0, 8, g_stream));       // (otherwise the first step's prep launch clears it)
   // sample one step ahead: step i's update launch also performs step i+1's prep (index copy + metadata gather)
   int slot = -1, next_slot = -1; const int64_t *pinned = nullptr, *next_pinned = nullptr;
   if (n_steps > 0) {
@@ -1125,7 +1125,7 @@ extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, 
     }
     // the target-net forward of step i+1 (theta- and the next indexes only) rides in step i's launches: run_forward / launch_kernel
     const bool hoist_out = next_pinned != nullptr && hoist_possible(h);
-    int rc = train_replay_slot(h, r, pinned, /*do_prep=*/i == 0, next_pinned, hoisted, hoist_out); if (rc) return rc;
+    int rc = train_replay_slot(h, r, pinned, /*do_prep=*/i == 0, next_pinned, hoisted, hoist_out, i == 0 ? h->cost_accum : nullptr); if (rc) return rc;
     hoisted = hoist_out;
     rc = replay_release_idx_batched(r, slot, false);
     if (rc) return rc;

@@ -497,7 +497,8 @@ hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, int* sta
 // prep: the sampled indexes arrive in a pinned host slot; one tiny workgroup copies them into device
 // memory and gathers (a, r, t) = (actions, rewards, terminals)[idx] (replay_memory.py:76-78) so that no
 // later kernel of the step touches host memory.
-__global__ void __launch_bounds__(256) prep_kernel(const PrepArgs p) {
+__global__ void __launch_bounds__(256) prep_kernel(const PrepArgs p, double* zero8) {
+  if (zero8 && threadIdx.x == 0) *zero8 = 0.0;                    // the cost accumulator of a train_many call (instead of a memset launch)
   for (int n = threadIdx.x; n < p.B; n += 256) {
     const int64_t i = p.idx_pinned[n];
     p.idx[n] = i;
@@ -505,8 +506,8 @@ __global__ void __launch_bounds__(256) prep_kernel(const PrepArgs p) {
     p.actions[n] = rec.action; p.rewards[n] = rec.reward; p.terminals[n] = rec.terminal;
   }
 }
-hipError_t launch_prep(const PrepArgs& p, hipStream_t s) {
-  hipLaunchKernelGGL(prep_kernel, dim3(1), dim3(256), 0, s, p);
+hipError_t launch_prep(const PrepArgs& p, hipStream_t s, double* zero8) {
+  hipLaunchKernelGGL(prep_kernel, dim3(1), dim3(256), 0, s, p, zero8);
   return hipGetLastError();
 }
 
