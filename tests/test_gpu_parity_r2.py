@@ -570,3 +570,30 @@ def test_bench_gather_with_index_sets(sd):
     bad = sets.copy(); bad[2, 7] = mem.count
     with pytest.raises(AssertionError):
         mem.bench_gather(bad, iters=2)
+
+
+def test_batched_slot_release_survives_interleaved_gathers(sd):
+    """The train paths release their pinned index slots in batches of 16 (one event record instead of 16).  A slot released by a train
+    call and not yet covered by an event must not be handed out again unflushed: 1 fused step, then > 64 getMinibatch() calls (each takes
+    a slot of the 64-slot ring), then more training — numbers identical to a learner that did the same training without the gathers."""
+    A, B, size = 4, 32, 3000
+    args = make_args(batch_size=B)
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 821, num_actions=A)
+    mem.sync_mirror()
+    lib = sd.load()
+    nets = []
+    for interleave in (0, 1):
+        n, _, _ = _net(sd, A, B, 822)
+        mt = (C.c_uint32 * 625)(); lib.sdqn_mt_seed(mt, 823)
+        random.seed(5)
+        for rounds in range(3):
+            n.train_from_memory(mem, 1, mt_state=mt, want_cost=False)
+            if interleave:
+                for _ in range(70):
+                    mem.getMinibatch()
+            n.train_from_memory(mem, 5, mt_state=mt, want_cost=False)
+        nets.append(n)
+    for which in (0, 2):
+        for i in range(5):
+            assert np.array_equal(nets[0].get_layer(i, which), nets[1].get_layer(i, which)), (which, i)
