@@ -545,8 +545,9 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->cost_out, 16));
   NCHK(dalloc(h, (void**)&h->cost_accum, 16));
   NCHK(dalloc(h, (void**)&h->st_states, (size_t)2 * B * STATE + SRC_PAD));
-  NCHK(dalloc(h, (void**)&h->st_act, B)); NCHK(dalloc(h, (void**)&h->st_term, B));
-  NCHK(dalloc(h, (void**)&h->st_rew, (size_t)B * 8));
+  // the minibatch's small arrays in ONE block [rewards 8 B | actions B | terminals B]: the tuple API uploads them with one copy
+  NCHK(dalloc(h, (void**)&h->st_rew, (size_t)B * 10));
+  h->st_act = reinterpret_cast<uint8_t*>(h->st_rew) + (size_t)B * 8; h->st_term = h->st_act + B;
   NCHK(dalloc(h, (void**)&h->d_idx, (size_t)B * 8));
   NCHK(dalloc(h, (void**)&h->d_idx_t, (size_t)B * 8));
   { hipError_t e = hipHostMalloc((void**)&h->h_f, (size_t)(2 * B * MAX_ACTIONS + B + 64) * 8, hipHostMallocMapped);
@@ -1049,13 +1050,15 @@ extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8
   uint8_t* st = h->h_stage[sl];
   const uint8_t *src_pre = pre, *src_post = post;
   if (!ours) { memcpy(st, pre, sb); memcpy(st + sb, post, sb); src_pre = st; src_post = st + sb; }
-  uint8_t* sm = st + 2 * sb;                                                  // [actions B | terminals B | rewards 8 B]
-  memcpy(sm, actions, h->B); memcpy(sm + h->B, terminals, h->B); memcpy(sm + 2 * (size_t)h->B, rewards, (size_t)h->B * 8);
-  HIPCHK(hipMemcpyAsync(h->st_states, src_pre, sb, hipMemcpyHostToDevice, g_stream));
-  HIPCHK(hipMemcpyAsync(h->st_states + sb, src_post, sb, hipMemcpyHostToDevice, g_stream));
-  HIPCHK(hipMemcpyAsync(h->st_act, sm, h->B, hipMemcpyHostToDevice, g_stream));
-  HIPCHK(hipMemcpyAsync(h->st_term, sm + h->B, h->B, hipMemcpyHostToDevice, g_stream));
-  HIPCHK(hipMemcpyAsync(h->st_rew, sm + 2 * (size_t)h->B, (size_t)h->B * 8, hipMemcpyHostToDevice, g_stream));
+  uint8_t* sm = st + 2 * sb;                                                  // [rewards 8 B | actions B | terminals B], as on the device
+  memcpy(sm, rewards, (size_t)h->B * 8); memcpy(sm + (size_t)h->B * 8, actions, h->B); memcpy(sm + (size_t)h->B * 9, terminals, h->B);
+  // every copy is a packet of its own in the stream: 2 (staged pre|post are contiguous) or 3 instead of 5
+  if (!ours) HIPCHK(hipMemcpyAsync(h->st_states, st, 2 * sb, hipMemcpyHostToDevice, g_stream));
+  else {
+    HIPCHK(hipMemcpyAsync(h->st_states, src_pre, sb, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(h->st_states + sb, src_post, sb, hipMemcpyHostToDevice, g_stream));
+  }
+  HIPCHK(hipMemcpyAsync(h->st_rew, sm, small, hipMemcpyHostToDevice, g_stream));
   HIPCHK(hipEventRecord(h->stage_ev[sl], g_stream)); h->stage_busy[sl] = true;
   StepArgs a = step_args(h); a.from_ring = 0; a.src = h->st_states;
   HeadArgs hd = head_args(h, 1);

@@ -4,6 +4,8 @@ foreign pageable arrays."""
 import os, sys, time, random
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+import simple_dqn_amd._lib as _L
+if os.environ.get("SDQN_LIB"): _L.lib_path = lambda: os.path.join(os.path.dirname(os.path.abspath(_L.__file__)), os.environ["SDQN_LIB"])   # A/B of two builds
 import simple_dqn_amd as sd
 from util import make_args, random_minibatch
 from bench import fill_ring
