@@ -120,10 +120,9 @@ static int replay_free(sdqn_replay_s* r) {
   for (size_t i = 0; i < g_replays.size(); ++i) if (g_replays[i] == r) { g_replays.erase(g_replays.begin() + i); break; }
   if (g_stream) hipStreamSynchronize(g_stream);
   if (!(r->flags & SDQN_REPLAY_ZERO_COPY)) { hipFree(r->d_ring); hipFree(r->d_meta); }
-  hipFree(r->d_pre); hipFree(r->d_post); hipFree(r->d_act); hipFree(r->d_term); hipFree(r->d_rew);
+  hipFree(r->d_pre); hipFree(r->d_rew);                   // (d_post / d_act / d_term live inside these two blocks, likewise on the host)
   hipHostFree(r->screens); hipHostFree(r->actions); hipHostFree(r->rewards); hipHostFree(r->terminals);
-  hipHostFree(r->h_meta); hipHostFree(r->h_pre); hipHostFree(r->h_post); hipHostFree(r->h_act);
-  hipHostFree(r->h_term); hipHostFree(r->h_rew); hipHostFree(r->h_idx);
+  hipHostFree(r->h_meta); hipHostFree(r->h_pre); hipHostFree(r->h_rew); hipHostFree(r->h_idx);
   for (int i = 0; i < NSLOT; ++i) if (r->slot_ev[i]) hipEventDestroy(r->slot_ev[i]);
   delete r;
   return SDQN_OK;
@@ -155,12 +154,14 @@ extern "C" int sdqn_replay_create(sdqn_replay_t* out, int64_t size, int H, int W
     RCHK(hipMemsetAsync(r->d_meta, 0, (size_t)size * sizeof(MetaRec), g_stream));
   }
   const size_t sb = (size_t)batch * STATE;
-  RCHK(hipMalloc((void**)&r->d_pre, sb)); RCHK(hipMalloc((void**)&r->d_post, sb));
-  RCHK(hipMalloc((void**)&r->d_act, batch)); RCHK(hipMalloc((void**)&r->d_term, batch));
-  RCHK(hipMalloc((void**)&r->d_rew, (size_t)batch * 8));
-  RCHK(hipHostMalloc((void**)&r->h_pre, sb, hf)); RCHK(hipHostMalloc((void**)&r->h_post, sb, hf));
-  RCHK(hipHostMalloc((void**)&r->h_act, batch, hf)); RCHK(hipHostMalloc((void**)&r->h_term, batch, hf));
-  RCHK(hipHostMalloc((void**)&r->h_rew, (size_t)batch * 8, hf));
+  // the gathered minibatch as two blocks — [pre | post] and [rewards 8 B | actions B | terminals B] — on the device and in pinned host
+  // memory alike: getMinibatch() brings it down with two copies and the tuple API sends it back up with two (every copy is a stream packet)
+  RCHK(hipMalloc((void**)&r->d_pre, 2 * sb)); r->d_post = r->d_pre + sb;
+  RCHK(hipMalloc((void**)&r->d_rew, (size_t)batch * 10));
+  r->d_act = reinterpret_cast<uint8_t*>(r->d_rew) + (size_t)batch * 8; r->d_term = r->d_act + batch;
+  RCHK(hipHostMalloc((void**)&r->h_pre, 2 * sb, hf)); r->h_post = r->h_pre + sb;
+  RCHK(hipHostMalloc((void**)&r->h_rew, (size_t)batch * 10, hf));
+  r->h_act = reinterpret_cast<uint8_t*>(r->h_rew) + (size_t)batch * 8; r->h_term = r->h_act + batch;
   RCHK(hipHostMalloc((void**)&r->h_idx, (size_t)NSLOT * batch * 8, hf));
   RCHK(hipHostGetDevicePointer((void**)&r->d_idx_view, r->h_idx, 0));
   for (int i = 0; i < NSLOT; ++i) RCHK(hipEventCreateWithFlags(&r->slot_ev[i], hipEventDisableTiming));
@@ -273,11 +274,8 @@ extern "C" int sdqn_replay_gather(sdqn_replay_t r, const int64_t* idx_host) {
 extern "C" int sdqn_replay_minibatch_to_host(sdqn_replay_t r) {
   ARGCHK(r, "NULL handle");
   const size_t sb = (size_t)r->B * STATE;
-  HIPCHK(hipMemcpyAsync(r->h_pre, r->d_pre, sb, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipMemcpyAsync(r->h_post, r->d_post, sb, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipMemcpyAsync(r->h_act, r->d_act, r->B, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipMemcpyAsync(r->h_rew, r->d_rew, (size_t)r->B * 8, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipMemcpyAsync(r->h_term, r->d_term, r->B, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpyAsync(r->h_pre, r->d_pre, 2 * sb, hipMemcpyDeviceToHost, g_stream));                 // [pre | post]
+  HIPCHK(hipMemcpyAsync(r->h_rew, r->d_rew, (size_t)r->B * 10, hipMemcpyDeviceToHost, g_stream));      // [rewards | actions | terminals]
   HIPCHK(hipStreamSynchronize(g_stream));
   return SDQN_OK;
 }
@@ -1048,16 +1046,11 @@ extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8
   bool ours = false;
   for (sdqn_replay_s* r : g_replays) ours |= (pre == r->h_pre && post == r->h_post && r->B == h->B);
   uint8_t* st = h->h_stage[sl];
-  const uint8_t *src_pre = pre, *src_post = post;
-  if (!ours) { memcpy(st, pre, sb); memcpy(st + sb, post, sb); src_pre = st; src_post = st + sb; }
+  if (!ours) { memcpy(st, pre, sb); memcpy(st + sb, post, sb); }
   uint8_t* sm = st + 2 * sb;                                                  // [rewards 8 B | actions B | terminals B], as on the device
   memcpy(sm, rewards, (size_t)h->B * 8); memcpy(sm + (size_t)h->B * 8, actions, h->B); memcpy(sm + (size_t)h->B * 9, terminals, h->B);
-  // every copy is a packet of its own in the stream: 2 (staged pre|post are contiguous) or 3 instead of 5
-  if (!ours) HIPCHK(hipMemcpyAsync(h->st_states, st, 2 * sb, hipMemcpyHostToDevice, g_stream));
-  else {
-    HIPCHK(hipMemcpyAsync(h->st_states, src_pre, sb, hipMemcpyHostToDevice, g_stream));
-    HIPCHK(hipMemcpyAsync(h->st_states + sb, src_post, sb, hipMemcpyHostToDevice, g_stream));
-  }
+  // every copy is a packet of its own in the stream: 2 instead of 5
+  HIPCHK(hipMemcpyAsync(h->st_states, ours ? pre : st, 2 * sb, hipMemcpyHostToDevice, g_stream));     // (a ReplayMemory's pre | post are one block too)
   HIPCHK(hipMemcpyAsync(h->st_rew, sm, small, hipMemcpyHostToDevice, g_stream));
   HIPCHK(hipEventRecord(h->stage_ev[sl], g_stream)); h->stage_busy[sl] = true;
   StepArgs a = step_args(h); a.from_ring = 0; a.src = h->st_states;
