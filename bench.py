@@ -595,12 +595,14 @@ def main():
     step_kernels = [p for p in prof if p["launches"] > 0]
     per_step = [p for p in step_kernels if p["launches"] >= n_prof] or step_kernels    # not the one-off prep / gather launches
     dom = max(per_step, key=lambda p: p["total_ms"])
-    # timed region: the dominant kernel stays bracketed with HIP events, but only every 16th launch — an event pair costs
+    # timed region: the dominant kernel stays bracketed with HIP events, but only every N-th launch — an event pair costs
     # 2-3 us of queue time, and bracketing every launch took 7 % off the step rate it is supposed to observe
-    # every 16th launch of the dominant kernel is bracketed, launch 0 included, so even the driver's 20-step run has live
-    # brackets inside the timed region (launches 0 and 16).  Measured on MI355X: an event pair in the dependent launch chain
+    # every N-th launch of the dominant kernel is bracketed, launch 0 included, so even the driver's 20-step run has a live
+    # bracket inside the timed region.  Measured on MI355X: an event pair in the dependent launch chain
     # costs far more than its own 2-3 us (bracketing EVERY launch of a 20-step run: -7 % step rate; every 4th: -2.3 %).
-    every = 16
+    # (round 2, after the per-step event record was removed from train_many: even every 16th launch was 0.7 us per step — 74.0 vs 74.8 —
+    #  so every 64th: launch 0 of the timed region is always bracketed, 47 brackets in the default 3 000-step run)
+    every = 64
     net.set_option("profile_every", every)
     net.profile(True, dom["id"])
     net.profile_reset()
