@@ -296,51 +296,73 @@ def oracle_view(mem, B):
 
 def q_mae_on_timed_ring(net, mem, B, A, mt, steps=10):
     """'Q-value MAE vs CPU ref' of the metric, on the TIMED configuration (same 1 M-frame ring, sampler state and network the timed
-    region left behind).  `steps` more train steps, two oracles beside the library:
-      * teacher-forced (the reported `mae` / `max_abs`): before every step the oracle is loaded with the library's (theta, theta-,
-        RMSProp s); both take the step on the same minibatch; Q-values of a held-out batch are compared after it.  `mae` is the mean
-        over the steps, `max_abs` the worst element of any step;
-      * free-running (`free_running`): one oracle loaded once, then `steps` steps on its own state — what round 1's verdict asked
-        for.  It agrees to ~3e-8 until a ReLU gate flips: a pre-activation within round-off of 0 lands on different sides in two
-        fp32 summation orders (tools/exp/qmae_diag.py shows the ORACLE separating from a copy of itself whose weights differ by
-        1e-8), after which the trajectories differ by a finite amount — O(1e-5) on a warm network, O(1e-3) in the first steps
-        after initialisation where RMSProp's normalised steps are +-lr/sqrt(1-rho) whatever the gradient's size.
-        `first_step_over_1e-5` names the step at which that happened (null: it did not)."""
-    import ctypes as C
+    region left behind).  `steps` more train steps of the library next to THREE oracles on the same minibatches:
+      * free-running fp32 oracle, loaded once with the library's (theta, theta-, RMSProp s): the metric as BASELINE.json words it.
+        Top-level `mae` / `max_abs` are THIS comparison after `steps` steps (round 1's semantics; ADVICE r2 — the teacher-forced
+        numbers no longer hide behind these keys);
+      * free-running fp64 oracle from the same start: the yardstick.  Two fp32 implementations of this algorithm separate by a
+        FINITE amount at the first ReLU gate whose pre-activation lands on different sides of 0 in their summation orders
+        (tools/exp/qmae_diag.py), so the honest bound on a free-running comparison is the fp32 oracle's OWN
+        distance from fp64 over the same steps: `hip_vs_fp64` must stay within 1.5 x `oracle_fp32_vs_fp64` (or under the
+        tolerance outright);
+      * teacher-forced fp32 oracle (`teacher_forced`): re-loaded with the library's state before every step, so each value is a
+        ONE-step error — catches a wrong kernel immediately, cannot see drift; reported with its own checks.
+    `checks` holds every pass / fail explicitly, `pass` their conjunction."""
     import numpy as np
     from oracle.dqn_numpy import OracleDQN
     from oracle.replay_numpy import MT19937
     net.sync()
+    tol = 1e-4
 
-    def load(o):
-        o.W = [w.copy() for w in net.get_weights(0)]
-        o.Wt = [w.copy() for w in net.get_weights(1)]
-        o.S = [w.copy() for w in net.get_weights(2)]
+    def load(o, dt=np.float32):
+        o.W = [w.astype(dt) for w in net.get_weights(0)]
+        o.Wt = [w.astype(dt) for w in net.get_weights(1)]
+        o.S = [w.astype(dt) for w in net.get_weights(2)]
 
     free = OracleDQN(A, batch_size=B, weights=net.get_weights(0)); load(free)
+    free64 = OracleDQN(A, batch_size=B, weights=net.get_weights(0), dtype=np.float64); load(free64, np.float64)
     forced = OracleDQN(A, batch_size=B, weights=net.get_weights(0))
     omem = oracle_view(mem, B)
     rng = MT19937(); rng.setstate(tuple(mt[:]))
     hold_rng = MT19937(); hold_rng.setstate(tuple(mt[:]))
     for _ in range(steps + 1):                                       # the batch after the comparison steps, as before
         hold = omem.getMinibatch(hold_rng)[0].copy()
-    tf_mae, tf_max, fr_max = [], [], []
+    tf_mae, tf_max, fr_max, fr_mae, o64_max, h64_max = [], [], [], [], [], []
     for _ in range(steps):
         mb = [x.copy() for x in omem.getMinibatch(rng)]
         load(forced)
         net.train_from_memory(mem, 1, mt_state=mt, want_cost=False)
-        free.train(mb); forced.train(mb)
+        free.train(mb); forced.train(mb); free64.train(mb)
         assert tuple(mt[:]) == rng.getstate(), "native sampler and oracle sampler diverged"
         q = net.predict(hold)
+        q64 = free64.predict(hold)
         e = np.abs(q - forced.predict(hold)); tf_mae.append(float(e.mean())); tf_max.append(float(e.max()))
-        ef = np.abs(q - free.predict(hold)); fr_max.append(float(ef.max()))
+        qf = free.predict(hold)
+        ef = np.abs(q - qf); fr_max.append(float(ef.max())); fr_mae.append(float(ef.mean()))
+        o64_max.append(float(np.abs(qf - q64).max())); h64_max.append(float(np.abs(q - q64).max()))
     first = next((i + 1 for i, v in enumerate(fr_max) if v > 1e-5), None)
-    return {"mae": float(np.mean(tf_mae)), "max_abs": float(max(tf_max)), "after_steps": steps, "tolerance": 1e-4, "tolerance_on": "mae",
-            "steps_with_gate_flip": int(sum(v > 1e-6 for v in tf_max)),   # tools/exp/qmae_diag.py: 6-8 of 80 steps on a young network, old and new kernels alike
-            "mode": "teacher-forced: oracle re-loaded with the library's (theta, theta-, s) before each of the steps; mean MAE / worst element",
-            "per_step_max_abs": [float("%.3g" % v) for v in tf_max],
-            "free_running": {"mae": float(ef.mean()), "max_abs": float(ef.max()), "after_steps": steps, "first_step_over_1e-5": first,
-                             "note": "oracle loaded once; separates by a finite amount at the first ReLU-gate flip (see docstring)"},
+    within_drift = h64_max[-1] <= max(1.5 * o64_max[-1], tol)
+    checks = {
+        "free_running_mae_lt_tol": bool(fr_mae[-1] < tol),
+        "free_running_hip_vs_fp64_within_1.5x_oracle_fp32_vs_fp64_or_tol": bool(within_drift),
+        "teacher_forced_mean_mae_lt_tol": bool(np.mean(tf_mae) < tol),
+        "teacher_forced_median_step_max_abs_lt_1e-5": bool(np.median(tf_max) < 1e-5),
+        "teacher_forced_worst_element_lt_2e-3": bool(max(tf_max) < 2e-3),      # a single flipped gate (tests/test_gpu_dqn.py uses the same bound)
+    }
+    ok = (checks["free_running_mae_lt_tol"] or within_drift) and checks["teacher_forced_mean_mae_lt_tol"] and \
+        checks["teacher_forced_median_step_max_abs_lt_1e-5"] and checks["teacher_forced_worst_element_lt_2e-3"]
+    g = lambda v: float("%.3g" % v)
+    return {"mae": g(fr_mae[-1]), "max_abs": g(fr_max[-1]), "after_steps": steps, "tolerance": tol,
+            "tolerance_on": "free-running mae after %d steps (fp32 oracle loaded once), OR the fp64 yardstick below" % steps,
+            "mode": "free-running", "pass": bool(ok), "checks": checks,
+            "free_running": {"mae": g(fr_mae[-1]), "max_abs": g(fr_max[-1]), "per_step_max_abs": [g(v) for v in fr_max],
+                             "first_step_over_1e-5": first,
+                             "hip_vs_fp64_max_abs": g(h64_max[-1]), "oracle_fp32_vs_fp64_max_abs": g(o64_max[-1]),
+                             "ratio": g(h64_max[-1] / max(o64_max[-1], 1e-30)),
+                             "note": "separates by a finite amount at the first ReLU-gate flip; bounded by the fp32 oracle's own drift from fp64"},
+            "teacher_forced": {"mae": g(float(np.mean(tf_mae))), "max_abs": g(max(tf_max)), "per_step_max_abs": [g(v) for v in tf_max],
+                               "steps_with_gate_flip": int(sum(v > 1e-6 for v in tf_max)),
+                               "note": "oracle re-loaded with the library's (theta, theta-, s) before each step: one-step errors"},
             "ring_frames": int(mem.size), "note": "same ring, same sampler state as the timed network"}
 
 
@@ -657,9 +679,9 @@ def main():
         if world == 1 and a.datatype == "float32" and not a.batch_norm:
             out.update(pre)                                    # replay_gather, replay_gather_large: measured before the warm-up
             if not a.profile_run:
-                # (B > 64: one step — free-running fp32 implementations separate through ReLU-gate flips, 8x as likely per
-                #  step at B = 256; the multi-step check at that size is teacher-forced: tests/test_gpu_parity_r2.py)
-                out["q_mae_vs_cpu_ref"] = q_mae_on_timed_ring(net, mem, B, A, mt, steps=10 if B <= 64 else 1)
+                # (B > 64: three steps — gate flips are 8x as likely per step at B = 256 and an oracle step costs ~1 s there;
+                #  the free-running number is judged against the fp64 yardstick at every size)
+                out["q_mae_vs_cpu_ref"] = q_mae_on_timed_ring(net, mem, B, A, mt, steps=10 if B <= 64 else 3)
             out["north_star_target"] = north_star_target(out, sd, B, A)
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(B, A, a.seed, a.cpu_baseline_seconds)

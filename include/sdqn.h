@@ -152,7 +152,11 @@ int sdqn_statebuf_read_device(sdqn_statebuf_t s, uint8_t* state_out);   /* test 
 /* Q-values of the buffered state -> float[A] (sync): sdqn_net_predict_one without the state upload */
 int sdqn_net_predict_state(sdqn_net_t h, sdqn_statebuf_t s, float* q_out);
 /* DeepQNetwork.train, deepqnetwork.py:107-172, minibatch given as host arrays.
- * cost_out nullable: NULL -> no synchronisation. */
+ * cost_out nullable: NULL -> the step itself is not waited for.  Buffer contract: when the call returns, all five arrays
+ * are free to be overwritten — pageable arrays were copied into a pinned double buffer; pre / post that ARE a
+ * ReplayMemory's pinned minibatch buffers (sdqn_replay_minibatch_ptrs) are uploaded in place and the call returns only
+ * after that upload has completed (the step's kernels are already enqueued behind it).
+ * Threading: handles are created, used and destroyed from ONE host thread (no internal locking). */
 int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8_t* actions, const int64_t* rewards,
                         const uint8_t* post, const uint8_t* terminals, float* cost_out);
 /* same step with the minibatch gathered on the device straight from the replay ring:

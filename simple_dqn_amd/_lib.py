@@ -110,16 +110,43 @@ def load():
     if not os.path.exists(path):
         raise SdqnError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
-    # the host driver only supports dmabuf IPC: without this RCCL's cross-process buffer registration fails with
-    # "hipIpcGetMemHandle: invalid argument" (must be in the environment before the HSA runtime initialises)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")      # kernel arguments in HBM (the stack's default; =0 costs 23 % of the step rate)
+    _runtime_env()
     lib = C.CDLL(path, mode=os.RTLD_NOW | os.RTLD_LOCAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError here == header/library mismatch
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def _hip_runtime_mapped():
+    try:
+        with open("/proc/self/maps") as f:
+            return any("libamdhip64" in line or "libhsa-runtime64" in line for line in f)
+    except OSError:
+        return False
+
+
+def _runtime_env():
+    """Two process-wide runtime knobs this library depends on.  They only take effect if they are in the environment BEFORE
+    the HSA / HIP runtime initialises, so they are set here only when no runtime is mapped yet (the launchers — bench.py,
+    main.py, tests/conftest — export them themselves); if a runtime is already up (torch imported first) and a knob is
+    missing, that is reported instead of silently depending on import order.
+      HSA_ENABLE_IPC_MODE_LEGACY=0 : the host driver only supports dmabuf IPC — without it RCCL's cross-process buffer
+                                     registration fails with "hipIpcGetMemHandle: invalid argument" (multi-GPU only)
+      HIP_FORCE_DEV_KERNARG=1      : kernel arguments in HBM (this stack's default; =0 costs 23 % of the step rate)"""
+    want = {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "HIP_FORCE_DEV_KERNARG": "1"}
+    missing = [k for k in want if k not in os.environ]
+    if not missing:
+        return
+    if _hip_runtime_mapped():
+        import warnings
+        warnings.warn("simple_dqn_amd: a HIP runtime was initialised before this library with %s unset; export %s before "
+                      "importing torch / HIP (data-parallel runs need the first, the step rate the second)"
+                      % (", ".join(missing), " ".join("%s=%s" % (k, want[k]) for k in missing)), RuntimeWarning, stacklevel=3)
+        return
+    for k in missing:
+        os.environ[k] = want[k]
 
 
 def bind_device(args):

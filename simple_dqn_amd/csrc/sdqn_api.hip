@@ -112,6 +112,7 @@ struct sdqn_replay_s {
   int64_t* h_idx = nullptr; int64_t* d_idx_view = nullptr;      // [NSLOT][B] pinned + its device alias
   hipEvent_t slot_ev[NSLOT]; bool slot_busy[NSLOT]; int next_slot = 0;
   int slot_cover[NSLOT]; int pending[NSLOT]; int npending = 0;   // batched release (train_many): slot s is free once slot_ev[slot_cover[s]] has completed
+  hipEvent_t mb_upload_ev = nullptr;      // tuple API: the H2D of h_pre | h_post issued by sdqn_net_train_host (waited for before that call returns)
 };
 
 static std::vector<sdqn_replay_s*> g_replays;      // live handles: sdqn_net_train_host recognises their pinned minibatch buffers
@@ -124,6 +125,7 @@ static int replay_free(sdqn_replay_s* r) {
   hipHostFree(r->screens); hipHostFree(r->actions); hipHostFree(r->rewards); hipHostFree(r->terminals);
   hipHostFree(r->h_meta); hipHostFree(r->h_pre); hipHostFree(r->h_rew); hipHostFree(r->h_idx);
   for (int i = 0; i < NSLOT; ++i) if (r->slot_ev[i]) hipEventDestroy(r->slot_ev[i]);
+  if (r->mb_upload_ev) hipEventDestroy(r->mb_upload_ev);
   delete r;
   return SDQN_OK;
 }
@@ -165,6 +167,7 @@ extern "C" int sdqn_replay_create(sdqn_replay_t* out, int64_t size, int H, int W
   RCHK(hipHostMalloc((void**)&r->h_idx, (size_t)NSLOT * batch * 8, hf));
   RCHK(hipHostGetDevicePointer((void**)&r->d_idx_view, r->h_idx, 0));
   for (int i = 0; i < NSLOT; ++i) RCHK(hipEventCreateWithFlags(&r->slot_ev[i], hipEventDisableTiming));
+  RCHK(hipEventCreateWithFlags(&r->mb_upload_ev, hipEventDisableTiming));
 #undef RCHK
   g_replays.push_back(r);
   *out = r;
@@ -679,7 +682,9 @@ extern "C" int sdqn_net_profile_read(sdqn_net_t h, int kernel, const char** name
 }
 extern "C" int sdqn_net_profile_reset(sdqn_net_t h) {
   ARGCHK(h, "NULL handle"); int rc = prof_collect(h); if (rc) return rc;
-  memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n); return SDQN_OK;
+  memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n);
+  memset(h->prof_seen, 0, sizeof h->prof_seen);      // launch 0 after a reset is bracketed again (profile_every counts from the reset)
+  return SDQN_OK;
 }
 
 // RCCL all-reduce on behalf of LAUNCH_ON: a failure keeps RCCL's own message (h->nccl_rc / sdqn_last_error) and is
@@ -1036,26 +1041,32 @@ extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8
   // No stream synchronisation (round 1 paid a full PCIe + sync bubble per step here): the caller's arrays are free to
   // change after return because they are either copied into a pinned double buffer of the library first (pageable
   // arrays), or ARE the pinned minibatch buffers of one of this library's ReplayMemory handles — what getMinibatch() returns
-  // for prestates / poststates —, whose next overwrite (gather + D2H) is ordered behind this H2D on the library stream.
+  // for prestates / poststates —, whose next overwrite by the library (gather + D2H) is ordered behind this H2D on the library
+  // stream; a HOST write to them could still race the DMA, so in that case the call returns only after the upload has completed
+  // (event wait AFTER every launch of the step is enqueued: the GPU never idles for it, the host waits ~30 us it would otherwise
+  // spend ahead of the stream).  Either way: once train() has returned the caller's five arrays are free, like the reference's.
   const int sl = h->stage_next; h->stage_next ^= 1;
   if (!h->h_stage[sl]) {
     HIPCHK(hipHostMalloc((void**)&h->h_stage[sl], 2 * sb + small, hipHostMallocDefault));
     HIPCHK(hipEventCreateWithFlags(&h->stage_ev[sl], hipEventDisableTiming));
   }
   if (h->stage_busy[sl]) { HIPCHK(hipEventSynchronize(h->stage_ev[sl])); h->stage_busy[sl] = false; }
-  bool ours = false;
-  for (sdqn_replay_s* r : g_replays) ours |= (pre == r->h_pre && post == r->h_post && r->B == h->B);
+  sdqn_replay_s* owner = nullptr;                               // (handles are created / destroyed / used from ONE host thread: sdqn.h)
+  for (sdqn_replay_s* r : g_replays) if (pre == r->h_pre && post == r->h_post && r->B == h->B) owner = r;
+  const bool ours = owner != nullptr;
   uint8_t* st = h->h_stage[sl];
   if (!ours) { memcpy(st, pre, sb); memcpy(st + sb, post, sb); }
   uint8_t* sm = st + 2 * sb;                                                  // [rewards 8 B | actions B | terminals B], as on the device
   memcpy(sm, rewards, (size_t)h->B * 8); memcpy(sm + (size_t)h->B * 8, actions, h->B); memcpy(sm + (size_t)h->B * 9, terminals, h->B);
   // every copy is a packet of its own in the stream: 2 instead of 5
   HIPCHK(hipMemcpyAsync(h->st_states, ours ? pre : st, 2 * sb, hipMemcpyHostToDevice, g_stream));     // (a ReplayMemory's pre | post are one block too)
+  if (ours) { HIPCHK(hipEventRecord(owner->mb_upload_ev, g_stream)); }   // waited for before this call returns
   HIPCHK(hipMemcpyAsync(h->st_rew, sm, small, hipMemcpyHostToDevice, g_stream));
   HIPCHK(hipEventRecord(h->stage_ev[sl], g_stream)); h->stage_busy[sl] = true;
   StepArgs a = step_args(h); a.from_ring = 0; a.src = h->st_states;
   HeadArgs hd = head_args(h, 1);
   int rc = run_train(h, a, hd); if (rc) return rc;
+  if (ours) { HIPCHK(hipEventSynchronize(owner->mb_upload_ev)); }
   if (cost_out) return read_cost(h, cost_out);
   return SDQN_OK;
 }

@@ -13,18 +13,24 @@ def pytest_configure(config):
 
 
 def _device_count():
-    try:
-        import ctypes as C
-        import simple_dqn_amd as sd
-        n = C.c_int(0)
-        return n.value if sd.load().sdqn_device_count(C.byref(n)) == 0 else 0
-    except Exception:
+    """Devices the LIBRARY sees.  Only 'no ROCm device here' may turn into skips: without /dev/kfd (this container) the
+    answer is 0; with a GPU node present every load / symbol / runtime error propagates, so a broken build on the GPU box
+    shows up as errors, never as a green run full of skips."""
+    if not os.path.exists("/dev/kfd"):
         return 0
+    import ctypes as C
+    import simple_dqn_amd as sd
+    lib = sd.load()                                   # missing .so / header-library mismatch: raises
+    n = C.c_int(0)
+    rc = lib.sdqn_device_count(C.byref(n))
+    if rc != 0:
+        raise RuntimeError("sdqn_device_count failed on a box with /dev/kfd: %s" % (lib.sdqn_last_error() or b"").decode())
+    return n.value
 
 
 def pytest_collection_modifyitems(config, items):
     """`-m gpu` tests need a ROCm device: on a box without one they are skipped (with the reason), not failed.  On a GPU
-    box nothing is skipped — a missing/unloadable libsdqn_hip.so there still fails loudly inside the tests."""
+    box nothing is skipped and an unloadable libsdqn_hip.so aborts the collection loudly (_device_count)."""
     gpu_items = [it for it in items if "gpu" in it.keywords]
     if not gpu_items or _device_count() > 0:
         return

@@ -496,6 +496,16 @@ def test_tuple_api_is_asynchronous_and_safe(sd):
     n2.train_from_memory(mem, 4)
     for i in range(5):
         assert np.array_equal(n1.get_layer(i, 0), n2.get_layer(i, 0)), i
+    # ... and the caller may WRITE those pinned views the moment train() has returned (the upload is waited for
+    # before the call returns): clobbering mem.prestates / mem.poststates after every step must not change the training
+    n3, _, _ = _net(sd, A, B, 714)
+    random.setstate(st)
+    for _ in range(4):
+        mb = mem.getMinibatch()
+        n3.train(mb)
+        mem.prestates[...] = 255; mem.poststates[...] = 0       # same memory as mb[0] / mb[3]
+    for i in range(5):
+        assert np.array_equal(n3.get_layer(i, 0), n2.get_layer(i, 0)), i
 
 
 # ---- multi-GPU readiness that a 1-GPU box can check --------------------------------------------------------------------
