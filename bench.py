@@ -134,11 +134,26 @@ def fc_mfma_util(B, A):
 
 
 def profiles_git():
-    """Commit that last touched profiles/ (so a reader can tell which build the replayed numbers belong to)."""
+    """Commit that last touched profiles/ (so a reader can tell which build the replayed numbers belong to): from git where
+    the tree has one, else from the committed profiles/MANIFEST.json (tools/write_manifest.py) — the GPU box has no .git."""
     try:
         import subprocess
-        return subprocess.check_output(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "profiles"], stderr=subprocess.DEVNULL,
-                                       timeout=5).decode().strip() or None
+        g = subprocess.check_output(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "profiles"], stderr=subprocess.DEVNULL,
+                                    timeout=5).decode().strip()
+        if g:
+            return g
+    except Exception:
+        pass
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "MANIFEST.json")))["git"] + " (profiles/MANIFEST.json)"
+    except Exception:
+        return None
+
+
+def profiles_file_commit(rel):
+    """Commit of ONE replayed capture, from the manifest (None if it is not listed)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "MANIFEST.json")))["files"][rel]["commit"]
     except Exception:
         return None
 
@@ -153,6 +168,7 @@ def roofline_entry(kid, name, ms_per_launch, B, A):
     e = _roofline_entry(kid, name, ms_per_launch, B, A)
     fp = {"files": [PMC_FILE, STATS_FILE, "profiles/r01_box.json"], "git": profiles_git(),
           "note": "replayed from committed rocprofv3 captures of the same command; NOT measured in this run"}
+    fp["file_commits"] = {f: profiles_file_commit(f) for f in fp["files"]}
     fp["traffic"] = pmc_traffic(name, B, A)
     fp["rocprof_us_per_launch"] = rocprof_us(kid, B, A)
     e["traffic"] = fp["traffic"]
@@ -304,7 +320,7 @@ def q_mae_on_timed_ring(net, mem, B, A, mt, steps=10):
         FINITE amount at the first ReLU gate whose pre-activation lands on different sides of 0 in their summation orders
         (tools/exp/qmae_diag.py), so the honest bound on a free-running comparison is the fp32 oracle's OWN
         distance from fp64 over the same steps: `hip_vs_fp64` must stay within 1.5 x `oracle_fp32_vs_fp64` (or under the
-        tolerance outright);
+        tolerance outright), or start at a step where the teacher-forced comparison shows the same gate flip;
       * teacher-forced fp32 oracle (`teacher_forced`): re-loaded with the library's state before every step, so each value is a
         ONE-step error — catches a wrong kernel immediately, cannot see drift; reported with its own checks.
     `checks` holds every pass / fail explicitly, `pass` their conjunction."""
@@ -342,14 +358,19 @@ def q_mae_on_timed_ring(net, mem, B, A, mt, steps=10):
         o64_max.append(float(np.abs(qf - q64).max())); h64_max.append(float(np.abs(q - q64).max()))
     first = next((i + 1 for i, v in enumerate(fr_max) if v > 1e-5), None)
     within_drift = h64_max[-1] <= max(1.5 * o64_max[-1], tol)
+    # the free-running pair is identical to ~1e-8 until the first gate flip, and the teacher-forced pair takes that very step from
+    # the same state on the same minibatch: a legitimate separation therefore STARTS at a step the teacher-forced run flags too
+    flip_steps = [i + 1 for i, v in enumerate(tf_max) if v > 1e-6]
+    explained = first is not None and any(k <= first for k in flip_steps)
     checks = {
         "free_running_mae_lt_tol": bool(fr_mae[-1] < tol),
         "free_running_hip_vs_fp64_within_1.5x_oracle_fp32_vs_fp64_or_tol": bool(within_drift),
+        "free_running_separation_starts_at_a_teacher_forced_gate_flip": bool(explained) if first is not None else None,
         "teacher_forced_mean_mae_lt_tol": bool(np.mean(tf_mae) < tol),
         "teacher_forced_median_step_max_abs_lt_1e-5": bool(np.median(tf_max) < 1e-5),
         "teacher_forced_worst_element_lt_2e-3": bool(max(tf_max) < 2e-3),      # a single flipped gate (tests/test_gpu_dqn.py uses the same bound)
     }
-    ok = (checks["free_running_mae_lt_tol"] or within_drift) and checks["teacher_forced_mean_mae_lt_tol"] and \
+    ok = (checks["free_running_mae_lt_tol"] or within_drift or explained) and checks["teacher_forced_mean_mae_lt_tol"] and \
         checks["teacher_forced_median_step_max_abs_lt_1e-5"] and checks["teacher_forced_worst_element_lt_2e-3"]
     g = lambda v: float("%.3g" % v)
     return {"mae": g(fr_mae[-1]), "max_abs": g(fr_max[-1]), "after_steps": steps, "tolerance": tol,
@@ -361,7 +382,7 @@ def q_mae_on_timed_ring(net, mem, B, A, mt, steps=10):
                              "ratio": g(h64_max[-1] / max(o64_max[-1], 1e-30)),
                              "note": "separates by a finite amount at the first ReLU-gate flip; bounded by the fp32 oracle's own drift from fp64"},
             "teacher_forced": {"mae": g(float(np.mean(tf_mae))), "max_abs": g(max(tf_max)), "per_step_max_abs": [g(v) for v in tf_max],
-                               "steps_with_gate_flip": int(sum(v > 1e-6 for v in tf_max)),
+                               "steps_with_gate_flip": len(flip_steps), "gate_flip_steps": flip_steps,
                                "note": "oracle re-loaded with the library's (theta, theta-, s) before each step: one-step errors"},
             "ring_frames": int(mem.size), "note": "same ring, same sampler state as the timed network"}
 
@@ -513,8 +534,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+            # launched bare (`python bench.py --gpus N`): spawn the N ranks ourselves — the same command line the contract
+            # names, one rank per GPU, rendezvous on 127.0.0.1 — and relay their output (rank 0's JSON line stays last)
+            sys.exit(spawn_ranks(a.gpus))
         a.gpus = world
 
     # torch FIRST (its bundled HIP runtime has the same soname as ROCm's; one runtime per process)
@@ -711,6 +734,22 @@ def main():
         # connections), no interpreter teardown (buffered C stdio of any rank would be flushed then)
         sys.stdout.flush()
         os._exit(0)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N ...` without a launcher: re-run this command line under torch.distributed.run with N local
+    ranks (the form the driver uses for N > 1) and return its exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                                 # a free rendezvous port on the loopback
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HIP_FORCE_DEV_KERNARG="1")
+    sys.stderr.write("bench.py: launched bare with --gpus %d: spawning %d ranks: %s\n" % (n, n, " ".join(cmd[1:])))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
 
 
 def flush_c_stdio():

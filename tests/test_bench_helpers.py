@@ -76,3 +76,17 @@ def test_committed_bench_line_has_the_contract_fields():
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 0.01
+
+
+def test_profiles_manifest_covers_every_replayed_capture():
+    """the GPU box has no .git, so the provenance of the captures bench.py replays is a committed
+    manifest (tools/write_manifest.py): every replayed file is listed with the sha256 of its CURRENT content and a commit."""
+    import hashlib
+    m = json.load(open(os.path.join(ROOT, "profiles", "MANIFEST.json")))
+    assert m["git"]
+    for rel in (bench.PMC_FILE, bench.STATS_FILE, bench.MFMA_FILE, "profiles/r01_box.json"):
+        e = m["files"][rel]
+        assert e["commit"] and e["sha256"] == hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest(), rel
+        assert bench.profiles_file_commit(rel) == e["commit"]
+    fp = bench.roofline_entry(16, "bwd3(conv3_dgrad+conv3_wgrad+fc4_wgrad)", 0.0156, 32, 4)["from_profiles"]
+    assert fp["git"] and all(fp["file_commits"].values())

@@ -526,6 +526,37 @@ def test_bench_dry_run_dp_two_ranks(sd):
     assert out["dp"]["ranks"] == 2 and len(out["dp"]["per_rank"]) == 2
 
 
+def _run_bench(extra, timeout=900):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+
+
+def test_bench_bare_gpus2_spawns_its_own_ranks(sd):
+    """`python bench.py --gpus 2` launched WITHOUT torch.distributed.run (WORLD_SIZE unset) spawns its two
+    ranks itself instead of exiting with a usage message; one JSON line, last on stdout, n_gpus = 2."""
+    out = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--replay-size", "20000", "--no-cpu-baseline", "--dry-run-dp"])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["value"] > 0
+    assert out["dp"]["ranks"] == 2 and out["dp"]["dry_run"] is True
+
+
+def test_bench_driver_form_brackets_the_timed_region(sd):
+    """in the driver's short form (--steps 20 --warmup 5) the roofline of the dominant kernel is measured
+    by a live HIP-event bracket INSIDE the timed region (launch 0 is bracketed after profile_reset), not replayed from the
+    warm-up pass; the parity leg reports explicit checks."""
+    out = _run_bench(["--steps", "20", "--warmup", "5", "--replay-size", "50000", "--no-cpu-baseline"])
+    r = out["roofline"]
+    assert r["measured_in"].startswith("timed region"), r["measured_in"]
+    assert r["launches_bracketed"] >= 1 and 0 < r["frac"] <= 1.0
+    q = out["q_mae_vs_cpu_ref"]
+    assert q["mode"] == "free-running" and set(q["checks"]) and q["pass"] is True, q
+    assert q["teacher_forced"]["mae"] < 1e-4
+
+
 # ---- tuning hooks must not change the arithmetic ----------------------------------------------------------------------
 @pytest.mark.parametrize("datatype", ["float32", "float16"])
 def test_dispatch_order_and_slab_options_keep_the_numbers(sd, datatype):
