@@ -174,6 +174,17 @@ int sdqn_net_sync(sdqn_net_t h);
  * gradient buffer (readable / writable per layer with which = 3); sdqn_net_apply_update then runs the optimizer on
  * whatever that buffer holds with divisor bsz (A9: grad / be.bsz, deepqnetwork.py:165 — nranks * batch_size under DP). */
 int sdqn_net_apply_update(sdqn_net_t h, double bsz);
+/* float16 mode, data parallel (no reference counterpart: deepqnetwork.py:46-48 disables Neon's DP; SURVEY.md §8e "fp16
+ * config: all-reduce fp16 grads with fp32 accumulation in RMSProp"): the two passes that bracket the half all-reduce, callable
+ * on their own so the exchange itself can be done by the caller.  to_half: the flat fp32 gradient sums * 2^k as IEEE half
+ * (uint16 bit patterns; k = device-side payload scale).  from_half: a summed half payload back into the fp32 gradient buffer
+ * (/ 2^k); a non-finite value raises the overflow flag and the next sdqn_net_apply_update skips the step (parameters and
+ * optimizer state untouched), counts it (sdqn_net_overflow_steps) and, in dynamic mode, halves the scale; 200 clean steps
+ * double it.  n = number of values of the flat buffer (sum of sdqn_net_layer_size over all layers). */
+int sdqn_net_grad_to_half(sdqn_net_t h, uint16_t* half_out, int64_t n);
+int sdqn_net_grad_from_half(sdqn_net_t h, const uint16_t* half_in, int64_t n);
+/* {overflow flag of the last from-half pass, log2 of the payload scale, clean steps since the scale last moved}; sync */
+int sdqn_net_half_payload_state(sdqn_net_t h, int* flag, int* scale_log2, int* clean_steps);
 /* q-values of the last train step: preq float[B,A] (online, prestates), maxpostq float[B] (sync) */
 int sdqn_net_last_q(sdqn_net_t h, float* preq, float* maxpostq);
 int sdqn_net_train_iterations(sdqn_net_t h, int64_t* n);     /* deepqnetwork.py:168 */

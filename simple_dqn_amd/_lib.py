@@ -77,6 +77,9 @@ SIGNATURES = {
     "sdqn_net_update_target": (C.c_int, [_vp]),
     "sdqn_net_sync": (C.c_int, [_vp]),
     "sdqn_net_apply_update": (C.c_int, [_vp, C.c_double]),
+    "sdqn_net_grad_to_half": (C.c_int, [_vp, C.POINTER(C.c_uint16), C.c_int64]),
+    "sdqn_net_grad_from_half": (C.c_int, [_vp, C.POINTER(C.c_uint16), C.c_int64]),
+    "sdqn_net_half_payload_state": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sdqn_net_last_q": (C.c_int, [_vp, _f32p, _f32p]),
     "sdqn_net_train_iterations": (C.c_int, [_vp, _i64p]),
     "sdqn_net_overflow_steps": (C.c_int, [_vp, _i64p]),

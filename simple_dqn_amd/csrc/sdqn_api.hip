@@ -394,6 +394,7 @@ struct sdqn_net_s {
   half_t* gh = nullptr; int* ovf_flag = nullptr; int64_t* ovf_count = nullptr;    // fp16 data parallel: half gradient payload, overflow flag / skipped steps
   int dp_half = 1, dp_half_scale_log2 = -1;  // fp16 mode: all-reduce the gradient as half; -1 = dynamic payload scale (starts at 2^10, device-side), >= 0 = fixed 2^n
   bool h16_wgrad_mfma = true;              // fp16 mode: weight gradients on packed-fp16 MFMA (LDS transposes); false = fp32 MFMA with half operands
+  bool half_payload_pending = false;       // sdqn_net_grad_from_half ran: the next sdqn_net_apply_update honours the overflow flag / moves the scale
   bool grad_only = false;                  // true: a train step stops after the local gradient sums (update mode 1): what a
                                            // data-parallel rank has before the all-reduce; sdqn_net_apply_update finishes it
   int nw_override[12] = {0};               // tuning hook
@@ -1166,8 +1167,47 @@ extern "C" int sdqn_net_apply_update(sdqn_net_t h, double bsz) {
   StepArgs a = step_args(h);
   UpdateArgs u = make_update_args(h, a);
   u.mode = 2; u.bsz = (float)bsz; u.skip_fc4 = 0;
+  if (h->half_payload_pending) {           // the gradient came back through the half payload: same overflow rule as the RCCL path
+    u.ovf_flag = h->ovf_flag; u.ovf_count = h->ovf_count; u.ovf_dynamic = h->dp_half_scale_log2 < 0 ? 1 : 0;
+    h->half_payload_pending = false;
+  }
   LAUNCH(K_UPDATE, launch_update(u, g_stream));
   if (h->bn) LAUNCH(K_BN, launch_bn_update(u, g_stream));
+  return SDQN_OK;
+}
+// float16 data parallel without a communicator: the two passes that bracket ncclAllReduce(ncclFloat16) in run_train, callable
+// on their own so that the exchange can be done by the caller (tests: gloo across two processes sharing one GPU).
+//   to_half  : g * 2^k -> IEEE half (k = the device-side payload scale), copied to the caller's buffer
+//   from_half: the caller's summed half payload -> g / 2^k in fp32; a non-finite value raises the step's overflow flag, which the
+//              next sdqn_net_apply_update honours (parameters untouched, skipped-step counter + 1, dynamic scale halved)
+extern "C" int sdqn_net_grad_to_half(sdqn_net_t h, uint16_t* out, int64_t n) {
+  ARGCHK(h && out, "NULL argument");
+  ARGCHK(h->gh && h->ovf_flag, "not a float16 network");
+  ARGCHK(n == h->NP, "the flat gradient holds %lld values, got %lld", (long long)h->NP, (long long)n);
+  { int rc = join_comm(h); if (rc) return rc; }
+  LAUNCH(K_UPDATE, launch_grad_to_half(h->g, h->gh, h->NP, h->ovf_flag, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  HIPCHK(hipMemcpy(out, h->gh, (size_t)n * 2, hipMemcpyDeviceToHost));
+  return SDQN_OK;
+}
+extern "C" int sdqn_net_grad_from_half(sdqn_net_t h, const uint16_t* in, int64_t n) {
+  ARGCHK(h && in, "NULL argument");
+  ARGCHK(h->gh && h->ovf_flag, "not a float16 network");
+  ARGCHK(n == h->NP, "the flat gradient holds %lld values, got %lld", (long long)h->NP, (long long)n);
+  { int rc = join_comm(h); if (rc) return rc; }
+  HIPCHK(hipStreamSynchronize(g_stream));
+  HIPCHK(hipMemcpy(h->gh, in, (size_t)n * 2, hipMemcpyHostToDevice));
+  LAUNCH(K_UPDATE, launch_grad_from_half(h->gh, h->g, h->NP, h->ovf_flag, g_stream));
+  h->half_payload_pending = true;
+  return SDQN_OK;
+}
+// {overflow flag of the last from-half pass, log2 of the payload scale, clean steps since the scale last moved} (sync)
+extern "C" int sdqn_net_half_payload_state(sdqn_net_t h, int* flag, int* scale_log2, int* clean_steps) {
+  ARGCHK(h, "NULL handle");
+  ARGCHK(h->ovf_flag, "not a float16 network");
+  { int rc = join_comm(h); if (rc) return rc; } HIPCHK(hipStreamSynchronize(g_stream));
+  int st[4]; HIPCHK(hipMemcpy(st, h->ovf_flag, 16, hipMemcpyDeviceToHost));
+  if (flag) *flag = st[0]; if (scale_log2) *scale_log2 = st[1]; if (clean_steps) *clean_steps = st[2];
   return SDQN_OK;
 }
 extern "C" int sdqn_net_sync(sdqn_net_t h) {
@@ -1209,6 +1249,13 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
     { int rc_ = join_comm(h); if (rc_) return rc_; } HIPCHK(hipStreamSynchronize(g_stream));
     h->dp_half_scale_log2 = value;
     const int st0[4] = {0, value < 0 ? 10 : value, 0, 0};
+    HIPCHK(hipMemcpy(h->ovf_flag, st0, 16, hipMemcpyHostToDevice));
+  }
+  else if (!strcmp(name, "dp_half_scale_seed")) {          // dynamic mode kept, scale STARTS at 2^value (tests of the scale state machine)
+    ARGCHK(value >= 0 && value <= 15 && h->ovf_flag, "bad scale seed (0..15; float16 networks only)");
+    { int rc_ = join_comm(h); if (rc_) return rc_; } HIPCHK(hipStreamSynchronize(g_stream));
+    h->dp_half_scale_log2 = -1;
+    const int st0[4] = {0, value, 0, 0};
     HIPCHK(hipMemcpy(h->ovf_flag, st0, 16, hipMemcpyHostToDevice));
   }
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }

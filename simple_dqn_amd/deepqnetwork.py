@@ -333,6 +333,31 @@ class DeepQNetwork:
         a data-parallel step (see option 'grad_only')."""
         _lib.check(self._lib.sdqn_net_apply_update(self._h, float(bsz)))
 
+    def flat_size(self):
+        """values in the flat weight / gradient buffer (float16 networks have no BatchNorm block)"""
+        n, tot = C.c_int64(), 0
+        for layer in range(5):
+            _lib.check(self._lib.sdqn_net_layer_size(self._h, layer, C.byref(n)))
+            tot += n.value
+        return tot
+
+    def grad_to_half(self):
+        """float16 data parallel, first half of the exchange: the flat gradient sums scaled by the payload scale as IEEE half
+        (np.float16 array, internal layout) — what a rank hands to the all-reduce."""
+        out = np.empty(self.flat_size(), dtype=np.float16)
+        _lib.check(self._lib.sdqn_net_grad_to_half(self._h, out.ctypes.data_as(C.POINTER(C.c_uint16)), out.size))
+        return out
+
+    def grad_from_half(self, payload):
+        """... second half: the SUMMED half payload back into the fp32 gradient buffer; apply_update() then honours its overflow flag."""
+        p = np.ascontiguousarray(payload, dtype=np.float16)
+        _lib.check(self._lib.sdqn_net_grad_from_half(self._h, p.ctypes.data_as(C.POINTER(C.c_uint16)), p.size))
+
+    def half_payload_state(self):
+        v = [C.c_int() for _ in range(3)]
+        _lib.check(self._lib.sdqn_net_half_payload_state(self._h, *[C.byref(x) for x in v]))
+        return dict(overflow=v[0].value, scale_log2=v[1].value, clean_steps=v[2].value)
+
     def dp_shutdown(self):
         _lib.check(self._lib.sdqn_dp_shutdown(self._h))
 
