@@ -65,6 +65,11 @@ def kernel_work(B, A):
         # --batch_norm only: average over the 17 BatchNorm launches of a step (forward: statistics read x once, apply reads x and
         # writes a for both nets; backward: partial + apply read d and x, apply writes d and its padded copy) = 11 X / 17
         19: dict(bytes=11 * (a1 + a2 + a3 + a4) // 17, flops=0),
+        # round 3: fc4_wgrad + fused RMSProp ride in the fc4_dgrad launch.  W4 is read ONCE algorithmically (dgrad operand and
+        # RMSProp input are the same 6.4 MB), its optimizer state is read and written, the new W4 written: a4 + 2 a3 (dgrad)
+        # + a4 + a3 (wgrad operands) + 4 w4
+        20: dict(bytes=(a4 + 2 * a3) + (a4 + a3) + 4 * w4, flops=2 * B * 512 * 3136 * 2),
+        21: dict(bytes=(a3 + w3 + 2 * a2) + (a2 + a3 + w3), flops=2 * B * 49 * 64 * 576 * 2),
     }
     # (default tile split: the whole fc4 wgrad + fused RMSProp read-modify-write — theta, s read and written — rides in bwd3)
 
@@ -96,8 +101,9 @@ def pmc_traffic(name, B, A):
 # substring of the rocprofv3 kernel name -> kernel id (kernels.h order); shared with tools/pmc_traffic.py
 ROCPROF_MATCH = [
     ("gemm_kernel<sdqn::Conv1Fwd", 0), ("gemm_kernel<sdqn::Conv2Fwd", 1), ("Conv3Fwd", 2), ("Fc4Fwd", 3),
-    ("head_kernel", 4), ("Fc4Dgrad", 5), ("update_kernel", 12), ("gather_kernel", 14), ("prep_kernel", 15),
+    ("head_kernel", 4), ("gemm_kernel<sdqn::Staged<sdqn::Fc4Dgrad>", 5), ("update_kernel", 12), ("gather_kernel", 14), ("prep_kernel", 15),
     ("gemm_multi_kernel<512, sdqn::Staged<sdqn::Conv3Dgrad>", 16), ("Conv2Dgrad", 17), ("Conv1Wgrad", 18),
+    ("Fc4DgradSig", 20), ("gemm_multi_kernel<512, sdqn::NoProblem, 2, sdqn::Staged<sdqn::Conv3Dgrad>", 21),
 ]
 
 

@@ -47,6 +47,10 @@ template <class P, class = void> struct a_group4 { static constexpr bool value =
 template <class P> struct a_group4<P, decltype((void)P::A_GROUP4)> { static constexpr bool value = P::A_GROUP4; };
 template <class P, class = void> struct uses_f16_wgrad { static constexpr bool value = false; };
 template <class P> struct uses_f16_wgrad<P, decltype((void)P::F16_WGRAD)> { static constexpr bool value = P::F16_WGRAD; };
+// SIGNALS: thread 0 calls P::signal(a, bx, by, bz) right after the barrier that follows the main loops of all waves of the tile
+// (every operand load of the tile has returned by then) — round 3's write-after-read hand-off between fc4_dgrad and fc4_wgrad
+template <class P, class = void> struct signals { static constexpr bool value = false; };
+template <class P> struct signals<P, decltype((void)P::SIGNALS)> { static constexpr bool value = P::SIGNALS; };
 template <class P, class = void> struct uses_f16_mfma { static constexpr bool value = false; };
 template <class P> struct uses_f16_mfma<P, decltype((void)P::F16_MFMA)> { static constexpr bool value = P::F16_MFMA; };
 
@@ -318,6 +322,7 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
     }
     __syncthreads();
     SDQN_STAMP(5);
+    if constexpr (signals<P>::value) { if (threadIdx.x == 0) P::signal(a, bx, by, bz); }
     for (int e = threadIdx.x; e < 1024; e += NT) {
       const int ml = e >> 5, nl = e & 31;
       float v = smem[ml * 33 + nl];

@@ -14,6 +14,8 @@ enum KernelId {
   K_BWD2,      // one launch: conv2_dgrad + conv2_wgrad (both depend on conv3_dgrad only) + a share of fc4_wgrad
   K_BWD1,      // one launch: conv1_wgrad + the last share of fc4_wgrad
   K_BN,        // --batch_norm: one BatchNorm layer, forward ([partial +] apply) or backward (partial + apply)
+  K_F4D_F4W,   // round 3, one launch: fc4_dgrad + fc4_wgrad (+ fused RMSProp of W4) — the wgrad only needs delta4 and a3
+  K_BWD3_CONV, // round 3: bwd3 without the fc4 share (conv3_dgrad + conv3_wgrad)
   K_COUNT
 };
 const char* kernel_name(int id);
@@ -130,6 +132,7 @@ struct LaunchTune {
   int hoist;                // bit 0: K_BWD2 / K_BWD1 carry the NEXT step's target conv1 / conv2; bit 1: K_CONV1_FWD / K_CONV2_FWD carry
                             // this step's target conv3 / fc4 and compute the online net only (StepArgs::nz = 1)
   int order;                // experiment (option "bwd_order"): order of the problems inside the fused backward launches
+  int r3;                   // round-3 launch variants (sdqn_kernels_r3.hip); bit 0: this K_FC4_DGRAD launch also carries the fc4_wgrad tiles
 };
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s);     // the GEMM-shaped stages (single or multi-problem launches)
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s);

@@ -110,6 +110,13 @@ struct StepArgs {
   // Rectlin: the BatchNorm + Rectlin pass of bn_kernels.hip follows) and the head variant that reads an activated a4
   int bn;
   const int64_t* idx_t;     // hoist option only (Conv1FwdTarget): the NEXT step's indexes, whose target conv1 rides in this step's K_BWD2
+  // ---- round 3 (appended: every earlier field keeps its offset) ----
+  // fc4_wgrad + fused RMSProp riding in the fc4_dgrad launch (sdqn_kernels_r3.hip): the dgrad tile of W4 row block j publishes
+  // "my reads of W4 rows [32 j, 32 j + 32) are done" as f4d_flags[16 j] = f4d_epoch; an fc4_wgrad tile of the same row block
+  // waits for it before its in-place RMSProp store (a write-after-read hand-off: no data crosses, so no cache visibility issue)
+  unsigned* f4d_flags;      // [NIN4 / 32][16] one word per row block, 64 B apart; [NIN4 / 32 * 16] = sticky time-out word
+  unsigned f4d_epoch;       // step number (monotonic, never 0): flags never need a reset
+  int r3_pad_;
 };
 
 // A9 + A10 in Neon's operation order (the library is built with -ffp-contract=off: one rounding per op)
@@ -453,6 +460,37 @@ struct Fc4Wgrad {   // gW4 = delta4 . a3^T (sum over batch, A8) in the W4i layou
   }
 #endif
 };
+
+#if defined(__HIPCC__)
+// fc4_dgrad + fc4_wgrad in ONE launch (round 3).  At B <= 32 the dgrad has a single M tile, so W4i rows [32 j, 32 j + 32)
+// are read by exactly ONE workgroup (dgrad tile j) — and rewritten in place by the 16 fc4_wgrad tiles (j, 0..15) when RMSProp
+// is fused into their epilogue.  Tile j publishes the end of its reads, the writers wait for it: the 25.7 MB read-modify-write
+// stream of W4 + its optimizer state then runs on the 158 CUs the 98 dgrad workgroups leave idle instead of lengthening bwd3.
+struct Fc4DgradSig : Fc4Dgrad {
+  static constexpr bool SIGNALS = true;
+  // called by thread 0 after the workgroup barrier that follows every wave's main loop (all operand loads have returned)
+  __device__ static void signal(const StepArgs& a, int bx, int by, int bz) {
+    (void)bx; (void)bz;
+    __hip_atomic_store(a.f4d_flags + by * 16, a.f4d_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+};
+struct Fc4WgradWait : Fc4Wgrad {
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi& e) {
+    if (a.fuse_rms) {                                  // (materialised gradient: written to g, nothing to wait for)
+      const unsigned* f = a.f4d_flags + (m0 >> 5) * 16;
+      int spins = 0;                                   // wave-uniform loop: every lane reads the same word
+      while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.f4d_epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > 4000000) {                       // ~ seconds: the producer tile never ran -> report, never hang
+          __hip_atomic_store(a.f4d_flags + (NIN4 / 32) * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    Fc4Wgrad::store16(a, z, ks, m0, n0, lane, M, N, v, e);
+  }
+};
+#endif
 
 struct Conv3Dgrad { // delta2 = full-correlation(d3p, W3) * 1[a2 > 0], written into the padded d2p
   static constexpr bool A_K = true, B_K = true;     // operand contiguous along k (-> LDS transpose) or along m/n

@@ -405,6 +405,8 @@ struct sdqn_net_s {
   int xcd_mask[K_COUNT] = {0};             // tuning hook "xcd:<kernel id>": per-launch problem mask (-1 = built-in)
   bool xcd_map = false;                    // XCD-contiguous tile map for EVERY launch: traffic ~ algorithmic, step ~1 % slower (bwd3);
                                            // built-in: only where it also wins time (fc4_fwd: the 7 K-slabs of a tile's W4 panel share an L2)
+  bool f4w_early = true;                   // round 3 (B <= 32, fp32): fc4_wgrad + fused RMSProp ride in the fc4_dgrad launch (K_F4D_F4W) instead of bwd3
+  unsigned* f4d_flags = nullptr;           // [NIN4 / 32][16] write-after-read flags of that launch + one sticky time-out word
   bool fused_launches = true;              // independent backward stages share one launch (K_BWD3, K_BWD2)
   bool two_streams = false;                // weight-gradient kernels on the side stream (measured slower eagerly: event waits)
   // profiler
@@ -550,6 +552,7 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   // the minibatch's small arrays in ONE block [rewards 8 B | actions B | terminals B]: the tuple API uploads them with one copy
   NCHK(dalloc(h, (void**)&h->st_rew, (size_t)B * 10));
   h->st_act = reinterpret_cast<uint8_t*>(h->st_rew) + (size_t)B * 8; h->st_term = h->st_act + B;
+  NCHK(dalloc(h, (void**)&h->f4d_flags, (size_t)(NIN4 / 32 + 1) * 16 * 4));
   NCHK(dalloc(h, (void**)&h->d_idx, (size_t)B * 8));
   NCHK(dalloc(h, (void**)&h->d_idx_t, (size_t)B * 8));
   { hipError_t e = hipHostMalloc((void**)&h->h_f, (size_t)(2 * B * MAX_ACTIONS + B + 64) * 8, hipHostMallocMapped);
@@ -711,6 +714,7 @@ static StepArgs step_args(sdqn_net_s* h) {
     a.loss_scale = (float)h->cfg.loss_scale; a.inv_loss_scale = (float)(1.0 / h->cfg.loss_scale);
   }
   a.f4w_first = 0; a.f4w_count = (NIN4 / 32) * (NFC / 32);
+  a.f4d_flags = h->f4d_flags; a.f4d_epoch = (unsigned)(h->train_iterations + 1);      // (never 0; one train step per value)
   a.fuse_rms = (!h->comm && !h->keep_grads && !h->grad_only && h->cfg.optimizer == 0) ? 1 : 0;
   a.theta_w = h->theta; a.state = h->state; a.bsz = (float)h->B;
   a.rho = (float)h->cfg.decay_rate; a.one_minus_rho = (float)(1.0 - h->cfg.decay_rate);
@@ -748,11 +752,11 @@ static BnArgs bn_args(sdqn_net_s* h, const StepArgs& a, int layer, int train) {
 }
 // tuning hook: per-launch XCD map mask override (sdqn_net_set_option "xcd:<id>", value = mask + 1; 0 = built-in)
 #define XCD_TUNE(ARGS, KID) do { if (h->xcd_mask[KID] > 0) (ARGS).xcd_map = h->xcd_mask[KID] - 1; } while (0)
-static hipError_t launch_tuned(sdqn_net_s* h, int id, StepArgs a, hipStream_t s, int hoist = 0) {
+static hipError_t launch_tuned(sdqn_net_s* h, int id, StepArgs a, hipStream_t s, int hoist = 0, int r3 = 0) {
   XCD_TUNE(a, id);
   LaunchTune t;
   for (int i = 0; i < 12; ++i) { t.nw_override[i] = h->nw_override[i]; t.rb[i] = h->rb[i]; }
-  t.hoist = hoist; t.order = h->bwd_order;
+  t.hoist = hoist; t.order = h->bwd_order; t.r3 = r3;
   return launch_kernel(id, a, t, s);
 }
 static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int hoist = 0) {
@@ -828,9 +832,15 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   // --batch_norm: the delta arriving at layer l (masked by its Rectlin) first goes back through BatchNorm l, in place
 #define BN_BWD(L) do { if (h->bn) LAUNCH(K_BN, launch_bn_backward(bn_args(h, a, (L), 1), g_stream)); } while (0)
   BN_BWD(3);
-  LAUNCH(K_FC4_DGRAD, launch_tuned(h, K_FC4_DGRAD, a, g_stream));
-  BN_BWD(2);
   const bool dp_ov = h->comm && h->comm2 && h->dp_overlap && h->fused_launches && !h->two_streams;
+  // round 3: fc4_wgrad (needs delta4 and a3 only) rides in the fc4_dgrad launch, whose 98 workgroups leave 158 CUs idle; with the
+  // fused RMSProp its in-place update of W4 is ordered behind the dgrad's reads by per-row-block flags (sdqn_kernels_r3.hip).
+  // Same tiles, same K split as the bwd3 form: bit-identical.  Not for the overlapped-DP / two-stream / hoist / fp16 / bn variants.
+  const bool f4_early = h->f4w_early && h->B <= 32 && h->cfg.datatype == 0 && !h->bn && h->fused_launches && !h->two_streams &&
+                        !dp_ov && !hoist && h->bwd_order == 0 && h->f4_share[0] == 100 && h->f4_share[1] == 0 && h->nw_override[K_FC4_DGRAD] == 0;
+  if (f4_early) LAUNCH(K_F4D_F4W, launch_tuned(h, K_FC4_DGRAD, a, g_stream, 0, 1));
+  else LAUNCH(K_FC4_DGRAD, launch_tuned(h, K_FC4_DGRAD, a, g_stream));
+  BN_BWD(2);
   if (dp_ov) {
     // data parallel, overlapped: ALL of fc4_wgrad rides the first backward launch, so the 6.4 MB fc4 gradient is
     // complete two launches before the step ends; its all-reduce and its optimizer update run on g_comm
@@ -856,13 +866,14 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     // for B > 32 (K-split workgroups) it all rides in the first one
     const int f4_tiles = (NIN4 / 32) * (NFC / 32);
     StepArgs b3 = a, b2 = a, b1 = a;
-    if (h->B <= 32) {
+    if (f4_early) { b3.f4w_count = b2.f4w_count = b1.f4w_count = 0; }
+    else if (h->B <= 32) {
       const int s3 = h->f4_share[0] * f4_tiles / 100, s2 = h->f4_share[1] * f4_tiles / 100;
       b3.f4w_first = 0; b3.f4w_count = s3;
       b2.f4w_first = s3; b2.f4w_count = s2;
       b1.f4w_first = s3 + s2; b1.f4w_count = f4_tiles - s3 - s2;
     } else { b3.f4w_first = 0; b3.f4w_count = f4_tiles; b2.f4w_count = b1.f4w_count = 0; }
-    LAUNCH(K_BWD3, launch_tuned(h, K_BWD3, b3, g_stream));
+    if (f4_early) LAUNCH(K_BWD3_CONV, launch_tuned(h, K_BWD3, b3, g_stream)); else LAUNCH(K_BWD3, launch_tuned(h, K_BWD3, b3, g_stream));
     BN_BWD(1);
     LAUNCH(K_BWD2, launch_tuned(h, K_BWD2, b2, g_stream, hoist & 1));
     BN_BWD(0);
@@ -1212,7 +1223,12 @@ extern "C" int sdqn_net_half_payload_state(sdqn_net_t h, int* flag, int* scale_l
 }
 extern "C" int sdqn_net_sync(sdqn_net_t h) {
   ARGCHK(h, "NULL handle"); int rc = join_comm(h); if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(g_stream)); return SDQN_OK;
+  HIPCHK(hipStreamSynchronize(g_stream));
+  // in-launch hand-offs are bounded spins: a producer that never ran would show up here, never as a hung GPU
+  unsigned timed_out = 0;
+  HIPCHK(hipMemcpy(&timed_out, h->f4d_flags + (NIN4 / 32) * 16, 4, hipMemcpyDeviceToHost));
+  if (timed_out) { set_error("fc4_wgrad waited for a fc4_dgrad tile that never signalled (in-launch hand-off timed out): results are invalid"); return SDQN_ERR_STATE; }
+  return SDQN_OK;
 }
 extern "C" int sdqn_net_last_q(sdqn_net_t h, float* preq, float* maxpostq) {
   ARGCHK(h, "NULL handle");
@@ -1260,6 +1276,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   }
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
+  else if (!strcmp(name, "f4w_early")) h->f4w_early = value != 0;       // 0: fc4_wgrad inside bwd3 (round-2 launch structure)
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;
   else if (!strcmp(name, "dp_sync_replicas")) h->dp_sync_replicas = value != 0;   // before dp_init
   else if (!strcmp(name, "dp_overlap")) h->dp_overlap = value != 0;     // before dp_init: 0 = single all-reduce on the library stream

@@ -15,7 +15,7 @@ static const char* k_names[K_COUNT] = {
   "fc4_dgrad", "fc4_wgrad", "conv3_dgrad", "conv3_wgrad", "conv2_dgrad", "conv2_wgrad",
   "conv1_wgrad", "update(reduce+fc5wgrad+rmsprop)", "rccl_allreduce", "replay_gather_u8", "prep(idx+meta)",
   "bwd3(conv3_dgrad+conv3_wgrad+fc4_wgrad)", "bwd2(conv2_dgrad+conv2_wgrad+fc4_wgrad)", "bwd1(conv1_wgrad+fc4_wgrad)",
-  "batchnorm(layer fwd/bwd)"};
+  "batchnorm(layer fwd/bwd)", "fc4_dgrad+fc4_wgrad(+rmsprop W4)", "bwd3(conv3_dgrad+conv3_wgrad)"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? k_names[id] : "?"; }
 
 template <class P>
@@ -35,7 +35,14 @@ static hipError_t launch_nw(int nw, const StepArgs& a, hipStream_t s) {
 // (measured: -1 % step rate when the new variants shared this file), so this file stays what round 1 tuned.
 hipError_t launch_kernel_ext(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled);
 
+hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled);
+
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s) {
+  if (t.r3) {                  // round-3 launch variants live in their own translation unit (same reason as sdqn_kernels_ext.hip)
+    bool handled = false;
+    const hipError_t e = launch_kernel_r3(id, a, t, s, &handled);
+    if (handled) return e;
+  }
   if (a.h16 || t.hoist || t.order || (a.B >= 128 && id >= 0 && id < 12 && t.rb[id] > 0)) {
     bool handled = false;
     const hipError_t e = launch_kernel_ext(id, a, t, s, &handled);

@@ -256,12 +256,16 @@ def test_fused_and_streamed_paths_bit_identical(sd):
     to the plain single-stream, materialised-gradient path."""
     A, B = 4, 32
     nets = []
-    for keep, two, fl, xm in ((0, 1, 0, 0), (1, 1, 0, 0), (0, 0, 1, 0), (1, 0, 1, 1), (0, 0, 1, 1), (0, 0, 0, 0), (1, 0, 0, 0)):
+    # last column (round 3): fc4_wgrad (+ fused RMSProp) riding in the fc4_dgrad launch behind write-after-read flags (default 1)
+    # vs inside bwd3 (round-2 launch structure)
+    for keep, two, fl, xm, f4e in ((0, 1, 0, 0, 1), (1, 1, 0, 0, 1), (0, 0, 1, 0, 1), (1, 0, 1, 1, 1), (0, 0, 1, 1, 1), (0, 0, 1, 0, 0),
+                                   (1, 0, 1, 0, 0), (0, 0, 0, 0, 1), (1, 0, 0, 0, 1)):
         n, _ = _pair(sd, A, B, 81)
         n.set_option("keep_gradients", keep)
         n.set_option("two_streams", two)
         n.set_option("fused_launches", fl)
         n.set_option("xcd_map", xm)              # placement may only change speed, never results
+        n.set_option("f4w_early", f4e)
         nets.append(n)
     for s in range(4):
         mb = random_minibatch(B, A, 82 + s)
@@ -273,6 +277,35 @@ def test_fused_and_streamed_paths_bit_identical(sd):
             assert np.array_equal(a, b)
         for a, b in zip(n.get_weights(2), nets[-1].get_weights(2)):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("A,B", [(4, 32), (6, 7)])
+def test_fc4_wgrad_in_dgrad_launch_bit_identical_in_the_fused_loop(sd, A, B):
+    """Round 3: K_F4D_F4W (fc4_dgrad + fc4_wgrad + RMSProp of W4 in one launch, in-place update ordered behind the dgrad's
+    reads of the same W4 rows by per-row-block flags) against the round-2 launch structure, through train_from_memory over
+    several calls (epochs continue across calls, a target sync in between), full and ragged batch: weights, RMSProp state
+    and mean cost bit-identical; the hand-off never times out (sync() would raise)."""
+    size = 3000
+    args = make_args(batch_size=B)
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 91, num_actions=A)
+    mem.sync_mirror()
+    outs = []
+    for f4e in (1, 0):
+        n, _ = _pair(sd, A, B, 92)
+        n.set_option("f4w_early", f4e)
+        random.seed(93)
+        costs = [n.train_from_memory(mem, 5, want_cost=True)]
+        n.update_target_network()
+        costs.append(n.train_from_memory(mem, 1, want_cost=True))
+        costs.append(n.train_from_memory(mem, 17, want_cost=True))
+        n.sync()
+        outs.append((n.get_weights(0), n.get_weights(2), costs))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, b)
+    assert outs[0][2] == outs[1][2]
 
 
 def test_target_network_semantics(sd):
