@@ -82,6 +82,8 @@ int sdqn_replay_get_state(sdqn_replay_t h, int64_t* count, int64_t* current);
 int sdqn_replay_set_state(sdqn_replay_t h, int64_t count, int64_t current);
 /* after writing the host views directly (bulk fill): copy slots [first, first+n) into the mirror */
 int sdqn_replay_upload(sdqn_replay_t h, int64_t first, int64_t n);
+/* the same for the packed metadata only (actions / rewards / terminals edited in place: 16 B per slot instead of 7 KB) */
+int sdqn_replay_upload_meta(sdqn_replay_t h, int64_t first, int64_t n);
 /* replay_memory.py:54-68 on this ring (terminals/count/current of the handle) */
 int sdqn_replay_sample(sdqn_replay_t h, uint32_t mt[SDQN_MT_WORDS], int64_t* idx_out, int64_t* draws_out);
 /* replay_memory.py:71-78: HIP gather of (s, a, r, s', terminal) by index into device HBM (async) */

@@ -52,6 +52,7 @@ SIGNATURES = {
     "sdqn_replay_get_state": (C.c_int, [_vp, _i64p, _i64p]),
     "sdqn_replay_set_state": (C.c_int, [_vp, C.c_int64, C.c_int64]),
     "sdqn_replay_upload": (C.c_int, [_vp, C.c_int64, C.c_int64]),
+    "sdqn_replay_upload_meta": (C.c_int, [_vp, C.c_int64, C.c_int64]),
     "sdqn_replay_sample": (C.c_int, [_vp, _u32p, _i64p, _i64p]),
     "sdqn_replay_gather": (C.c_int, [_vp, _i64p]),
     "sdqn_replay_minibatch_to_host": (C.c_int, [_vp]),

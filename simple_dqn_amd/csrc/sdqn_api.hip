@@ -223,6 +223,18 @@ extern "C" int sdqn_replay_upload(sdqn_replay_t r, int64_t first, int64_t n) {
   HIPCHK(hipStreamSynchronize(g_stream));
   return SDQN_OK;
 }
+// metadata only (actions / rewards / terminals of slots [first, first + n) re-packed and sent): 16 B per slot instead of 7 KB
+extern "C" int sdqn_replay_upload_meta(sdqn_replay_t r, int64_t first, int64_t n) {
+  ARGCHK(r && first >= 0 && n >= 0 && first + n <= r->size, "bad upload range");
+  for (int64_t i = first; i < first + n; ++i) {
+    MetaRec& m = r->h_meta[i];
+    m.reward = r->rewards[i]; m.action = r->actions[i]; m.terminal = r->terminals[i] ? 1 : 0;
+  }
+  if (!(r->flags & SDQN_REPLAY_ZERO_COPY) && n > 0)
+    HIPCHK(hipMemcpyAsync(r->d_meta + first, r->h_meta + first, (size_t)n * sizeof(MetaRec), hipMemcpyHostToDevice, g_stream));
+  HIPCHK(hipStreamSynchronize(g_stream));
+  return SDQN_OK;
+}
 extern "C" int sdqn_replay_sample(sdqn_replay_t r, uint32_t* mt, int64_t* idx_out, int64_t* draws_out) {
   ARGCHK(r, "NULL handle");
   return sample_checked(mt, r->terminals, r->count, r->current, r->hist, r->B, idx_out, draws_out);
@@ -405,7 +417,7 @@ struct sdqn_net_s {
   int xcd_mask[K_COUNT] = {0};             // tuning hook "xcd:<kernel id>": per-launch problem mask (-1 = built-in)
   bool xcd_map = false;                    // XCD-contiguous tile map for EVERY launch: traffic ~ algorithmic, step ~1 % slower (bwd3);
                                            // built-in: only where it also wins time (fc4_fwd: the 7 K-slabs of a tile's W4 panel share an L2)
-  bool f4w_early = true;                   // round 3 (B <= 32, fp32): fc4_wgrad + fused RMSProp ride in the fc4_dgrad launch (K_F4D_F4W) instead of bwd3
+  bool f4w_early = false;                  // round 3 (B <= 32, fp32): fc4_wgrad + fused RMSProp ride in the fc4_dgrad launch (K_F4D_F4W) instead of bwd3
   unsigned* f4d_flags = nullptr;           // [NIN4 / 32][16] write-after-read flags of that launch + one sticky time-out word
   bool fused_launches = true;              // independent backward stages share one launch (K_BWD3, K_BWD2)
   bool two_streams = false;                // weight-gradient kernels on the side stream (measured slower eagerly: event waits)

@@ -12,6 +12,7 @@ import random
 import numpy as np
 
 from . import _lib
+from ._tracked import DirtySlots, TrackedArray
 
 logger = logging.getLogger(__name__)
 HBM_MIRROR, ZERO_COPY = 1, 2
@@ -31,11 +32,17 @@ class ReplayMemory:
         self._h = h
         ps, pa, pr, pt = _lib._u8p(), _lib._u8p(), _lib._i64p(), _lib._u8p()
         _lib.check(self._lib.sdqn_replay_host_ptrs(h, C.byref(ps), C.byref(pa), C.byref(pr), C.byref(pt)))
-        # replay_memory.py:10-13 — same dtypes (np.integer resolves to int64 on Linux)
-        self.actions = np.ctypeslib.as_array(pa, shape=(size,))
-        self.rewards = np.ctypeslib.as_array(pr, shape=(size,))
-        self.screens = np.ctypeslib.as_array(ps, shape=(size,) + self.dims)
-        self.terminals = np.ctypeslib.as_array(pt, shape=(size,)).view(np.bool_)
+        # replay_memory.py:10-13 — same dtypes (np.integer resolves to int64 on Linux).  The reference has ONE copy of the ring;
+        # here these are views of the pinned master copy and the kernels read an HBM mirror, so the views TRACK in-place writes
+        # (_tracked.py) and the slots they touched are uploaded before the next device use (_check_mirror): coherent like one copy
+        self._flags = flags
+        self._dirty_frames, self._dirty_meta = DirtySlots(), DirtySlots()
+        raw = {"actions": np.ctypeslib.as_array(pa, shape=(size,)), "rewards": np.ctypeslib.as_array(pr, shape=(size,)),
+               "screens": np.ctypeslib.as_array(ps, shape=(size,) + self.dims),
+               "terminals": np.ctypeslib.as_array(pt, shape=(size,)).view(np.bool_)}
+        self._ring_base = {k: (v.__array_interface__["data"][0], v.nbytes // size) for k, v in raw.items()}   # (address, bytes per slot)
+        self.actions, self.rewards = TrackedArray(raw["actions"], self, "actions"), TrackedArray(raw["rewards"], self, "rewards")
+        self.screens, self.terminals = TrackedArray(raw["screens"], self, "screens"), TrackedArray(raw["terminals"], self, "terminals")
         mp, mq, ma, mr, mt = _lib._u8p(), _lib._u8p(), _lib._u8p(), _lib._i64p(), _lib._u8p()
         _lib.check(self._lib.sdqn_replay_minibatch_ptrs(h, C.byref(mp), C.byref(mq), C.byref(ma), C.byref(mr), C.byref(mt)))
         shp = (self.batch_size, self.history_length) + self.dims
@@ -44,8 +51,6 @@ class ReplayMemory:
         self._mb_actions = np.ctypeslib.as_array(ma, shape=(self.batch_size,))
         self._mb_rewards = np.ctypeslib.as_array(mr, shape=(self.batch_size,))
         self._mb_terminals = np.ctypeslib.as_array(mt, shape=(self.batch_size,)).view(np.bool_)
-        self._flags = flags
-        self._mirror_stale = False      # set when count / current are assigned directly: the tell-tale of a bulk fill through the numpy views
         self._idx = np.empty(self.batch_size, dtype=np.int64)
         self._mt = (C.c_uint32 * _lib.MT_WORDS)()
         self.last_indexes = None
@@ -69,7 +74,6 @@ class ReplayMemory:
     @count.setter
     def count(self, v):
         _lib.check(self._lib.sdqn_replay_set_state(self._h, int(v), self._state()[1]))
-        self._mirror_stale = self._flags != ZERO_COPY
 
     @property
     def current(self):
@@ -78,15 +82,31 @@ class ReplayMemory:
     @current.setter
     def current(self, v):
         _lib.check(self._lib.sdqn_replay_set_state(self._h, self._state()[0], int(v)))
-        self._mirror_stale = self._flags != ZERO_COPY
+
+    # ---- coherence of the HBM mirror with the numpy views -----------------------------------------------------------
+    def _mark_dirty_bytes(self, kind, lo, hi):
+        """Called by the tracked views: memory [lo, hi) of ring array `kind` was written in place."""
+        if self._flags == ZERO_COPY:
+            return                                      # kernels read the pinned views themselves
+        base, bps = self._ring_base[kind]
+        first, last = max(0, (lo - base) // bps), min(self.size, -((base - hi) // bps))     # floor / ceil in slots
+        if last > first:
+            (self._dirty_frames if kind == "screens" else self._dirty_meta).mark(first, last)
 
     def _check_mirror(self):
-        """The reference has one copy of the ring; here the numpy attributes are the pinned master copy and kernels read an
-        HBM mirror that add() keeps current.  Writing the views directly (a bulk fill: `mem.screens[:] = ...; mem.count = n`)
-        leaves the mirror behind — detected through the direct count / current assignment that such a fill needs, and
-        refused loudly instead of training on stale frames."""
-        assert not self._mirror_stale, ("the replay ring was filled through its numpy views (count / current were assigned "
-                                        "directly): call mem.sync_mirror() before sampling or training from it")
+        """Before every device use of the ring: slots written through the numpy views since the last upload go to the HBM
+        mirror now (frames and packed metadata separately — a rewards-only edit does not re-send 7 KB per slot)."""
+        frames = self._dirty_frames.take()
+        for lo, hi in frames:
+            _lib.check(self._lib.sdqn_replay_upload(self._h, lo, hi - lo))           # (also re-packs + sends the range's metadata)
+        for lo, hi in self._dirty_meta.take():
+            if not any(a <= lo and hi <= b for a, b in frames):
+                _lib.check(self._lib.sdqn_replay_upload_meta(self._h, lo, hi - lo))
+
+    @property
+    def mirror_dirty(self):
+        """(frames, metadata) slot ranges written through the views and not yet uploaded — None when clean."""
+        return (list(self._dirty_frames.iv) or None, list(self._dirty_meta.iv) or None)
 
     def add(self, action, reward, screen, terminal):               # :26-34
         assert screen.shape == self.dims
@@ -103,10 +123,13 @@ class ReplayMemory:
         return self.screens[indexes, ...]
 
     def sync_mirror(self, first=0, n=None):
-        """After writing the numpy views directly (bulk fills), copy slots into the HBM mirror."""
+        """Explicit upload of ring slots [first, first + n) into the HBM mirror.  Not needed after writes through the numpy
+        attributes (tracked, uploaded automatically before the next device use); needed after writes that bypass numpy
+        (buffer protocol: memoryview / readinto / ctypes)."""
         n = self.size - first if n is None else n
         _lib.check(self._lib.sdqn_replay_upload(self._h, first, n))
-        self._mirror_stale = False
+        if first == 0 and n == self.size:
+            self._dirty_frames.take(); self._dirty_meta.take()
 
     def sample_indexes(self):
         """replay_memory.py:54-68 on Python's GLOBAL random stream (shared with agent.py:32,50-51)."""

@@ -3,7 +3,7 @@
 // measured on this stack next to the forms round 1/2 measured (single counter, release/acquire fences per workgroup), and the
 // dependent-dispatch floor measured GPU-side (graph replay / pre-filled queue) instead of by a host-bound eager burst.
 //
-//   hipcc --offload-arch=gfx950 -O3 -o handoff_r3 handoff_r3.hip -ldl && timeout 300 ./handoff_r3 [all|boundary|barrier|chain] [lib.so]
+//   hipcc --offload-arch=gfx950 -O3 -o handoff_r3 handoff_r3.hip -ldl && timeout 300 ./handoff_r3 [all|boundary|barrier|chain|stores] [lib.so]
 //
 // Every spin is bounded and abortable: a wrong residency / ordering assumption ends a section with "ABORT", never a hung GPU.
 #include <hip/hip_runtime.h>
@@ -395,6 +395,71 @@ static int section_chain() {
   return 0;
 }
 
+// ============================================================ D. store flavour vs the end-of-kernel write-back ================
+// A kernel boundary writes back every dirty L2 line the predecessor left ("+ B / 6 TB/s", guide row `boundary`).  Do write-through
+// stores (issued while the kernel still computes) make the boundary cheaper than plain stores whose lines are flushed at the end?
+// Stage = every workgroup reads 16 KB of the previous stage (plain 16-B loads), spins on MFMA-free ALU work for `work` iterations,
+// and writes `out_floats` floats with store flavour F: 0 plain dwordx4, 1 sc1 dwordx4, 2 nt dwordx4, 3 sc0 sc1 dwordx4,
+// 4 sc1 DWORD stores (lanes along the row, what a lane-per-column epilogue issues), 5 plain dword stores.
+template <int F>
+__global__ void __launch_bounds__(512) store_stage(const float* src, float* dst, int s, int in_floats, int out_floats, int work) {
+  const int G = gridDim.x, b = blockIdx.x;
+  const int from = (b * 37 + 11 + s) % G;
+  float acc = 0.0f;
+  for (int i = threadIdx.x * 4; i < in_floats; i += 512 * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)from * out_floats + i);
+    acc += v.x + v.y + v.z + v.w;
+  }
+  for (int k = 0; k < work; ++k) acc = acc * 1.000001f + 0.5f;          // a dependent ALU chain: the "compute" the stores could hide under
+  auto rd = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (int)((size_t)G * out_floats * 4), 0x00020000);
+  if (F <= 3) {
+    for (int i = threadIdx.x * 4; i < out_floats; i += 512 * 4) {
+      u4 v; v.x = v.y = v.z = v.w = __float_as_uint(acc + (float)i);
+      const int off = (int)(((size_t)b * out_floats + i) * 4);
+      if (F == 0) *reinterpret_cast<u4*>(dst + (size_t)b * out_floats + i) = v;
+      else __builtin_amdgcn_raw_buffer_store_b128(v, rd, off, 0, F == 1 ? 16 : (F == 2 ? 2 : 17));
+    }
+  } else {
+    for (int i = threadIdx.x; i < out_floats; i += 512) {
+      const float v = acc + (float)i;
+      if (F == 4) __hip_atomic_store(dst + (size_t)b * out_floats + i, v, RLX_AGENT);
+      else dst[(size_t)b * out_floats + i] = v;
+    }
+  }
+}
+template <int F>
+static int store_row(const char* what, int G, int out_kb, int work) {
+  const int out_floats = out_kb * 256, in_floats = 4096;
+  float *b0, *b1; CK(hipMalloc(&b0, (size_t)G * out_floats * 4)); CK(hipMalloc(&b1, (size_t)G * out_floats * 4));
+  CK(hipMemset(b0, 0, (size_t)G * out_floats * 4)); CK(hipMemset(b1, 0, (size_t)G * out_floats * 4));
+  hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipGraph_t g; hipGraphExec_t ex; float ms = 0;
+  CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  for (int i = 0; i < 100; ++i) hipLaunchKernelGGL((store_stage<F>), dim3(G), dim3(512), 0, st, (i & 1) ? b1 : b0, (i & 1) ? b0 : b1, i, in_floats, out_floats, work);
+  CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+  CK(hipGraphLaunch(ex, st)); CK(hipStreamSynchronize(st));
+  CK(hipEventRecord(e0, st)); for (int r = 0; r < 5; ++r) CK(hipGraphLaunch(ex, st)); CK(hipEventRecord(e1, st));
+  CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("  %-34s %4d WG x512 thr, 16 KB in, %3d KB out per WG (%5.1f MB per stage), ALU work %5d: %6.2f us/stage\n",
+         what, G, out_kb, G * out_kb / 1024.0, work, ms * 1000.f / 500);
+  fflush(stdout);
+  CK(hipGraphExecDestroy(ex)); CK(hipGraphDestroy(g)); CK(hipFree(b0)); CK(hipFree(b1)); CK(hipStreamDestroy(st));
+  return 0;
+}
+static int section_stores() {
+  printf("== D. store flavour of a stage's OUTPUT vs the dirty-line write-back at the kernel boundary (dependent launches, hipGraph)\n");
+  for (int work : {0, 4000}) for (int G : {256, 512}) for (int kb : {16, 64, 128}) {
+    if (store_row<0>("plain dwordx4", G, kb, work)) return 1;
+    if (store_row<1>("sc1 dwordx4 (write-through)", G, kb, work)) return 1;
+    if (store_row<2>("nt dwordx4", G, kb, work)) return 1;
+    if (store_row<3>("sc0 sc1 dwordx4", G, kb, work)) return 1;
+    if (store_row<5>("plain dword (lane per column)", G, kb, work)) return 1;
+    if (store_row<4>("sc1 dword (lane per column)", G, kb, work)) return 1;
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const char* what = argc > 1 ? argv[1] : "all";
   const char* lib = argc > 2 ? argv[2] : nullptr;
@@ -403,5 +468,6 @@ int main(int argc, char** argv) {
   if (!strcmp(what, "all") || !strcmp(what, "boundary")) if (section_boundary(lib)) return 1;
   if (!strcmp(what, "all") || !strcmp(what, "barrier")) if (section_barrier()) return 2;
   if (!strcmp(what, "all") || !strcmp(what, "chain")) if (section_chain()) return 3;
+  if (!strcmp(what, "all") || !strcmp(what, "stores")) if (section_stores()) return 4;
   return 0;
 }
