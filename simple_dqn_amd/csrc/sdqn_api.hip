@@ -418,6 +418,7 @@ struct sdqn_net_s {
   bool xcd_map = false;                    // XCD-contiguous tile map for EVERY launch: traffic ~ algorithmic, step ~1 % slower (bwd3);
                                            // built-in: only where it also wins time (fc4_fwd: the 7 K-slabs of a tile's W4 panel share an L2)
   bool f4w_early = false;                  // round 3 (B <= 32, fp32): fc4_wgrad + fused RMSProp ride in the fc4_dgrad launch (K_F4D_F4W) instead of bwd3
+  bool conv3_c36 = true;                   // round 3: conv3_fwd on 36-deep K-chunks (one chunk per wave; sdqn_kernels_r3.hip)
   unsigned* f4d_flags = nullptr;           // [NIN4 / 32][16] write-after-read flags of that launch + one sticky time-out word
   bool fused_launches = true;              // independent backward stages share one launch (K_BWD3, K_BWD2)
   bool two_streams = false;                // weight-gradient kernels on the side stream (measured slower eagerly: event waits)
@@ -810,7 +811,9 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int
   StepArgs fm = a; fm.xcd_map = 1; fm.idx_t = nullptr;
   LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, fm, g_stream));
   LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, fm, g_stream));
-  { StepArgs f3 = fm; f3.xcd_map = a.xcd_map; LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, f3, g_stream)); }
+  { StepArgs f3 = fm; f3.xcd_map = a.xcd_map;
+    const int c36 = (h->conv3_c36 && !h->hoist && h->nw_override[K_CONV3_FWD] == 0) ? 2 : 0;      // (hoist: the riding target conv3 uses the 32-deep routine)
+    LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, f3, g_stream, 0, c36)); }
   { int rc = join_comm(h); if (rc) return rc; }                // conv1..3 of this step overlap the previous step's fc4 all-reduce
   LAUNCH(K_FC4_FWD, launch_tuned(h, K_FC4_FWD, fm, g_stream));
   LAUNCH(K_HEAD, launch_head(a, hd, g_stream));
@@ -1288,6 +1291,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   }
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
+  else if (!strcmp(name, "conv3_c36")) h->conv3_c36 = value != 0;       // 0: conv3_fwd on the engine's 32-deep chunks (round-2 kernel)
   else if (!strcmp(name, "f4w_early")) h->f4w_early = value != 0;       // 0: fc4_wgrad inside bwd3 (round-2 launch structure)
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;
   else if (!strcmp(name, "dp_sync_replicas")) h->dp_sync_replicas = value != 0;   // before dp_init

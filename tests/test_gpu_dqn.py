@@ -308,6 +308,25 @@ def test_fc4_wgrad_in_dgrad_launch_bit_identical_in_the_fused_loop(sd, A, B):
     assert outs[0][2] == outs[1][2]
 
 
+def test_conv3_36_deep_chunks_against_the_32_deep_routine(sd):
+    """Round 3: conv3_fwd splits K = 576 into 16 chunks of 36 (one per wave) instead of 18 of 32.  Same exact-fp32 MFMA, another
+    partition of the K sum: a3 and Q agree with the 32-deep routine to fp32 round-off (<= 2e-6 relative to max|a3|), with the
+    oracle to the same bound as before, for a full batch, a ragged one (M = 7 x 49 rows: partial tiles) and batch-of-one."""
+    for A, B in ((4, 32), (6, 7)):
+        mb = random_minibatch(B, A, 301)
+        outs = []
+        for c36 in (1, 0):
+            n, o = _pair(sd, A, B, 300)
+            n.set_option("conv3_c36", c36)
+            q = n.predict(mb[0])
+            a3 = n.debug_read("a3", B * 49 * 64)
+            outs.append((q, a3, n.predict_one(mb[0][0])))
+        (q1, a31, p1), (q0, a30, p0) = outs
+        assert np.abs(a31 - a30).max() <= 2e-6 * np.abs(a30).max() and not np.array_equal(a31, a30)
+        assert np.abs(q1 - q0).max() < 1e-5 and np.abs(q1 - o.predict(mb[0])).max() < Q_TOL
+        assert np.array_equal(p1, q1[0])                                # predict_one == row 0 of the padded batch, same routine
+
+
 def test_target_network_semantics(sd):
     A, B = 4, 8
     net, o = _pair(sd, A, B, 41)
