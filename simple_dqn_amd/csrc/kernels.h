@@ -137,7 +137,7 @@ struct LaunchTune {
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s);     // the GEMM-shaped stages (single or multi-problem launches)
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s);
 hipError_t launch_update(const UpdateArgs& u, hipStream_t s);
-hipError_t launch_gather(const GatherArgs& g, hipStream_t s);
+hipError_t launch_gather(const GatherArgs& g, hipStream_t s, const int64_t* host_idx = nullptr);   // host_idx (B <= 256): indexes inside the kernel arguments
 hipError_t launch_bn_forward(const BnArgs& b, hipStream_t s);      // [partial +] apply
 hipError_t launch_bn_backward(const BnArgs& b, hipStream_t s);     // partial + apply
 hipError_t launch_bn_update(const UpdateArgs& u, hipStream_t s);   // optimizer step of the [beta | gamma] block (g already holds the sums)

@@ -282,6 +282,12 @@ static GatherArgs gather_args(sdqn_replay_s* r, const int64_t* didx) {
 }
 extern "C" int sdqn_replay_gather(sdqn_replay_t r, const int64_t* idx_host) {
   ARGCHK(r && idx_host, "NULL argument");
+  if (r->B <= 256) {               // the indexes ride in the kernel arguments: no pinned slot, no release event (sdqn_kernels.hip)
+    for (int i = 0; i < r->B; ++i)
+      ARGCHK(idx_host[i] >= r->hist && idx_host[i] < r->count, "index %lld out of range (count %lld)", (long long)idx_host[i], (long long)r->count);
+    HIPCHK(launch_gather(gather_args(r, nullptr), g_stream, idx_host));
+    return SDQN_OK;
+  }
   int slot; const int64_t* didx; int rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
   HIPCHK(launch_gather(gather_args(r, didx), g_stream));
   return replay_release_idx(r, slot);
@@ -299,9 +305,10 @@ extern "C" int sdqn_replay_bench_gather(sdqn_replay_t r, const int64_t* idx_host
   int slot; const int64_t* didx; int rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   GatherArgs g = gather_args(r, didx);
-  HIPCHK(launch_gather(g, g_stream));                                        // warm
+  const int64_t* inl = r->B <= 256 ? idx_host : nullptr;                     // the launch form sdqn_replay_gather uses
+  HIPCHK(launch_gather(g, g_stream, inl));                                   // warm
   HIPCHK(hipEventRecord(e0, g_stream));
-  for (int i = 0; i < iters; ++i) HIPCHK(launch_gather(g, g_stream));
+  for (int i = 0; i < iters; ++i) HIPCHK(launch_gather(g, g_stream, inl));
   HIPCHK(hipEventRecord(e1, g_stream));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
@@ -323,7 +330,10 @@ extern "C" int sdqn_replay_bench_gather_sets(sdqn_replay_t r, const int64_t* idx
   GatherArgs g = gather_args(r, d);
   HIPCHK(launch_gather(g, g_stream));                                        // warm (code object, not data: set 0 comes round last)
   HIPCHK(hipEventRecord(e0, g_stream));
-  for (int i = 0; i < iters; ++i) { g.idx = d + (size_t)((i + 1) % nsets) * B; HIPCHK(launch_gather(g, g_stream)); }
+  for (int i = 0; i < iters; ++i) {
+    const size_t set = (size_t)((i + 1) % nsets) * B;
+    g.idx = d + set; HIPCHK(launch_gather(g, g_stream, B <= 256 ? idx_host + set : nullptr));
+  }
   HIPCHK(hipEventRecord(e1, g_stream));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));

@@ -521,9 +521,15 @@ hipError_t launch_prep(const PrepArgs& p, hipStream_t s, double* zero8) {
 // ------------------------------------------------------------------------------------------------
 // standalone replay gather: 16 B/lane coalesced loads of the 5 contiguous frames screens[i-4 : i+1],
 // each written to prestates[k] (frames 0..3) and poststates[k] (frames 1..4).  7056 = 441 * 16.
-__global__ void __launch_bounds__(256) gather_kernel(const GatherArgs g) {
+// INLINE (B <= 256, what getMinibatch() uses): the sampled indexes travel IN the kernel-argument block — they are host data at
+// launch time anyway (replay_memory.py:54-68 samples on the host) — so a workgroup's index is one scalar load from the
+// argument segment instead of a pointer load followed by a dependent global load: one memory round trip less on the launch's
+// critical path (the whole launch is three of them), no pinned index slot, no slot-release event in the stream.
+struct IdxBlock { int64_t v[256]; };
+template <bool INLINE>
+__global__ void __launch_bounds__(256) gather_kernel(const GatherArgs g, const IdxBlock ib) {
   const int n = blockIdx.y;
-  const int64_t index = g.idx[n];
+  const int64_t index = INLINE ? ib.v[n] : g.idx[n];
   constexpr int V = FRAME / 16;                                    // 441 uint4 per frame
   const uint4* src = reinterpret_cast<const uint4*>(g.ring + (index - C0) * (int64_t)FRAME);
   uint4* pre = reinterpret_cast<uint4*>(g.pre + (int64_t)n * STATE);
@@ -539,8 +545,15 @@ __global__ void __launch_bounds__(256) gather_kernel(const GatherArgs g) {
   }
 }
 
-hipError_t launch_gather(const GatherArgs& g, hipStream_t s) {
-  hipLaunchKernelGGL(gather_kernel, dim3(9, g.B), dim3(256), 0, s, g);
+hipError_t launch_gather(const GatherArgs& g, hipStream_t s, const int64_t* host_idx) {
+  if (host_idx && g.B <= 256) {
+    IdxBlock ib;
+    memcpy(ib.v, host_idx, (size_t)g.B * sizeof(int64_t));
+    hipLaunchKernelGGL(gather_kernel<true>, dim3(9, g.B), dim3(256), 0, s, g, ib);
+  } else {
+    IdxBlock ib; ib.v[0] = 0;
+    hipLaunchKernelGGL(gather_kernel<false>, dim3(9, g.B), dim3(256), 0, s, g, ib);
+  }
   return hipGetLastError();
 }
 
