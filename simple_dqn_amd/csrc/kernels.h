@@ -70,6 +70,7 @@ struct UpdateArgs {
   float beta1, one_minus_beta1, beta2, one_minus_beta2, lr_t;   // Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t), t = epoch+1
   half_t* wh;                   // fp16 mode: half copies of theta refreshed by the update (master layout / transposed)
   half_t* wht;
+  unsigned short* w1p;          // conv1's three bf16 planes of the ONLINE net, rewritten with W1 (nullptr: not maintained)
   int64_t bn_first;             // --batch_norm: element offset of the [beta|gamma] block (bn_update_kernel); BN_PARAMS elements
   const int* ovf_flag;          // fp16 data parallel (update_kernel<true>): != 0 -> the all-reduced half gradient overflowed, leave theta / state untouched
   int64_t* ovf_count;           //   ... and count the skipped step
@@ -132,7 +133,7 @@ struct LaunchTune {
   int hoist;                // bit 0: K_BWD2 / K_BWD1 carry the NEXT step's target conv1 / conv2; bit 1: K_CONV1_FWD / K_CONV2_FWD carry
                             // this step's target conv3 / fc4 and compute the online net only (StepArgs::nz = 1)
   int order;                // experiment (option "bwd_order"): order of the problems inside the fused backward launches
-  int r3;                   // round-3 launch variants (sdqn_kernels_r3.hip); bit 0: this K_FC4_DGRAD launch also carries the fc4_wgrad tiles; bit 1: conv3_fwd on 36-deep K-chunks
+  int r3;                   // round-3 launch variants (sdqn_kernels_r3.hip); bit 0: this K_FC4_DGRAD launch also carries the fc4_wgrad tiles; bit 1: conv3_fwd on 36-deep K-chunks; bit 2: conv1_fwd on packed-bf16 MFMA
 };
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s);     // the GEMM-shaped stages (single or multi-problem launches)
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s);
@@ -144,6 +145,7 @@ hipError_t launch_bn_update(const UpdateArgs& u, hipStream_t s);   // optimizer 
 hipError_t launch_prep(const PrepArgs& p, hipStream_t s, double* zero8 = nullptr);   // zero8: an 8-byte accumulator the launch also clears
 hipError_t launch_grad_to_half(const float* g, half_t* gh, int64_t n, int* state, hipStream_t s);       // fp16 DP payload; state = {flag, log2 scale, good steps}
 hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, int* state, hipStream_t s);
+hipError_t launch_w1_planes(const float* theta, unsigned short* w1p, hipStream_t s);   // conv1's three bf16 weight planes of one net (problems.h: split_bf16x3)
 hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s);   // fp16 mode: rebuild both half copies
 
 }  // namespace sdqn

@@ -117,6 +117,10 @@ struct StepArgs {
   unsigned* f4d_flags;      // [NIN4 / 32][16] one word per row block, 64 B apart; [NIN4 / 32 * 16] = sticky time-out word
   unsigned f4d_epoch;       // step number (monotonic, never 0): flags never need a reset
   int r3_pad_;
+  // conv1 forward on packed-bf16 MFMA (sdqn_kernels_r3.hip): W1 of the online [0] / target [1] net as THREE bf16 planes whose sum is
+  // the fp32 weight exactly, each [32 output maps][256 k] with k contiguous — written by whoever writes W1 (update kernel, set_weights,
+  // target sync)
+  const unsigned short* w1p[2];
 };
 
 // A9 + A10 in Neon's operation order (the library is built with -ffp-contract=off: one rounding per op)
@@ -154,6 +158,21 @@ __device__ inline void rms_step2(float& w0, float& w1, float& st0, float& st1, f
   w0 = w.x; w1 = w.y; st0 = st.x; st1 = st.y;
 }
 #endif
+
+// fp32 -> three bf16 (bit patterns) with hi + mid + lo == w EXACTLY: bf16 keeps 8 significant bits, every residual of a
+// round-to-nearest split has at most 16, then 8 — all representable, so the two subtractions are exact (weights are finite and far
+// from the subnormal range)
+SDQN_HD uint16_t bf16_rn(float f) {
+  union { float f; uint32_t u; } x; x.f = f;
+  return (uint16_t)((x.u + 0x7FFFu + ((x.u >> 16) & 1u)) >> 16);
+}
+SDQN_HD float bf16_up(uint16_t b) { union { float f; uint32_t u; } x; x.u = (uint32_t)b << 16; return x.f; }
+SDQN_HD void split_bf16x3(float w, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
+  hi = bf16_rn(w); const float r1 = w - bf16_up(hi);
+  mid = bf16_rn(r1); const float r2 = r1 - bf16_up(mid);
+  lo = bf16_rn(r2);
+}
+constexpr int W1P_PLANE = K1 * CRS1;      // elements per plane: [32 maps][256 k]
 
 SDQN_HD int64_t sbase(const StepArgs& a, int z, int n) {
   // replay_memory.py:71-72: prestate = screens[i-4:i], poststate = screens[i-3:i+1]

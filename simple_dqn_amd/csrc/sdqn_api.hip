@@ -428,6 +428,8 @@ struct sdqn_net_s {
   bool xcd_map = false;                    // XCD-contiguous tile map for EVERY launch: traffic ~ algorithmic, step ~1 % slower (bwd3);
                                            // built-in: only where it also wins time (fc4_fwd: the 7 K-slabs of a tile's W4 panel share an L2)
   bool f4w_early = false;                  // round 3 (B <= 32, fp32): fc4_wgrad + fused RMSProp ride in the fc4_dgrad launch (K_F4D_F4W) instead of bwd3
+  bool conv1_bf16 = true;                  // round 3: conv1_fwd on packed-bf16 MFMA (bytes x 3-way bf16 split of W1; sdqn_kernels_r3.hip)
+  unsigned short* w1p[2] = {nullptr, nullptr};   // the three bf16 planes of W1, online / target net ([3][32][256] each)
   bool conv3_c36 = true;                   // round 3: conv3_fwd on 36-deep K-chunks (one chunk per wave; sdqn_kernels_r3.hip)
   unsigned* f4d_flags = nullptr;           // [NIN4 / 32][16] write-after-read flags of that launch + one sticky time-out word
   bool fused_launches = true;              // independent backward stages share one launch (K_BWD3, K_BWD2)
@@ -576,6 +578,10 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->st_rew, (size_t)B * 10));
   h->st_act = reinterpret_cast<uint8_t*>(h->st_rew) + (size_t)B * 8; h->st_term = h->st_act + B;
   NCHK(dalloc(h, (void**)&h->f4d_flags, (size_t)(NIN4 / 32 + 1) * 16 * 4));
+  if (c->datatype == 0) {                  // (all-zero planes == all-zero W1, which is what the zeroed theta holds until set_weights)
+    NCHK(dalloc(h, (void**)&h->w1p[0], (size_t)3 * W1P_PLANE * 2));
+    if (c->target_enabled) NCHK(dalloc(h, (void**)&h->w1p[1], (size_t)3 * W1P_PLANE * 2)); else h->w1p[1] = h->w1p[0];
+  }
   NCHK(dalloc(h, (void**)&h->d_idx, (size_t)B * 8));
   NCHK(dalloc(h, (void**)&h->d_idx_t, (size_t)B * 8));
   { hipError_t e = hipHostMalloc((void**)&h->h_f, (size_t)(2 * B * MAX_ACTIONS + B + 64) * 8, hipHostMallocMapped);
@@ -639,6 +645,11 @@ extern "C" int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const fl
   if (h->cfg.datatype == 1 && which <= 1) {      // fp16 mode: the half copies follow the master weights
     const int zz = (which == 1 && h->theta_t != h->theta) ? 1 : 0;
     HIPCHK(launch_refresh16(zz ? h->theta_t : h->theta, h->wh[zz], h->wht[zz], g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+  }
+  if (h->w1p[0] && which <= 1 && layer == 0) {   // conv1's bf16 planes follow W1
+    const int zz = (which == 1 && h->theta_t != h->theta) ? 1 : 0;
+    HIPCHK(launch_w1_planes(zz ? h->theta_t : h->theta, h->w1p[zz], g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
   }
   return SDQN_OK;
@@ -737,6 +748,7 @@ static StepArgs step_args(sdqn_net_s* h) {
     a.loss_scale = (float)h->cfg.loss_scale; a.inv_loss_scale = (float)(1.0 / h->cfg.loss_scale);
   }
   a.f4w_first = 0; a.f4w_count = (NIN4 / 32) * (NFC / 32);
+  a.w1p[0] = h->w1p[0]; a.w1p[1] = h->w1p[1];
   a.f4d_flags = h->f4d_flags; a.f4d_epoch = (unsigned)(h->train_iterations + 1);      // (never 0; one train step per value)
   a.fuse_rms = (!h->comm && !h->keep_grads && !h->grad_only && h->cfg.optimizer == 0) ? 1 : 0;
   a.theta_w = h->theta; a.state = h->state; a.bsz = (float)h->B;
@@ -819,7 +831,7 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int
   // XCD-contiguous tile map where it wins time (tools/sweep_xcd.py, tools/ab_options.py): conv1_fwd +0.5 %, conv2_fwd
   // +0.2 %, fc4_fwd +0.6 % of the step rate; slower for conv3_fwd, fc4_dgrad and every backward launch
   StepArgs fm = a; fm.xcd_map = 1; fm.idx_t = nullptr;
-  LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, fm, g_stream));
+  LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, fm, g_stream, 0, (h->conv1_bf16 && !h->hoist && h->nw_override[K_CONV1_FWD] == 0) ? 4 : 0));
   LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, fm, g_stream));
   { StepArgs f3 = fm; f3.xcd_map = a.xcd_map;
     const int c36 = (h->conv3_c36 && !h->hoist && h->nw_override[K_CONV3_FWD] == 0) ? 2 : 0;      // (hoist: the riding target conv3 uses the 32-deep routine)
@@ -840,6 +852,7 @@ static UpdateArgs make_update_args(sdqn_net_s* h, const StepArgs& a) {
   u.skip_fc4 = a.fuse_rms;
   u.opt = h->cfg.optimizer; u.state2 = h->state2;
   if (h->cfg.datatype == 1) { u.wh = h->wh[0]; u.wht = h->wht[0]; }
+  u.w1p = h->w1p[0];
   u.bn_first = h->bn ? h->NPW : 0;
   if (u.opt == 1) {            // Neon Adam [neon-recalled]: t = epoch + 1, l = lr*sqrt(1-b2^t)/(1-b1^t), math in Python floats
     const double b1 = h->cfg.beta_1, b2 = h->cfg.beta_2, t = (double)h->epoch + 1.0;
@@ -1187,6 +1200,8 @@ extern "C" int sdqn_net_update_target(sdqn_net_t h) {
   { int rc = join_comm(h); if (rc) return rc; }
   if (h->theta_t != h->theta) {
     HIPCHK(hipMemcpyAsync(h->theta_t, h->theta, (size_t)h->NP * 4, hipMemcpyDeviceToDevice, g_stream));   // deepqnetwork.py:102-105
+    if (h->w1p[0] && h->w1p[1] != h->w1p[0])
+      HIPCHK(hipMemcpyAsync(h->w1p[1], h->w1p[0], (size_t)3 * W1P_PLANE * 2, hipMemcpyDeviceToDevice, g_stream));
     if (h->cfg.datatype == 1) {
       HIPCHK(hipMemcpyAsync(h->wh[1], h->wh[0], (size_t)OFF5 * 2, hipMemcpyDeviceToDevice, g_stream));
       HIPCHK(hipMemcpyAsync(h->wht[1], h->wht[0], (size_t)OFF5 * 2, hipMemcpyDeviceToDevice, g_stream));
@@ -1301,6 +1316,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   }
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
+  else if (!strcmp(name, "conv1_bf16")) h->conv1_bf16 = value != 0;     // 0: conv1_fwd on the fp32-MFMA engine (round-2 kernel)
   else if (!strcmp(name, "conv3_c36")) h->conv3_c36 = value != 0;       // 0: conv3_fwd on the engine's 32-deep chunks (round-2 kernel)
   else if (!strcmp(name, "f4w_early")) h->f4w_early = value != 0;       // 0: fc4_wgrad inside bwd3 (round-2 launch structure)
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;
@@ -1393,6 +1409,10 @@ extern "C" int sdqn_dp_init(sdqn_net_t h, const char* rccl_path, const char id[1
     if (h->theta_t != h->theta) NCCLCHK(g_rccl.Broadcast(h->theta_t, h->theta_t, (size_t)h->NP, 7, 0, h->comm, g_stream));
     NCCLCHK(g_rccl.Broadcast(h->state, h->state, (size_t)h->NP, 7, 0, h->comm, g_stream));
     if (h->state2) NCCLCHK(g_rccl.Broadcast(h->state2, h->state2, (size_t)h->NP, 7, 0, h->comm, g_stream));
+    if (h->w1p[0]) {
+      HIPCHK(launch_w1_planes(h->theta, h->w1p[0], g_stream));
+      if (h->w1p[1] != h->w1p[0]) HIPCHK(launch_w1_planes(h->theta_t, h->w1p[1], g_stream));
+    }
     if (h->cfg.datatype == 1) {
       HIPCHK(launch_refresh16(h->theta, h->wh[0], h->wht[0], g_stream));
       if (h->theta_t != h->theta) HIPCHK(launch_refresh16(h->theta_t, h->wh[1], h->wht[1], g_stream));

@@ -283,6 +283,15 @@ __device__ inline void opt_apply4(float* __restrict__ theta, float* __restrict__
   *reinterpret_cast<float4*>(theta + e) = w;
   *reinterpret_cast<float4*>(st1 + e) = a;
   if (u.opt != 0) *reinterpret_cast<float4*>(st2 + e) = b;
+  if (u.w1p && e < OFF2) {                        // conv1's bf16 planes follow W1 (e = k * 32 + n: 4 consecutive maps of one k)
+    const int k = (int)(e >> 5), n = (int)(e & 31);
+    const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint16_t hi, mid, lo; split_bf16x3(wv[i], hi, mid, lo);
+      u.w1p[(n + i) * CRS1 + k] = hi; u.w1p[W1P_PLANE + (n + i) * CRS1 + k] = mid; u.w1p[2 * W1P_PLANE + (n + i) * CRS1 + k] = lo;
+    }
+  }
   if (u.wh && e < OFF5) {                         // fp16 mode: refresh both half copies of these 4 weights
     const int L = e < OFF2 ? 0 : (e < OFF3 ? 1 : (e < OFF4 ? 2 : 3));
     const int off = L == 0 ? OFF1 : (L == 1 ? OFF2 : (L == 2 ? OFF3 : OFF4));

@@ -1,6 +1,7 @@
 // sdqn_kernels_r3.hip — round-3 launch variants of the default fp32 step (own translation unit: hipcc's schedule of a kernel
 // depends on what else is instantiated beside it, see sdqn_kernels.hip).
 //
+//   K_CONV1_FWD with LaunchTune::r3 bit 2: conv1_bf16_kernel below (bytes x 3-way bf16 split of W1 on packed-bf16 MFMA).
 //   K_CONV3_FWD with LaunchTune::r3 bit 1 (B < 128): gemm36_kernel below.
 //   K_FC4_DGRAD with LaunchTune::r3 bit 0 (B <= 32): ONE launch of 1024-thread workgroups =
 //       98 x Staged<Fc4DgradSig> tiles (16 waves each, K = 512 split over the waves)          block ids 0..97   (dispatched first)
@@ -77,10 +78,103 @@ __global__ void __launch_bounds__(1024) gemm36_kernel(const StepArgs a) {
   }
 }
 
+// ---- conv1 forward on packed-bf16 MFMA --------------------------------------------------------------------------------------
+// conv1's input is bytes.  An integer 0..255 is EXACT in bf16, and an fp32 weight is exactly the sum of three bf16 numbers
+// (problems.h: split_bf16x3), so  sum_k x_k w_k = sum_k x_k hi_k + sum_k x_k mid_k + sum_k x_k lo_k  with every product exact
+// (8 x 8 significant bits) on v_mfma_f32_32x32x16_bf16: 3 instructions of 32 cycles per 16 k instead of 8 fp32 MFMAs of 64 —
+// 5.3x less matrix-pipe time for the same fp32-accumulated sum.  The 1/255 of deepqnetwork.py:100 is applied once to the sum
+// (IEEE division) instead of to every pixel: (sum_k x_k w_k) / 255 vs sum_k fl(x_k / 255) w_k — both within fp32 round-off of the
+// exact value, in a different order (the oracle's BLAS has its own); covered by the same per-stage tolerances as before.
+//   * one WAVE per 32 x 32 output tile (32 positions x all 32 maps), no K split, no LDS combine: 16 k-steps = two kernel rows (r, r+1)
+//     of one input frame each; lane (i, h) feeds row i with the 8 bytes frame[c][4 y + r + h][4 x .. 4 x + 7] (ONE 8-byte load — the
+//     32 lanes of a half-wave read one contiguous 132-byte span), converted with v_cvt_f32_ubyte + v_perm (bf16 = upper half of the float)
+//   * the three weight planes live in LDS ([plane][map][k], pitch 264: ds_read_b128 of the 16-lane groups is conflict-free), loaded
+//     once per workgroup; a wave runs `tpw` tiles back to back at B >= 128
+//   * epilogue: / 255, Rectlin, NHWC store — no barrier anywhere after the plane load
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int W1P_PITCH = CRS1 + 8;
+
+__global__ void __launch_bounds__(256) conv1_bf16_kernel(const StepArgs a, int tiles_per_net, int wgs_per_net, int tpw) {
+  __shared__ __attribute__((aligned(16))) unsigned short sw[3 * K1 * W1P_PITCH];          // 50 688 B
+  const int zi = blockIdx.x / wgs_per_net, wg = blockIdx.x - zi * wgs_per_net;
+  const int z = zi;                                                                          // 0 online, 1 target (nz = 1: online only)
+  {
+    const uint4* wp = reinterpret_cast<const uint4*>(a.w1p[z]);
+    static_assert(3 * K1 * (CRS1 / 8) == 12 * 256, "3072 chunks of 8 bf16: 12 per thread");
+    uint4 v[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) v[u] = wp[threadIdx.x + 256 * u];                           // all 12 loads in flight before the first LDS store
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int c = threadIdx.x + 256 * u, row = c >> 5, cc = c & 31;
+      *reinterpret_cast<uint4*>(sw + row * W1P_PITCH + cc * 8) = v[u];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int M = a.B * PIX1;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+  for (int it = 0; it < tpw; ++it) {
+    const int tile = (wg * 4 + wave) * tpw + it;
+    if (tile >= tiles_per_net) break;                                                         // wave-uniform
+    const int m0 = tile * 32, mrow = m0 + i;
+    const uint8_t* src = a.src + row1(a, z, mrow < M ? mrow : M - 1) + h * W0;
+    u32x2 raw[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) raw[t] = *reinterpret_cast<const u32x2*>(src + (t >> 2) * FRAME + 2 * (t & 3) * W0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const unsigned short* bw = sw + i * W1P_PITCH + 8 * h;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      union { uint32_t u[4]; bf16x8_t v; } A;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const uint32_t w = d ? raw[t].y : raw[t].x;
+        const uint32_t f0 = __float_as_uint((float)(w & 255u)), f1 = __float_as_uint((float)((w >> 8) & 255u));
+        const uint32_t f2 = __float_as_uint((float)((w >> 16) & 255u)), f3 = __float_as_uint((float)(w >> 24));
+        A.u[2 * d] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);                             // {hi16(f1), hi16(f0)}: exact bf16 of 0..255
+        A.u[2 * d + 1] = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const bf16x8_t Bv = *reinterpret_cast<const bf16x8_t*>(bw + p * (K1 * W1P_PITCH) + 16 * t);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, Bv, acc, 0, 0, 0);
+      }
+    }
+    float* out = a.a1 + ((int64_t)z * M + m0 + 4 * h) * K1 + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = (r & 3) + 8 * (r >> 2);
+      if (m0 + 4 * h + ml < M) out[ml * K1] = fmaxf(acc[r] / 255.0f, 0.0f);
+    }
+  }
+}
+
+// the three planes of one net's W1 from its fp32 weights (after set_weights / replica broadcast; the update kernel writes them itself)
+__global__ void __launch_bounds__(256) w1_planes_kernel(const float* theta, unsigned short* w1p) {
+  const int e = blockIdx.x * 256 + threadIdx.x;                       // e = k * 32 + n (W1i layout [(c,r,s)][map])
+  if (e >= NW1) return;
+  const int k = e >> 5, n = e & 31;
+  uint16_t hi, mid, lo; split_bf16x3(theta[OFF1 + e], hi, mid, lo);
+  w1p[n * CRS1 + k] = hi; w1p[W1P_PLANE + n * CRS1 + k] = mid; w1p[2 * W1P_PLANE + n * CRS1 + k] = lo;
+}
+hipError_t launch_w1_planes(const float* theta, unsigned short* w1p, hipStream_t s) {
+  hipLaunchKernelGGL(w1_planes_kernel, dim3(NW1 / 256), dim3(256), 0, s, theta, w1p);
+  return hipGetLastError();
+}
+
 hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = true;
   if (id == K_FC4_DGRAD && (t.r3 & 1) && a.B <= 32 && !a.h16 && a.f4w_count > 0 && a.f4d_flags)
     return launch_multi<1024, Staged<Fc4DgradSig>, 16, Fc4WgradWait, 1, NoProblem, 2>(a, true, false, s);
+  if (id == K_CONV1_FWD && (t.r3 & 4) && !a.h16 && !a.bn && a.w1p[0] && a.w1p[a.nz > 1 ? 1 : 0]) {
+    const int tiles = (a.B * PIX1 + 31) / 32, tpw = a.B >= 128 ? 4 : 1, wgs = (tiles + 4 * tpw - 1) / (4 * tpw);
+    hipLaunchKernelGGL(conv1_bf16_kernel, dim3(a.nz * wgs), dim3(256), 0, s, a, tiles, wgs, tpw);
+    return hipGetLastError();
+  }
   if (id == K_CONV3_FWD && (t.r3 & 2) && a.B < 128 && !a.h16 && !a.bn) {
     static_assert(CRS3 == 16 * 36, "conv3's K is 16 chunks of 36");
     const dim3 grid((Conv3Fwd::M(a) + 31) / 32, (Conv3Fwd::N(a) + 31) / 32, Conv3Fwd::nbz(a));

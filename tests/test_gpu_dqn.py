@@ -308,6 +308,47 @@ def test_fc4_wgrad_in_dgrad_launch_bit_identical_in_the_fused_loop(sd, A, B):
     assert outs[0][2] == outs[1][2]
 
 
+@pytest.mark.parametrize("A,B", [(4, 32), (6, 7), (3, 160)])
+def test_conv1_on_bf16_mfma_against_the_fp32_engine(sd, A, B):
+    """Round 3: conv1_fwd as bytes x (hi + mid + lo) on v_mfma_f32_32x32x16_bf16 — every product exact, fp32 accumulation, one
+    division by 255 of the sum — against the fp32-MFMA engine kernel (x / 255 per pixel, fmaf chain): a1 within 1e-6 of max|a1|
+    (fp32 round-off of a 256-term sum; measured ~2e-7), Q within 1e-5, the oracle within the usual 1e-4.  The three weight planes
+    must follow W1 through every writer: set_weights, the update kernel (train steps), target sync, snapshot load."""
+    mb = random_minibatch(B, A, 311)
+    nets = []
+    for bf in (1, 0):
+        n, o = _pair(sd, A, B, 310)
+        n.set_option("conv1_bf16", bf)
+        nets.append(n)
+    n1, n0 = nets
+
+    def a1_of(n):
+        n.predict(mb[0])
+        return n.debug_read("a1", B * 400 * 32)                       # online net's conv1 output (z = 0)
+
+    a, b = a1_of(n1), a1_of(n0)
+    assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max() and (b > 0).mean() > 0.2
+    assert np.abs(n1.predict(mb[0]) - n0.predict(mb[0])).max() < 1e-5
+    assert np.abs(n1.predict(mb[0]) - o.predict(mb[0])).max() < Q_TOL
+    if B <= 32:
+        assert np.array_equal(n1.predict_one(mb[0][0]), n1.predict(mb[0])[0])
+    # planes follow the update kernel: after training both nets (each on its own kernel) conv1 of the NEW weights still agrees
+    for s_ in range(3):
+        step = random_minibatch(B, A, 320 + s_)
+        n1.train(step); n0.train(step); o.train(step)
+    n0.set_weights(n1.get_weights(0), 0); n0.set_weights(n1.get_weights(1), 1)     # same weights again (the two trajectories differ by round-off)
+    a, b = a1_of(n1), a1_of(n0)
+    assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max()
+    # target sync copies the planes: the TARGET net's conv1 (z = 1 of a train step) uses the new weights
+    n1.update_target_network(); n0.update_target_network()
+    step = random_minibatch(B, A, 330)
+    n1.set_option("grad_only", 1); n0.set_option("grad_only", 1)
+    n1.train(step); n0.train(step)
+    t1, t0 = n1.debug_read("a1", 2 * B * 400 * 32)[B * 400 * 32:], n0.debug_read("a1", 2 * B * 400 * 32)[B * 400 * 32:]
+    assert np.abs(t1 - t0).max() <= 1e-6 * np.abs(t0).max() and np.abs(t0).max() > 0
+    assert np.abs(n1.last_q()[1] - n0.last_q()[1]).max() < 1e-5                     # max_a Q'(s') of both
+
+
 def test_conv3_36_deep_chunks_against_the_32_deep_routine(sd):
     """Round 3: conv3_fwd splits K = 576 into 16 chunks of 36 (one per wave) instead of 18 of 32.  Same exact-fp32 MFMA, another
     partition of the K sum: a3 and Q agree with the 32-deep routine to fp32 round-off (<= 2e-6 relative to max|a3|), with the
