@@ -133,6 +133,7 @@ struct LaunchTune {
   int hoist;                // bit 0: K_BWD2 / K_BWD1 carry the NEXT step's target conv1 / conv2; bit 1: K_CONV1_FWD / K_CONV2_FWD carry
                             // this step's target conv3 / fc4 and compute the online net only (StepArgs::nz = 1)
   int order;                // experiment (option "bwd_order"): order of the problems inside the fused backward launches
+  const int64_t* host_idx;  // ring paths, B <= 32: this step's sampled indexes in HOST memory (they ride in the kernel arguments of conv1_bf16_kernel)
   int r3;                   // round-3 launch variants (sdqn_kernels_r3.hip); bit 0: this K_FC4_DGRAD launch also carries the fc4_wgrad tiles; bit 1: conv3_fwd on 36-deep K-chunks; bit 2: conv1_fwd on packed-bf16 MFMA
 };
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s);     // the GEMM-shaped stages (single or multi-problem launches)

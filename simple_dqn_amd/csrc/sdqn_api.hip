@@ -430,6 +430,7 @@ struct sdqn_net_s {
   bool f4w_early = false;                  // round 3 (B <= 32, fp32): fc4_wgrad + fused RMSProp ride in the fc4_dgrad launch (K_F4D_F4W) instead of bwd3
   bool conv1_bf16 = true;                  // round 3: conv1_fwd on packed-bf16 MFMA (bytes x 3-way bf16 split of W1; sdqn_kernels_r3.hip)
   unsigned short* w1p[2] = {nullptr, nullptr};   // the three bf16 planes of W1, online / target net ([3][32][256] each)
+  const int64_t* host_idx_cur = nullptr;   // ring paths: host copy of the indexes of the step being enqueued (valid during run_train only)
   bool conv3_c36 = true;                   // round 3: conv3_fwd on 36-deep K-chunks (one chunk per wave; sdqn_kernels_r3.hip)
   unsigned* f4d_flags = nullptr;           // [NIN4 / 32][16] write-after-read flags of that launch + one sticky time-out word
   bool fused_launches = true;              // independent backward stages share one launch (K_BWD3, K_BWD2)
@@ -791,7 +792,7 @@ static hipError_t launch_tuned(sdqn_net_s* h, int id, StepArgs a, hipStream_t s,
   XCD_TUNE(a, id);
   LaunchTune t;
   for (int i = 0; i < 12; ++i) { t.nw_override[i] = h->nw_override[i]; t.rb[i] = h->rb[i]; }
-  t.hoist = hoist; t.order = h->bwd_order; t.r3 = r3;
+  t.hoist = hoist; t.order = h->bwd_order; t.r3 = r3; t.host_idx = h->host_idx_cur;
   return launch_kernel(id, a, t, s);
 }
 static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int hoist = 0) {
@@ -1147,8 +1148,13 @@ static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pin
   HeadArgs hd = head_args(h, 1);
   const int hoist = (hoist_out ? 1 : 0) | (hoist_in ? 2 : 0);
   if (hoist_out) { a.idx_t = h->d_idx_t; hd.next_idx_pinned = next_pinned; hd.next_idx_dev = h->d_idx_t; hd.next_B = h->B; }
-  if (next_pinned) { PrepArgs np = prep_args(h, r, next_pinned); return run_train(h, a, hd, &np, hoist); }
-  return run_train(h, a, hd, nullptr, hoist);
+  // the slot's HOST address (pinned_idx is its device alias): conv1's tiles take their indexes from the kernel arguments
+  h->host_idx_cur = r->h_idx + (pinned_idx - r->d_idx_view);
+  int rc;
+  if (next_pinned) { PrepArgs np = prep_args(h, r, next_pinned); rc = run_train(h, a, hd, &np, hoist); }
+  else rc = run_train(h, a, hd, nullptr, hoist);
+  h->host_idx_cur = nullptr;
+  return rc;
 }
 extern "C" int sdqn_net_train_replay(sdqn_net_t h, sdqn_replay_t r, const int64_t* idx_host, float* cost_out) {
   ARGCHK(h && r && idx_host, "NULL argument");

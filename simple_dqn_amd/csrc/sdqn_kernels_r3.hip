@@ -94,10 +94,36 @@ __global__ void __launch_bounds__(1024) gemm36_kernel(const StepArgs a) {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 constexpr int W1P_PITCH = CRS1 + 8;
 
-__global__ void __launch_bounds__(256) conv1_bf16_kernel(const StepArgs a, int tiles_per_net, int wgs_per_net, int tpw) {
+// IDX_IN: the sampled ring indexes ride in the kernel arguments (B <= 32, ring paths: they are host data at launch time), so a
+// tile's frame origin needs no dependent global load — a 32-row tile touches at most two samples: two scalar loads + a select.
+struct IdxIn { int64_t v[32]; };
+
+template <bool IDX_IN>
+__global__ void __launch_bounds__(256) conv1_bf16_kernel(const StepArgs a, const IdxIn ix, int tiles_per_net, int wgs_per_net, int tpw) {
   __shared__ __attribute__((aligned(16))) unsigned short sw[3 * K1 * W1P_PITCH];          // 50 688 B
   const int zi = blockIdx.x / wgs_per_net, wg = blockIdx.x - zi * wgs_per_net;
   const int z = zi;                                                                          // 0 online, 1 target (nz = 1: online only)
+  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int M = a.B * PIX1;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+  const int tile0 = (wg * 4 + wave) * tpw;
+  // frame bytes of one tile: 16 x 8-byte loads per lane, issued before anything waits
+  auto load_tile = [&](int tile, u32x2* raw) {
+    const int m0 = tile * 32, mrow = m0 + i, mc = mrow < M ? mrow : M - 1;
+    int64_t org;
+    if constexpr (IDX_IN) {
+      const int n_lo = m0 / PIX1;                                                            // wave-uniform
+      const int64_t i_lo = ix.v[n_lo], i_hi = ix.v[n_lo + 1 < a.B ? n_lo + 1 : n_lo];
+      const int n = mc / PIX1, pix = mc - n * PIX1, p = pix / Q1, q = pix - p * Q1;
+      org = ((n == n_lo ? i_lo : i_hi) - C0 + z) * (int64_t)FRAME + (int64_t)(p * ST1) * W0 + q * ST1;
+    } else org = row1(a, z, mc);
+    const uint8_t* src = a.src + org + h * W0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) raw[t] = *reinterpret_cast<const u32x2*>(src + (t >> 2) * FRAME + 2 * (t & 3) * W0);
+  };
+  u32x2 raw[16];
+  if (tile0 < tiles_per_net) load_tile(tile0, raw);                                          // in flight under the plane fill below
   {
     const uint4* wp = reinterpret_cast<const uint4*>(a.w1p[z]);
     static_assert(3 * K1 * (CRS1 / 8) == 12 * 256, "3072 chunks of 8 bf16: 12 per thread");
@@ -111,37 +137,33 @@ __global__ void __launch_bounds__(256) conv1_bf16_kernel(const StepArgs a, int t
     }
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int M = a.B * PIX1;
-  typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+  const unsigned short* bw = sw + i * W1P_PITCH + 8 * h;
   for (int it = 0; it < tpw; ++it) {
-    const int tile = (wg * 4 + wave) * tpw + it;
+    const int tile = tile0 + it;
     if (tile >= tiles_per_net) break;                                                         // wave-uniform
-    const int m0 = tile * 32, mrow = m0 + i;
-    const uint8_t* src = a.src + row1(a, z, mrow < M ? mrow : M - 1) + h * W0;
-    u32x2 raw[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) raw[t] = *reinterpret_cast<const u32x2*>(src + (t >> 2) * FRAME + 2 * (t & 3) * W0);
+    const int m0 = tile * 32;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const unsigned short* bw = sw + i * W1P_PITCH + 8 * h;
+    union { uint32_t u[4]; bf16x8_t v; } A[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
-      union { uint32_t u[4]; bf16x8_t v; } A;
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
         const uint32_t w = d ? raw[t].y : raw[t].x;
         const uint32_t f0 = __float_as_uint((float)(w & 255u)), f1 = __float_as_uint((float)((w >> 8) & 255u));
         const uint32_t f2 = __float_as_uint((float)((w >> 16) & 255u)), f3 = __float_as_uint((float)(w >> 24));
-        A.u[2 * d] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);                             // {hi16(f1), hi16(f0)}: exact bf16 of 0..255
-        A.u[2 * d + 1] = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
+        A[t].u[2 * d] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);                          // {hi16(f1), hi16(f0)}: exact bf16 of 0..255
+        A[t].u[2 * d + 1] = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
       }
+    }
+    if (it + 1 < tpw && tile + 1 < tiles_per_net) load_tile(tile + 1, raw);                  // next tile's bytes fly under this tile's MFMAs
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         const bf16x8_t Bv = *reinterpret_cast<const bf16x8_t*>(bw + p * (K1 * W1P_PITCH) + 16 * t);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, Bv, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[t].v, Bv, acc, 0, 0, 0);
       }
     }
     float* out = a.a1 + ((int64_t)z * M + m0 + 4 * h) * K1 + i;
@@ -172,7 +194,14 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     return launch_multi<1024, Staged<Fc4DgradSig>, 16, Fc4WgradWait, 1, NoProblem, 2>(a, true, false, s);
   if (id == K_CONV1_FWD && (t.r3 & 4) && !a.h16 && !a.bn && a.w1p[0] && a.w1p[a.nz > 1 ? 1 : 0]) {
     const int tiles = (a.B * PIX1 + 31) / 32, tpw = a.B >= 128 ? 4 : 1, wgs = (tiles + 4 * tpw - 1) / (4 * tpw);
-    hipLaunchKernelGGL(conv1_bf16_kernel, dim3(a.nz * wgs), dim3(256), 0, s, a, tiles, wgs, tpw);
+    IdxIn ix;
+    if (t.host_idx && a.from_ring && a.B <= 32) {
+      memcpy(ix.v, t.host_idx, (size_t)a.B * sizeof(int64_t));
+      hipLaunchKernelGGL(conv1_bf16_kernel<true>, dim3(a.nz * wgs), dim3(256), 0, s, a, ix, tiles, wgs, tpw);
+    } else {
+      ix.v[0] = 0;
+      hipLaunchKernelGGL(conv1_bf16_kernel<false>, dim3(a.nz * wgs), dim3(256), 0, s, a, ix, tiles, wgs, tpw);
+    }
     return hipGetLastError();
   }
   if (id == K_CONV3_FWD && (t.r3 & 2) && a.B < 128 && !a.h16 && !a.bn) {
