@@ -1466,8 +1466,12 @@ extern "C" int sdqn_debug_time_kernel(sdqn_net_t h, sdqn_replay_t r, const int64
   StepArgs a = step_args(h); a.from_ring = 1; a.src = r->d_ring; a.idx = h->d_idx;
   HIPCHK(hipStreamSynchronize(g_stream));
   HIPCHK(set_timing_buffer(d));
-  for (int rep = 0; rep < 3; ++rep) {                                               // last launch's stamps survive
+  // kernel ids >= 100: round-3 variants — 100 conv1 on bf16 MFMA (warm: third launch on the same indexes), 101 the same, ONE launch
+  // (frames never touched before: HBM + TLB cold, what a train step sees), 102 conv3_fwd on 36-deep chunks
+  for (int rep = 0; rep < (kernel == 101 ? 1 : 3); ++rep) {                         // last launch's stamps survive
     if (kernel == K_HEAD) { HeadArgs hd = head_args(h, 1); HIPCHK(launch_head(a, hd, g_stream)); }
+    else if (kernel == 100 || kernel == 101) { h->host_idx_cur = idx_host; const hipError_t le = launch_tuned(h, K_CONV1_FWD, a, g_stream, 0, 4); h->host_idx_cur = nullptr; HIPCHK(le); }
+    else if (kernel == 102) HIPCHK(launch_tuned(h, K_CONV3_FWD, a, g_stream, 0, 2));
     else HIPCHK(launch_tuned(h, kernel, a, g_stream));
   }
   HIPCHK(hipStreamSynchronize(g_stream));

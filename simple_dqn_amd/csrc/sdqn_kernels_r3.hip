@@ -90,89 +90,155 @@ __global__ void __launch_bounds__(1024) gemm36_kernel(const StepArgs a) {
 //     32 lanes of a half-wave read one contiguous 132-byte span), converted with v_cvt_f32_ubyte + v_perm (bf16 = upper half of the float)
 //   * the three weight planes live in LDS ([plane][map][k], pitch 264: ds_read_b128 of the 16-lane groups is conflict-free), loaded
 //     once per workgroup; a wave runs `tpw` tiles back to back at B >= 128
-//   * epilogue: / 255, Rectlin, NHWC store — no barrier anywhere after the plane load
+//   * epilogue: / 255 (reciprocal multiply + one fma correction: within an ulp of the IEEE quotient), Rectlin, NHWC store — no barrier
+//     anywhere after the plane load
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 constexpr int W1P_PITCH = CRS1 + 8;
 
-// IDX_IN: the sampled ring indexes ride in the kernel arguments (B <= 32, ring paths: they are host data at launch time), so a
-// tile's frame origin needs no dependent global load — a 32-row tile touches at most two samples: two scalar loads + a select.
+// Everything the kernel reads from its arguments fits ONE 64-byte scalar load (the engine's StepArgs is ~450 bytes and hipcc fetched
+// it piecemeal: five dependent scalar round trips, 2.5 k of the tile's 11 k cycles — tools/phase_timing.py).
+// IDX_IN: the sampled ring indexes ride behind that block in the kernel arguments (B <= 32, ring paths: they are host data at launch
+// time); every lane fetches "its" index (lane & 31) with one vector load from the argument segment at wave start, the tile's two
+// candidates (a 32-row tile touches at most two samples) come out with v_readlane: no dependent global load, no second scalar trip.
+struct Conv1Args {
+  const uint8_t* src; float* a1; const unsigned short* w1p[2]; const int64_t* idx;
+  int B, nz, from_ring, tiles_per_net, wgs_per_net, tpw;
+};
 struct IdxIn { int64_t v[32]; };
 
+__device__ __forceinline__ float div255(float s) {        // s / 255 to within an ulp: reciprocal multiply + one fma correction
+  const float r = 1.0f / 255.0f;
+  const float q = s * r;
+  return fmaf(fmaf(-q, 255.0f, s), r, q);
+}
+
 template <bool IDX_IN>
-__global__ void __launch_bounds__(256) conv1_bf16_kernel(const StepArgs a, const IdxIn ix, int tiles_per_net, int wgs_per_net, int tpw) {
+__global__ void __launch_bounds__(256) conv1_bf16_kernel(const Conv1Args c, const IdxIn ix) {
   __shared__ __attribute__((aligned(16))) unsigned short sw[3 * K1 * W1P_PITCH];          // 50 688 B
-  const int zi = blockIdx.x / wgs_per_net, wg = blockIdx.x - zi * wgs_per_net;
-  const int z = zi;                                                                          // 0 online, 1 target (nz = 1: online only)
   const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  int64_t my_idx = 0;
+  if constexpr (IDX_IN) {                                   // issued first: needs nothing but the argument-segment pointer
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    my_idx = *reinterpret_cast<const int64_t*>(ka + sizeof(Conv1Args) + 8 * i);
+  }
+  (void)ix;
+  {   // every argument field in flight NOW, one wait: left alone hipcc fetches each field where it is first used (five dependent scalar trips)
+    const uint8_t* f0 = c.src; float* f1 = c.a1; const unsigned short *f2 = c.w1p[0], *f3 = c.w1p[1]; const int64_t* f4 = c.idx;
+    int g0 = c.B, g1 = c.from_ring, g2 = c.tiles_per_net, g3 = c.wgs_per_net, g4 = c.tpw;
+    asm volatile("" :: "s"(f0), "s"(f1), "s"(f2), "s"(f3), "s"(f4), "s"(g0), "s"(g1), "s"(g2), "s"(g3), "s"(g4));
+  }
+  const int zi = blockIdx.x / c.wgs_per_net, wg = blockIdx.x - zi * c.wgs_per_net;
+  const int z = zi;                                                                          // 0 online, 1 target (nz = 1: online only)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int M = a.B * PIX1;
+  const int M = c.B * PIX1, tiles_per_net = c.tiles_per_net, tpw = c.tpw;
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
   const int tile0 = (wg * 4 + wave) * tpw;
+  SDQN_STAMP(0);
   // frame bytes of one tile: 16 x 8-byte loads per lane, issued before anything waits
   auto load_tile = [&](int tile, u32x2* raw) {
     const int m0 = tile * 32, mrow = m0 + i, mc = mrow < M ? mrow : M - 1;
+    const int n = mc / PIX1, pix = mc - n * PIX1, p = pix / Q1, q = pix - p * Q1;
     int64_t org;
     if constexpr (IDX_IN) {
-      const int n_lo = m0 / PIX1;                                                            // wave-uniform
-      const int64_t i_lo = ix.v[n_lo], i_hi = ix.v[n_lo + 1 < a.B ? n_lo + 1 : n_lo];
-      const int n = mc / PIX1, pix = mc - n * PIX1, p = pix / Q1, q = pix - p * Q1;
-      org = ((n == n_lo ? i_lo : i_hi) - C0 + z) * (int64_t)FRAME + (int64_t)(p * ST1) * W0 + q * ST1;
-    } else org = row1(a, z, mc);
-    const uint8_t* src = a.src + org + h * W0;
+      const int n_lo = m0 / PIX1, n_hi = n_lo + 1 < c.B ? n_lo + 1 : n_lo;                  // wave-uniform
+      const uint32_t lo0 = __builtin_amdgcn_readlane((int)(my_idx & 0xFFFFFFFF), n_lo), lo1 = __builtin_amdgcn_readlane((int)(my_idx >> 32), n_lo);
+      const uint32_t hi0 = __builtin_amdgcn_readlane((int)(my_idx & 0xFFFFFFFF), n_hi), hi1 = __builtin_amdgcn_readlane((int)(my_idx >> 32), n_hi);
+      const int64_t i_lo = (int64_t)(((uint64_t)lo1 << 32) | lo0), i_hi = (int64_t)(((uint64_t)hi1 << 32) | hi0);
+      org = ((n == n_lo ? i_lo : i_hi) - C0 + z) * (int64_t)FRAME;
+    } else org = c.from_ring ? (c.idx[n] - C0 + z) * (int64_t)FRAME : ((int64_t)z * c.B + n) * (int64_t)STATE;       // problems.h: sbase
+    const uint8_t* src = c.src + org + (int64_t)(p * ST1 + h) * W0 + q * ST1;
 #pragma unroll
     for (int t = 0; t < 16; ++t) raw[t] = *reinterpret_cast<const u32x2*>(src + (t >> 2) * FRAME + 2 * (t & 3) * W0);
   };
   u32x2 raw[16];
+#ifdef SDQN_TIMING
+#pragma unroll
+  for (int t = 0; t < 16; ++t) raw[t] = (u32x2){0u, 0u};
+#endif
   if (tile0 < tiles_per_net) load_tile(tile0, raw);                                          // in flight under the plane fill below
+  SDQN_STAMP(1);
   {
-    const uint4* wp = reinterpret_cast<const uint4*>(a.w1p[z]);
+    const uint4* wp = reinterpret_cast<const uint4*>(c.w1p[z]);
     static_assert(3 * K1 * (CRS1 / 8) == 12 * 256, "3072 chunks of 8 bf16: 12 per thread");
     uint4 v[12];
 #pragma unroll
     for (int u = 0; u < 12; ++u) v[u] = wp[threadIdx.x + 256 * u];                           // all 12 loads in flight before the first LDS store
 #pragma unroll
     for (int u = 0; u < 12; ++u) {
-      const int c = threadIdx.x + 256 * u, row = c >> 5, cc = c & 31;
-      *reinterpret_cast<uint4*>(sw + row * W1P_PITCH + cc * 8) = v[u];
+      const int cc = threadIdx.x + 256 * u, row = cc >> 5, col = cc & 31;
+      *reinterpret_cast<uint4*>(sw + row * W1P_PITCH + col * 8) = v[u];
     }
   }
+  SDQN_STAMP(2);
   __syncthreads();
+  SDQN_STAMP(3);
+#ifdef SDQN_TIMING
+  asm volatile("" :: "v"(raw[0].x), "v"(raw[15].y));
+  SDQN_STAMP(4);
+#endif
   const unsigned short* bw = sw + i * W1P_PITCH + 8 * h;
+  auto cvt = [](const u32x2& r, bf16x8_t& out) {                                              // 8 bytes -> 8 exact bf16
+    union { uint32_t u[4]; bf16x8_t v; } A;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const uint32_t w = d ? r.y : r.x;
+      const uint32_t f0 = __float_as_uint((float)(w & 255u)), f1 = __float_as_uint((float)((w >> 8) & 255u));
+      const uint32_t f2 = __float_as_uint((float)((w >> 16) & 255u)), f3 = __float_as_uint((float)(w >> 24));
+      A.u[2 * d] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);                               // {hi16(f1), hi16(f0)}: bf16 = upper half of the float
+      A.u[2 * d + 1] = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
+    }
+    out = A.v;
+  };
   for (int it = 0; it < tpw; ++it) {
     const int tile = tile0 + it;
     if (tile >= tiles_per_net) break;                                                         // wave-uniform
     const int m0 = tile * 32;
-    f32x16 acc;
+    u32x2 nxt[16];
+    const bool more = it + 1 < tpw && tile + 1 < tiles_per_net;
+    if (more) load_tile(tile + 1, nxt);                                                      // next tile's bytes fly under this tile's MFMAs
+    // one accumulator per weight plane: three independent MFMA chains (a single wave per SIMD has nothing else to hide the
+    // dependent-accumulator latency behind); summed hi + mid + lo at the end.  B fragments are read one step ahead.
+    f32x16 acc0, acc1, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    union { uint32_t u[4]; bf16x8_t v; } A[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const uint32_t w = d ? raw[t].y : raw[t].x;
-        const uint32_t f0 = __float_as_uint((float)(w & 255u)), f1 = __float_as_uint((float)((w >> 8) & 255u));
-        const uint32_t f2 = __float_as_uint((float)((w >> 16) & 255u)), f3 = __float_as_uint((float)(w >> 24));
-        A[t].u[2 * d] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);                          // {hi16(f1), hi16(f0)}: exact bf16 of 0..255
-        A[t].u[2 * d + 1] = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
-      }
-    }
-    if (it + 1 < tpw && tile + 1 < tiles_per_net) load_tile(tile + 1, raw);                  // next tile's bytes fly under this tile's MFMAs
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; acc2[r] = 0.0f; }
+    bf16x8_t Bc0 = *reinterpret_cast<const bf16x8_t*>(bw), Bc1 = *reinterpret_cast<const bf16x8_t*>(bw + K1 * W1P_PITCH),
+             Bc2 = *reinterpret_cast<const bf16x8_t*>(bw + 2 * K1 * W1P_PITCH), Ac;
+    cvt(raw[0], Ac);
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
+      bf16x8_t Bn0 = Bc0, Bn1 = Bc1, Bn2 = Bc2, An = Ac;
+      if (t + 1 < 16) {
+        Bn0 = *reinterpret_cast<const bf16x8_t*>(bw + 16 * (t + 1));
+        Bn1 = *reinterpret_cast<const bf16x8_t*>(bw + K1 * W1P_PITCH + 16 * (t + 1));
+        Bn2 = *reinterpret_cast<const bf16x8_t*>(bw + 2 * K1 * W1P_PITCH + 16 * (t + 1));
+        cvt(raw[t + 1], An);
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac, Bc0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac, Bc1, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac, Bc2, acc2, 0, 0, 0);
+      Ac = An; Bc0 = Bn0; Bc1 = Bn1; Bc2 = Bn2;
+    }
+#ifdef SDQN_TIMING
+    asm volatile("" :: "v"(acc0[0]), "v"(acc1[7]), "v"(acc2[15]));
+    SDQN_STAMP(5);
+#endif
+    float* out = c.a1 + ((int64_t)z * M + m0 + 4 * h) * K1 + i;
+    if (m0 + 32 <= M) {                                                                       // full tile (wave-uniform): no per-row guard
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        const bf16x8_t Bv = *reinterpret_cast<const bf16x8_t*>(bw + p * (K1 * W1P_PITCH) + 16 * t);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[t].v, Bv, acc, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2)) * K1] = fmaxf(div255((acc0[r] + acc1[r]) + acc2[r]), 0.0f);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = (r & 3) + 8 * (r >> 2);
+        if (m0 + 4 * h + ml < M) out[ml * K1] = fmaxf(div255((acc0[r] + acc1[r]) + acc2[r]), 0.0f);
       }
     }
-    float* out = a.a1 + ((int64_t)z * M + m0 + 4 * h) * K1 + i;
+    if (more) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = (r & 3) + 8 * (r >> 2);
-      if (m0 + 4 * h + ml < M) out[ml * K1] = fmaxf(acc[r] / 255.0f, 0.0f);
+      for (int t = 0; t < 16; ++t) raw[t] = nxt[t];
     }
   }
+  SDQN_STAMP(6);
 }
 
 // the three planes of one net's W1 from its fp32 weights (after set_weights / replica broadcast; the update kernel writes them itself)
@@ -194,13 +260,17 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     return launch_multi<1024, Staged<Fc4DgradSig>, 16, Fc4WgradWait, 1, NoProblem, 2>(a, true, false, s);
   if (id == K_CONV1_FWD && (t.r3 & 4) && !a.h16 && !a.bn && a.w1p[0] && a.w1p[a.nz > 1 ? 1 : 0]) {
     const int tiles = (a.B * PIX1 + 31) / 32, tpw = a.B >= 128 ? 4 : 1, wgs = (tiles + 4 * tpw - 1) / (4 * tpw);
+    Conv1Args c; c.src = a.src; c.a1 = a.a1; c.w1p[0] = a.w1p[0]; c.w1p[1] = a.w1p[1]; c.idx = a.idx;
+    c.B = a.B; c.nz = a.nz; c.from_ring = a.from_ring; c.tiles_per_net = tiles; c.wgs_per_net = wgs; c.tpw = tpw;
+    static_assert(sizeof(Conv1Args) == 64 && sizeof(Conv1Args) % 8 == 0, "one 64-byte scalar load; the index block follows 8-byte aligned");
     IdxIn ix;
     if (t.host_idx && a.from_ring && a.B <= 32) {
+      memset(ix.v, 0, sizeof ix.v);
       memcpy(ix.v, t.host_idx, (size_t)a.B * sizeof(int64_t));
-      hipLaunchKernelGGL(conv1_bf16_kernel<true>, dim3(a.nz * wgs), dim3(256), 0, s, a, ix, tiles, wgs, tpw);
+      hipLaunchKernelGGL(conv1_bf16_kernel<true>, dim3(a.nz * wgs), dim3(256), 0, s, c, ix);
     } else {
-      ix.v[0] = 0;
-      hipLaunchKernelGGL(conv1_bf16_kernel<false>, dim3(a.nz * wgs), dim3(256), 0, s, a, ix, tiles, wgs, tpw);
+      memset(ix.v, 0, sizeof ix.v);
+      hipLaunchKernelGGL(conv1_bf16_kernel<false>, dim3(a.nz * wgs), dim3(256), 0, s, c, ix);
     }
     return hipGetLastError();
   }
@@ -213,5 +283,9 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
   *handled = false;
   return hipSuccess;
 }
+
+#ifdef SDQN_TIMING
+hipError_t set_timing_buffer_r3(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sdqn_dbg), &p, sizeof p); }
+#endif
 
 }  // namespace sdqn

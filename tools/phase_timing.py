@@ -12,14 +12,15 @@ lib.sdqn_debug_time_kernel.restype = C.c_int
 lib.sdqn_debug_time_kernel.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_uint64), C.c_int]
 B, A = int(os.environ.get("B", 32)), 4
 args = make_args(batch_size=B)
-mem = sd.ReplayMemory(50000, args); fill_ring(mem, 1, A)
+mem = sd.ReplayMemory(int(os.environ.get("RING", 50000)), args); fill_ring(mem, 1, A)
 net = sd.DeepQNetwork(A, args); net.update_target_network()
 net.set_option("fused_launches", 0)
 if os.environ.get("XCD"): net.set_option("xcd_map", int(os.environ["XCD"]))
 mt = (C.c_uint32 * 625)(); lib.sdqn_mt_seed(mt, 5)
 net.train_from_memory(mem, 20, mt_state=mt, want_cost=False); net.sync()
 random.seed(1); idx = np.array(mem.sample_indexes())
-names = {0: "conv1_fwd", 1: "conv2_fwd", 2: "conv3_fwd", 3: "fc4_fwd", 5: "fc4_dgrad", 6: "fc4_wgrad", 7: "conv3_dgrad", 8: "conv3_wgrad", 9: "conv2_dgrad", 10: "conv2_wgrad", 11: "conv1_wgrad"}
+idx_cold = np.array(mem.sample_indexes())
+names = {100: "conv1_bf16 warm", 101: "conv1_bf16 cold", 0: "conv1_fwd", 1: "conv2_fwd", 2: "conv3_fwd", 3: "fc4_fwd", 5: "fc4_dgrad", 6: "fc4_wgrad", 7: "conv3_dgrad", 8: "conv3_wgrad", 9: "conv2_dgrad", 10: "conv2_wgrad", 11: "conv1_wgrad"}
 MAXB = 4096
 out = np.zeros((MAXB, 8), np.uint64)
 L.check(lib.sdqn_debug_time_kernel(net._h, mem._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), 4, out.ctypes.data_as(C.POINTER(C.c_uint64)), MAXB))
@@ -29,12 +30,14 @@ print("head: blocks %d; median cycles per phase [entry->loads landed, ->shuffles
       % (len(v), np.median(d, axis=0).astype(int).tolist(), int(np.median(v[:, 7] - v[:, 0]))), flush=True)
 for kid, nm in names.items():
     out = np.zeros((MAXB, 8), np.uint64)
-    L.check(lib.sdqn_debug_time_kernel(net._h, mem._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), kid, out.ctypes.data_as(C.POINTER(C.c_uint64)), MAXB))
+    use = idx_cold if kid == 101 else idx
+    L.check(lib.sdqn_debug_time_kernel(net._h, mem._h, use.ctypes.data_as(C.POINTER(C.c_int64)), kid, out.ctypes.data_as(C.POINTER(C.c_uint64)), MAXB))
     v = out[out[:, 0] > 0].astype(np.int64)
     if len(v) == 0:
         print(nm, "no stamps"); continue
     t0 = v[:, 0].min()
     ph = ["entry->addr", "addr->loads issued", "issued->operands landed", "->mfma done", "->barrier", "->stores issued"]
+    if kid >= 100: ph = ["entry->frame loads issued", "->plane loads+LDS stores issued", "->barrier passed", "->frame bytes landed", "->mfma done", "->stores issued"]
     cols = [1, 2, 3, 4, 5, 6]
     d = {}
     prev = v[:, 0]
