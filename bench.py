@@ -103,7 +103,7 @@ ROCPROF_MATCH = [
     ("gemm_kernel<sdqn::Conv1Fwd", 0), ("gemm_kernel<sdqn::Conv2Fwd", 1), ("Conv3Fwd", 2), ("Fc4Fwd", 3),
     ("head_kernel", 4), ("gemm_kernel<sdqn::Staged<sdqn::Fc4Dgrad>", 5), ("update_kernel", 12), ("gather_kernel", 14), ("prep_kernel", 15),
     ("gemm_multi_kernel<512, sdqn::Staged<sdqn::Conv3Dgrad>", 16), ("Conv2Dgrad", 17), ("Conv1Wgrad", 18),
-    ("Fc4DgradSig", 20), ("gemm_multi_kernel<512, sdqn::NoProblem, 2, sdqn::Staged<sdqn::Conv3Dgrad>", 21),
+    ("conv1_bf16_kernel", 0), ("Fc4DgradSig", 20), ("gemm_multi_kernel<512, sdqn::NoProblem, 2, sdqn::Staged<sdqn::Conv3Dgrad>", 21),
 ]
 
 
@@ -507,6 +507,24 @@ def gather_large(sd, args_factory, mem_small_fill, A, Bbig=4096):
     return e
 
 
+def allreduce_model(n, payload_bytes):
+    """What the ONE collective of a data-parallel step should cost on an 8 x MI355X node, from the link arithmetic (SURVEY.md §5;
+    a MODEL to judge an N-GPU record against, not a measurement — no N > 1 communicator has run on the builder's 1-GPU boxes).
+    Ring all-reduce: 2 (N - 1) steps, each moving payload / N bytes per rank over point-to-point xGMI (153 GB/s per link and
+    direction; RCCL spreads rings over the links a rank has to its N - 1 peers, at most 7), plus a per-step latency alpha."""
+    if n < 2:
+        return None
+    link, alpha_us = 153e9, 2.5
+    links = min(n - 1, 7)
+    steps = 2 * (n - 1)
+    wire_us = steps * (payload_bytes / n) / (link * links) * 1e6
+    return {"ranks": n, "payload_bytes": int(payload_bytes), "steps": steps, "alpha_us_per_step": alpha_us, "link_GBps": link / 1e9,
+            "links_used": links, "wire_us": round(wire_us, 2), "latency_us": round(steps * alpha_us, 1),
+            "expected_us": round(wire_us + steps * alpha_us, 1),
+            "note": "model: 2(N-1) x (alpha + payload / (N x links x 153 GB/s)); the step is ~71 us, so the serial all-reduce is the "
+                    "scaling limiter at every N and --dp-overlap (fc4's 95 % of the payload under the rest of the step) is the lever"}
+
+
 def b256_leg(sd, make_args, seed, steps=300, warmup=100, ring=200000):
     """BASELINE.json configs[2] ("Pong, batch_size=256: stress conv LDS tiling + HBM bandwidth") measured in the SAME process as the
     headline so that the driver's JSON line carries it: the throughput regime, where the north-star's
@@ -747,7 +765,10 @@ def main():
         if dp_rows is not None:
             # what RCCL itself reports per rank (ncclCommCount / UserRank / CuDevice) next to the bound devices: the evidence
             # that the gradient all-reduce spanned N ranks on N devices (all -1 in --dry-run-dp: no communicator is created)
+            payload = 4 * (8192 + 32768 + 36864 + 1605632 + 512 * A) // (2 if a.datatype == "float16" else 1)
             out["dp"] = {"ranks": world, "rccl_ranks_seen": sorted({r["comm_ranks"] for r in dp_rows}),
+                         "allreduce_model": allreduce_model(world, payload),
+                         "allreduce_model_all_n": {str(n): allreduce_model(n, payload)["expected_us"] for n in (2, 4, 8)},
                          "devices": [r["bound_device"] for r in dp_rows], "dry_run": bool(a.dry_run_dp), "per_rank": dp_rows}
         out["roofline"] = roofline_entry(dom["id"], dom["name"], live["total_ms"] / max(live["launches"], 1), B, A)
         out["roofline"]["measured_in"] = live_src
