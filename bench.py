@@ -115,7 +115,7 @@ def rocprof_us(kid, B, A):
     try:
         import csv
         rows = [r for r in csv.reader(l for l in open(os.path.join(ROOT, STATS_FILE)) if not l.startswith("#"))]
-        for sub, k in ROCPROF_MATCH:
+        for sub, k in ROCPROF_MATCH:                        # (a kernel id may be listed under several builds' kernel names)
             if k == kid:
                 for r in rows[1:]:
                     if sub in r[0]:
