@@ -431,6 +431,7 @@ struct sdqn_net_s {
   bool conv1_bf16 = true;                  // round 3: conv1_fwd on packed-bf16 MFMA (bytes x 3-way bf16 split of W1; sdqn_kernels_r3.hip)
   unsigned short* w1p[2] = {nullptr, nullptr};   // the three bf16 planes of W1, online / target net ([3][32][256] each)
   const int64_t* host_idx_cur = nullptr;   // ring paths: host copy of the indexes of the step being enqueued (valid during run_train only)
+  bool conv1w_bf16 = true;                 // round 3: conv1_wgrad on packed-bf16 MFMA (bytes x on-the-fly bf16 split of delta1)
   bool conv3_c36 = true;                   // round 3: conv3_fwd on 36-deep K-chunks (one chunk per wave; sdqn_kernels_r3.hip)
   unsigned* f4d_flags = nullptr;           // [NIN4 / 32][16] write-after-read flags of that launch + one sticky time-out word
   bool fused_launches = true;              // independent backward stages share one launch (K_BWD3, K_BWD2)
@@ -919,7 +920,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     // conv1_wgrad on the XCD-contiguous tile map: the 8 m-tiles of a K-slab read the same frames, so a slab's tiles belong on ONE XCD's L2
     // (L2 <-> fabric traffic of the launch 15.8 -> 4.0 MB = 1.4x algorithmic, rocprofv3 PMC; step rate -0.1 %: the re-reads were MALL hits)
     b1.xcd_map |= 2;
-    LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream, hoist & 1));
+    LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream, hoist & 1, (h->conv1w_bf16 && !hoist && b1.f4w_count == 0 && h->nw_override[K_CONV1_WGRAD] == 0) ? 8 : 0));
   } else {
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[1], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[1], 0)); }
   // fc4_wgrad may update W4 in place (fused RMSProp): it must not start before fc4_dgrad has read W4
@@ -1323,6 +1324,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else if (!strcmp(name, "conv1_bf16")) h->conv1_bf16 = value != 0;     // 0: conv1_fwd on the fp32-MFMA engine (round-2 kernel)
+  else if (!strcmp(name, "conv1w_bf16")) h->conv1w_bf16 = value != 0;   // 0: conv1_wgrad on the fp32-MFMA engine (round-2 kernel)
   else if (!strcmp(name, "conv3_c36")) h->conv3_c36 = value != 0;       // 0: conv3_fwd on the engine's 32-deep chunks (round-2 kernel)
   else if (!strcmp(name, "f4w_early")) h->f4w_early = value != 0;       // 0: fc4_wgrad inside bwd3 (round-2 launch structure)
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;

@@ -2,6 +2,7 @@
 // depends on what else is instantiated beside it, see sdqn_kernels.hip).
 //
 //   K_CONV1_FWD with LaunchTune::r3 bit 2: conv1_bf16_kernel below (bytes x 3-way bf16 split of W1 on packed-bf16 MFMA).
+//   K_BWD1 with LaunchTune::r3 bit 3 (no fc4 share in the launch): conv1_wgrad_bf16_kernel (bytes x on-the-fly 3-way bf16 split of delta1).
 //   K_CONV3_FWD with LaunchTune::r3 bit 1 (B < 128): gemm36_kernel below.
 //   K_FC4_DGRAD with LaunchTune::r3 bit 0 (B <= 32): ONE launch of 1024-thread workgroups =
 //       98 x Staged<Fc4DgradSig> tiles (16 waves each, K = 512 split over the waves)          block ids 0..97   (dispatched first)
@@ -241,6 +242,120 @@ __global__ void __launch_bounds__(256) conv1_bf16_kernel(const Conv1Args c, cons
   SDQN_STAMP(6);
 }
 
+// ---- conv1 weight gradient on packed-bf16 MFMA ---------------------------------------------------------------------------
+// gW1[(c,r,s)][map] = sum over (sample, y, x) of byte(c, 4y + r, 4x + s) / 255 * delta1(sample, y, x, map): the bytes are exact in
+// bf16 again, and the fp32 deltas are split into three bf16 (hi + mid + lo == delta exactly, problems.h) ON THE FLY by the lanes that
+// load them (v_cvt_pk_bf16_f32 + exact residuals): 3 MFMAs of 32 cycles per 16 k instead of 8 of 64, every product exact, fp32
+// accumulation, ONE division by 255 of each split-K partial.  Same tile = (32 rows of (c,r,s), all 32 maps, one K slab), same 16
+// waves x one 32-deep chunk each, same slab layout and fixed-order LDS combine as the engine's Conv1Wgrad -> the update kernel reads it
+// unchanged.  A: lane (row, h) takes two aligned groups of 4 consecutive output positions with ONE unaligned 16-byte ring load each
+// (bytes 0, 4, 8, 12: the engine's A_GROUP4 trick); the groups' (sample, y, x) are wave-uniform per half-wave: scalar index math.
+struct C1wArgs { const uint8_t* src; const float* d1; float* slab1; const int64_t* idx; int B, from_ring, tps1, Kt; };
+
+template <bool IDX_IN>
+__global__ void __launch_bounds__(1024) conv1_wgrad_bf16_kernel(const C1wArgs c, const IdxIn ix) {
+  __shared__ float smem[16 * PANEL];
+  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  int64_t my_idx = 0;
+  if constexpr (IDX_IN) {
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    my_idx = *reinterpret_cast<const int64_t*>(ka + sizeof(C1wArgs) + 8 * i);
+  }
+  (void)ix;
+  {
+    const uint8_t* f0 = c.src; const float* f1 = c.d1; float* f2 = c.slab1; const int64_t* f4 = c.idx;
+    int g0 = c.B, g1 = c.from_ring, g2 = c.tps1, g3 = c.Kt;
+    asm volatile("" :: "s"(f0), "s"(f1), "s"(f2), "s"(f4), "s"(g0), "s"(g1), "s"(g2), "s"(g3));
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bx = blockIdx.x, ks = blockIdx.z;
+  const int m = 32 * bx + i;
+  const int colm = (m >> 6) * FRAME + ((m >> 3) & 7) * W0 + (m & 7);                         // problems.h: col1
+  const int Kt = c.Kt, kb = ks * c.tps1 * 32;
+  int ke = kb + c.tps1 * 32; if (ke > Kt) ke = Kt;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(1)));
+  // origin of the aligned group of 4 positions starting at k4 (wave-uniform arithmetic; the two half-waves differ by 8 positions)
+  auto group_org = [&](int k4u) -> int64_t {
+    const int k4 = k4u < Kt - 4 ? k4u : Kt - 4;
+    const int n = k4 / PIX1, pix = k4 - n * PIX1, y = pix / Q1, x = pix - y * Q1;
+    int64_t base;
+    if constexpr (IDX_IN) {
+      const uint32_t lo = __builtin_amdgcn_readlane((int)(my_idx & 0xFFFFFFFF), n), hi = __builtin_amdgcn_readlane((int)(my_idx >> 32), n);
+      base = ((int64_t)(((uint64_t)hi << 32) | lo) - C0) * (int64_t)FRAME;
+    } else base = c.from_ring ? (c.idx[n] - C0) * (int64_t)FRAME : (int64_t)n * STATE;        // problems.h: sbase, z = 0
+    return base + (int64_t)(y * ST1) * W0 + x * ST1;
+  };
+  auto load_chunk = [&](int kc, u32x4* ra, float* rb) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int64_t o0 = group_org(kc + 16 * st + 4 * g), o1 = group_org(kc + 16 * st + 8 + 4 * g);
+        ra[2 * st + g] = *reinterpret_cast<const u32x4*>(c.src + (h ? o1 : o0) + colm);
+      }
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = kc + 16 * st + 8 * h + e, kcl = k < Kt ? k : Kt - 1;
+        const float v = c.d1[(uint32_t)(kcl * K1 + i)];
+        rb[8 * st + e] = k < ke ? v : 0.0f;
+      }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  int kc = kb + wave * 32;
+  u32x4 ra[4]; float rb[16];
+  if (kc < ke) load_chunk(kc, ra, rb);
+  while (kc < ke) {
+    u32x4 na[4]; float nb[16];
+    const int kn = kc + 16 * 32;
+    if (kn < ke) load_chunk(kn, na, nb);                                                    // next chunk's operands fly under this chunk's work
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      union { uint32_t u[4]; bf16x8_t v; } A;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const u32x4 w = ra[2 * st + g];
+        const uint32_t f0 = __float_as_uint((float)(w.x & 255u)), f1 = __float_as_uint((float)(w.y & 255u));
+        const uint32_t f2 = __float_as_uint((float)(w.z & 255u)), f3 = __float_as_uint((float)(w.w & 255u));
+        A.u[2 * g] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);
+        A.u[2 * g + 1] = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
+      }
+      bf16x8_t B0, B1, B2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = rb[8 * st + e];
+        const __bf16 hi = (__bf16)x; const float r1 = x - (float)hi;
+        const __bf16 mid = (__bf16)r1; const float r2 = r1 - (float)mid;
+        B0[e] = hi; B1[e] = mid; B2[e] = (__bf16)r2;
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, B0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, B1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, B2, acc, 0, 0, 0);
+    }
+    kc = kn;
+    if (kc < ke) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ra[t] = na[t];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) rb[t] = nb[t];
+    }
+  }
+  float* cw = smem + wave * PANEL;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + i] = acc[r];
+  __syncthreads();
+  {
+    const int e = threadIdx.x, ml = e >> 5, nl = e & 31;
+    float v = smem[ml * 33 + nl];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) v += smem[w * PANEL + ml * 33 + nl];                       // fixed order
+    c.slab1[(int64_t)ks * NW1 + (32 * bx + ml) * K1 + nl] = div255(v);
+  }
+}
+
 // the three planes of one net's W1 from its fp32 weights (after set_weights / replica broadcast; the update kernel writes them itself)
 __global__ void __launch_bounds__(256) w1_planes_kernel(const float* theta, unsigned short* w1p) {
   const int e = blockIdx.x * 256 + threadIdx.x;                       // e = k * 32 + n (W1i layout [(c,r,s)][map])
@@ -272,6 +387,17 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
       memset(ix.v, 0, sizeof ix.v);
       hipLaunchKernelGGL(conv1_bf16_kernel<false>, dim3(a.nz * wgs), dim3(256), 0, s, c, ix);
     }
+    return hipGetLastError();
+  }
+  if (id == K_BWD1 && (t.r3 & 8) && a.f4w_count == 0 && !a.h16 && !a.bn) {
+    C1wArgs c; c.src = a.src; c.d1 = a.d1; c.slab1 = a.slab1; c.idx = a.idx; c.B = a.B; c.from_ring = a.from_ring; c.tps1 = a.tps1; c.Kt = a.B * PIX1;
+    static_assert(sizeof(C1wArgs) == 48, "the index block follows at byte 48 of the argument segment");
+    const dim3 grid(CRS1 / 32, 1, Conv1Wgrad::nbz(a));
+    IdxIn ix; memset(ix.v, 0, sizeof ix.v);
+    if (t.host_idx && a.from_ring && a.B <= 32) {
+      memcpy(ix.v, t.host_idx, (size_t)a.B * sizeof(int64_t));
+      hipLaunchKernelGGL(conv1_wgrad_bf16_kernel<true>, grid, dim3(1024), 0, s, c, ix);
+    } else hipLaunchKernelGGL(conv1_wgrad_bf16_kernel<false>, grid, dim3(1024), 0, s, c, ix);
     return hipGetLastError();
   }
   if (id == K_CONV3_FWD && (t.r3 & 2) && a.B < 128 && !a.h16 && !a.bn) {

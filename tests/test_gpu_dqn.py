@@ -349,6 +349,40 @@ def test_conv1_on_bf16_mfma_against_the_fp32_engine(sd, A, B):
     assert np.abs(n1.last_q()[1] - n0.last_q()[1]).max() < 1e-5                     # max_a Q'(s') of both
 
 
+@pytest.mark.parametrize("A,B", [(4, 32), (6, 7), (3, 160)])
+def test_conv1_wgrad_on_bf16_mfma_against_the_fp32_engine(sd, A, B):
+    """Round 3: conv1's weight gradient as bytes x (hi + mid + lo of delta1, split on the fly) on packed-bf16 MFMA, one
+    division by 255 per split-K partial, against the fp32-MFMA engine (x / 255 per pixel): gW1 within 2e-6 of max|gW1| (fp32
+    round-off of 400 B-term sums), the oracle within the usual bound; ragged batch (odd B: half-filled last chunk) and a
+    multi-chunk-per-wave batch; ring path (indexes in the kernel arguments) and tuple path give the same bits."""
+    mb = random_minibatch(B, A, 341)
+    gs = []
+    for bf in (1, 0):
+        n, o = _pair(sd, A, B, 340)
+        n.set_option("conv1w_bf16", bf)
+        n.set_option("keep_gradients", 1)
+        n.set_option("grad_only", 1)
+        n.train(mb)
+        gs.append(n.get_layer(0, 3))
+    g_or, _, _, _ = o.gradients(mb)
+    sc = np.abs(gs[1]).max()
+    assert sc > 0 and np.abs(gs[0] - gs[1]).max() <= 2e-6 * sc, float(np.abs(gs[0] - gs[1]).max() / sc)
+    assert np.abs(gs[0] - g_or[0]).max() <= 1e-4 * max(1e-3, np.abs(g_or[0]).max())
+    if B == 32:                                                       # ring path: same bits as the tuple path on the same states
+        size = 600
+        args = make_args(batch_size=B)
+        mem = sd.ReplayMemory(size, args)
+        synthetic_fill(mem, 342, num_actions=A)
+        idx = np.arange(10, 10 + 7 * B, 7)
+        mbr = [x.copy() for x in mem.gather(idx)]
+        n1, _ = _pair(sd, A, B, 343); n2, _ = _pair(sd, A, B, 343)
+        for n in (n1, n2):
+            n.set_option("keep_gradients", 1); n.set_option("grad_only", 1)
+        n1.train_indexes(mem, idx); n2.train(tuple(mbr))
+        for l in range(5):
+            assert np.array_equal(n1.get_layer(l, 3), n2.get_layer(l, 3)), l
+
+
 def test_conv3_36_deep_chunks_against_the_32_deep_routine(sd):
     """Round 3: conv3_fwd splits K = 576 into 16 chunks of 36 (one per wave) instead of 18 of 32.  Same exact-fp32 MFMA, another
     partition of the K sum: a3 and Q agree with the 32-deep routine to fp32 round-off (<= 2e-6 relative to max|a3|), with the

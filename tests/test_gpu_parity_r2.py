@@ -362,6 +362,7 @@ def test_hoisted_target_forward_is_bit_identical(sd):
             n.set_option("hoist", hoist)
             n.set_option("conv3_c36", 0)                     # the riding target conv3 is the 32-deep routine: same routine on both sides
             n.set_option("conv1_bf16", 0)                    # ... and the hoisted target conv1 the fp32-MFMA engine's
+            n.set_option("conv1w_bf16", 0)                   # (bwd1 carries the hoisted target conv2 only in its multi-problem engine form)
             n.set_option("keep_gradients", keep)
             mt = (C.c_uint32 * 625)(); lib.sdqn_mt_seed(mt, 703)
             c = []
