@@ -431,7 +431,7 @@ struct sdqn_net_s {
   bool conv1_bf16 = true;                  // round 3: conv1_fwd on packed-bf16 MFMA (bytes x 3-way bf16 split of W1; sdqn_kernels_r3.hip)
   unsigned short* w1p[2] = {nullptr, nullptr};   // the three bf16 planes of W1, online / target net ([3][32][256] each)
   const int64_t* host_idx_cur = nullptr;   // ring paths: host copy of the indexes of the step being enqueued (valid during run_train only)
-  bool conv1w_bf16 = true;                 // round 3: conv1_wgrad on packed-bf16 MFMA (bytes x on-the-fly bf16 split of delta1)
+  int conv1w_bf16 = 1;                 // round 3: conv1_wgrad on packed-bf16 MFMA (bytes x on-the-fly bf16 split of delta1)
   bool conv3_c36 = true;                   // round 3: conv3_fwd on 36-deep K-chunks (one chunk per wave; sdqn_kernels_r3.hip)
   unsigned* f4d_flags = nullptr;           // [NIN4 / 32][16] write-after-read flags of that launch + one sticky time-out word
   bool fused_launches = true;              // independent backward stages share one launch (K_BWD3, K_BWD2)
@@ -876,6 +876,10 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   // round 3: fc4_wgrad (needs delta4 and a3 only) rides in the fc4_dgrad launch, whose 98 workgroups leave 158 CUs idle; with the
   // fused RMSProp its in-place update of W4 is ordered behind the dgrad's reads by per-row-block flags (sdqn_kernels_r3.hip).
   // Same tiles, same K split as the bwd3 form: bit-identical.  Not for the overlapped-DP / two-stream / hoist / fp16 / bn variants.
+  // conv1's weight gradient on packed-bf16 MFMA (sdqn_kernels_r3.hip) in EVERY launch structure (fused / unfused / two streams: same bits);
+  // B < 128 only: in the throughput regime the on-the-fly split of delta1 makes it VALU-bound (measured 3 580 vs 4 063 steps/s at B = 256;
+  // option value 2 forces it for experiments)
+  const bool c1w = (h->conv1w_bf16 == 2 || (h->conv1w_bf16 == 1 && h->B < 128)) && h->cfg.datatype == 0 && !h->bn && !hoist && h->nw_override[K_CONV1_WGRAD] == 0;
   const bool f4_early = h->f4w_early && h->B <= 32 && h->cfg.datatype == 0 && !h->bn && h->fused_launches && !h->two_streams &&
                         !dp_ov && !hoist && h->bwd_order == 0 && h->f4_share[0] == 100 && h->f4_share[1] == 0 && h->nw_override[K_FC4_DGRAD] == 0;
   if (f4_early) LAUNCH(K_F4D_F4W, launch_tuned(h, K_FC4_DGRAD, a, g_stream, 0, 1));
@@ -899,7 +903,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     BN_BWD(1);
     LAUNCH(K_BWD2, launch_tuned(h, K_BWD2, b2, g_stream));
     BN_BWD(0);
-    LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream));
+    LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream, 0, c1w ? 8 : 0));
   } else
   if (h->fused_launches && !h->two_streams) {
     // fc4 wgrad (1568 tiles at B <= 32) is spread over the three backward launches as background traffic;
@@ -920,7 +924,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     // conv1_wgrad on the XCD-contiguous tile map: the 8 m-tiles of a K-slab read the same frames, so a slab's tiles belong on ONE XCD's L2
     // (L2 <-> fabric traffic of the launch 15.8 -> 4.0 MB = 1.4x algorithmic, rocprofv3 PMC; step rate -0.1 %: the re-reads were MALL hits)
     b1.xcd_map |= 2;
-    LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream, hoist & 1, (h->conv1w_bf16 && !hoist && b1.f4w_count == 0 && h->nw_override[K_CONV1_WGRAD] == 0) ? 8 : 0));
+    LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream, hoist & 1, (c1w && b1.f4w_count == 0) ? 8 : 0));
   } else {
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[1], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[1], 0)); }
   // fc4_wgrad may update W4 in place (fused RMSProp): it must not start before fc4_dgrad has read W4
@@ -932,7 +936,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   LAUNCH_ON(ss, K_CONV2_WGRAD, launch_tuned(h, K_CONV2_WGRAD, a, ss));        // needs d2p, a1
   LAUNCH(K_CONV2_DGRAD, launch_tuned(h, K_CONV2_DGRAD, a, g_stream));
   BN_BWD(0);
-  LAUNCH(K_CONV1_WGRAD, launch_tuned(h, K_CONV1_WGRAD, a, g_stream));
+  LAUNCH(K_CONV1_WGRAD, launch_tuned(h, K_CONV1_WGRAD, a, g_stream, 0, c1w ? 8 : 0));
   if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[3], ss)); HIPCHK(hipStreamWaitEvent(g_stream, g_ev[3], 0)); }
   }
   UpdateArgs u = make_update_args(h, a);
@@ -1324,7 +1328,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else if (!strcmp(name, "conv1_bf16")) h->conv1_bf16 = value != 0;     // 0: conv1_fwd on the fp32-MFMA engine (round-2 kernel)
-  else if (!strcmp(name, "conv1w_bf16")) h->conv1w_bf16 = value != 0;   // 0: conv1_wgrad on the fp32-MFMA engine (round-2 kernel)
+  else if (!strcmp(name, "conv1w_bf16")) h->conv1w_bf16 = value;   // 0: conv1_wgrad on the fp32-MFMA engine (round-2 kernel)
   else if (!strcmp(name, "conv3_c36")) h->conv3_c36 = value != 0;       // 0: conv3_fwd on the engine's 32-deep chunks (round-2 kernel)
   else if (!strcmp(name, "f4w_early")) h->f4w_early = value != 0;       // 0: fc4_wgrad inside bwd3 (round-2 launch structure)
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;

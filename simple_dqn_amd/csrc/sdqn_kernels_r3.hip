@@ -274,18 +274,23 @@ __global__ void __launch_bounds__(1024) conv1_wgrad_bf16_kernel(const C1wArgs c,
   const int Kt = c.Kt, kb = ks * c.tps1 * 32;
   int ke = kb + c.tps1 * 32; if (ke > Kt) ke = Kt;
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(1)));
-  // origin of the aligned group of 4 positions starting at k4 (wave-uniform arithmetic; the two half-waves differ by 8 positions)
-  auto group_org = [&](int k4u) -> int64_t {
-    const int k4 = k4u < Kt - 4 ? k4u : Kt - 4;
-    const int n = k4 / PIX1, pix = k4 - n * PIX1, y = pix / Q1, x = pix - y * Q1;
-    int64_t base;
-    if constexpr (IDX_IN) {
-      const uint32_t lo = __builtin_amdgcn_readlane((int)(my_idx & 0xFFFFFFFF), n), hi = __builtin_amdgcn_readlane((int)(my_idx >> 32), n);
-      base = ((int64_t)(((uint64_t)hi << 32) | lo) - C0) * (int64_t)FRAME;
-    } else base = c.from_ring ? (c.idx[n] - C0) * (int64_t)FRAME : (int64_t)n * STATE;        // problems.h: sbase, z = 0
-    return base + (int64_t)(y * ST1) * W0 + x * ST1;
-  };
+  // a 32-deep chunk touches at most two samples: their ring indexes are fetched ONCE per chunk (two readlanes / two scalar loads issued
+  // together), the origin of each aligned group of 4 positions is wave-uniform arithmetic on top (the half-waves differ by 8 positions)
   auto load_chunk = [&](int kc, u32x4* ra, float* rb) {
+    const int n0 = kc / PIX1, n1 = n0 + 1 < c.B ? n0 + 1 : n0;
+    int64_t i0, i1;
+    if constexpr (IDX_IN) {
+      const uint32_t a0 = __builtin_amdgcn_readlane((int)(my_idx & 0xFFFFFFFF), n0), a1 = __builtin_amdgcn_readlane((int)(my_idx >> 32), n0);
+      const uint32_t b0 = __builtin_amdgcn_readlane((int)(my_idx & 0xFFFFFFFF), n1), b1 = __builtin_amdgcn_readlane((int)(my_idx >> 32), n1);
+      i0 = (int64_t)(((uint64_t)a1 << 32) | a0); i1 = (int64_t)(((uint64_t)b1 << 32) | b0);
+    } else if (c.from_ring) { i0 = c.idx[n0]; i1 = c.idx[n1]; }
+    else { i0 = n0; i1 = n1; }
+    const int64_t unit = c.from_ring ? (int64_t)FRAME : (int64_t)STATE, off = c.from_ring ? -(int64_t)C0 * FRAME : 0;     // problems.h: sbase, z = 0
+    auto group_org = [&](int k4u) -> int64_t {
+      const int k4 = k4u < Kt - 4 ? k4u : Kt - 4;
+      const int n = k4 / PIX1, pix = k4 - n * PIX1, y = pix / Q1, x = pix - y * Q1;
+      return (n == n0 ? i0 : i1) * unit + off + (int64_t)(y * ST1) * W0 + x * ST1;
+    };
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -389,7 +394,7 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     }
     return hipGetLastError();
   }
-  if (id == K_BWD1 && (t.r3 & 8) && a.f4w_count == 0 && !a.h16 && !a.bn) {
+  if ((id == K_BWD1 || id == K_CONV1_WGRAD) && (t.r3 & 8) && (id == K_CONV1_WGRAD || a.f4w_count == 0) && !a.h16 && !a.bn) {
     C1wArgs c; c.src = a.src; c.d1 = a.d1; c.slab1 = a.slab1; c.idx = a.idx; c.B = a.B; c.from_ring = a.from_ring; c.tps1 = a.tps1; c.Kt = a.B * PIX1;
     static_assert(sizeof(C1wArgs) == 48, "the index block follows at byte 48 of the argument segment");
     const dim3 grid(CRS1 / 32, 1, Conv1Wgrad::nbz(a));
