@@ -70,6 +70,8 @@ def kernel_work(B, A):
         # + a4 + a3 (wgrad operands) + 4 w4
         20: dict(bytes=(a4 + 2 * a3) + (a4 + a3) + 4 * w4, flops=2 * B * 512 * 3136 * 2),
         21: dict(bytes=(a3 + w3 + 2 * a2) + (a2 + a3 + w3), flops=2 * B * 49 * 64 * 576 * 2),
+        # round 3: update(i) + conv1_fwd(i + 1) in one launch = the sum of the two
+        22: dict(bytes=(npar - 1605632) * f * 5 + (25 * w1 + 6 * w2 + 4 * w3) + B * 5 * 7056 + 2 * a1 + 2 * w1, flops=8 * (npar - 1605632) + 2 * 2 * B * 400 * 32 * 256),
     }
     # (default tile split: the whole fc4 wgrad + fused RMSProp read-modify-write — theta, s read and written — rides in bwd3)
 
@@ -103,7 +105,7 @@ ROCPROF_MATCH = [
     ("gemm_kernel<sdqn::Conv1Fwd", 0), ("gemm_kernel<sdqn::Conv2Fwd", 1), ("Conv3Fwd", 2), ("Fc4Fwd", 3),
     ("head_kernel", 4), ("gemm_kernel<sdqn::Staged<sdqn::Fc4Dgrad>", 5), ("update_kernel", 12), ("gather_kernel", 14), ("prep_kernel", 15),
     ("gemm_multi_kernel<512, sdqn::Staged<sdqn::Conv3Dgrad>", 16), ("Conv2Dgrad", 17), ("Conv1Wgrad", 18),
-    ("conv1_bf16_kernel", 0), ("conv1_wgrad_bf16_kernel", 18), ("Fc4DgradSig", 20), ("gemm_multi_kernel<512, sdqn::NoProblem, 2, sdqn::Staged<sdqn::Conv3Dgrad>", 21),
+    ("conv1_bf16_kernel", 0), ("conv1_wgrad_bf16_kernel", 18), ("upd_conv1_kernel", 22), ("Fc4DgradSig", 20), ("gemm_multi_kernel<512, sdqn::NoProblem, 2, sdqn::Staged<sdqn::Conv3Dgrad>", 21),
 ]
 
 

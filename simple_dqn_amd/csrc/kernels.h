@@ -16,6 +16,7 @@ enum KernelId {
   K_BN,        // --batch_norm: one BatchNorm layer, forward ([partial +] apply) or backward (partial + apply)
   K_F4D_F4W,   // round 3, one launch: fc4_dgrad + fc4_wgrad (+ fused RMSProp of W4) — the wgrad only needs delta4 and a3
   K_BWD3_CONV, // round 3: bwd3 without the fc4 share (conv3_dgrad + conv3_wgrad)
+  K_UPD_CONV1, // round 3: update(i) + conv1_fwd(i + 1) in one launch
   K_COUNT
 };
 const char* kernel_name(int id);
@@ -71,6 +72,7 @@ struct UpdateArgs {
   half_t* wh;                   // fp16 mode: half copies of theta refreshed by the update (master layout / transposed)
   half_t* wht;
   unsigned short* w1p;          // conv1's three bf16 planes of the ONLINE net, rewritten with W1 (nullptr: not maintained)
+  unsigned* w1_ctr;             // fused update + conv1 launch only: counts the W1 blocks whose write-through stores are out (monotonic across launches)
   int64_t bn_first;             // --batch_norm: element offset of the [beta|gamma] block (bn_update_kernel); BN_PARAMS elements
   const int* ovf_flag;          // fp16 data parallel (update_kernel<true>): != 0 -> the all-reduced half gradient overflowed, leave theta / state untouched
   int64_t* ovf_count;           //   ... and count the skipped step
@@ -146,6 +148,8 @@ hipError_t launch_bn_update(const UpdateArgs& u, hipStream_t s);   // optimizer 
 hipError_t launch_prep(const PrepArgs& p, hipStream_t s, double* zero8 = nullptr);   // zero8: an 8-byte accumulator the launch also clears
 hipError_t launch_grad_to_half(const float* g, half_t* gh, int64_t n, int* state, hipStream_t s);       // fp16 DP payload; state = {flag, log2 scale, good steps}
 hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, int* state, hipStream_t s);
+// round 3: update(i) + conv1_fwd(i + 1) as one launch (sdqn_kernels_r3.hip); u.skip_fc4 must be 1, u.w1_ctr == ctr
+hipError_t launch_upd_conv1(const UpdateArgs& u, const StepArgs& a, const int64_t* host_idx, unsigned* ctr, unsigned target, unsigned* timeout, hipStream_t s);
 hipError_t launch_w1_planes(const float* theta, unsigned short* w1p, hipStream_t s);   // conv1's three bf16 weight planes of one net (problems.h: split_bf16x3)
 hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s);   // fp16 mode: rebuild both half copies
 

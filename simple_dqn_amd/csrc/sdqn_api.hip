@@ -431,6 +431,9 @@ struct sdqn_net_s {
   bool conv1_bf16 = true;                  // round 3: conv1_fwd on packed-bf16 MFMA (bytes x 3-way bf16 split of W1; sdqn_kernels_r3.hip)
   unsigned short* w1p[2] = {nullptr, nullptr};   // the three bf16 planes of W1, online / target net ([3][32][256] each)
   const int64_t* host_idx_cur = nullptr;   // ring paths: host copy of the indexes of the step being enqueued (valid during run_train only)
+  bool fuse_upd = true;                    // round 3: inside train_many, update(i) and conv1_fwd(i + 1) are ONE launch (sdqn_kernels_r3.hip: upd_conv1_kernel)
+  bool has_pending_upd = false; UpdateArgs pending_upd;      // the deferred optimizer pass of the previous step (never outlives a train_many call)
+  unsigned* w1_ctr = nullptr; unsigned w1_epochs = 0;        // [0] W1 blocks counted in (monotonic: 64 per fused launch), [1] sticky time-out word
   int conv1w_bf16 = 1;                 // round 3: conv1_wgrad on packed-bf16 MFMA (bytes x on-the-fly bf16 split of delta1)
   bool conv3_c36 = true;                   // round 3: conv3_fwd on 36-deep K-chunks (one chunk per wave; sdqn_kernels_r3.hip)
   unsigned* f4d_flags = nullptr;           // [NIN4 / 32][16] write-after-read flags of that launch + one sticky time-out word
@@ -580,6 +583,7 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->st_rew, (size_t)B * 10));
   h->st_act = reinterpret_cast<uint8_t*>(h->st_rew) + (size_t)B * 8; h->st_term = h->st_act + B;
   NCHK(dalloc(h, (void**)&h->f4d_flags, (size_t)(NIN4 / 32 + 1) * 16 * 4));
+  NCHK(dalloc(h, (void**)&h->w1_ctr, 64));
   if (c->datatype == 0) {                  // (all-zero planes == all-zero W1, which is what the zeroed theta holds until set_weights)
     NCHK(dalloc(h, (void**)&h->w1p[0], (size_t)3 * W1P_PLANE * 2));
     if (c->target_enabled) NCHK(dalloc(h, (void**)&h->w1p[1], (size_t)3 * W1P_PLANE * 2)); else h->w1p[1] = h->w1p[0];
@@ -833,6 +837,14 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int
   // XCD-contiguous tile map where it wins time (tools/sweep_xcd.py, tools/ab_options.py): conv1_fwd +0.5 %, conv2_fwd
   // +0.2 %, fc4_fwd +0.6 % of the step rate; slower for conv3_fwd, fc4_dgrad and every backward launch
   StepArgs fm = a; fm.xcd_map = 1; fm.idx_t = nullptr;
+  if (h->has_pending_upd) {
+    // the previous step's optimizer pass rides in front of this step's conv1 (train_many only): one launch, the online conv1
+    // workgroups wait for the 64 W1 blocks of the same launch (upd_conv1_kernel)
+    h->has_pending_upd = false;
+    h->w1_epochs += 1;
+    UpdateArgs pu = h->pending_upd; pu.w1_ctr = h->w1_ctr;
+    LAUNCH(K_UPD_CONV1, launch_upd_conv1(pu, fm, h->host_idx_cur, h->w1_ctr, 64u * h->w1_epochs, h->w1_ctr + 1, g_stream));
+  } else
   LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, fm, g_stream, 0, (h->conv1_bf16 && !h->hoist && h->nw_override[K_CONV1_FWD] == 0) ? 4 : 0));
   LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, fm, g_stream));
   { StepArgs f3 = fm; f3.xcd_map = a.xcd_map;
@@ -863,7 +875,7 @@ static UpdateArgs make_update_args(sdqn_net_s* h, const StepArgs& a) {
   }
   return u;
 }
-static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const PrepArgs* next = nullptr, int hoist = 0) {
+static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const PrepArgs* next = nullptr, int hoist = 0, bool defer_update = false) {
   int rc = run_forward(h, a, hd, hoist); if (rc) return rc;
   // Backward.  Critical path on the library stream: fc4_dgrad -> conv3_dgrad -> conv2_dgrad -> conv1_wgrad.
   // The three other weight-gradient kernels only need the delta of their layer, so they run beside it
@@ -973,6 +985,9 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   } else if (h->grad_only) {
     u.mode = 1; u.bsz = (float)h->B;                                            // local sums -> g, nothing applied
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
+  } else if (defer_update && a.fuse_rms && !h->bn) {
+    u.mode = 0; u.bsz = (float)h->B;
+    h->pending_upd = u; h->has_pending_upd = true;            // launched together with the next step's conv1 (run_forward)
   } else {
     u.mode = 0; u.bsz = (float)h->B;
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
@@ -1147,7 +1162,8 @@ static bool hoist_possible(sdqn_net_s* h) {
          !(h->comm && h->comm2 && h->dp_overlap) && h->f4_share[0] == 100 && h->f4_share[1] == 0 && h->theta_t != h->theta;
 }
 static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pinned_idx, bool do_prep = true,
-                             const int64_t* next_pinned = nullptr, bool hoist_in = false, bool hoist_out = false, double* zero8 = nullptr) {
+                             const int64_t* next_pinned = nullptr, bool hoist_in = false, bool hoist_out = false, double* zero8 = nullptr,
+                             bool defer_update = false) {
   if (do_prep) { PrepArgs p = prep_args(h, r, pinned_idx); LAUNCH(K_PREP, launch_prep(p, g_stream, zero8)); }
   StepArgs a = step_args(h); a.from_ring = 1; a.src = r->d_ring; a.idx = h->d_idx;
   HeadArgs hd = head_args(h, 1);
@@ -1156,7 +1172,7 @@ static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pin
   // the slot's HOST address (pinned_idx is its device alias): conv1's tiles take their indexes from the kernel arguments
   h->host_idx_cur = r->h_idx + (pinned_idx - r->d_idx_view);
   int rc;
-  if (next_pinned) { PrepArgs np = prep_args(h, r, next_pinned); rc = run_train(h, a, hd, &np, hoist); }
+  if (next_pinned) { PrepArgs np = prep_args(h, r, next_pinned); rc = run_train(h, a, hd, &np, hoist, defer_update); }
   else rc = run_train(h, a, hd, nullptr, hoist);
   h->host_idx_cur = nullptr;
   return rc;
@@ -1193,12 +1209,18 @@ extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, 
     }
     // the target-net forward of step i+1 (theta- and the next indexes only) rides in step i's launches: run_forward / launch_kernel
     const bool hoist_out = next_pinned != nullptr && hoist_possible(h);
-    int rc = train_replay_slot(h, r, pinned, /*do_prep=*/i == 0, next_pinned, hoisted, hoist_out, i == 0 ? h->cost_accum : nullptr); if (rc) return rc;
+    // round 3: this step's optimizer pass is launched together with the NEXT step's conv1 (default fp32 single-learner path, B <= 32:
+    // the fused kernel takes the next indexes from its arguments); the last step of a call keeps its own update launch
+    const bool defer = next_pinned != nullptr && h->fuse_upd && h->B <= 32 && h->cfg.datatype == 0 && !h->bn && !h->comm && !h->grad_only &&
+                       !h->keep_grads && !h->hoist && h->conv1_bf16 && h->fused_launches && !h->two_streams && h->nw_override[K_CONV1_FWD] == 0 &&
+                       h->theta_t != h->theta && !(r->flags & SDQN_REPLAY_ZERO_COPY);
+    int rc = train_replay_slot(h, r, pinned, /*do_prep=*/i == 0, next_pinned, hoisted, hoist_out, i == 0 ? h->cost_accum : nullptr, defer); if (rc) return rc;
     hoisted = hoist_out;
     rc = replay_release_idx_batched(r, slot, false);
     if (rc) return rc;
     slot = next_slot; pinned = next_pinned;
   }
+  if (h->has_pending_upd) { set_error("internal: a deferred update outlived train_many"); return SDQN_ERR_STATE; }
   if (mean_cost) {
     HIPCHK(hipMemcpyAsync(h->h_f, h->cost_accum, 8, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
@@ -1279,6 +1301,8 @@ extern "C" int sdqn_net_sync(sdqn_net_t h) {
   unsigned timed_out = 0;
   HIPCHK(hipMemcpy(&timed_out, h->f4d_flags + (NIN4 / 32) * 16, 4, hipMemcpyDeviceToHost));
   if (timed_out) { set_error("fc4_wgrad waited for a fc4_dgrad tile that never signalled (in-launch hand-off timed out): results are invalid"); return SDQN_ERR_STATE; }
+  HIPCHK(hipMemcpy(&timed_out, h->w1_ctr + 1, 4, hipMemcpyDeviceToHost));
+  if (timed_out) { set_error("conv1 waited for W1 blocks of the fused update that never signalled (in-launch hand-off timed out): results are invalid"); return SDQN_ERR_STATE; }
   return SDQN_OK;
 }
 extern "C" int sdqn_net_last_q(sdqn_net_t h, float* preq, float* maxpostq) {
@@ -1328,6 +1352,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else if (!strcmp(name, "conv1_bf16")) h->conv1_bf16 = value != 0;     // 0: conv1_fwd on the fp32-MFMA engine (round-2 kernel)
+  else if (!strcmp(name, "fuse_upd")) h->fuse_upd = value != 0;         // 0: the optimizer pass is always its own launch
   else if (!strcmp(name, "conv1w_bf16")) h->conv1w_bf16 = value;   // 0: conv1_wgrad on the fp32-MFMA engine (round-2 kernel)
   else if (!strcmp(name, "conv3_c36")) h->conv3_c36 = value != 0;       // 0: conv3_fwd on the engine's 32-deep chunks (round-2 kernel)
   else if (!strcmp(name, "f4w_early")) h->f4w_early = value != 0;       // 0: fc4_wgrad inside bwd3 (round-2 launch structure)

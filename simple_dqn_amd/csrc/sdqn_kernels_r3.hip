@@ -13,6 +13,7 @@
 //   (problems.h: Fc4DgradSig / Fc4WgradWait) — a write-after-read hand-off, no data crosses between the workgroups.
 #include "gemm_engine.h"
 #include "kernels.h"
+#include "update_body.h"
 
 namespace sdqn {
 
@@ -113,23 +114,22 @@ __device__ __forceinline__ float div255(float s) {        // s / 255 to within a
   return fmaf(fmaf(-q, 255.0f, s), r, q);
 }
 
-template <bool IDX_IN>
-__global__ void __launch_bounds__(256) conv1_bf16_kernel(const Conv1Args c, const IdxIn ix) {
-  __shared__ __attribute__((aligned(16))) unsigned short sw[3 * K1 * W1P_PITCH];          // 50 688 B
+// FUSED: the body runs inside the "update + next step's conv1" launch (upd_conv1_kernel below).  Target-net workgroups come first in
+// block order and need nothing from the update; ONLINE workgroups take W1 straight from theta — written by the update blocks of the
+// same launch with write-through stores — after those 64 blocks have counted themselves in (one relaxed poll by one lane, sc1 loads,
+// no fence), and split it into the three LDS planes themselves (the same split_bf16x3 as the global planes: same bits).
+struct FusedW1 { const float* theta; unsigned* ctr; unsigned target; unsigned* timeout; };
+
+template <bool IDX_IN, bool FUSED>
+__device__ __forceinline__ void conv1_bf16_body(const Conv1Args& c, const int64_t my_idx, const int cb, unsigned short* sw, const FusedW1& fw) {
   const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-  int64_t my_idx = 0;
-  if constexpr (IDX_IN) {                                   // issued first: needs nothing but the argument-segment pointer
-    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
-    my_idx = *reinterpret_cast<const int64_t*>(ka + sizeof(Conv1Args) + 8 * i);
-  }
-  (void)ix;
   {   // every argument field in flight NOW, one wait: left alone hipcc fetches each field where it is first used (five dependent scalar trips)
     const uint8_t* f0 = c.src; float* f1 = c.a1; const unsigned short *f2 = c.w1p[0], *f3 = c.w1p[1]; const int64_t* f4 = c.idx;
     int g0 = c.B, g1 = c.from_ring, g2 = c.tiles_per_net, g3 = c.wgs_per_net, g4 = c.tpw;
     asm volatile("" :: "s"(f0), "s"(f1), "s"(f2), "s"(f3), "s"(f4), "s"(g0), "s"(g1), "s"(g2), "s"(g3), "s"(g4));
   }
-  const int zi = blockIdx.x / c.wgs_per_net, wg = blockIdx.x - zi * c.wgs_per_net;
-  const int z = zi;                                                                          // 0 online, 1 target (nz = 1: online only)
+  const int zi = cb / c.wgs_per_net, wg = cb - zi * c.wgs_per_net;
+  const int z = FUSED ? 1 - zi : zi;                                                         // 0 online, 1 target (nz = 1: online only); FUSED: target first
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int M = c.B * PIX1, tiles_per_net = c.tiles_per_net, tpw = c.tpw;
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
@@ -158,7 +158,31 @@ __global__ void __launch_bounds__(256) conv1_bf16_kernel(const Conv1Args c, cons
 #endif
   if (tile0 < tiles_per_net) load_tile(tile0, raw);                                          // in flight under the plane fill below
   SDQN_STAMP(1);
-  {
+  if (FUSED && z == 0) {
+    if (threadIdx.x == 0) {                                   // the 64 W1 blocks of THIS launch have published (bounded: never a hung GPU)
+      int spins = 0;
+      while ((int)(__hip_atomic_load(fw.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fw.target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 8000000) { __hip_atomic_store(fw.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    __syncthreads();
+    typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fw.theta + OFF1), 0, NW1 * 4, 0x00020000);
+    u4_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((threadIdx.x + 256 * u) * 16), 0, 16);      // sc1: past L1
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = (threadIdx.x + 256 * u) * 4, k = e >> 5, n = e & 31;                     // W1i [(c,r,s)][map]: 4 consecutive maps of one k
+      const uint32_t wv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint16_t hi, mid, lo; split_bf16x3(__uint_as_float(wv[j]), hi, mid, lo);
+        sw[(n + j) * W1P_PITCH + k] = hi; sw[(K1 + n + j) * W1P_PITCH + k] = mid; sw[(2 * K1 + n + j) * W1P_PITCH + k] = lo;
+      }
+    }
+  } else {
     const uint4* wp = reinterpret_cast<const uint4*>(c.w1p[z]);
     static_assert(3 * K1 * (CRS1 / 8) == 12 * 256, "3072 chunks of 8 bf16: 12 per thread");
     uint4 v[12];
@@ -240,6 +264,39 @@ __global__ void __launch_bounds__(256) conv1_bf16_kernel(const Conv1Args c, cons
     }
   }
   SDQN_STAMP(6);
+}
+
+template <bool IDX_IN>
+__global__ void __launch_bounds__(256) conv1_bf16_kernel(const Conv1Args c, const IdxIn ix) {
+  __shared__ __attribute__((aligned(16))) unsigned short sw[3 * K1 * W1P_PITCH];          // 50 688 B
+  int64_t my_idx = 0;
+  if constexpr (IDX_IN) {                                   // issued first: needs nothing but the argument-segment pointer
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    my_idx = *reinterpret_cast<const int64_t*>(ka + sizeof(Conv1Args) + 8 * (threadIdx.x & 31));
+  }
+  (void)ix;
+  const FusedW1 fw = {nullptr, nullptr, 0u, nullptr};
+  conv1_bf16_body<IDX_IN, false>(c, my_idx, (int)blockIdx.x, sw, fw);
+}
+
+// ---- update(i) + conv1_fwd(i + 1) in ONE launch (train_many, steps after the first of a call; B <= 32 ring path) ------------
+// The optimizer pass is the last launch of a step and conv1 the first of the next: nothing between them but a kernel boundary.
+// Block order: [update blocks (W1 first) | target-net conv1 | online conv1].  Only the online conv1 workgroups depend on the update,
+// and only on W1 (8 192 of the 1.7 M parameters); the target-net half runs beside the update.  One launch, one boundary less, and
+// the 5 us latency chain of the update overlaps the target half of conv1.
+__global__ void __launch_bounds__(256) upd_conv1_kernel(const UpdateArgs u, const Conv1Args c, const IdxIn ix, const FusedW1 fw, const int n_upd) {
+  __shared__ __attribute__((aligned(16))) unsigned short sw[3 * K1 * W1P_PITCH];
+  static_assert(sizeof(UpdateArgs) % 8 == 0 && sizeof(Conv1Args) % 8 == 0, "argument blocks are 8-byte aligned: the index block's offset is their sum");
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int64_t my_idx = *reinterpret_cast<const int64_t*>(ka + sizeof(UpdateArgs) + sizeof(Conv1Args) + 8 * (threadIdx.x & 31));
+  (void)ix;
+  if ((int)blockIdx.x < n_upd) {
+    float4 (*part)[32] = reinterpret_cast<float4 (*)[32]>(sw);                               // 4 KB
+    float* cost_sh = reinterpret_cast<float*>(sw) + 1024;                                    // 16 KB behind it
+    update_body<false, true>(u, (int)blockIdx.x, n_upd, part, cost_sh);
+    return;
+  }
+  conv1_bf16_body<true, true>(c, my_idx, (int)blockIdx.x - n_upd, sw, fw);
 }
 
 // ---- conv1 weight gradient on packed-bf16 MFMA ---------------------------------------------------------------------------
@@ -359,6 +416,17 @@ __global__ void __launch_bounds__(1024) conv1_wgrad_bf16_kernel(const C1wArgs c,
     for (int w = 1; w < 16; ++w) v += smem[w * PANEL + ml * 33 + nl];                       // fixed order
     c.slab1[(int64_t)ks * NW1 + (32 * bx + ml) * K1 + nl] = div255(v);
   }
+}
+
+hipError_t launch_upd_conv1(const UpdateArgs& u, const StepArgs& a, const int64_t* host_idx, unsigned* ctr, unsigned target, unsigned* timeout, hipStream_t s) {
+  const int tiles = (a.B * PIX1 + 31) / 32, wgs = (tiles + 3) / 4;
+  Conv1Args c; c.src = a.src; c.a1 = a.a1; c.w1p[0] = a.w1p[0]; c.w1p[1] = a.w1p[1]; c.idx = a.idx;
+  c.B = a.B; c.nz = 2; c.from_ring = 1; c.tiles_per_net = tiles; c.wgs_per_net = wgs; c.tpw = 1;
+  IdxIn ix; memset(ix.v, 0, sizeof ix.v); memcpy(ix.v, host_idx, (size_t)a.B * sizeof(int64_t));
+  FusedW1 fw; fw.theta = a.theta[0]; fw.ctr = ctr; fw.target = target; fw.timeout = timeout;
+  const int n_upd = CONV_BLOCKS + u.A * FC5_BLOCKS_PER_ACTION + 2;                          // launch_update's grid with the fc4 part fused into bwd3
+  hipLaunchKernelGGL(upd_conv1_kernel, dim3(n_upd + 2 * wgs), dim3(256), 0, s, u, c, ix, fw, n_upd);
+  return hipGetLastError();
 }
 
 // the three planes of one net's W1 from its fp32 weights (after set_weights / replica broadcast; the update kernel writes them itself)

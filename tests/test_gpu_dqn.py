@@ -402,6 +402,36 @@ def test_conv3_36_deep_chunks_against_the_32_deep_routine(sd):
         assert np.array_equal(p1, q1[0])                                # predict_one == row 0 of the padded batch, same routine
 
 
+@pytest.mark.parametrize("A,B", [(4, 32), (6, 7)])
+def test_update_fused_with_next_conv1_is_bit_identical(sd, A, B):
+    """Round 3: inside train_many the optimizer pass of step i and conv1 of step i + 1 are ONE launch (upd_conv1_kernel: the online
+    conv1 workgroups wait for the 64 W1 blocks of the same launch, read W1 with sc1 loads and split it into bf16 planes themselves).
+    Against the two-launch form (option fuse_upd = 0) through calls of 5, 1 and 17 steps with a target sync in between, full and
+    ragged batch: weights, optimizer state, mean costs and the next predict bit-identical; the hand-off never times out (sync raises)."""
+    size = 3000
+    args = make_args(batch_size=B)
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 95, num_actions=A)
+    hold = random_minibatch(B, A, 96)[0]
+    outs = []
+    for fuse in (1, 0):
+        n, _ = _pair(sd, A, B, 97)
+        n.set_option("fuse_upd", fuse)
+        random.seed(98)
+        costs = [n.train_from_memory(mem, 5, want_cost=True)]
+        n.update_target_network()
+        costs.append(n.train_from_memory(mem, 1, want_cost=True))
+        costs.append(n.train_from_memory(mem, 17, want_cost=True))
+        n.sync()
+        outs.append((n.get_weights(0), n.get_weights(2), costs, n.predict(hold)))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, b)
+    assert outs[0][2] == outs[1][2] and np.array_equal(outs[0][3], outs[1][3])
+    assert not np.array_equal(outs[0][0][0], xavier_weights(A, 97)[0])                 # (W1 did move)
+
+
 def test_target_network_semantics(sd):
     A, B = 4, 8
     net, o = _pair(sd, A, B, 41)
