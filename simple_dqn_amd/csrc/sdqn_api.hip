@@ -431,7 +431,8 @@ struct sdqn_net_s {
   bool conv1_bf16 = true;                  // round 3: conv1_fwd on packed-bf16 MFMA (bytes x 3-way bf16 split of W1; sdqn_kernels_r3.hip)
   unsigned short* w1p[2] = {nullptr, nullptr};   // the three bf16 planes of W1, online / target net ([3][32][256] each)
   const int64_t* host_idx_cur = nullptr;   // ring paths: host copy of the indexes of the step being enqueued (valid during run_train only)
-  bool fuse_upd = true;                    // round 3: inside train_many, update(i) and conv1_fwd(i + 1) are ONE launch (sdqn_kernels_r3.hip: upd_conv1_kernel)
+  int fuse_dbg = 0;                        // experiment only: 1 = the online conv1 blocks do not wait (WRONG results, timing of the wait)
+  bool fuse_upd = false;                   // round 3: inside train_many, update(i) and conv1_fwd(i + 1) are ONE launch (sdqn_kernels_r3.hip: upd_conv1_kernel)
   bool has_pending_upd = false; UpdateArgs pending_upd;      // the deferred optimizer pass of the previous step (never outlives a train_many call)
   unsigned* w1_ctr = nullptr; unsigned w1_epochs = 0;        // [0] W1 blocks counted in (monotonic: 64 per fused launch), [1] sticky time-out word
   int conv1w_bf16 = 1;                 // round 3: conv1_wgrad on packed-bf16 MFMA (bytes x on-the-fly bf16 split of delta1)
@@ -843,7 +844,7 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int
     h->has_pending_upd = false;
     h->w1_epochs += 1;
     UpdateArgs pu = h->pending_upd; pu.w1_ctr = h->w1_ctr;
-    LAUNCH(K_UPD_CONV1, launch_upd_conv1(pu, fm, h->host_idx_cur, h->w1_ctr, 64u * h->w1_epochs, h->w1_ctr + 1, g_stream));
+    LAUNCH(K_UPD_CONV1, launch_upd_conv1(pu, fm, h->host_idx_cur, h->w1_ctr, h->fuse_dbg == 1 ? 0u : 64u * h->w1_epochs, h->w1_ctr + 1, g_stream));
   } else
   LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, fm, g_stream, 0, (h->conv1_bf16 && !h->hoist && h->nw_override[K_CONV1_FWD] == 0) ? 4 : 0));
   LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, fm, g_stream));
@@ -1352,6 +1353,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else if (!strcmp(name, "conv1_bf16")) h->conv1_bf16 = value != 0;     // 0: conv1_fwd on the fp32-MFMA engine (round-2 kernel)
+  else if (!strcmp(name, "fuse_dbg")) h->fuse_dbg = value;
   else if (!strcmp(name, "fuse_upd")) h->fuse_upd = value != 0;         // 0: the optimizer pass is always its own launch
   else if (!strcmp(name, "conv1w_bf16")) h->conv1w_bf16 = value;   // 0: conv1_wgrad on the fp32-MFMA engine (round-2 kernel)
   else if (!strcmp(name, "conv3_c36")) h->conv3_c36 = value != 0;       // 0: conv3_fwd on the engine's 32-deep chunks (round-2 kernel)
@@ -1503,6 +1505,12 @@ extern "C" int sdqn_debug_time_kernel(sdqn_net_t h, sdqn_replay_t r, const int64
     if (kernel == K_HEAD) { HeadArgs hd = head_args(h, 1); HIPCHK(launch_head(a, hd, g_stream)); }
     else if (kernel == 100 || kernel == 101) { h->host_idx_cur = idx_host; const hipError_t le = launch_tuned(h, K_CONV1_FWD, a, g_stream, 0, 4); h->host_idx_cur = nullptr; HIPCHK(le); }
     else if (kernel == 102) HIPCHK(launch_tuned(h, K_CONV3_FWD, a, g_stream, 0, 2));
+    else if (kernel == 103) {              // the fused update + conv1 launch (the update applies whatever the slabs hold: timing only)
+      UpdateArgs u = make_update_args(h, a); u.mode = 0; u.bsz = (float)h->B; u.skip_fc4 = 1; u.w1_ctr = h->w1_ctr;
+      h->w1_epochs += 1;
+      HIPCHK(launch_upd_conv1(u, a, idx_host, h->w1_ctr, 64u * h->w1_epochs, h->w1_ctr + 1, g_stream));
+    }
+    else if (kernel == 104) { UpdateArgs u = make_update_args(h, a); u.mode = 0; u.bsz = (float)h->B; u.skip_fc4 = 1; HIPCHK(launch_update(u, g_stream)); }
     else HIPCHK(launch_tuned(h, kernel, a, g_stream));
   }
   HIPCHK(hipStreamSynchronize(g_stream));

@@ -58,6 +58,10 @@ constexpr int FC5_BLOCKS_PER_ACTION = NFC / 4 / 32;   // 4 workgroups of 32 floa
 template <bool OVF, bool FUSED = false>
 __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bid, const int nblocks, float4 (*part)[32], float* cost_sh) {
   const int t = threadIdx.x;
+#ifdef SDQN_TIMING
+  SDQN_STAMP(0);
+  struct StampAtExit { __device__ ~StampAtExit() { SDQN_STAMP(7); } } stamp_at_exit_;
+#endif
   bool skip_apply = false;
   if constexpr (OVF) {
     skip_apply = u.ovf_flag[0] != 0;
