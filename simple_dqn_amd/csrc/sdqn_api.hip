@@ -431,6 +431,7 @@ struct sdqn_net_s {
   bool conv1_bf16 = true;                  // round 3: conv1_fwd on packed-bf16 MFMA (bytes x 3-way bf16 split of W1; sdqn_kernels_r3.hip)
   unsigned short* w1p[2] = {nullptr, nullptr};   // the three bf16 planes of W1, online / target net ([3][32][256] each)
   const int64_t* host_idx_cur = nullptr;   // ring paths: host copy of the indexes of the step being enqueued (valid during run_train only)
+  int fwd_rb = 0;                          // experiment: bit 0 conv2_fwd, bit 1 conv3_fwd on the 1 x 2 register-blocked routine (one workgroup per 32 x 64 block)
   int fuse_dbg = 0;                        // experiment only: 1 = the online conv1 blocks do not wait (WRONG results, timing of the wait)
   bool fuse_upd = false;                   // round 3: inside train_many, update(i) and conv1_fwd(i + 1) are ONE launch (sdqn_kernels_r3.hip: upd_conv1_kernel)
   bool has_pending_upd = false; UpdateArgs pending_upd;      // the deferred optimizer pass of the previous step (never outlives a train_many call)
@@ -847,9 +848,9 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int
     LAUNCH(K_UPD_CONV1, launch_upd_conv1(pu, fm, h->host_idx_cur, h->w1_ctr, h->fuse_dbg == 1 ? 0u : 64u * h->w1_epochs, h->w1_ctr + 1, g_stream));
   } else
   LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, fm, g_stream, 0, (h->conv1_bf16 && !h->hoist && h->nw_override[K_CONV1_FWD] == 0) ? 4 : 0));
-  LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, fm, g_stream));
+  LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, fm, g_stream, 0, (h->fwd_rb & 1) ? 16 : 0));
   { StepArgs f3 = fm; f3.xcd_map = a.xcd_map;
-    const int c36 = (h->conv3_c36 && !h->hoist && h->nw_override[K_CONV3_FWD] == 0) ? 2 : 0;      // (hoist: the riding target conv3 uses the 32-deep routine)
+    const int c36 = (h->fwd_rb & 2) ? 32 : ((h->conv3_c36 && !h->hoist && h->nw_override[K_CONV3_FWD] == 0) ? 2 : 0);      // (hoist: the riding target conv3 uses the 32-deep routine)
     LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, f3, g_stream, 0, c36)); }
   { int rc = join_comm(h); if (rc) return rc; }                // conv1..3 of this step overlap the previous step's fc4 all-reduce
   LAUNCH(K_FC4_FWD, launch_tuned(h, K_FC4_FWD, fm, g_stream));
@@ -1354,6 +1355,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else if (!strcmp(name, "conv1_bf16")) h->conv1_bf16 = value != 0;     // 0: conv1_fwd on the fp32-MFMA engine (round-2 kernel)
   else if (!strcmp(name, "fuse_dbg")) h->fuse_dbg = value;
+  else if (!strcmp(name, "fwd_rb")) h->fwd_rb = value;
   else if (!strcmp(name, "fuse_upd")) h->fuse_upd = value != 0;         // 0: the optimizer pass is always its own launch
   else if (!strcmp(name, "conv1w_bf16")) h->conv1w_bf16 = value;   // 0: conv1_wgrad on the fp32-MFMA engine (round-2 kernel)
   else if (!strcmp(name, "conv3_c36")) h->conv3_c36 = value != 0;       // 0: conv3_fwd on the engine's 32-deep chunks (round-2 kernel)

@@ -479,6 +479,11 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     } else hipLaunchKernelGGL(conv1_wgrad_bf16_kernel<false>, grid, dim3(1024), 0, s, c, ix);
     return hipGetLastError();
   }
+  // conv2 / conv3 forward with ONE workgroup per 32 x 64 output block (N = 64 = two 32-wide tiles): the register-blocked routine with
+  // 1 x 2 accumulators per wave loads the gathered A rows once for both tiles (the gather is the expensive operand: 64 cache lines per
+  // load instruction).  Same k order per accumulator as the unblocked tile: bit-identical.
+  if (id == K_CONV2_FWD && (t.r3 & 16) && a.B < 128 && !a.h16 && !a.bn) return launch_gemm<RB<Conv2Fwd, 1, 2>, 16>(a, s);
+  if (id == K_CONV3_FWD && (t.r3 & 32) && a.B < 128 && !a.h16 && !a.bn) return launch_gemm<RB<Conv3Fwd, 1, 2>, 16>(a, s);
   if (id == K_CONV3_FWD && (t.r3 & 2) && a.B < 128 && !a.h16 && !a.bn) {
     static_assert(CRS3 == 16 * 36, "conv3's K is 16 chunks of 36");
     const dim3 grid((Conv3Fwd::M(a) + 31) / 32, (Conv3Fwd::N(a) + 31) / 32, Conv3Fwd::nbz(a));
