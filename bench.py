@@ -733,8 +733,11 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run(a.steps)
+    t_enq = time.perf_counter() - t0                                 # (diagnostic only: when the host had enqueued everything)
     barrier()
     el = time.perf_counter() - t0
+    if os.environ.get("SDQN_BENCH_TRACE"):
+        sys.stderr.write("trace: enqueue returned after %.1f us, region %.1f us (%d steps)\n" % (t_enq * 1e6, el * 1e6, a.steps))
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
