@@ -136,6 +136,7 @@ struct LaunchTune {
                             // this step's target conv3 / fc4 and compute the online net only (StepArgs::nz = 1)
   int order;                // experiment (option "bwd_order"): order of the problems inside the fused backward launches
   const int64_t* host_idx;  // ring paths, B <= 32: this step's sampled indexes in HOST memory (they ride in the kernel arguments of conv1_bf16_kernel)
+  int r3_xcd;               // round-3 kernels' XCD-contiguous tile maps: bit 0 conv1_fwd (bf16), bit 1 conv1_wgrad (bf16)
   int r3;                   // round-3 launch variants (sdqn_kernels_r3.hip); bit 0: this K_FC4_DGRAD launch also carries the fc4_wgrad tiles; bit 1: conv3_fwd on 36-deep K-chunks; bit 2: conv1_fwd on packed-bf16 MFMA
 };
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s);     // the GEMM-shaped stages (single or multi-problem launches)
@@ -149,7 +150,7 @@ hipError_t launch_prep(const PrepArgs& p, hipStream_t s, double* zero8 = nullptr
 hipError_t launch_grad_to_half(const float* g, half_t* gh, int64_t n, int* state, hipStream_t s);       // fp16 DP payload; state = {flag, log2 scale, good steps}
 hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, int* state, hipStream_t s);
 // round 3: update(i) + conv1_fwd(i + 1) as one launch (sdqn_kernels_r3.hip); u.skip_fc4 must be 1, u.w1_ctr == ctr
-hipError_t launch_upd_conv1(const UpdateArgs& u, const StepArgs& a, const int64_t* host_idx, unsigned* ctr, unsigned target, unsigned* timeout, hipStream_t s);
+hipError_t launch_upd_conv1(const UpdateArgs& u, const StepArgs& a, const int64_t* host_idx, unsigned* ctr, unsigned target, unsigned* timeout, int xcd, hipStream_t s);
 hipError_t launch_w1_planes(const float* theta, unsigned short* w1p, hipStream_t s);   // conv1's three bf16 weight planes of one net (problems.h: split_bf16x3)
 hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s);   // fp16 mode: rebuild both half copies
 

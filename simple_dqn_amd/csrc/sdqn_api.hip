@@ -432,6 +432,7 @@ struct sdqn_net_s {
   bool conv1_bf16 = true;                  // round 3: conv1_fwd on packed-bf16 MFMA (bytes x 3-way bf16 split of W1; sdqn_kernels_r3.hip)
   unsigned short* w1p[2] = {nullptr, nullptr};   // the three bf16 planes of W1, online / target net ([3][32][256] each)
   const int64_t* host_idx_cur = nullptr;   // ring paths: host copy of the indexes of the step being enqueued (valid during run_train only)
+  int r3_xcd = 2;                          // XCD-contiguous tile maps of the round-3 kernels: bit 0 conv1_fwd (bf16), bit 1 conv1_wgrad (bf16)
   int fwd_rb = 0;                          // experiment: bit 0 conv2_fwd, bit 1 conv3_fwd on the 1 x 2 register-blocked routine (one workgroup per 32 x 64 block)
   bool handoff_launched = false;           // a launch with an in-launch hand-off (f4w_early / fuse_upd) was enqueued since the last sync
   int fuse_dbg = 0;                        // experiment only: 1 = the online conv1 blocks do not wait (WRONG results, timing of the wait)
@@ -801,7 +802,7 @@ static hipError_t launch_tuned(sdqn_net_s* h, int id, StepArgs a, hipStream_t s,
   XCD_TUNE(a, id);
   LaunchTune t;
   for (int i = 0; i < 12; ++i) { t.nw_override[i] = h->nw_override[i]; t.rb[i] = h->rb[i]; }
-  t.hoist = hoist; t.order = h->bwd_order; t.r3 = r3; t.host_idx = h->host_idx_cur;
+  t.hoist = hoist; t.order = h->bwd_order; t.r3 = r3; t.host_idx = h->host_idx_cur; t.r3_xcd = h->r3_xcd;
   return launch_kernel(id, a, t, s);
 }
 static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int hoist = 0) {
@@ -847,7 +848,7 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int
     h->has_pending_upd = false; h->handoff_launched = true;
     h->w1_epochs += 1;
     UpdateArgs pu = h->pending_upd; pu.w1_ctr = h->w1_ctr;
-    LAUNCH(K_UPD_CONV1, launch_upd_conv1(pu, fm, h->host_idx_cur, h->w1_ctr, h->fuse_dbg == 1 ? 0u : 64u * h->w1_epochs, h->w1_ctr + 1, g_stream));
+    LAUNCH(K_UPD_CONV1, launch_upd_conv1(pu, fm, h->host_idx_cur, h->w1_ctr, h->fuse_dbg == 1 ? 0u : 64u * h->w1_epochs, h->w1_ctr + 1, h->r3_xcd & 1, g_stream));
   } else
   LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, fm, g_stream, 0, (h->conv1_bf16 && !h->hoist && h->nw_override[K_CONV1_FWD] == 0) ? 4 : 0));
   LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, fm, g_stream, 0, (h->fwd_rb & 1) ? 16 : 0));
@@ -1368,6 +1369,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "conv1_bf16")) h->conv1_bf16 = value != 0;     // 0: conv1_fwd on the fp32-MFMA engine (round-2 kernel)
   else if (!strcmp(name, "fuse_dbg")) h->fuse_dbg = value;
   else if (!strcmp(name, "fwd_rb")) h->fwd_rb = value;
+  else if (!strcmp(name, "r3_xcd")) h->r3_xcd = value;
   else if (!strcmp(name, "fuse_upd")) h->fuse_upd = value != 0;         // 0: the optimizer pass is always its own launch
   else if (!strcmp(name, "conv1w_bf16")) h->conv1w_bf16 = value;   // 0: conv1_wgrad on the fp32-MFMA engine (round-2 kernel)
   else if (!strcmp(name, "conv3_c36")) h->conv3_c36 = value != 0;       // 0: conv3_fwd on the engine's 32-deep chunks (round-2 kernel)
@@ -1522,7 +1524,7 @@ extern "C" int sdqn_debug_time_kernel(sdqn_net_t h, sdqn_replay_t r, const int64
     else if (kernel == 103) {              // the fused update + conv1 launch (the update applies whatever the slabs hold: timing only)
       UpdateArgs u = make_update_args(h, a); u.mode = 0; u.bsz = (float)h->B; u.skip_fc4 = 1; u.w1_ctr = h->w1_ctr;
       h->w1_epochs += 1;
-      HIPCHK(launch_upd_conv1(u, a, idx_host, h->w1_ctr, 64u * h->w1_epochs, h->w1_ctr + 1, g_stream));
+      HIPCHK(launch_upd_conv1(u, a, idx_host, h->w1_ctr, 64u * h->w1_epochs, h->w1_ctr + 1, h->r3_xcd & 1, g_stream));
     }
     else if (kernel == 104) { UpdateArgs u = make_update_args(h, a); u.mode = 0; u.bsz = (float)h->B; u.skip_fc4 = 1; HIPCHK(launch_update(u, g_stream)); }
     else HIPCHK(launch_tuned(h, kernel, a, g_stream));

@@ -104,7 +104,7 @@ constexpr int W1P_PITCH = CRS1 + 8;
 // candidates (a 32-row tile touches at most two samples) come out with v_readlane: no dependent global load, no second scalar trip.
 struct Conv1Args {
   const uint8_t* src; float* a1; const unsigned short* w1p[2]; const int64_t* idx;
-  int B, nz, from_ring, tiles_per_net, wgs_per_net, tpw;
+  int B, nz, from_ring, tiles_per_net, wgs_per_net, tpw, xcd, pad_;
 };
 struct IdxIn { int64_t v[32]; };
 
@@ -128,7 +128,8 @@ __device__ __forceinline__ void conv1_bf16_body(const Conv1Args& c, const int64_
     int g0 = c.B, g1 = c.from_ring, g2 = c.tiles_per_net, g3 = c.wgs_per_net, g4 = c.tpw;
     asm volatile("" :: "s"(f0), "s"(f1), "s"(f2), "s"(f3), "s"(f4), "s"(g0), "s"(g1), "s"(g2), "s"(g3), "s"(g4));
   }
-  const int zi = cb / c.wgs_per_net, wg = cb - zi * c.wgs_per_net;
+  // (XCD-contiguous map inside each net: neighbouring tiles share frames and halo rows)
+  const int zi = cb / c.wgs_per_net, wg = c.xcd ? xcd_tile_id(cb - zi * c.wgs_per_net, c.wgs_per_net) : cb - zi * c.wgs_per_net;
   const int z = FUSED ? 1 - zi : zi;                                                         // 0 online, 1 target (nz = 1: online only); FUSED: target first
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int M = c.B * PIX1, tiles_per_net = c.tiles_per_net, tpw = c.tpw;
@@ -313,7 +314,7 @@ __global__ void __launch_bounds__(256) upd_conv1_kernel(const UpdateArgs u, cons
 // waves x one 32-deep chunk each, same slab layout and fixed-order LDS combine as the engine's Conv1Wgrad -> the update kernel reads it
 // unchanged.  A: lane (row, h) takes two aligned groups of 4 consecutive output positions with ONE unaligned 16-byte ring load each
 // (bytes 0, 4, 8, 12: the engine's A_GROUP4 trick); the groups' (sample, y, x) are wave-uniform per half-wave: scalar index math.
-struct C1wArgs { const uint8_t* src; const float* d1; float* slab1; const int64_t* idx; int B, from_ring, tps1, Kt; };
+struct C1wArgs { const uint8_t* src; const float* d1; float* slab1; const int64_t* idx; int B, from_ring, tps1, Kt, xcd, pad_; };
 
 template <bool IDX_IN>
 __global__ void __launch_bounds__(1024) conv1_wgrad_bf16_kernel(const C1wArgs c, const IdxIn ix) {
@@ -331,7 +332,11 @@ __global__ void __launch_bounds__(1024) conv1_wgrad_bf16_kernel(const C1wArgs c,
     asm volatile("" :: "s"(f0), "s"(f1), "s"(f2), "s"(f4), "s"(g0), "s"(g1), "s"(g2), "s"(g3));
   }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bx = blockIdx.x, ks = blockIdx.z;
+  // XCD-contiguous tile map (gemm_engine.h: xcd_tile_id): the 8 row tiles of a K slab read the same frames and deltas, so a slab belongs on
+  // ONE XCD's L2 (workgroup b runs on XCD b % 8: without the map a slab's 8 tiles land on 8 different L2s, 5.6x the algorithmic traffic)
+  const int lin = (int)(blockIdx.x + gridDim.x * blockIdx.z);
+  const int tl = c.xcd ? xcd_tile_id(lin, (int)(gridDim.x * gridDim.z)) : lin;
+  const int bx = tl & 7, ks = tl >> 3;
   const int m = 32 * bx + i;
   const int colm = (m >> 6) * FRAME + ((m >> 3) & 7) * W0 + (m & 7);                         // problems.h: col1
   const int Kt = c.Kt, kb = ks * c.tps1 * 32;
@@ -424,10 +429,10 @@ __global__ void __launch_bounds__(1024) conv1_wgrad_bf16_kernel(const C1wArgs c,
   }
 }
 
-hipError_t launch_upd_conv1(const UpdateArgs& u, const StepArgs& a, const int64_t* host_idx, unsigned* ctr, unsigned target, unsigned* timeout, hipStream_t s) {
+hipError_t launch_upd_conv1(const UpdateArgs& u, const StepArgs& a, const int64_t* host_idx, unsigned* ctr, unsigned target, unsigned* timeout, int xcd, hipStream_t s) {
   const int tiles = (a.B * PIX1 + 31) / 32, wgs = (tiles + 3) / 4;
   Conv1Args c; c.src = a.src; c.a1 = a.a1; c.w1p[0] = a.w1p[0]; c.w1p[1] = a.w1p[1]; c.idx = a.idx;
-  c.B = a.B; c.nz = 2; c.from_ring = 1; c.tiles_per_net = tiles; c.wgs_per_net = wgs; c.tpw = 1;
+  c.B = a.B; c.nz = 2; c.from_ring = 1; c.tiles_per_net = tiles; c.wgs_per_net = wgs; c.tpw = 1; c.xcd = xcd; c.pad_ = 0;
   IdxIn ix; memset(ix.v, 0, sizeof ix.v); memcpy(ix.v, host_idx, (size_t)a.B * sizeof(int64_t));
   FusedW1 fw; fw.theta = a.theta[0]; fw.ctr = ctr; fw.target = target; fw.timeout = timeout;
   const int n_upd = CONV_BLOCKS + u.A * FC5_BLOCKS_PER_ACTION + 2;                          // launch_update's grid with the fc4 part fused into bwd3
@@ -455,8 +460,8 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
   if (id == K_CONV1_FWD && (t.r3 & 4) && !a.h16 && !a.bn && a.w1p[0] && a.w1p[a.nz > 1 ? 1 : 0]) {
     const int tiles = (a.B * PIX1 + 31) / 32, tpw = a.B >= 128 ? 4 : 1, wgs = (tiles + 4 * tpw - 1) / (4 * tpw);
     Conv1Args c; c.src = a.src; c.a1 = a.a1; c.w1p[0] = a.w1p[0]; c.w1p[1] = a.w1p[1]; c.idx = a.idx;
-    c.B = a.B; c.nz = a.nz; c.from_ring = a.from_ring; c.tiles_per_net = tiles; c.wgs_per_net = wgs; c.tpw = tpw;
-    static_assert(sizeof(Conv1Args) == 64 && sizeof(Conv1Args) % 8 == 0, "one 64-byte scalar load; the index block follows 8-byte aligned");
+    c.B = a.B; c.nz = a.nz; c.from_ring = a.from_ring; c.tiles_per_net = tiles; c.wgs_per_net = wgs; c.tpw = tpw; c.xcd = t.r3_xcd & 1; c.pad_ = 0;
+    static_assert(sizeof(Conv1Args) == 72, "the index block follows 8-byte aligned at byte 72");
     IdxIn ix;
     if (t.host_idx && a.from_ring && a.B <= 32) {
       memset(ix.v, 0, sizeof ix.v);
@@ -469,8 +474,8 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     return hipGetLastError();
   }
   if ((id == K_BWD1 || id == K_CONV1_WGRAD) && (t.r3 & 8) && (id == K_CONV1_WGRAD || a.f4w_count == 0) && !a.h16 && !a.bn) {
-    C1wArgs c; c.src = a.src; c.d1 = a.d1; c.slab1 = a.slab1; c.idx = a.idx; c.B = a.B; c.from_ring = a.from_ring; c.tps1 = a.tps1; c.Kt = a.B * PIX1;
-    static_assert(sizeof(C1wArgs) == 48, "the index block follows at byte 48 of the argument segment");
+    C1wArgs c; c.src = a.src; c.d1 = a.d1; c.slab1 = a.slab1; c.idx = a.idx; c.B = a.B; c.from_ring = a.from_ring; c.tps1 = a.tps1; c.Kt = a.B * PIX1; c.xcd = (t.r3_xcd >> 1) & 1; c.pad_ = 0;
+    static_assert(sizeof(C1wArgs) == 56, "the index block follows at byte 56 of the argument segment");
     const dim3 grid(CRS1 / 32, 1, Conv1Wgrad::nbz(a));
     IdxIn ix; memset(ix.v, 0, sizeof ix.v);
     if (t.host_idx && a.from_ring && a.B <= 32) {
