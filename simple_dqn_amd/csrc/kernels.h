@@ -46,6 +46,11 @@ struct PrepArgs {                // pinned index slot + ring metadata -> device-
   int64_t* rewards;
   uint8_t* terminals;
   int B;
+  // B <= 32: the indexes themselves (host data at launch time) ride in the kernel arguments, so the prep block of the update launch
+  // starts with a load from the argument segment instead of a zero-copy read of pinned host memory over PCIe (~2 us: it was the longest
+  // dependency chain of the whole update launch)
+  int idx_in_valid;
+  int64_t idx_in[32];
 };
 
 struct UpdateArgs {
@@ -137,6 +142,7 @@ struct LaunchTune {
   int order;                // experiment (option "bwd_order"): order of the problems inside the fused backward launches
   const int64_t* host_idx;  // ring paths, B <= 32: this step's sampled indexes in HOST memory (they ride in the kernel arguments of conv1_bf16_kernel)
   int r3_xcd;               // round-3 kernels' XCD-contiguous tile maps: bit 0 conv1_fwd (bf16), bit 1 conv1_wgrad (bf16)
+  int wt;                   // write-through (sc1) epilogue stores per launch: 1 conv2_fwd, 2 conv3_fwd, 4 fc4_fwd, 8 fc4_dgrad, 16 bwd3, 32 bwd2, 64 conv1_wgrad, 128 conv1_fwd
   int r3;                   // round-3 launch variants (sdqn_kernels_r3.hip); bit 0: this K_FC4_DGRAD launch also carries the fc4_wgrad tiles; bit 1: conv3_fwd on 36-deep K-chunks; bit 2: conv1_fwd on packed-bf16 MFMA
 };
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s);     // the GEMM-shaped stages (single or multi-problem launches)

@@ -433,6 +433,8 @@ struct sdqn_net_s {
   unsigned short* w1p[2] = {nullptr, nullptr};   // the three bf16 planes of W1, online / target net ([3][32][256] each)
   const int64_t* host_idx_cur = nullptr;   // ring paths: host copy of the indexes of the step being enqueued (valid during run_train only)
   int r3_xcd = 2;                          // XCD-contiguous tile maps of the round-3 kernels: bit 0 conv1_fwd (bf16), bit 1 conv1_wgrad (bf16)
+  bool prep_inline = true;                 // B <= 32: the next step's indexes ride in the update launch's kernel arguments (no PCIe read in its prep block)
+  int wt = 247;                            // write-through epilogue stores, bit per launch (kernels.h: LaunchTune::wt); all but fc4_dgrad (measured -0.15 %)
   int fwd_rb = 0;                          // experiment: bit 0 conv2_fwd, bit 1 conv3_fwd on the 1 x 2 register-blocked routine (one workgroup per 32 x 64 block)
   bool handoff_launched = false;           // a launch with an in-launch hand-off (f4w_early / fuse_upd) was enqueued since the last sync
   int fuse_dbg = 0;                        // experiment only: 1 = the online conv1 blocks do not wait (WRONG results, timing of the wait)
@@ -802,7 +804,7 @@ static hipError_t launch_tuned(sdqn_net_s* h, int id, StepArgs a, hipStream_t s,
   XCD_TUNE(a, id);
   LaunchTune t;
   for (int i = 0; i < 12; ++i) { t.nw_override[i] = h->nw_override[i]; t.rb[i] = h->rb[i]; }
-  t.hoist = hoist; t.order = h->bwd_order; t.r3 = r3; t.host_idx = h->host_idx_cur; t.r3_xcd = h->r3_xcd;
+  t.hoist = hoist; t.order = h->bwd_order; t.r3 = r3; t.host_idx = h->host_idx_cur; t.r3_xcd = h->r3_xcd; t.wt = h->wt;
   return launch_kernel(id, a, t, s);
 }
 static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int hoist = 0) {
@@ -1148,8 +1150,13 @@ extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8
 }
 
 static PrepArgs prep_args(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pinned_idx) {
-  PrepArgs p; p.idx_pinned = pinned_idx; p.meta = r->d_meta; p.idx = h->d_idx; p.actions = h->st_act;
+  PrepArgs p; memset(&p, 0, sizeof p);
+  p.idx_pinned = pinned_idx; p.meta = r->d_meta; p.idx = h->d_idx; p.actions = h->st_act;
   p.rewards = h->st_rew; p.terminals = h->st_term; p.B = h->B;
+  if (h->B <= 32 && h->prep_inline) {            // the slot's host copy (pinned_idx is its device alias)
+    memcpy(p.idx_in, r->h_idx + (pinned_idx - r->d_idx_view), (size_t)h->B * sizeof(int64_t));
+    p.idx_in_valid = 1;
+  }
   return p;
 }
 // ring paths take (a, r, t) from the ring: an action the network has no output for would index past the Q row in the
@@ -1369,6 +1376,8 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "conv1_bf16")) h->conv1_bf16 = value != 0;     // 0: conv1_fwd on the fp32-MFMA engine (round-2 kernel)
   else if (!strcmp(name, "fuse_dbg")) h->fuse_dbg = value;
   else if (!strcmp(name, "fwd_rb")) h->fwd_rb = value;
+  else if (!strcmp(name, "wt")) h->wt = value;
+  else if (!strcmp(name, "prep_inline")) h->prep_inline = value != 0;
   else if (!strcmp(name, "r3_xcd")) h->r3_xcd = value;
   else if (!strcmp(name, "fuse_upd")) h->fuse_upd = value != 0;         // 0: the optimizer pass is always its own launch
   else if (!strcmp(name, "conv1w_bf16")) h->conv1w_bf16 = value;   // 0: conv1_wgrad on the fp32-MFMA engine (round-2 kernel)

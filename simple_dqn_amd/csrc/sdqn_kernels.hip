@@ -39,7 +39,7 @@ hipError_t launch_kernel_ext(int id, const StepArgs& a, const LaunchTune& t, hip
 hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled);
 
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s) {
-  if (t.r3) {                  // round-3 launch variants live in their own translation unit (same reason as sdqn_kernels_ext.hip)
+  if (t.r3 || t.wt) {          // round-3 launch variants live in their own translation unit (same reason as sdqn_kernels_ext.hip)
     bool handled = false;
     const hipError_t e = launch_kernel_r3(id, a, t, s, &handled);
     if (handled) return e;
@@ -357,8 +357,9 @@ hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, int* sta
 // later kernel of the step touches host memory.
 __global__ void __launch_bounds__(256) prep_kernel(const PrepArgs p, double* zero8) {
   if (zero8 && threadIdx.x == 0) *zero8 = 0.0;                    // the cost accumulator of a train_many call (instead of a memset launch)
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(PrepArgs, idx_in);      // (first kernel parameter)
   for (int n = threadIdx.x; n < p.B; n += 256) {
-    const int64_t i = p.idx_pinned[n];
+    const int64_t i = p.idx_in_valid ? *reinterpret_cast<const int64_t*>(ka + 8 * (n & 31)) : p.idx_pinned[n];
     p.idx[n] = i;
     const MetaRec rec = p.meta[i];
     p.actions[n] = rec.action; p.rewards[n] = rec.reward; p.terminals[n] = rec.terminal;

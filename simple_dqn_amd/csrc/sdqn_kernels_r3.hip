@@ -17,6 +17,66 @@
 
 namespace sdqn {
 
+// ---- write-through epilogues ----------------------------------------------------------------------------------------------------
+// A kernel boundary writes back every dirty L2 line its predecessor left; a stage whose output leaves with write-through (sc1) stores
+// while it still computes has nothing left to flush (tools/exp/handoff_r3.hip section D: ~0.03 us per MB at the next boundary; in the
+// step, where the next launch waits for exactly those bytes, a1 alone was worth 0.7 us).  Same problems, same arithmetic, only the
+// store instruction of the epilogue differs: results are bit-identical.  LaunchTune::wt selects them per launch.
+__device__ __forceinline__ void wt_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+struct Conv2FwdWT : Conv2Fwd {
+  __device__ static void store(const StepArgs& a, int z, int, int m, int n, float v) { wt_store(&a.a2[((int64_t)z * M(a) + m) * K2 + n], fmaxf(v, 0.0f)); }
+};
+struct Conv3FwdWT : Conv3Fwd {
+  __device__ static void store(const StepArgs& a, int z, int, int m, int n, float v) { wt_store(&a.a3[((int64_t)z * M(a) + m) * K3 + n], fmaxf(v, 0.0f)); }
+};
+struct Fc4FwdWT : Fc4Fwd {
+  __device__ static void store(const StepArgs& a, int z, int ks, int m, int n, float v) { wt_store(&a.slab4[(((int64_t)ks * 2 + z) * a.B + m) * NFC + n], v); }
+};
+struct Fc4DgradWT : Fc4Dgrad {
+  __device__ static void store(const StepArgs& a, int, int, int m, int n, float v) {
+    const int pix = n >> 6, f = n & 63, p = pix / Q3, q = pix - p * Q3;
+    const float dv = a.a3[(int64_t)m * NIN4 + n] > 0.0f ? v : 0.0f;
+    wt_store(&a.d3p[((m * PD3 + p + 2) * PD3 + q + 2) * K3 + f], dv);
+    wt_store(&a.d3[(int64_t)m * NIN4 + n], dv);
+  }
+};
+struct Conv3DgradWT : Conv3Dgrad {
+  __device__ static void store(const StepArgs& a, int, int, int m, int c, float v) {
+    const float dv = a.a2[(int64_t)m * K2 + c] > 0.0f ? v : 0.0f;
+    wt_store(&a.d2p[prow2(m) + c], dv);
+    wt_store(&a.d2[(int64_t)m * K2 + c], dv);
+  }
+};
+struct Conv3WgradWT : Conv3Wgrad {
+  __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab3[(int64_t)ks * NW3 + m * K3 + n], v); }
+};
+struct Conv2DgradWT : Conv2Dgrad {
+  __device__ static void store(const StepArgs& a, int z, int, int m, int c, float v) {
+    const int py = z >> 1, px = z & 1;
+    const int n = m / 100, pix = m - n * 100, i = pix / 10, j = pix - i * 10;
+    const int o = ((n * P1 + 2 * i + py) * Q1 + 2 * j + px) * K1 + c;
+    wt_store(&a.d1[o], a.a1[o] > 0.0f ? v : 0.0f);
+  }
+};
+struct Conv2WgradWT : Conv2Wgrad {
+  __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab2[(int64_t)ks * NW2 + m * K2 + n], v); }
+};
+struct Fc4WgradWT : Fc4Wgrad {          // the 12.8 MB of new W4 + RMSProp state (or the 6.4 MB gradient) leave write-through
+  __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi& e) {
+    const uint32_t base = epi_base(m0, n0, lane);
+    auto stw = [](float* p, uint32_t off, float x) { wt_store(reinterpret_cast<float*>(reinterpret_cast<char*>(p) + off), x); };
+    if (!a.fuse_rms) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stw(a.g, base + epi_row(r), v[r]);
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) rms_step2(e.w[r], e.w[r + 1], e.st[r], e.st[r + 1], v[r], v[r + 1], a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { stw(a.theta_w, base + epi_row(r), e.w[r]); stw(a.state, base + epi_row(r), e.st[r]); }
+  }
+};
+
 // ---- conv3 forward with 36-deep K-chunks -----------------------------------------------------------------------------------
 // K = 576 = 18 chunks of 32: over the 16 waves of a tile that is two waves with TWO chunks and fourteen with one — and the
 // direct-load routine has no prefetch across chunks, so the tile's life is two serial (operand round trip + 16 MFMAs) legs:
@@ -257,7 +317,11 @@ __device__ __forceinline__ void conv1_bf16_body(const Conv1Args& c, const int64_
     float* out = c.a1 + ((int64_t)z * M + m0 + 4 * h) * K1 + i;
     if (m0 + 32 <= M) {                                                                       // full tile (wave-uniform): no per-row guard
 #pragma unroll
-      for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2)) * K1] = fmaxf(div255((acc0[r] + acc1[r]) + acc2[r]), 0.0f);
+      for (int r = 0; r < 16; ++r) {
+        const float v = fmaxf(div255((acc0[r] + acc1[r]) + acc2[r]), 0.0f);
+        if (c.pad_) wt_store(out + ((r & 3) + 8 * (r >> 2)) * K1, v);             // write-through (LaunchTune::wt bit 7)
+        else out[((r & 3) + 8 * (r >> 2)) * K1] = v;
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -425,7 +489,8 @@ __global__ void __launch_bounds__(1024) conv1_wgrad_bf16_kernel(const C1wArgs c,
     float v = smem[ml * 33 + nl];
 #pragma unroll
     for (int w = 1; w < 16; ++w) v += smem[w * PANEL + ml * 33 + nl];                       // fixed order
-    c.slab1[(int64_t)ks * NW1 + (32 * bx + ml) * K1 + nl] = div255(v);
+    float* dst = c.slab1 + (int64_t)ks * NW1 + (32 * bx + ml) * K1 + nl;
+    if (c.pad_) wt_store(dst, div255(v)); else *dst = div255(v);
   }
 }
 
@@ -460,7 +525,7 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
   if (id == K_CONV1_FWD && (t.r3 & 4) && !a.h16 && !a.bn && a.w1p[0] && a.w1p[a.nz > 1 ? 1 : 0]) {
     const int tiles = (a.B * PIX1 + 31) / 32, tpw = a.B >= 128 ? 4 : 1, wgs = (tiles + 4 * tpw - 1) / (4 * tpw);
     Conv1Args c; c.src = a.src; c.a1 = a.a1; c.w1p[0] = a.w1p[0]; c.w1p[1] = a.w1p[1]; c.idx = a.idx;
-    c.B = a.B; c.nz = a.nz; c.from_ring = a.from_ring; c.tiles_per_net = tiles; c.wgs_per_net = wgs; c.tpw = tpw; c.xcd = t.r3_xcd & 1; c.pad_ = 0;
+    c.B = a.B; c.nz = a.nz; c.from_ring = a.from_ring; c.tiles_per_net = tiles; c.wgs_per_net = wgs; c.tpw = tpw; c.xcd = t.r3_xcd & 1; c.pad_ = (t.wt >> 7) & 1;
     static_assert(sizeof(Conv1Args) == 72, "the index block follows 8-byte aligned at byte 72");
     IdxIn ix;
     if (t.host_idx && a.from_ring && a.B <= 32) {
@@ -474,7 +539,7 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     return hipGetLastError();
   }
   if ((id == K_BWD1 || id == K_CONV1_WGRAD) && (t.r3 & 8) && (id == K_CONV1_WGRAD || a.f4w_count == 0) && !a.h16 && !a.bn) {
-    C1wArgs c; c.src = a.src; c.d1 = a.d1; c.slab1 = a.slab1; c.idx = a.idx; c.B = a.B; c.from_ring = a.from_ring; c.tps1 = a.tps1; c.Kt = a.B * PIX1; c.xcd = (t.r3_xcd >> 1) & 1; c.pad_ = 0;
+    C1wArgs c; c.src = a.src; c.d1 = a.d1; c.slab1 = a.slab1; c.idx = a.idx; c.B = a.B; c.from_ring = a.from_ring; c.tps1 = a.tps1; c.Kt = a.B * PIX1; c.xcd = (t.r3_xcd >> 1) & 1; c.pad_ = (t.wt >> 6) & 1;
     static_assert(sizeof(C1wArgs) == 56, "the index block follows at byte 56 of the argument segment");
     const dim3 grid(CRS1 / 32, 1, Conv1Wgrad::nbz(a));
     IdxIn ix; memset(ix.v, 0, sizeof ix.v);
@@ -487,12 +552,20 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
   // conv2 / conv3 forward with ONE workgroup per 32 x 64 output block (N = 64 = two 32-wide tiles): the register-blocked routine with
   // 1 x 2 accumulators per wave loads the gathered A rows once for both tiles (the gather is the expensive operand: 64 cache lines per
   // load instruction).  Same k order per accumulator as the unblocked tile: bit-identical.
+  if (a.B <= 32 && !a.h16 && !a.bn && t.wt && !t.hoist && !t.order && !(id >= 0 && id < 12 && t.nw_override[id] > 0)) {       // write-through epilogues: the default launch forms with the *WT problems
+    if (id == K_CONV2_FWD && (t.wt & 1) && !(t.r3 & 16)) return launch_gemm<Conv2FwdWT, 16>(a, s);
+    if (id == K_FC4_FWD && (t.wt & 4)) return launch_gemm<Staged<Fc4FwdWT>, 14>(a, s);
+    if (id == K_FC4_DGRAD && (t.wt & 8) && !(t.r3 & 1)) return launch_gemm<Staged<Fc4DgradWT>, 16>(a, s);
+    if (id == K_BWD3 && (t.wt & 16) && a.f4w_count > 0) return launch_multi<512, Staged<Conv3DgradWT>, 8, Conv3WgradWT, 8, Fc4WgradWT, 1>(a, true, true, s);
+    if (id == K_BWD2 && (t.wt & 32) && a.f4w_count == 0) return launch_multi<512, NoProblem, 2, Conv2DgradWT, 8, Conv2WgradWT, 8>(a, true, true, s);
+  }
   if (id == K_CONV2_FWD && (t.r3 & 16) && a.B < 128 && !a.h16 && !a.bn) return launch_gemm<RB<Conv2Fwd, 1, 2>, 16>(a, s);
   if (id == K_CONV3_FWD && (t.r3 & 32) && a.B < 128 && !a.h16 && !a.bn) return launch_gemm<RB<Conv3Fwd, 1, 2>, 16>(a, s);
   if (id == K_CONV3_FWD && (t.r3 & 2) && a.B < 128 && !a.h16 && !a.bn) {
     static_assert(CRS3 == 16 * 36, "conv3's K is 16 chunks of 36");
     const dim3 grid((Conv3Fwd::M(a) + 31) / 32, (Conv3Fwd::N(a) + 31) / 32, Conv3Fwd::nbz(a));
-    hipLaunchKernelGGL((gemm36_kernel<Conv3Fwd>), grid, dim3(1024), 0, s, a);
+    if ((t.wt & 2) && a.B <= 32) hipLaunchKernelGGL((gemm36_kernel<Conv3FwdWT>), grid, dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL((gemm36_kernel<Conv3Fwd>), grid, dim3(1024), 0, s, a);
     return hipGetLastError();
   }
   *handled = false;

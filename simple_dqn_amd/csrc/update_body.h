@@ -2,6 +2,7 @@
 // device function, so that both the plain update launch (sdqn_kernels.hip) and round 3's fused "update + next step's conv1" launch
 // (sdqn_kernels_r3.hip) run the very same code.
 #pragma once
+#include <cstddef>
 #include "kernels.h"
 
 namespace sdqn {
@@ -166,8 +167,10 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bid, 
     }
   }
   if (u.next.B > 0 && bid == first_dense) {             // next step's prep rides along (every reader of idx is done)
+    // (UpdateArgs is the first kernel parameter of both launches that run this body: its offset in the argument segment is 0)
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(UpdateArgs, next) + offsetof(PrepArgs, idx_in);
     for (int n = t; n < u.next.B; n += 256) {
-      const int64_t i = u.next.idx_pinned[n];
+      const int64_t i = u.next.idx_in_valid ? *reinterpret_cast<const int64_t*>(ka + 8 * (n & 31)) : u.next.idx_pinned[n];
       u.next.idx[n] = i;
       const MetaRec rec = u.next.meta[i];
       u.next.actions[n] = rec.action; u.next.rewards[n] = rec.reward; u.next.terminals[n] = rec.terminal;
