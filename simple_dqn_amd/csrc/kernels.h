@@ -77,6 +77,7 @@ struct UpdateArgs {
   half_t* wh;                   // fp16 mode: half copies of theta refreshed by the update (master layout / transposed)
   half_t* wht;
   unsigned short* w1p;          // conv1's three bf16 planes of the ONLINE net, rewritten with W1 (nullptr: not maintained)
+  int wt;                       // 1: the new parameters / optimizer state leave with write-through (sc1) stores
   unsigned* w1_ctr;             // fused update + conv1 launch only: counts the W1 blocks whose write-through stores are out (monotonic across launches)
   int64_t bn_first;             // --batch_norm: element offset of the [beta|gamma] block (bn_update_kernel); BN_PARAMS elements
   const int* ovf_flag;          // fp16 data parallel (update_kernel<true>): != 0 -> the all-reduced half gradient overflowed, leave theta / state untouched

@@ -434,7 +434,7 @@ struct sdqn_net_s {
   const int64_t* host_idx_cur = nullptr;   // ring paths: host copy of the indexes of the step being enqueued (valid during run_train only)
   int r3_xcd = 2;                          // XCD-contiguous tile maps of the round-3 kernels: bit 0 conv1_fwd (bf16), bit 1 conv1_wgrad (bf16)
   bool prep_inline = true;                 // B <= 32: the next step's indexes ride in the update launch's kernel arguments (no PCIe read in its prep block)
-  int wt = 247;                            // write-through epilogue stores, bit per launch (kernels.h: LaunchTune::wt); all but fc4_dgrad (measured -0.15 %)
+  int wt = 511;                            // write-through epilogue stores, bit per launch (kernels.h: LaunchTune::wt; bit 8 = the update kernel)
   int fwd_rb = 0;                          // experiment: bit 0 conv2_fwd, bit 1 conv3_fwd on the 1 x 2 register-blocked routine (one workgroup per 32 x 64 block)
   bool handoff_launched = false;           // a launch with an in-launch hand-off (f4w_early / fuse_upd) was enqueued since the last sync
   int fuse_dbg = 0;                        // experiment only: 1 = the online conv1 blocks do not wait (WRONG results, timing of the wait)
@@ -874,6 +874,7 @@ static UpdateArgs make_update_args(sdqn_net_s* h, const StepArgs& a) {
   u.opt = h->cfg.optimizer; u.state2 = h->state2;
   if (h->cfg.datatype == 1) { u.wh = h->wh[0]; u.wht = h->wht[0]; }
   u.w1p = h->w1p[0];
+  u.wt = (h->wt >> 8) & 1;
   u.bn_first = h->bn ? h->NPW : 0;
   if (u.opt == 1) {            // Neon Adam [neon-recalled]: t = epoch + 1, l = lr*sqrt(1-b2^t)/(1-b1^t), math in Python floats
     const double b1 = h->cfg.beta_1, b2 = h->cfg.beta_2, t = (double)h->epoch + 1.0;

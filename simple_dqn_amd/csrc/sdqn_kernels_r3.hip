@@ -61,7 +61,15 @@ struct Conv2DgradWT : Conv2Dgrad {
 struct Conv2WgradWT : Conv2Wgrad {
   __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab2[(int64_t)ks * NW2 + m * K2 + n], v); }
 };
+struct Conv1WgradWT : Conv1Wgrad {
+  __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab1[(int64_t)ks * NW1 + m * K1 + n], v); }
+};
 struct Fc4WgradWT : Fc4Wgrad {          // the 12.8 MB of new W4 + RMSProp state (or the 6.4 MB gradient) leave write-through
+  __device__ static void store(const StepArgs& a, int, int, int m, int n, float v) {          // K-split form (B > 32)
+    const int64_t e = OFF4 + (int64_t)m * NFC + n;
+    if (a.fuse_rms) { float st = a.state[e]; const float w = rms_step(a.theta_w[e], st, v, a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps); wt_store(&a.theta_w[e], w); wt_store(&a.state[e], st); }
+    else wt_store(&a.g[e], v);
+  }
   __device__ static void store16(const StepArgs& a, int z, int ks, int m0, int n0, int lane, int M, int N, const float* v, Epi& e) {
     const uint32_t base = epi_base(m0, n0, lane);
     auto stw = [](float* p, uint32_t off, float x) { wt_store(reinterpret_cast<float*>(reinterpret_cast<char*>(p) + off), x); };
@@ -558,6 +566,16 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     if (id == K_FC4_DGRAD && (t.wt & 8) && !(t.r3 & 1)) return launch_gemm<Staged<Fc4DgradWT>, 16>(a, s);
     if (id == K_BWD3 && (t.wt & 16) && a.f4w_count > 0) return launch_multi<512, Staged<Conv3DgradWT>, 8, Conv3WgradWT, 8, Fc4WgradWT, 1>(a, true, true, s);
     if (id == K_BWD2 && (t.wt & 32) && a.f4w_count == 0) return launch_multi<512, NoProblem, 2, Conv2DgradWT, 8, Conv2WgradWT, 8>(a, true, true, s);
+  }
+  if (a.B >= 128 && !a.h16 && !a.bn && t.wt && !t.hoist && !t.order && !(id >= 0 && id < 12 && (t.nw_override[id] > 0 || t.rb[id] > 0))) {
+    // throughput regime: the same launch forms as sdqn_kernels.hip, write-through epilogues
+    if (id == K_CONV2_FWD && (t.wt & 1)) return launch_gemm<Staged<Conv2FwdWT>, 8>(a, s);
+    if (id == K_CONV3_FWD && (t.wt & 2)) return launch_gemm<Staged<Conv3FwdWT>, 8>(a, s);
+    if (id == K_FC4_FWD && (t.wt & 4)) return launch_gemm<Staged<Fc4FwdWT>, 8>(a, s);
+    if (id == K_FC4_DGRAD && (t.wt & 8)) return launch_gemm<Staged<Fc4DgradWT>, 4>(a, s);
+    if (id == K_BWD3 && (t.wt & 16) && a.f4w_count > 0) return launch_multi<512, Fc4WgradWT, 8, Staged<Conv3DgradWT>, 8, Conv3WgradWT, 8>(a, true, true, s);
+    if (id == K_BWD2 && (t.wt & 32) && a.f4w_count == 0) return launch_multi<512, NoProblem, 2, Staged<Conv2DgradWT>, 8, Conv2WgradWT, 8>(a, true, true, s);
+    if (id == K_BWD1 && (t.wt & 64) && a.f4w_count == 0 && !(t.r3 & 8)) return launch_multi<1024, NoProblem, 2, Conv1WgradWT, 16, NoProblem, 2>(a, true, false, s);
   }
   if (id == K_CONV2_FWD && (t.r3 & 16) && a.B < 128 && !a.h16 && !a.bn) return launch_gemm<RB<Conv2Fwd, 1, 2>, 16>(a, s);
   if (id == K_CONV3_FWD && (t.r3 & 32) && a.B < 128 && !a.h16 && !a.bn) return launch_gemm<RB<Conv3Fwd, 1, 2>, 16>(a, s);

@@ -22,8 +22,15 @@ __device__ inline void opt_apply4(float* __restrict__ theta, float* __restrict__
     typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
     u4_t v; v.x = __float_as_uint(w.x); v.y = __float_as_uint(w.y); v.z = __float_as_uint(w.z); v.w = __float_as_uint(w.w);
     __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc((void*)theta, 0, NW1 * 4, 0x00020000), (int)(e * 4), 0, 16);
-  } else *reinterpret_cast<float4*>(theta + e) = w;
-  *reinterpret_cast<float4*>(st1 + e) = a;
+  } else if (u.wt) {                                  // write-through (nothing left to flush at the kernel boundary: sdqn_kernels_r3.hip)
+    typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+    u4_t v; v.x = __float_as_uint(w.x); v.y = __float_as_uint(w.y); v.z = __float_as_uint(w.z); v.w = __float_as_uint(w.w);
+    constexpr int FLAT_BYTES = (OFF5 + MAX_ACTIONS * NFC) * 4;                // (wave-uniform descriptors: base of the flat buffer + per-lane offset)
+    __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc((void*)theta, 0, FLAT_BYTES, 0x00020000), (int)(e * 4), 0, 16);
+    v.x = __float_as_uint(a.x); v.y = __float_as_uint(a.y); v.z = __float_as_uint(a.z); v.w = __float_as_uint(a.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc((void*)st1, 0, FLAT_BYTES, 0x00020000), (int)(e * 4), 0, 16);
+  } else { *reinterpret_cast<float4*>(theta + e) = w; *reinterpret_cast<float4*>(st1 + e) = a; }
+  if (FUSED && e < OFF2) *reinterpret_cast<float4*>(st1 + e) = a;
   if (u.opt != 0) *reinterpret_cast<float4*>(st2 + e) = b;
   if (u.w1p && e < OFF2) {                        // conv1's bf16 planes follow W1 (e = k * 32 + n: 4 consecutive maps of one k)
     const int k = (int)(e >> 5), n = (int)(e & 31);
