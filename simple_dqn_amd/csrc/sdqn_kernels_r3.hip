@@ -22,6 +22,10 @@ namespace sdqn {
 // while it still computes has nothing left to flush (tools/exp/handoff_r3.hip section D: ~0.03 us per MB at the next boundary; in the
 // step, where the next launch waits for exactly those bytes, a1 alone was worth 0.7 us).  Same problems, same arithmetic, only the
 // store instruction of the epilogue differs: results are bit-identical.  LaunchTune::wt selects them per launch.
+#ifndef SDQN_NT_W4
+#define SDQN_NT_W4 0
+#endif
+constexpr bool NT_W4 = SDQN_NT_W4 != 0;      // experiment: non-temporal loads of the streamed W4 operand
 __device__ __forceinline__ void wt_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 struct Conv2FwdWT : Conv2Fwd {
   __device__ static void store(const StepArgs& a, int z, int, int m, int n, float v) { wt_store(&a.a2[((int64_t)z * M(a) + m) * K2 + n], fmaxf(v, 0.0f)); }
@@ -29,10 +33,16 @@ struct Conv2FwdWT : Conv2Fwd {
 struct Conv3FwdWT : Conv3Fwd {
   __device__ static void store(const StepArgs& a, int z, int, int m, int n, float v) { wt_store(&a.a3[((int64_t)z * M(a) + m) * K3 + n], fmaxf(v, 0.0f)); }
 };
+__device__ __forceinline__ f4 ld4_nt(const float* p) {          // streamed-once operand (W4: every element is read by exactly one workgroup)
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p)); f4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
+}
 struct Fc4FwdWT : Fc4Fwd {
+  __device__ static f4 b_load4(const StepArgs& a, int z, int o) { return NT_W4 ? ld4_nt(a.theta[z] + OFF4 + o) : ld4(a.theta[z] + OFF4 + o); }
   __device__ static void store(const StepArgs& a, int z, int ks, int m, int n, float v) { wt_store(&a.slab4[(((int64_t)ks * 2 + z) * a.B + m) * NFC + n], v); }
 };
 struct Fc4DgradWT : Fc4Dgrad {
+  __device__ static f4 b_load4(const StepArgs& a, int, int o) { return NT_W4 ? ld4_nt(a.theta[0] + OFF4 + o) : ld4(a.theta[0] + OFF4 + o); }
   __device__ static void store(const StepArgs& a, int, int, int m, int n, float v) {
     const int pix = n >> 6, f = n & 63, p = pix / Q3, q = pix - p * Q3;
     const float dv = a.a3[(int64_t)m * NIN4 + n] > 0.0f ? v : 0.0f;

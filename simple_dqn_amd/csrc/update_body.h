@@ -11,9 +11,10 @@ namespace sdqn {
 // conv1 workgroups of the SAME launch can read them with sc1 loads once the W1 blocks have signalled (no fence anywhere)
 template <bool FUSED = false>
 __device__ inline void opt_apply4(float* __restrict__ theta, float* __restrict__ st1, float* __restrict__ st2,
-                                  int64_t e, const float4& gs, const UpdateArgs& u) {
-  float4 w = *reinterpret_cast<float4*>(theta + e);
-  float4 a = *reinterpret_cast<float4*>(st1 + e);
+                                  int64_t e, const float4& gs, const UpdateArgs& u, const float4* pre = nullptr) {
+  // pre: theta[e] and state[e] already fetched by the caller (issued together with the slab loads: one memory round trip less)
+  float4 w = pre ? pre[0] : *reinterpret_cast<float4*>(theta + e);
+  float4 a = pre ? pre[1] : *reinterpret_cast<float4*>(st1 + e);
   float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
   if (u.opt != 0) b = *reinterpret_cast<float4*>(st2 + e);
   w.x = opt_apply(w.x, a.x, b.x, gs.x, u); w.y = opt_apply(w.y, a.y, b.y, gs.y, u);
@@ -84,6 +85,9 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bid, 
     const int c4 = t & 31, sg = t >> 5;
     const int64_t e = ((int64_t)bid * 32 + c4) * 4;
     float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pre[2] = {gs, gs};
+    const bool applies = sg == 0 && u.mode != 1 && !skip_apply;
+    if (applies) { pre[0] = *reinterpret_cast<const float4*>(u.theta + e); pre[1] = *reinterpret_cast<const float4*>(u.state + e); }
     if (u.mode == 2) {
       if (sg == 0) gs = *reinterpret_cast<const float4*>(u.g + e);
     } else {
@@ -92,20 +96,16 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bid, 
       const int64_t nw = L == 0 ? NW1 : (L == 1 ? NW2 : NW3);
       const float* sp = u.slab[L] + off;
       const int ns = u.ns[L];
-      int s = sg;
-      for (; s + 24 < ns; s += 32) {                                          // 4 independent 16 B loads in flight
-        const float4 v0 = *reinterpret_cast<const float4*>(sp + (int64_t)s * nw);
-        const float4 v1 = *reinterpret_cast<const float4*>(sp + (int64_t)(s + 8) * nw);
-        const float4 v2 = *reinterpret_cast<const float4*>(sp + (int64_t)(s + 16) * nw);
-        const float4 v3 = *reinterpret_cast<const float4*>(sp + (int64_t)(s + 24) * nw);
-        gs.x += v0.x; gs.y += v0.y; gs.z += v0.z; gs.w += v0.w;
-        gs.x += v1.x; gs.y += v1.y; gs.z += v1.z; gs.w += v1.w;
-        gs.x += v2.x; gs.y += v2.y; gs.z += v2.z; gs.w += v2.w;
-        gs.x += v3.x; gs.y += v3.y; gs.z += v3.z; gs.w += v3.w;
-      }
-      for (; s < ns; s += 8) {
-        const float4 v = *reinterpret_cast<const float4*>(sp + (int64_t)s * nw);
-        gs.x += v.x; gs.y += v.y; gs.z += v.z; gs.w += v.w;
+      // slabs sg, sg + 8, sg + 16, ... in increasing order (the order IS the result: fixed).  Four loads are issued together whatever ns
+      // (clamped index + select instead of a data-dependent loop: a 25-slab reduction was three dependent memory round trips for seven
+      // of the eight slab groups)
+      for (int s = sg; s < ns; s += 32) {
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int sj = s + 8 * j; v[j] = *reinterpret_cast<const float4*>(sp + (int64_t)(sj < ns ? sj : ns - 1) * nw); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (s + 8 * j < ns) { gs.x += v[j].x; gs.y += v[j].y; gs.z += v[j].z; gs.w += v[j].w; }
       }
       part[sg][c4] = gs;
       __syncthreads();
@@ -115,7 +115,7 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bid, 
         *reinterpret_cast<float4*>(u.g + e) = gs;
       }
     }
-    if (sg == 0 && u.mode != 1 && !skip_apply) opt_apply4<FUSED>(u.theta, u.state, u.state2, e, gs, u);
+    if (applies) opt_apply4<FUSED>(u.theta, u.state, u.state2, e, gs, u, pre);
     if (FUSED && bid < NW1 / 128) {                 // this block held 128 floats of W1: its write-through stores are out -> count it in
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
