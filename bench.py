@@ -105,7 +105,8 @@ ROCPROF_MATCH = [
     ("gemm_kernel<sdqn::Conv1Fwd", 0), ("gemm_kernel<sdqn::Conv2Fwd", 1), ("Conv3Fwd", 2), ("Fc4Fwd", 3),
     ("head_kernel", 4), ("gemm_kernel<sdqn::Staged<sdqn::Fc4Dgrad>", 5), ("update_kernel", 12), ("gather_kernel", 14), ("prep_kernel", 15),
     ("gemm_multi_kernel<512, sdqn::Staged<sdqn::Conv3Dgrad>", 16), ("Conv2Dgrad", 17), ("Conv1Wgrad", 18),
-    ("conv1_bf16_kernel", 0), ("conv1_wgrad_bf16_kernel", 18), ("upd_conv1_kernel", 22), ("Fc4DgradSig", 20), ("gemm_multi_kernel<512, sdqn::NoProblem, 2, sdqn::Staged<sdqn::Conv3Dgrad>", 21),
+    ("conv1_bf16_kernel", 0), ("conv1_wgrad_bf16_kernel", 18), ("upd_conv1_kernel", 22), ("Fc4DgradSig", 20),
+    ("gemm_kernel<sdqn::Staged<sdqn::Fc4DgradWT>", 5), ("gemm_multi_kernel<512, sdqn::Staged<sdqn::Conv3DgradWT>", 16), ("gemm_multi_kernel<512, sdqn::NoProblem, 2, sdqn::Staged<sdqn::Conv3Dgrad>", 21),
 ]
 
 
