@@ -168,9 +168,10 @@ def profiles_file_commit(rel):
 
 
 def roofline_entry(kid, name, ms_per_launch, B, A):
-    """Everything at the top level of the entry is measured LIVE in this run: `achieved` uses the HIP-event bracket of
-    each launch (us_per_launch), which also contains the ~2 us dispatch gap of a dependent launch and is therefore
-    conservative.  Numbers REPLAYED from committed rocprofv3 captures (PMC traffic, kernel-trace duration, box peaks) sit
+    """Everything at the top level of the entry is measured LIVE in this run: `achieved` uses HIP events that carry the
+    launch's own dispatch-packet begin / end timestamps (hipExtLaunchKernel start / stop events on the library stream:
+    the same two timestamps rocprofv3 --kernel-trace reports, which contain the dependent-launch boundary; no marker
+    packets are added to the queue — round 2's hipEventRecord brackets measured ~2.6 us more than the kernel trace).  Numbers REPLAYED from committed rocprofv3 captures (PMC traffic, kernel-trace duration, box peaks) sit
     under `from_profiles` with the files they come from; `traffic` at the top level repeats the PMC figure only because
     the bench contract names that key — it is a committed capture, not a measurement of this run (null when the capture
     does not cover this shape)."""
@@ -744,7 +745,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t[0])
     live = [p for p in net.profile_read() if p["id"] == dom["id"]][0]
-    live_src = "timed region, every %d%s launch bracketed" % (every, "th" if every > 3 else ("nd" if every == 2 else "rd"))
+    live_src = "timed region, every %d%s launch carries start/stop events (kernel-packet timestamps)" % (every, "th" if every > 3 else ("nd" if every == 2 else "rd"))
     if live["launches"] == 0:                                        # (K = 0)
         live, live_src = dom, "warm-up pass (no timed launches)"
     net.profile(False)

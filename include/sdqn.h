@@ -203,15 +203,16 @@ int sdqn_net_set_epoch(sdqn_net_t h, int epoch);
  * independent backward stages share one grid), "xcd_map" (0 default = only where it wins time: conv1/conv2/fc4 forward; 1: the
  * XCD-contiguous workgroup->tile map for every launch), "dp_overlap" (0 default; 1 BEFORE sdqn_dp_init: fc4 gradient
  * all-reduced and applied on a second communicator + stream), "dp_sync_replicas" (1 default: sdqn_dp_init broadcasts rank 0's online net,
- * target net and optimizer state so every learner starts from — and keeps — the same network; 0 BEFORE sdqn_dp_init: keep own), "profile_every" (N: sdqn_net_profile brackets every N-th
- * launch), "nw:<kernel id>" / "xcd:<kernel id>" / "f4_share3" / "f4_share2" (tuning hooks) */
+ * target net and optimizer state so every learner starts from — and keeps — the same network; 0 BEFORE sdqn_dp_init: keep own), "profile_every" (N: sdqn_net_profile times every N-th
+ * launch), "profile_mode" (1 default: the launch records its own dispatch-packet begin / end timestamps into the event pair through hipExtLaunchKernel —
+ * what rocprofv3 --kernel-trace reports, nothing added to the queue; 0: hipEventRecord markers around the launch, ~2.6 us more per launch), "nw:<kernel id>" / "xcd:<kernel id>" / "f4_share3" / "f4_share2" (tuning hooks) */
 int sdqn_net_set_option(sdqn_net_t h, const char* name, int value);
 
 /* test hook: raw read-back of an internal device buffer ("a1","a2","a3","a4","d4","d3p","d2p","d1","q",
  * "dq","g","theta","cost_terms"; internal layouts documented in simple_dqn_amd/csrc/problems.h) */
 int sdqn_net_debug_read(sdqn_net_t h, const char* name, float* out, int64_t n);
 
-/* per-kernel device timing (HIP events on the library stream), for bench.py's roofline leg.
+/* per-kernel device timing (HIP events on the library stream; see option "profile_mode"), for bench.py's roofline leg.
  * kernel < 0 brackets every kernel of the step, otherwise only that kernel id. */
 int sdqn_net_profile(sdqn_net_t h, int enable, int kernel);
 int sdqn_net_profile_count(int* n_kernels);

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include "problems.h"
+#include "launch.h"
 
 namespace sdqn {
 
@@ -650,7 +651,7 @@ struct NoProblem {            // placeholder third problem for two-problem launc
 template <class P, int NW>
 inline hipError_t launch_gemm(const StepArgs& a, hipStream_t stream) {
   dim3 grid((P::M(a) + tile_m<P>() - 1) / tile_m<P>(), (P::N(a) + tile_n<P>() - 1) / tile_n<P>(), P::nbz(a));
-  hipLaunchKernelGGL((gemm_kernel<P, NW>), grid, dim3(NW * 64), 0, stream, a);
+  SDQN_LAUNCH((gemm_kernel<P, NW>), grid, dim3(NW * 64), 0, stream, a);
   return hipGetLastError();
 }
 
@@ -668,7 +669,7 @@ inline hipError_t launch_multi(const StepArgs& a, bool has1, bool has2, hipStrea
   if (has1) multi_fill<NT, P1, NW1>(a, d, 1);
   if (has2) multi_fill<NT, P2, NW2>(a, d, 2);
   if (d.n[0] + d.n[1] + d.n[2] == 0) return hipSuccess;
-  hipLaunchKernelGGL((gemm_multi_kernel<NT, P0, NW0, P1, NW1, P2, NW2>), dim3(d.n[0] + d.n[1] + d.n[2]), dim3(NT), 0, stream, a, d);
+  SDQN_LAUNCH((gemm_multi_kernel<NT, P0, NW0, P1, NW1, P2, NW2>), dim3(d.n[0] + d.n[1] + d.n[2]), dim3(NT), 0, stream, a, d);
   return hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "problems.h"
+#include "launch.h"
 
 namespace sdqn {
 

@@ -448,6 +448,7 @@ struct sdqn_net_s {
   bool two_streams = false;                // weight-gradient kernels on the side stream (measured slower eagerly: event waits)
   // profiler
   bool prof_on = false; int prof_filter = -1;
+  int prof_mode = 1;                                        // 1: kernel-packet timestamps (hipExtLaunchKernel), 0: hipEventRecord markers around the launch
   int prof_every = 1; int64_t prof_seen[K_COUNT] = {0};     // bracket only every prof_every-th launch of a kernel (an event pair costs ~2-3 us of queue time)
   std::vector<ProfPair> prof_pending; std::vector<hipEvent_t> prof_free;
   double prof_ms[K_COUNT]; int64_t prof_n[K_COUNT];
@@ -706,17 +707,26 @@ static int prof_event(sdqn_net_s* h, hipEvent_t* e) {
   if (!h->prof_free.empty()) { *e = h->prof_free.back(); h->prof_free.pop_back(); return SDQN_OK; }
   HIPCHK(hipEventCreate(e)); return SDQN_OK;
 }
+// profile_mode 1 (default): the launch itself records its dispatch packet's begin / end timestamps into the pair (launch.h:
+// what rocprofv3 --kernel-trace reports, nothing added to the queue); 0, and always for launches that are not ONE kernel
+// (RCCL, BatchNorm's two passes): hipEventRecord markers around the launch (adds ~2.6 us of packet processing to the figure)
+static inline bool prof_single_kernel(int kid) { return kid != K_ALLREDUCE && kid != K_BN; }
 #define LAUNCH_ON(STRM, KID, expr) do { \
   const bool pf_ = h->prof_on && (h->prof_filter < 0 || h->prof_filter == (KID)) && (h->prof_seen[KID]++ % h->prof_every) == 0; ProfPair pp_; \
+  const bool px_ = pf_ && h->prof_mode == 1 && prof_single_kernel(KID); \
   if (pf_) { pp_.id = (KID); int r1_ = prof_event(h, &pp_.a); if (r1_) return r1_; r1_ = prof_event(h, &pp_.b); if (r1_) return r1_; \
-             HIPCHK(hipEventRecord(pp_.a, (STRM))); } \
+             if (px_) { sdqn::LaunchEvents& le = sdqn::launch_events(); le.start = pp_.a; le.stop = pp_.b; le.used = false; } \
+             else HIPCHK(hipEventRecord(pp_.a, (STRM))); } \
   hipError_t le_ = (expr); \
+  bool pu_ = true; \
+  if (px_) { sdqn::LaunchEvents& le = sdqn::launch_events(); pu_ = le.used; le.start = le.stop = nullptr; le.used = false; } \
   if (le_ != hipSuccess) { \
     if ((KID) == K_ALLREDUCE && h->nccl_rc != 0) { \
       set_error("ncclAllReduce (rank %d of %d) -> %s", h->rank, h->nranks, g_rccl.GetErrorString ? g_rccl.GetErrorString(h->nccl_rc) : "rccl error"); \
       return SDQN_ERR_RCCL; } \
     set_error("launch %s -> %s", kernel_name(KID), hipGetErrorString(le_)); return SDQN_ERR_HIP; } \
-  if (pf_) { HIPCHK(hipEventRecord(pp_.b, (STRM))); h->prof_pending.push_back(pp_); \
+  if (pf_ && !pu_) { h->prof_free.push_back(pp_.a); h->prof_free.push_back(pp_.b); }     /* (a launch path that did not take the events: no sample) */ \
+  else if (pf_) { if (!px_) HIPCHK(hipEventRecord(pp_.b, (STRM))); h->prof_pending.push_back(pp_); \
              if (h->prof_pending.size() > 16384) { int r2_ = prof_collect(h); if (r2_) return r2_; } } \
 } while (0)
 #define LAUNCH(KID, expr) LAUNCH_ON(g_stream, KID, expr)
@@ -1389,6 +1399,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "dp_overlap")) h->dp_overlap = value != 0;     // before dp_init: 0 = single all-reduce on the library stream
   else if (!strcmp(name, "f4_share3")) h->f4_share[0] = value;
   else if (!strcmp(name, "f4_share2")) h->f4_share[1] = value;
+  else if (!strcmp(name, "profile_mode")) { ARGCHK(value == 0 || value == 1, "profile_mode must be 0 (event markers) or 1 (kernel-packet timestamps)"); h->prof_mode = value; }
   else if (!strcmp(name, "profile_every")) { ARGCHK(value >= 1, "profile_every must be >= 1"); h->prof_every = value; }
   else if (!strncmp(name, "xcd:", 4)) {                    // tuning: XCD-map problem mask of kernel id (value = mask + 1, 0 = built-in)
     int id = atoi(name + 4);

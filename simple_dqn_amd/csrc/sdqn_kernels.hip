@@ -18,6 +18,7 @@ static const char* k_names[K_COUNT] = {
   "bwd3(conv3_dgrad+conv3_wgrad+fc4_wgrad)", "bwd2(conv2_dgrad+conv2_wgrad+fc4_wgrad)", "bwd1(conv1_wgrad+fc4_wgrad)",
   "batchnorm(layer fwd/bwd)", "fc4_dgrad+fc4_wgrad(+rmsprop W4)", "bwd3(conv3_dgrad+conv3_wgrad)", "update(i)+conv1_fwd(i+1)"};
 const char* kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? k_names[id] : "?"; }
+LaunchEvents& launch_events() { static thread_local LaunchEvents le; return le; }
 
 template <class P>
 static hipError_t launch_nw(int nw, const StepArgs& a, hipStream_t s) {
@@ -263,15 +264,15 @@ hipError_t set_timing_buffer(unsigned long long* p) {
 
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
   if (h.next_B > 0 && !a.bn) {                       // option "hoist": + one workgroup fetching the next step's indexes
-    if (a.A <= 4) hipLaunchKernelGGL((head_kernel<4, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
-    else if (a.A <= 8) hipLaunchKernelGGL((head_kernel<8, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
-    else hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
+    if (a.A <= 4) SDQN_LAUNCH((head_kernel<4, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
+    else if (a.A <= 8) SDQN_LAUNCH((head_kernel<8, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
+    else SDQN_LAUNCH((head_kernel<MAX_ACTIONS, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
     return hipGetLastError();
   }
-  if (a.bn) hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, true>), dim3(a.B), dim3(512), 0, s, a, h);     // --batch_norm (not tuned per bucket)
-  else if (a.A <= 4) hipLaunchKernelGGL((head_kernel<4, false>), dim3(a.B), dim3(512), 0, s, a, h);
-  else if (a.A <= 8) hipLaunchKernelGGL((head_kernel<8, false>), dim3(a.B), dim3(512), 0, s, a, h);
-  else hipLaunchKernelGGL((head_kernel<MAX_ACTIONS, false>), dim3(a.B), dim3(512), 0, s, a, h);
+  if (a.bn) SDQN_LAUNCH((head_kernel<MAX_ACTIONS, true>), dim3(a.B), dim3(512), 0, s, a, h);     // --batch_norm (not tuned per bucket)
+  else if (a.A <= 4) SDQN_LAUNCH((head_kernel<4, false>), dim3(a.B), dim3(512), 0, s, a, h);
+  else if (a.A <= 8) SDQN_LAUNCH((head_kernel<8, false>), dim3(a.B), dim3(512), 0, s, a, h);
+  else SDQN_LAUNCH((head_kernel<MAX_ACTIONS, false>), dim3(a.B), dim3(512), 0, s, a, h);
   return hipGetLastError();
 }
 
@@ -286,8 +287,8 @@ hipError_t launch_update(const UpdateArgs& u, hipStream_t s) {
   int dense = 2;                                                   // hosts the ride-along prep and the cost mean
   if (!u.skip_fc4) { dense = (NW4 / 4 + 255) / 256; if (dense > 1792) dense = 1792; }
   const dim3 grid(CONV_BLOCKS + u.A * FC5_BLOCKS_PER_ACTION + dense);
-  if (u.ovf_flag) hipLaunchKernelGGL(update_kernel<true>, grid, dim3(256), 0, s, u);
-  else hipLaunchKernelGGL(update_kernel<false>, grid, dim3(256), 0, s, u);
+  if (u.ovf_flag) SDQN_LAUNCH(update_kernel<true>, grid, dim3(256), 0, s, u);
+  else SDQN_LAUNCH(update_kernel<false>, grid, dim3(256), 0, s, u);
   return hipGetLastError();
 }
 
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(256) prep_kernel(const PrepArgs p, double* zer
   }
 }
 hipError_t launch_prep(const PrepArgs& p, hipStream_t s, double* zero8) {
-  hipLaunchKernelGGL(prep_kernel, dim3(1), dim3(256), 0, s, p, zero8);
+  SDQN_LAUNCH(prep_kernel, dim3(1), dim3(256), 0, s, p, zero8);
   return hipGetLastError();
 }
 
@@ -401,10 +402,10 @@ hipError_t launch_gather(const GatherArgs& g, hipStream_t s, const int64_t* host
   if (host_idx && g.B <= 256) {
     IdxBlock ib;
     memcpy(ib.v, host_idx, (size_t)g.B * sizeof(int64_t));
-    hipLaunchKernelGGL(gather_kernel<true>, dim3(9, g.B), dim3(256), 0, s, g, ib);
+    SDQN_LAUNCH(gather_kernel<true>, dim3(9, g.B), dim3(256), 0, s, g, ib);
   } else {
     IdxBlock ib; ib.v[0] = 0;
-    hipLaunchKernelGGL(gather_kernel<false>, dim3(9, g.B), dim3(256), 0, s, g, ib);
+    SDQN_LAUNCH(gather_kernel<false>, dim3(9, g.B), dim3(256), 0, s, g, ib);
   }
   return hipGetLastError();
 }

@@ -519,7 +519,7 @@ hipError_t launch_upd_conv1(const UpdateArgs& u, const StepArgs& a, const int64_
   IdxIn ix; memset(ix.v, 0, sizeof ix.v); memcpy(ix.v, host_idx, (size_t)a.B * sizeof(int64_t));
   FusedW1 fw; fw.theta = a.theta[0]; fw.ctr = ctr; fw.target = target; fw.timeout = timeout;
   const int n_upd = CONV_BLOCKS + u.A * FC5_BLOCKS_PER_ACTION + 2;                          // launch_update's grid with the fc4 part fused into bwd3
-  hipLaunchKernelGGL(upd_conv1_kernel, dim3(n_upd + 2 * wgs), dim3(256), 0, s, u, c, ix, fw, n_upd);
+  SDQN_LAUNCH(upd_conv1_kernel, dim3(n_upd + 2 * wgs), dim3(256), 0, s, u, c, ix, fw, n_upd);
   return hipGetLastError();
 }
 
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(256) w1_planes_kernel(const float* theta, unsi
   w1p[n * CRS1 + k] = hi; w1p[W1P_PLANE + n * CRS1 + k] = mid; w1p[2 * W1P_PLANE + n * CRS1 + k] = lo;
 }
 hipError_t launch_w1_planes(const float* theta, unsigned short* w1p, hipStream_t s) {
-  hipLaunchKernelGGL(w1_planes_kernel, dim3(NW1 / 256), dim3(256), 0, s, theta, w1p);
+  SDQN_LAUNCH(w1_planes_kernel, dim3(NW1 / 256), dim3(256), 0, s, theta, w1p);
   return hipGetLastError();
 }
 
@@ -549,10 +549,10 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     if (t.host_idx && a.from_ring && a.B <= 32) {
       memset(ix.v, 0, sizeof ix.v);
       memcpy(ix.v, t.host_idx, (size_t)a.B * sizeof(int64_t));
-      hipLaunchKernelGGL(conv1_bf16_kernel<true>, dim3(a.nz * wgs), dim3(256), 0, s, c, ix);
+      SDQN_LAUNCH(conv1_bf16_kernel<true>, dim3(a.nz * wgs), dim3(256), 0, s, c, ix);
     } else {
       memset(ix.v, 0, sizeof ix.v);
-      hipLaunchKernelGGL(conv1_bf16_kernel<false>, dim3(a.nz * wgs), dim3(256), 0, s, c, ix);
+      SDQN_LAUNCH(conv1_bf16_kernel<false>, dim3(a.nz * wgs), dim3(256), 0, s, c, ix);
     }
     return hipGetLastError();
   }
@@ -563,8 +563,8 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     IdxIn ix; memset(ix.v, 0, sizeof ix.v);
     if (t.host_idx && a.from_ring && a.B <= 32) {
       memcpy(ix.v, t.host_idx, (size_t)a.B * sizeof(int64_t));
-      hipLaunchKernelGGL(conv1_wgrad_bf16_kernel<true>, grid, dim3(1024), 0, s, c, ix);
-    } else hipLaunchKernelGGL(conv1_wgrad_bf16_kernel<false>, grid, dim3(1024), 0, s, c, ix);
+      SDQN_LAUNCH(conv1_wgrad_bf16_kernel<true>, grid, dim3(1024), 0, s, c, ix);
+    } else SDQN_LAUNCH(conv1_wgrad_bf16_kernel<false>, grid, dim3(1024), 0, s, c, ix);
     return hipGetLastError();
   }
   // conv2 / conv3 forward with ONE workgroup per 32 x 64 output block (N = 64 = two 32-wide tiles): the register-blocked routine with
@@ -592,8 +592,8 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
   if (id == K_CONV3_FWD && (t.r3 & 2) && a.B < 128 && !a.h16 && !a.bn) {
     static_assert(CRS3 == 16 * 36, "conv3's K is 16 chunks of 36");
     const dim3 grid((Conv3Fwd::M(a) + 31) / 32, (Conv3Fwd::N(a) + 31) / 32, Conv3Fwd::nbz(a));
-    if ((t.wt & 2) && a.B <= 32) hipLaunchKernelGGL((gemm36_kernel<Conv3FwdWT>), grid, dim3(1024), 0, s, a);
-    else hipLaunchKernelGGL((gemm36_kernel<Conv3Fwd>), grid, dim3(1024), 0, s, a);
+    if ((t.wt & 2) && a.B <= 32) SDQN_LAUNCH((gemm36_kernel<Conv3FwdWT>), grid, dim3(1024), 0, s, a);
+    else SDQN_LAUNCH((gemm36_kernel<Conv3Fwd>), grid, dim3(1024), 0, s, a);
     return hipGetLastError();
   }
   *handled = false;

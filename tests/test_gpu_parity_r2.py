@@ -684,3 +684,37 @@ def test_batched_slot_release_survives_interleaved_gathers(sd):
     for which in (0, 2):
         for i in range(5):
             assert np.array_equal(nets[0].get_layer(i, which), nets[1].get_layer(i, which)), (which, i)
+
+
+@pytest.mark.gpu
+def test_profile_modes_packet_timestamps_against_event_markers(sd):
+    """The live per-kernel timing of bench.py's roofline leg: with profile_mode 1 (default) the launch itself records its
+    dispatch packet's begin / end timestamps (hipExtLaunchKernel), with 0 hipEventRecord markers bracket it.  Both must
+    see every launch of the step; the packet figure is the smaller one (a marker pair adds its own packet processing) and
+    must be a plausible kernel time."""
+    import simple_dqn_amd as S
+    B, A = 32, 4
+    args = make_args(batch_size=B)
+    mem = S.ReplayMemory(20000, args)
+    synthetic_fill(mem, 3, num_actions=A)
+    mem.sync_mirror()
+    net = S.DeepQNetwork(A, args)
+    net.update_target_network()
+    mt = (C.c_uint32 * 625)(); S.load().sdqn_mt_seed(mt, 11)
+    net.train_from_memory(mem, 100, mt_state=mt, want_cost=False); net.sync()
+    per = {}
+    for mode in (1, 0):
+        net.set_option("profile_mode", mode); net.set_option("profile_every", 1)
+        net.profile(True, -1); net.profile_reset()
+        net.train_from_memory(mem, 200, mt_state=mt, want_cost=False); net.sync()
+        per[mode] = {p["name"]: (p["total_ms"] / p["launches"] * 1e3, p["launches"]) for p in net.profile_read() if p["launches"] > 0}
+        net.profile(False)
+    net.set_option("profile_mode", 1)
+    step = [k for k, (us, n) in per[0].items() if n >= 200]
+    assert len(step) >= 10, per[0]
+    for k in step:
+        assert k in per[1] and per[1][k][1] == per[0][k][1], (k, per[1].get(k), per[0][k])
+        us1, us0 = per[1][k][0], per[0][k][0]
+        assert 1.0 < us1 < 40.0, (k, us1)
+        assert us1 < us0 + 0.5, (k, us1, us0)
+    assert sum(per[1][k][0] for k in step) < sum(per[0][k][0] for k in step) - 5.0
