@@ -14,6 +14,8 @@ mt = (C.c_uint32 * 625)(); sd.load().sdqn_mt_seed(mt, 5)
 idx = np.array([mem.sample_indexes().copy() for _ in range(256)])
 mem.bench_gather(idx, iters=512)
 net.train_from_memory(mem, 5, mt_state=mt, want_cost=False); net.sync()
+if os.environ.get("PRE_STEPS"):                  # sustained training before the short calls
+    net.train_from_memory(mem, int(os.environ["PRE_STEPS"]), mt_state=mt, want_cost=False); net.sync()
 if os.environ.get("GAP_MS"): time.sleep(float(os.environ["GAP_MS"]) / 1e3)
 out = []
 for k in range(12):
