@@ -99,14 +99,15 @@ int sdqn_replay_bench_gather_sets(sdqn_replay_t h, const int64_t* idx_host, int 
 /* ---- Q-network: src/deepqnetwork.py ---------------------------------------- */
 typedef struct {
   int batch_size;          /* args.batch_size      deepqnetwork.py:19 */
-  int history_length;      /* args.history_length  :21 (must be 4) */
-  int screen_height;       /* :22 (must be 84) */
-  int screen_width;        /* :22 (must be 84) */
+  int history_length;      /* args.history_length  :21 (main.py:34).  84 x 84 x 4 runs on the tuned kernels; any other    */
+  int screen_height;       /* :22 (main.py:28)      geometry the layer stack of :83-91 accepts runs on the generic    */
+  int screen_width;        /* :22 (main.py:27)      im2col + GEMM path (csrc/generic_net.hip): float32 / float64 only */
   int num_actions;         /* :18 */
   int target_enabled;      /* bool(args.target_steps) :64 */
   int optimizer;           /* args.optimizer :50-59: 0 rmsprop, 1 adam, 2 adadelta */
-  int datatype;            /* args.datatype :33: 0 float32; 1 float16 = half activations/deltas/MFMA weight operands,
-                              fp32 accumulation, master weights and optimizer state (BASELINE.json configs[4]) */
+  int datatype;            /* args.datatype :33 (main.py:53): 0 float32; 1 float16 = half activations/deltas/MFMA weight operands,
+                              fp32 accumulation, master weights and optimizer state (BASELINE.json configs[4]);
+                              2 float64 = the whole step in double (generic path) */
   /* Python floats (doubles) exactly as argparse hands them over; the library rounds to fp32
    * where Neon's fp32 backend would (lr, decay, epsilon, clip) and keeps doubles where the
    * reference does host-side float math (discount, reward clip: deepqnetwork.py:136-143).  */
@@ -135,8 +136,12 @@ int sdqn_net_destroy(sdqn_net_t h);
 int sdqn_net_layer_size(sdqn_net_t h, int layer, int64_t* n);
 int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const float* w, int64_t n);
 int sdqn_net_get_weights(sdqn_net_t h, int which, int layer, float* w, int64_t n);   /* sync */
+/* the same in double: what a float64 network exchanges without a round trip through float (other networks convert) */
+int sdqn_net_set_weights_f64(sdqn_net_t h, int which, int layer, const double* w, int64_t n);
+int sdqn_net_get_weights_f64(sdqn_net_t h, int which, int layer, double* w, int64_t n);   /* sync */
 /* DeepQNetwork.predict, deepqnetwork.py:174-186: states u8[B,4,84,84] -> q float[B,A] (sync) */
 int sdqn_net_predict(sdqn_net_t h, const uint8_t* states, float* q_out);
+int sdqn_net_predict_f64(sdqn_net_t h, const uint8_t* states, double* q_out);      /* float64 networks: Q-values in double */
 /* acting path: Q-values of ONE state u8[4,84,84] -> float[A].  The reference pads the
  * current state to a full minibatch of zero rows only because Neon cannot change its batch size
  * (src/state_buffer.py:13-24, src/agent.py:55-61) and then uses row 0; this computes exactly that row. */

@@ -30,6 +30,7 @@ class NetCfg(C.Structure):
 
 
 _u8p, _i64p, _f32p, _u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+_f64p = C.POINTER(C.c_double)
 _vp = C.c_void_p
 
 # name -> (restype, argtypes); every symbol include/sdqn.h declares
@@ -64,6 +65,9 @@ SIGNATURES = {
     "sdqn_net_set_weights": (C.c_int, [_vp, C.c_int, C.c_int, _f32p, C.c_int64]),
     "sdqn_net_get_weights": (C.c_int, [_vp, C.c_int, C.c_int, _f32p, C.c_int64]),
     "sdqn_net_predict": (C.c_int, [_vp, _u8p, _f32p]),
+    "sdqn_net_predict_f64": (C.c_int, [_vp, _u8p, _f64p]),
+    "sdqn_net_set_weights_f64": (C.c_int, [_vp, C.c_int, C.c_int, _f64p, C.c_int64]),
+    "sdqn_net_get_weights_f64": (C.c_int, [_vp, C.c_int, C.c_int, _f64p, C.c_int64]),
     "sdqn_net_predict_one": (C.c_int, [_vp, _u8p, _f32p]),
     "sdqn_statebuf_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int]),
     "sdqn_statebuf_destroy": (C.c_int, [_vp]),

@@ -13,6 +13,7 @@
 
 #include "../../include/sdqn.h"
 #include "kernels.h"
+#include "generic_net.h"
 #include "sampler.h"
 
 using namespace sdqn;
@@ -104,6 +105,8 @@ extern "C" int sdqn_sample_indices(uint32_t* mt, const uint8_t* terminals, int64
 static const int NSLOT = 64;     // pinned index slots: kernels read the sampled indexes zero-copy
 struct sdqn_replay_s {
   int64_t size = 0; int H = 0, W = 0, hist = 0, B = 0, flags = 0;
+  int64_t frame = 0, state = 0;                    // bytes per screen / per state (hist screens); the tuned kernels need 84 x 84 x 4
+  bool tuned_geom = true;
   int64_t count = 0, current = 0;
   uint8_t* screens = nullptr; uint8_t* actions = nullptr; int64_t* rewards = nullptr; uint8_t* terminals = nullptr;  // pinned master
   MetaRec* h_meta = nullptr;                       // pinned packed metadata (source of the per-add H2D)
@@ -134,12 +137,14 @@ static int replay_free(sdqn_replay_s* r) {
 extern "C" int sdqn_replay_create(sdqn_replay_t* out, int64_t size, int H, int W, int hist, int batch, int flags) {
   ARGCHK(out, "handle pointer is NULL");
   ARGCHK(size > hist && batch > 0, "bad replay geometry (size=%lld, batch=%d)", (long long)size, batch);
-  ARGCHK(H == H0 && W == W0 && hist == C0, "this build supports 84x84 screens with history_length 4 (got %dx%d, %d)", H, W, hist);
+  ARGCHK(H > 0 && W > 0 && hist > 0 && H <= 4096 && W <= 4096 && hist <= 64, "bad screen geometry %dx%d, history_length %d", H, W, hist);
   if (!flags) flags = SDQN_REPLAY_HBM_MIRROR;
   STREAMCHK();
   sdqn_replay_s* r = new sdqn_replay_s();
   memset(r->slot_ev, 0, sizeof r->slot_ev); memset(r->slot_busy, 0, sizeof r->slot_busy); memset(r->slot_cover, 0, sizeof r->slot_cover); r->npending = 0;
   r->size = size; r->H = H; r->W = W; r->hist = hist; r->B = batch; r->flags = flags;
+  r->frame = (int64_t)H * W; r->state = r->frame * hist; r->tuned_geom = (H == H0 && W == W0 && hist == C0);
+  const int64_t FRAME = r->frame, STATE = r->state;     // (shadow the 84 x 84 x 4 constants of problems.h in this function)
   const unsigned hf = hipHostMallocMapped | hipHostMallocPortable;
 #define RCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s -> %s", #x, hipGetErrorString(e_)); replay_free(r); return SDQN_ERR_HIP; } } while (0)
   RCHK(hipHostMalloc((void**)&r->screens, (size_t)size * FRAME + SRC_PAD, hf));     // + slack: conv1_wgrad's 16-byte patch loads (problems.h)
@@ -191,6 +196,7 @@ extern "C" int sdqn_replay_minibatch_ptrs(sdqn_replay_t r, uint8_t** pre, uint8_
 
 extern "C" int sdqn_replay_add(sdqn_replay_t r, int action, int64_t reward, const uint8_t* screen, int terminal) {
   ARGCHK(r && screen, "NULL argument");
+  const int64_t FRAME = r->frame;
   const int64_t c = r->current;                                   // replay_memory.py:29-32
   r->actions[c] = (uint8_t)action; r->rewards[c] = reward; r->terminals[c] = terminal ? 1 : 0;
   memcpy(r->screens + c * FRAME, screen, FRAME);
@@ -213,6 +219,7 @@ extern "C" int sdqn_replay_set_state(sdqn_replay_t r, int64_t count, int64_t cur
 }
 extern "C" int sdqn_replay_upload(sdqn_replay_t r, int64_t first, int64_t n) {
   ARGCHK(r && first >= 0 && n >= 0 && first + n <= r->size, "bad upload range");
+  const int64_t FRAME = r->frame;
   for (int64_t i = first; i < first + n; ++i) {
     MetaRec& m = r->h_meta[i];
     m.reward = r->rewards[i]; m.action = r->actions[i]; m.terminal = r->terminals[i] ? 1 : 0;
@@ -281,8 +288,19 @@ static GatherArgs gather_args(sdqn_replay_s* r, const int64_t* didx) {
   GatherArgs g; g.ring = r->d_ring; g.meta = r->d_meta; g.idx = didx; g.pre = r->d_pre; g.post = r->d_post;
   g.actions = r->d_act; g.rewards = r->d_rew; g.terminals = r->d_term; g.B = r->B; return g;
 }
+static int replay_gather_generic(sdqn_replay_s* r, const int64_t* didx) {      // any geometry (generic_net.hip)
+  GatherGenericArgs g; g.ring = r->d_ring; g.meta = r->d_meta; g.idx = didx; g.pre = r->d_pre; g.post = r->d_post;
+  g.actions = r->d_act; g.rewards = r->d_rew; g.terminals = r->d_term; g.B = r->B; g.hist = r->hist; g.frame = r->frame;
+  HIPCHK(launch_gather_generic(g, g_stream));
+  return SDQN_OK;
+}
 extern "C" int sdqn_replay_gather(sdqn_replay_t r, const int64_t* idx_host) {
   ARGCHK(r && idx_host, "NULL argument");
+  if (!r->tuned_geom) {
+    int slot; const int64_t* didx; int rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
+    rc = replay_gather_generic(r, didx); if (rc) return rc;
+    return replay_release_idx(r, slot);
+  }
   if (r->B <= 256) {               // the indexes ride in the kernel arguments: no pinned slot, no release event (sdqn_kernels.hip)
     for (int i = 0; i < r->B; ++i)
       ARGCHK(idx_host[i] >= r->hist && idx_host[i] < r->count, "index %lld out of range (count %lld)", (long long)idx_host[i], (long long)r->count);
@@ -295,7 +313,7 @@ extern "C" int sdqn_replay_gather(sdqn_replay_t r, const int64_t* idx_host) {
 }
 extern "C" int sdqn_replay_minibatch_to_host(sdqn_replay_t r) {
   ARGCHK(r, "NULL handle");
-  const size_t sb = (size_t)r->B * STATE;
+  const size_t sb = (size_t)r->B * r->state;
   HIPCHK(hipMemcpyAsync(r->h_pre, r->d_pre, 2 * sb, hipMemcpyDeviceToHost, g_stream));                 // [pre | post]
   HIPCHK(hipMemcpyAsync(r->h_rew, r->d_rew, (size_t)r->B * 10, hipMemcpyDeviceToHost, g_stream));      // [rewards | actions | terminals]
   HIPCHK(hipStreamSynchronize(g_stream));
@@ -303,6 +321,7 @@ extern "C" int sdqn_replay_minibatch_to_host(sdqn_replay_t r) {
 }
 extern "C" int sdqn_replay_bench_gather(sdqn_replay_t r, const int64_t* idx_host, int iters, float* ms_per_launch) {
   ARGCHK(r && idx_host && iters > 0 && ms_per_launch, "bad arguments");
+  ARGCHK(r->tuned_geom, "bench_gather times the 84x84x4 kernel");
   int slot; const int64_t* didx; int rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
   hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
   GatherArgs g = gather_args(r, didx);
@@ -321,6 +340,7 @@ extern "C" int sdqn_replay_bench_gather(sdqn_replay_t r, const int64_t* idx_host
 // same states twice in a row, and a repeated set is served from L2 / MALL after its first launch instead of HBM.
 extern "C" int sdqn_replay_bench_gather_sets(sdqn_replay_t r, const int64_t* idx_host, int nsets, int iters, float* ms_per_launch) {
   ARGCHK(r && idx_host && nsets > 0 && iters > 0 && ms_per_launch, "bad arguments");
+  ARGCHK(r->tuned_geom, "bench_gather_sets times the 84x84x4 kernel");
   const int B = r->B;
   for (int64_t i = 0; i < (int64_t)nsets * B; ++i)
     ARGCHK(idx_host[i] >= r->hist && idx_host[i] < r->count, "index %lld out of range (count %lld)", (long long)idx_host[i], (long long)r->count);
@@ -390,6 +410,7 @@ static int rccl_load(const char* path) {
 // ---- network -------------------------------------------------------------------------------------------
 struct ProfPair { int id; hipEvent_t a, b; };
 struct sdqn_net_s {
+  GenericNet* gen = nullptr;               // float64 / non-84x84x4 configurations: the whole network lives there (generic_net.hip)
   sdqn_net_cfg cfg; int B = 0, A = 0; int64_t NP = 0;   // NP: floats per flat buffer (weights [+ BatchNorm params + running stats])
   int64_t NPW = 0;                         // weights only = offset of the BatchNorm block
   bool bn = false;                         // --batch_norm
@@ -471,6 +492,7 @@ static int join_comm(sdqn_net_s* h);
 static int net_free(sdqn_net_s* h) {
   if (!h) return SDQN_OK;
   if (g_stream) hipStreamSynchronize(g_stream);
+  delete h->gen; h->gen = nullptr;
   if (g_comm) hipStreamSynchronize(g_comm);
   if (h->comm2 && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm2);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
@@ -490,13 +512,25 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   ARGCHK(c->batch_size > 0 && c->batch_size <= 4096, "bad batch_size %d", c->batch_size);
   ARGCHK(c->num_actions > 0 && c->num_actions <= MAX_ACTIONS, "num_actions must be in 1..%d (got %d)", MAX_ACTIONS, c->num_actions);
   ARGCHK(c->optimizer >= 0 && c->optimizer <= 2, "unknown optimizer %d", c->optimizer);
-  ARGCHK(c->datatype == 0 || c->datatype == 1, "datatype must be 0 (float32) or 1 (float16)");
+  ARGCHK(c->datatype >= 0 && c->datatype <= 2, "datatype must be 0 (float32), 1 (float16) or 2 (float64)");
   ARGCHK(!(c->batch_norm != 0.0 && c->datatype != 0), "batch_norm is float32 only");
-  ARGCHK(c->screen_height == H0 && c->screen_width == W0 && c->history_length == C0,
-         "this build supports 84x84 screens with history_length 4 (got %dx%d, %d)", c->screen_height, c->screen_width, c->history_length);
+  ARGCHK(c->screen_height > 0 && c->screen_width > 0 && c->history_length > 0 && c->screen_height <= 4096 && c->screen_width <= 4096 &&
+         c->history_length <= 64, "bad screen geometry %dx%d, history_length %d", c->screen_height, c->screen_width, c->history_length);
+  const bool tuned_geom = c->screen_height == H0 && c->screen_width == W0 && c->history_length == C0;
+  ARGCHK(tuned_geom || (c->datatype != 1 && c->batch_norm == 0.0),
+         "float16 and batch_norm are implemented for 84x84 screens with history_length 4 (got %dx%d, %d)", c->screen_height, c->screen_width, c->history_length);
   STREAMCHK();
   sdqn_net_s* h = new sdqn_net_s();
   h->cfg = *c; h->B = c->batch_size; h->A = c->num_actions; h->NPW = OFF5 + (int64_t)h->A * NFC;
+  if (c->datatype == 2 || !tuned_geom) {            // main.py:27-28,34,53: same layer stack, other sizes / float64 arithmetic
+    std::string err;
+    h->gen = make_generic_net(*c, g_stream, &err);
+    if (!h->gen) { set_error("%s", err.c_str()); delete h; return SDQN_ERR_HIP; }
+    h->NP = h->NPW = h->gen->param_count();
+    memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n);
+    *out = h;
+    return SDQN_OK;
+  }
   h->bn = c->batch_norm != 0.0;
   h->NP = h->NPW + (h->bn ? 2 * BN_PARAMS : 0);
   memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_n, 0, sizeof h->prof_n);
@@ -633,13 +667,46 @@ static bool bn_layer_span(sdqn_net_s* h, int which, int layer, float** base, int
 }
 extern "C" int sdqn_net_layer_size(sdqn_net_t h, int layer, int64_t* n) {
   ARGCHK(h && n && layer >= 0 && layer < (h->bn ? 9 : 5), "bad arguments");
+  if (h->gen) { *n = h->gen->layer_size(layer); return SDQN_OK; }
   if (layer >= 5) { *n = 2 * bn_features(layer - 5); return SDQN_OK; }
   int64_t rows, cols, off; layer_dims(layer, h->A, rows, cols, off);
   *n = rows * cols;
   return SDQN_OK;
 }
+#define GENCHK(x) do { hipError_t ge_ = (x); if (ge_ != hipSuccess) { set_error("%s -> %s", #x, hipGetErrorString(ge_)); return ge_ == hipErrorInvalidValue ? SDQN_ERR_ARG : SDQN_ERR_HIP; } } while (0)
+static int gen_set(sdqn_net_s* h, int which, int layer, const void* w, int64_t n, bool f64) {
+  ARGCHK(layer >= 0 && layer < 5 && which >= 0 && which <= 4 && which != 3, "bad arguments (which %d, layer %d)", which, layer);
+  ARGCHK(which != 4 || h->cfg.optimizer != 0, "this optimizer has no second state");
+  ARGCHK(n == h->gen->layer_size(layer), "layer %d holds %lld values, got %lld", layer, (long long)h->gen->layer_size(layer), (long long)n);
+  GENCHK(h->gen->set_param(which, layer, w, f64));
+  return SDQN_OK;
+}
+static int gen_get(sdqn_net_s* h, int which, int layer, void* w, int64_t n, bool f64) {
+  ARGCHK(layer >= 0 && layer < 5 && which >= 0 && which <= 4, "bad arguments (which %d, layer %d)", which, layer);
+  ARGCHK(which != 4 || h->cfg.optimizer != 0, "this optimizer has no second state");
+  ARGCHK(n == h->gen->layer_size(layer), "layer %d holds %lld values, got %lld", layer, (long long)h->gen->layer_size(layer), (long long)n);
+  GENCHK(h->gen->get_param(which, layer, w, f64));
+  return SDQN_OK;
+}
+// double-precision forms of set_weights / get_weights / predict / last_q: what a `--datatype float64` network (main.py:53) exchanges
+// without a round trip through float.  On float32 / float16 networks they convert.
+extern "C" int sdqn_net_set_weights_f64(sdqn_net_t h, int which, int layer, const double* w, int64_t n) {
+  ARGCHK(h && w && n >= 0, "NULL argument");
+  if (h->gen) return gen_set(h, which, layer, w, n, true);
+  std::vector<float> tmp((size_t)n); for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = (float)w[i];
+  return sdqn_net_set_weights(h, which, layer, tmp.data(), n);
+}
+extern "C" int sdqn_net_get_weights_f64(sdqn_net_t h, int which, int layer, double* w, int64_t n) {
+  ARGCHK(h && w && n >= 0, "NULL argument");
+  if (h->gen) return gen_get(h, which, layer, w, n, true);
+  std::vector<float> tmp((size_t)n);
+  int rc = sdqn_net_get_weights(h, which, layer, tmp.data(), n); if (rc) return rc;
+  for (int64_t i = 0; i < n; ++i) w[i] = (double)tmp[(size_t)i];
+  return SDQN_OK;
+}
 extern "C" int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const float* w, int64_t n) {
   ARGCHK(h && w, "NULL argument");
+  if (h->gen) return gen_set(h, which, layer, w, n, false);
   if (layer >= 5) {
     float* base; int64_t cnt;
     ARGCHK(which != 3 && bn_layer_span(h, which, layer, &base, &cnt), "no such BatchNorm buffer (which %d, layer %d)", which, layer);
@@ -670,6 +737,7 @@ extern "C" int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const fl
 }
 extern "C" int sdqn_net_get_weights(sdqn_net_t h, int which, int layer, float* w, int64_t n) {
   ARGCHK(h && w, "NULL argument");
+  if (h->gen) return gen_get(h, which, layer, w, n, false);
   if (layer >= 5) {
     float* base; int64_t cnt;
     ARGCHK(bn_layer_span(h, which, layer, &base, &cnt), "no such BatchNorm buffer (which %d, layer %d)", which, layer);
@@ -732,7 +800,8 @@ static inline bool prof_single_kernel(int kid) { return kid != K_ALLREDUCE && ki
 #define LAUNCH(KID, expr) LAUNCH_ON(g_stream, KID, expr)
 
 extern "C" int sdqn_net_profile(sdqn_net_t h, int enable, int kernel) {
-  ARGCHK(h && kernel < K_COUNT, "bad arguments"); h->prof_on = enable != 0; h->prof_filter = kernel; return SDQN_OK;
+  ARGCHK(h && kernel < K_COUNT, "bad arguments");
+  if (h->gen) return SDQN_OK; h->prof_on = enable != 0; h->prof_filter = kernel; return SDQN_OK;
 }
 extern "C" int sdqn_net_profile_count(int* n) { ARGCHK(n, "NULL"); *n = K_COUNT; return SDQN_OK; }
 extern "C" int sdqn_net_profile_read(sdqn_net_t h, int kernel, const char** name, double* total_ms, int64_t* launches) {
@@ -1021,8 +1090,17 @@ static int read_cost(sdqn_net_s* h, float* cost_out) {
   return SDQN_OK;
 }
 
+extern "C" int sdqn_net_predict_f64(sdqn_net_t h, const uint8_t* states, double* q_out) {
+  ARGCHK(h && states && q_out, "NULL argument");
+  if (h->gen) { GENCHK(h->gen->predict_host(states, h->B, q_out, true)); return SDQN_OK; }
+  std::vector<float> tmp((size_t)h->B * h->A);
+  int rc = sdqn_net_predict(h, states, tmp.data()); if (rc) return rc;
+  for (size_t i = 0; i < tmp.size(); ++i) q_out[i] = (double)tmp[i];
+  return SDQN_OK;
+}
 extern "C" int sdqn_net_predict(sdqn_net_t h, const uint8_t* states, float* q_out) {
   ARGCHK(h && states && q_out, "NULL argument");
+  if (h->gen) { GENCHK(h->gen->predict_host(states, h->B, q_out, false)); return SDQN_OK; }
   HIPCHK(hipMemcpyAsync(h->st_states, states, (size_t)h->B * STATE, hipMemcpyHostToDevice, g_stream));
   StepArgs a = step_args(h); a.nz = 1; a.from_ring = 0; a.src = h->st_states;
   HeadArgs hd = head_args(h, 0);
@@ -1035,6 +1113,7 @@ extern "C" int sdqn_net_predict(sdqn_net_t h, const uint8_t* states, float* q_ou
 
 extern "C" int sdqn_net_predict_one(sdqn_net_t h, const uint8_t* state, float* q_out) {
   ARGCHK(h && state && q_out, "NULL argument");
+  if (h->gen) { GENCHK(h->gen->predict_host(state, 1, q_out, false)); return SDQN_OK; }
   HIPCHK(hipMemcpyAsync(h->st_states, state, (size_t)STATE, hipMemcpyHostToDevice, g_stream));
   StepArgs a = step_args(h); a.B = 1; a.nz = 1; a.from_ring = 0; a.src = h->st_states;   // same buffers, batch of one
   HeadArgs hd = head_args(h, 0);
@@ -1055,13 +1134,15 @@ struct sdqn_statebuf_s {
   uint8_t* host = nullptr;       // [hist][FRAME] mirror in state_buffer.py order (oldest first)
   uint8_t* stage = nullptr;      // pinned [SB_SLOTS][FRAME]: staging slot i feeds ring slot i
   int hist = 0;
+  int64_t frame = 0;             // bytes per screen
   int pos = 0;                   // slot of the newest frame; window = slots [pos-hist+1, pos]
 };
 extern "C" int sdqn_statebuf_create(sdqn_statebuf_t* out, int H, int W, int hist) {
   ARGCHK(out, "NULL argument");
-  ARGCHK(H == H0 && W == W0 && hist == C0, "this build supports 84x84 screens with history_length 4 (got %dx%d, %d)", H, W, hist);
+  ARGCHK(H > 0 && W > 0 && hist > 0 && hist < SB_SLOTS / 2 && H <= 4096 && W <= 4096, "bad screen geometry %dx%d, history_length %d", H, W, hist);
   STREAMCHK();
-  sdqn_statebuf_s* s = new sdqn_statebuf_s(); s->hist = hist; s->pos = hist - 1;
+  sdqn_statebuf_s* s = new sdqn_statebuf_s(); s->hist = hist; s->pos = hist - 1; s->frame = (int64_t)H * W;
+  const int64_t FRAME = s->frame;
   hipError_t e = hipMalloc((void**)&s->d, (size_t)SB_SLOTS * FRAME);
   if (e == hipSuccess) e = hipMemsetAsync(s->d, 0, (size_t)SB_SLOTS * FRAME, g_stream);
   if (e == hipSuccess) e = hipHostMalloc((void**)&s->stage, (size_t)SB_SLOTS * FRAME, hipHostMallocDefault);
@@ -1080,6 +1161,7 @@ extern "C" int sdqn_statebuf_destroy(sdqn_statebuf_t s) {
 }
 extern "C" int sdqn_statebuf_add(sdqn_statebuf_t s, const uint8_t* screen) {
   ARGCHK(s && screen, "NULL argument");
+  const int64_t FRAME = s->frame;
   memmove(s->host, s->host + FRAME, (size_t)(s->hist - 1) * FRAME);           // state_buffer.py:17
   memcpy(s->host + (size_t)(s->hist - 1) * FRAME, screen, FRAME);             // :18
   if (s->pos + 1 == SB_SLOTS) {
@@ -1097,22 +1179,25 @@ extern "C" int sdqn_statebuf_add(sdqn_statebuf_t s, const uint8_t* screen) {
 }
 extern "C" int sdqn_statebuf_reset(sdqn_statebuf_t s) {
   ARGCHK(s, "NULL handle");
+  const int64_t FRAME = s->frame;
   memset(s->host, 0, (size_t)s->hist * FRAME);                                // state_buffer.py:27
   HIPCHK(hipMemsetAsync(s->d + (size_t)(s->pos - s->hist + 1) * FRAME, 0, (size_t)s->hist * FRAME, g_stream));
   return SDQN_OK;
 }
 extern "C" int sdqn_statebuf_get(sdqn_statebuf_t s, uint8_t* out) {
-  ARGCHK(s && out, "NULL argument"); memcpy(out, s->host, (size_t)s->hist * FRAME); return SDQN_OK;
+  ARGCHK(s && out, "NULL argument"); memcpy(out, s->host, (size_t)s->hist * s->frame); return SDQN_OK;
 }
-static const uint8_t* statebuf_window(sdqn_statebuf_s* s) { return s->d + (size_t)(s->pos - s->hist + 1) * FRAME; }
+static const uint8_t* statebuf_window(sdqn_statebuf_s* s) { return s->d + (size_t)(s->pos - s->hist + 1) * s->frame; }
 extern "C" int sdqn_statebuf_read_device(sdqn_statebuf_t s, uint8_t* out) {
   ARGCHK(s && out, "NULL argument");
-  HIPCHK(hipMemcpyAsync(out, statebuf_window(s), (size_t)s->hist * FRAME, hipMemcpyDeviceToHost, g_stream));
+  HIPCHK(hipMemcpyAsync(out, statebuf_window(s), (size_t)s->hist * s->frame, hipMemcpyDeviceToHost, g_stream));
   HIPCHK(hipStreamSynchronize(g_stream));
   return SDQN_OK;
 }
 extern "C" int sdqn_net_predict_state(sdqn_net_t h, sdqn_statebuf_t sb, float* q_out) {
   ARGCHK(h && sb && q_out, "NULL argument");
+  ARGCHK((size_t)sb->hist * sb->frame == (h->gen ? h->gen->state_bytes() : (size_t)STATE), "state buffer geometry differs from the network's");
+  if (h->gen) { GENCHK(h->gen->predict_dev(statebuf_window(sb), 1, q_out, false)); return SDQN_OK; }
   StepArgs a = step_args(h); a.B = 1; a.nz = 1; a.from_ring = 0; a.src = statebuf_window(sb);   // batch of one, read in place
   HeadArgs hd = head_args(h, 0);
   int rc = run_forward(h, a, hd); if (rc) return rc;
@@ -1126,6 +1211,12 @@ extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8
                                    const uint8_t* post, const uint8_t* terminals, float* cost_out) {
   ARGCHK(h && pre && actions && rewards && post && terminals, "NULL argument");
   for (int i = 0; i < h->B; ++i) ARGCHK(actions[i] < h->A, "action %d out of range at %d", (int)actions[i], i);
+  if (h->gen) {
+    GENCHK(h->gen->train_host(pre, actions, rewards, post, terminals, h->epoch));
+    h->train_iterations += 1;
+    if (cost_out) { double c; GENCHK(h->gen->read_cost(&c)); *cost_out = (float)c; }
+    return SDQN_OK;
+  }
   const size_t sb = (size_t)h->B * STATE, small = (size_t)h->B * 10;
   // No stream synchronisation (round 1 paid a full PCIe + sync bubble per step here): the caller's arrays are free to
   // change after return because they are either copied into a pinned double buffer of the library first (pageable
@@ -1200,9 +1291,25 @@ static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pin
   h->host_idx_cur = nullptr;
   return rc;
 }
+// float64 / other geometries: sample on the host, gather on the device into the replay handle's minibatch buffers, train from there
+static int gen_train_replay(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* idx_host) {
+  ARGCHK((size_t)r->state == h->gen->state_bytes(), "replay geometry (%dx%d, history %d) differs from the network's", r->H, r->W, r->hist);
+  int slot; const int64_t* didx; int rc = check_ring_actions(h, r, idx_host); if (rc) return rc;
+  rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
+  rc = replay_gather_generic(r, didx); if (rc) return rc;
+  rc = replay_release_idx_batched(r, slot, false); if (rc) return rc;
+  GENCHK(h->gen->train_dev(r->d_pre, r->d_post, r->d_act, r->d_rew, r->d_term, h->epoch));
+  h->train_iterations += 1;
+  return SDQN_OK;
+}
 extern "C" int sdqn_net_train_replay(sdqn_net_t h, sdqn_replay_t r, const int64_t* idx_host, float* cost_out) {
   ARGCHK(h && r && idx_host, "NULL argument");
   ARGCHK(r->B == h->B, "replay batch_size %d != network batch_size %d", r->B, h->B);
+  if (h->gen) {
+    int rc = gen_train_replay(h, r, idx_host); if (rc) return rc;
+    if (cost_out) { double c; GENCHK(h->gen->read_cost(&c)); *cost_out = (float)c; }
+    return SDQN_OK;
+  }
   int slot; const int64_t* didx; int rc = check_ring_actions(h, r, idx_host); if (rc) return rc;
   rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
   rc = train_replay_slot(h, r, didx); if (rc) return rc;
@@ -1213,6 +1320,17 @@ extern "C" int sdqn_net_train_replay(sdqn_net_t h, sdqn_replay_t r, const int64_
 extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, int n_steps, float* mean_cost) {
   ARGCHK(h && r && mt && n_steps >= 0, "bad arguments");
   ARGCHK(r->B == h->B, "replay batch_size %d != network batch_size %d", r->B, h->B);
+  if (h->gen) {
+    std::vector<int64_t> gi((size_t)r->B);
+    GENCHK(h->gen->reset_cost_sum());
+    for (int i = 0; i < n_steps; ++i) {
+      int rc = sample_checked(mt, r->terminals, r->count, r->current, r->hist, r->B, gi.data(), nullptr); if (rc) return rc;
+      rc = gen_train_replay(h, r, gi.data()); if (rc) return rc;
+    }
+    int rc = replay_flush_pending(r); if (rc) return rc;
+    if (mean_cost) { double sum; GENCHK(h->gen->read_cost_sum(&sum)); *mean_cost = n_steps ? (float)(sum / n_steps) : 0.0f; }
+    return SDQN_OK;
+  }
   std::vector<int64_t> idx((size_t)r->B);
   if (n_steps == 0) HIPCHK(hipMemsetAsync(h->cost_accum, 0, 8, g_stream));       // (otherwise the first step's prep launch clears it)
   // sample one step ahead: step i's update launch also performs step i+1's prep (index copy + metadata gather)
@@ -1253,6 +1371,7 @@ extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, 
 }
 extern "C" int sdqn_net_update_target(sdqn_net_t h) {
   ARGCHK(h, "NULL handle");
+  if (h->gen) { GENCHK(h->gen->update_target()); return SDQN_OK; }
   { int rc = join_comm(h); if (rc) return rc; }
   if (h->theta_t != h->theta) {
     HIPCHK(hipMemcpyAsync(h->theta_t, h->theta, (size_t)h->NP * 4, hipMemcpyDeviceToDevice, g_stream));   // deepqnetwork.py:102-105
@@ -1270,6 +1389,7 @@ extern "C" int sdqn_net_update_target(sdqn_net_t h) {
 // rank does after the all-reduce with bsz = nranks * batch_size (A9: grad / be.bsz, deepqnetwork.py:165).
 extern "C" int sdqn_net_apply_update(sdqn_net_t h, double bsz) {
   ARGCHK(h && bsz > 0, "bad arguments");
+  if (h->gen) { set_error("data parallel (grad_only / apply_update) is implemented for the 84x84x4 float32 / float16 configurations"); return SDQN_ERR_STATE; }
   { int rc = join_comm(h); if (rc) return rc; }
   StepArgs a = step_args(h);
   UpdateArgs u = make_update_args(h, a);
@@ -1318,7 +1438,9 @@ extern "C" int sdqn_net_half_payload_state(sdqn_net_t h, int* flag, int* scale_l
   return SDQN_OK;
 }
 extern "C" int sdqn_net_sync(sdqn_net_t h) {
-  ARGCHK(h, "NULL handle"); int rc = join_comm(h); if (rc) return rc;
+  ARGCHK(h, "NULL handle");
+  if (h->gen) { HIPCHK(hipStreamSynchronize(g_stream)); return SDQN_OK; }
+  int rc = join_comm(h); if (rc) return rc;
   // short waits are polled (a blocking hipStreamSynchronize costs 10-20 us of wake-up latency: 1 % of a 20-step call); anything
   // longer than ~2 ms falls through to the blocking wait
   { const auto t0 = std::chrono::steady_clock::now();
@@ -1340,6 +1462,7 @@ extern "C" int sdqn_net_sync(sdqn_net_t h) {
 }
 extern "C" int sdqn_net_last_q(sdqn_net_t h, float* preq, float* maxpostq) {
   ARGCHK(h, "NULL handle");
+  if (h->gen) { GENCHK(h->gen->last_q(preq, maxpostq, false)); return SDQN_OK; }
   const size_t nq = (size_t)h->B * h->A;
   HIPCHK(hipMemcpyAsync(h->h_f, h->q, nq * 4, hipMemcpyDeviceToHost, g_stream));
   HIPCHK(hipMemcpyAsync(h->h_f + nq, h->maxq, (size_t)h->B * 4, hipMemcpyDeviceToHost, g_stream));
@@ -1363,6 +1486,12 @@ extern "C" int sdqn_net_set_epoch(sdqn_net_t h, int epoch) { ARGCHK(h && epoch >
 
 extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   ARGCHK(h && name, "NULL argument");
+  if (h->gen) {                                   // the generic path has no tuning knobs; the ones that change semantics are refused
+    if (!strcmp(name, "grad_only") || !strcmp(name, "dp_overlap") || !strcmp(name, "keep_gradients")) {
+      ARGCHK(value == 0 || !strcmp(name, "keep_gradients"), "option %s is implemented for the 84x84x4 float32 / float16 configurations", name);
+    }
+    return SDQN_OK;
+  }
   if (!strcmp(name, "keep_gradients")) h->keep_grads = value != 0;
   else if (!strcmp(name, "grad_only")) h->grad_only = value != 0;
   else if (!strcmp(name, "h16_wgrad_mfma")) h->h16_wgrad_mfma = value != 0;
@@ -1438,6 +1567,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
 // test hook: raw read of an internal device buffer (internal layouts, see problems.h)
 extern "C" int sdqn_net_debug_read(sdqn_net_t h, const char* name, float* out, int64_t n) {
   ARGCHK(h && name && out, "NULL argument");
+  ARGCHK(!h->gen, "debug_read exposes the tuned path's internal buffers (84x84x4 float32 / float16 only)");
   const int B = h->B;
   struct { const char* n; float* p; int64_t len; } tab[] = {
     {"a1", h->a1, (int64_t)2 * B * PIX1 * K1}, {"a2", h->a2, (int64_t)2 * B * PIX2 * K2}, {"a3", h->a3, (int64_t)2 * B * PIX3 * K3},
@@ -1461,6 +1591,7 @@ extern "C" int sdqn_dp_unique_id(const char* rccl_path, char id[128]) {
 }
 extern "C" int sdqn_dp_init(sdqn_net_t h, const char* rccl_path, const char id[128], int rank, int nranks) {
   ARGCHK(h && id && nranks >= 1 && rank >= 0 && rank < nranks, "bad arguments");
+  if (h->gen) { set_error("data parallel is implemented for the 84x84x4 float32 / float16 configurations"); return SDQN_ERR_STATE; }
   if (h->comm) { set_error("data parallel already initialised"); return SDQN_ERR_STATE; }
   int rc = rccl_load(rccl_path); if (rc) return rc;
   Id128 u; memcpy(u.b, id, 128);

@@ -14,9 +14,15 @@ from . import _lib
 
 logger = logging.getLogger(__name__)
 
-# (rows, cols) in Neon layout per layer for 84x84x4 inputs (deepqnetwork.py:83-91)
-def layer_shapes(num_actions):
-    return [(256, 32), (512, 64), (576, 64), (512, 3136), (num_actions, 512)]
+# (rows, cols) in Neon layout per layer (deepqnetwork.py:83-91): conv (C*R*S, K), affine (nout, nin);
+# 84x84x4 inputs give (256, 32), (512, 64), (576, 64), (512, 3136), (A, 512)
+def layer_shapes(num_actions, history_length=4, screen_height=84, screen_width=84):
+    shapes, c, h, w = [], history_length, screen_height, screen_width
+    for (r, s_, k, st) in ((8, 8, 32, 4), (4, 4, 64, 2), (3, 3, 64, 1)):
+        assert h >= r and w >= s_, "screen too small for the layer stack of deepqnetwork.py:83-87"
+        shapes.append((c * r * s_, k))
+        h, w, c = (h - r) // st + 1, (w - s_) // st + 1, k
+    return shapes + [(512, c * h * w), (num_actions, 512)]
 
 
 class DeepQNetwork:
@@ -34,9 +40,17 @@ class DeepQNetwork:
         if getattr(args, "backend", "hip") == "cpu":
             raise NotImplementedError("there is no CPU backend: libsdqn_hip is MI355X-only")
         dt = str(getattr(args, "datatype", "float32"))
-        if dt not in ("float32", "float16"):
-            raise NotImplementedError("datatype %s: float32 and float16 (half activations, fp32 master weights) are implemented" % dt)
+        if dt not in ("float32", "float16", "float64"):                                 # main.py:53
+            raise NotImplementedError("datatype %s: float16, float32 and float64 are implemented" % dt)
         self.datatype = dt
+        # float64 and screens other than 84x84x4 run on the library's generic im2col + GEMM path (csrc/generic_net.hip), everything
+        # else on the tuned kernels; the choice is the library's, from the configuration alone
+        self._f64 = dt == "float64"
+        self._np = np.float64 if self._f64 else np.float32
+        self._shapes = layer_shapes(num_actions, self.history_length, *self.screen_dim)
+        tuned_geom = (self.history_length,) + tuple(self.screen_dim) == (4, 84, 84)
+        if not tuned_geom and (dt == "float16" or self.batch_norm):
+            raise NotImplementedError("float16 and batch_norm are implemented for 84x84 screens with history_length 4")
         if getattr(args, "stochastic_round", False):                                    # main.py:54 -> gen_backend(stochastic_round=...)
             raise NotImplementedError("stochastic rounding (a Neon fp16 GPU-backend feature) is not implemented")
         if self.batch_norm and dt != "float32":
@@ -55,7 +69,7 @@ class DeepQNetwork:
         cfg.learning_rate = float(getattr(args, "learning_rate", 0.00025))
         cfg.decay_rate = float(getattr(args, "decay_rate", 0.95))
         cfg.optimizer = ("rmsprop", "adam", "adadelta").index(optimizer)              # :50-59
-        cfg.datatype = 1 if dt == "float16" else 0                                   # :33
+        cfg.datatype = {"float32": 0, "float16": 1, "float64": 2}[dt]                # :33
         cfg.loss_scale = float(getattr(args, "loss_scale", 1024.0))
         cfg.batch_norm = 1.0 if self.batch_norm else 0.0                              # :83-89 Conv/Affine(batch_norm=...)
         # Neon's defaults (the reference passes none): RMSProp/Adadelta epsilon 1e-6, Adam epsilon 1e-8, betas 0.9/0.999
@@ -81,10 +95,10 @@ class DeepQNetwork:
         # (gen_backend(rng_seed=args.random_seed), :31: seed 0 is a seed here, unlike main.py:89's `if args.random_seed`)
         rng = np.random.RandomState(getattr(args, "random_seed", None))
         for which in ((0, 1) if cfg.target_enabled else (0,)):
-            for i, shp in enumerate(layer_shapes(num_actions)):
+            for i, shp in enumerate(self._shapes):
                 fan_in = shp[0] if i < 3 else shp[1]
                 k = np.sqrt(3.0 / fan_in)
-                self.set_layer(i, rng.uniform(-k, k, size=shp).astype(np.float32), which)
+                self.set_layer(i, rng.uniform(-k, k, size=shp).astype(self._np), which)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -93,13 +107,19 @@ class DeepQNetwork:
 
     # ---- weights at the boundary are ALWAYS in Neon layout --------------------------------------
     def set_layer(self, layer, w, which=0):
-        w = np.ascontiguousarray(w, dtype=np.float32)
-        assert w.shape == layer_shapes(self.num_actions)[layer], (w.shape, layer)
-        _lib.check(self._lib.sdqn_net_set_weights(self._h, which, layer, _lib.ptr(w, C.c_float), w.size))
+        w = np.ascontiguousarray(w, dtype=self._np)
+        assert w.shape == self._shapes[layer], (w.shape, layer)
+        if self._f64:
+            _lib.check(self._lib.sdqn_net_set_weights_f64(self._h, which, layer, _lib.ptr(w, C.c_double), w.size))
+        else:
+            _lib.check(self._lib.sdqn_net_set_weights(self._h, which, layer, _lib.ptr(w, C.c_float), w.size))
 
     def get_layer(self, layer, which=0):
-        w = np.empty(layer_shapes(self.num_actions)[layer], dtype=np.float32)
-        _lib.check(self._lib.sdqn_net_get_weights(self._h, which, layer, _lib.ptr(w, C.c_float), w.size))
+        w = np.empty(self._shapes[layer], dtype=self._np)
+        if self._f64:
+            _lib.check(self._lib.sdqn_net_get_weights_f64(self._h, which, layer, _lib.ptr(w, C.c_double), w.size))
+        else:
+            _lib.check(self._lib.sdqn_net_get_weights(self._h, which, layer, _lib.ptr(w, C.c_float), w.size))
         return w
 
     # --batch_norm: BatchNorm layer l = 0..3 (after conv1, conv2, conv3, fc4).  which as above for (beta, gamma);
@@ -157,12 +177,15 @@ class DeepQNetwork:
     def predict(self, states):                                     # :174-186
         assert states.shape == ((self.batch_size, self.history_length,) + self.screen_dim)
         st = np.ascontiguousarray(states, dtype=np.uint8)
-        q = np.empty((self.batch_size, self.num_actions), dtype=np.float32)
-        _lib.check(self._lib.sdqn_net_predict(self._h, _lib.ptr(st, C.c_uint8), _lib.ptr(q, C.c_float)))
+        q = np.empty((self.batch_size, self.num_actions), dtype=self._np)
+        if self._f64:
+            _lib.check(self._lib.sdqn_net_predict_f64(self._h, _lib.ptr(st, C.c_uint8), _lib.ptr(q, C.c_double)))
+        else:
+            _lib.check(self._lib.sdqn_net_predict(self._h, _lib.ptr(st, C.c_uint8), _lib.ptr(q, C.c_float)))
         return q
 
     def predict_one(self, state):
-        """Acting-path fast path: Q-values of one state u8[4,84,84] -> float32[A]; identical to
+        """Acting-path fast path: Q-values of one state u8[hist,H,W] -> float32[A]; identical to
         predict(padded_batch)[0] (agent.py:55-61) without computing the zero rows."""
         assert state.shape == (self.history_length,) + self.screen_dim
         st = np.ascontiguousarray(state, dtype=np.uint8)
