@@ -728,8 +728,8 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-        net.sync()
+        net.sync()                   # the library's own wait first: it polls its stream (a blocking device-wide wait wakes up 10-20 us late)
+        torch.cuda.synchronize()     # ... then the device-wide one the contract asks for (returns at once: the device is idle)
 
     # ---- the standalone replay-gather measurements (getMinibatch()'s kernel at B and at B = 4096) run FIRST: other kernels on
     # other buffers, and they leave the device at its working clocks before the W warm-up steps (a 5-step warm-up straight after

@@ -1310,6 +1310,7 @@ extern "C" int sdqn_net_train_replay(sdqn_net_t h, sdqn_replay_t r, const int64_
     if (cost_out) { double c; GENCHK(h->gen->read_cost(&c)); *cost_out = (float)c; }
     return SDQN_OK;
   }
+  ARGCHK(r->tuned_geom, "replay geometry (%dx%d, history %d) differs from the network's (84x84, 4)", r->H, r->W, r->hist);
   int slot; const int64_t* didx; int rc = check_ring_actions(h, r, idx_host); if (rc) return rc;
   rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
   rc = train_replay_slot(h, r, didx); if (rc) return rc;
@@ -1331,6 +1332,7 @@ extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, 
     if (mean_cost) { double sum; GENCHK(h->gen->read_cost_sum(&sum)); *mean_cost = n_steps ? (float)(sum / n_steps) : 0.0f; }
     return SDQN_OK;
   }
+  ARGCHK(r->tuned_geom, "replay geometry (%dx%d, history %d) differs from the network's (84x84, 4)", r->H, r->W, r->hist);
   std::vector<int64_t> idx((size_t)r->B);
   if (n_steps == 0) HIPCHK(hipMemsetAsync(h->cost_accum, 0, 8, g_stream));       // (otherwise the first step's prep launch clears it)
   // sample one step ahead: step i's update launch also performs step i+1's prep (index copy + metadata gather)

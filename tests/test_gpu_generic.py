@@ -165,7 +165,13 @@ def test_what_stays_refused_says_so(sd):
         sd.DeepQNetwork(4, make_args(batch_size=4, history_length=2, batch_norm=True))
     with pytest.raises(AssertionError):                         # 20 x 20 screens do not survive conv2 (deepqnetwork.py:85)
         sd.DeepQNetwork(4, make_args(batch_size=4, screen_height=20, screen_width=20))
+    mem = sd.ReplayMemory(200, make_args(batch_size=4, screen_height=60, screen_width=52, history_length=3))
+    synthetic_fill(mem, 1, num_actions=4); mem.sync_mirror()
+    with pytest.raises(AssertionError):                         # a 60 x 52 x 3 ring cannot feed an 84 x 84 x 4 network
+        sd.DeepQNetwork(4, make_args(batch_size=4)).train_from_memory(mem, 1)
     net = sd.DeepQNetwork(4, make_args(batch_size=4, datatype="float64"))
+    with pytest.raises(AssertionError):
+        net.train_from_memory(mem, 1)
     with pytest.raises((RuntimeError, AssertionError)):
         net.apply_update(8)
     with pytest.raises((RuntimeError, AssertionError)):
