@@ -12,6 +12,7 @@
 //   inside bwd3.  The in-place update is ordered behind the dgrad's reads of the same W4 rows by one flag word per row block
 //   (problems.h: Fc4DgradSig / Fc4WgradWait) — a write-after-read hand-off, no data crosses between the workgroups.
 #include "gemm_engine.h"
+#include "problems_h16.h"
 #include "kernels.h"
 #include "update_body.h"
 
@@ -536,6 +537,45 @@ hipError_t launch_w1_planes(const float* theta, unsigned short* w1p, hipStream_t
   return hipGetLastError();
 }
 
+// ---- float16 mode: the same write-through epilogues (half outputs leave with 2-byte sc1 stores), every launch but bwd3 -----------------------------------
+__device__ __forceinline__ void wt_store_h(half_t* p, half_t v) {
+  union { half_t h; unsigned short u; } c; c.h = v;
+  __hip_atomic_store(reinterpret_cast<unsigned short*>(p), c.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct Conv1FwdHWT : Conv1FwdH {
+  __device__ static void store(const StepArgs& a, int z, int, int m, int n, float v) { wt_store_h(&a.h_a1[((int64_t)z * M(a) + m) * K1 + n], (half_t)fmaxf(v, 0.0f)); }
+};
+struct Conv2FwdHWT : Conv2FwdH {
+  __device__ static void store(const StepArgs& a, int z, int, int m, int n, float v) { wt_store_h(&a.h_a2[((int64_t)z * M(a) + m) * K2 + n], (half_t)fmaxf(v, 0.0f)); }
+};
+struct Conv3FwdHWT : Conv3FwdH {
+  __device__ static void store(const StepArgs& a, int z, int, int m, int n, float v) { wt_store_h(&a.h_a3[((int64_t)z * M(a) + m) * K3 + n], (half_t)fmaxf(v, 0.0f)); }
+};
+struct Fc4FwdHWT : Fc4FwdH {
+  __device__ static void store(const StepArgs& a, int z, int ks, int m, int n, float v) { wt_store(&a.slab4[(((int64_t)ks * 2 + z) * a.B + m) * NFC + n], v); }
+};
+struct Fc4DgradHWT : Fc4DgradH {
+  __device__ static void store(const StepArgs& a, int, int, int m, int n, float v) {
+    int pix = n >> 6, f = n & 63, p = pix / Q3, q = pix - p * Q3;
+    const half_t dv = (float)a.h_a3[(int64_t)m * NIN4 + n] > 0.0f ? (half_t)v : (half_t)0.0f;
+    wt_store_h(&a.h_d3p[((m * PD3 + p + 2) * PD3 + q + 2) * K3 + f], dv);
+    wt_store_h(&a.h_d3[(int64_t)m * NIN4 + n], dv);
+  }
+};
+struct Conv2DgradHWT : Conv2DgradH {
+  __device__ static void store(const StepArgs& a, int z, int, int m, int c, float v) {
+    int py = z >> 1, px = z & 1;
+    int n = m / 100, pix = m - n * 100, i = pix / 10, j = pix - i * 10;
+    int o = ((n * P1 + 2 * i + py) * Q1 + 2 * j + px) * K1 + c;
+    wt_store_h(&a.h_d1[o], (float)a.h_a1[o] > 0.0f ? (half_t)v : (half_t)0.0f);
+  }
+};
+struct Conv2WgradHWWT : Conv2WgradHW {
+  __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab2[(int64_t)ks * NW2 + m * K2 + n], v * a.inv_loss_scale); }
+};
+struct Conv1WgradHWWT : Conv1WgradHW {
+  __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab1[(int64_t)ks * NW1 + m * K1 + n], v * a.inv_loss_scale); }
+};
 hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = true;
   if (id == K_FC4_DGRAD && (t.r3 & 1) && a.B <= 32 && !a.h16 && a.f4w_count > 0 && a.f4d_flags)
@@ -570,6 +610,16 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
   // conv2 / conv3 forward with ONE workgroup per 32 x 64 output block (N = 64 = two 32-wide tiles): the register-blocked routine with
   // 1 x 2 accumulators per wave loads the gathered A rows once for both tiles (the gather is the expensive operand: 64 cache lines per
   // load instruction).  Same k order per accumulator as the unblocked tile: bit-identical.
+  if (a.B <= 32 && a.h16 == 2 && !a.bn && t.wt && !t.order && !(id >= 0 && id < 12 && t.nw_override[id] > 0)) {      // float16 mode, default launch forms
+    if (id == K_CONV1_FWD && (t.wt & 128)) return launch_gemm<Conv1FwdHWT, 8>(a, s);
+    if (id == K_CONV2_FWD && (t.wt & 1)) return launch_gemm<Conv2FwdHWT, 16>(a, s);
+    if (id == K_CONV3_FWD && (t.wt & 2)) return launch_gemm<Conv3FwdHWT, 16>(a, s);
+    if (id == K_FC4_FWD && (t.wt & 4)) return launch_gemm<Fc4FwdHWT, 14>(a, s);
+    if (id == K_FC4_DGRAD && (t.wt & 8)) return launch_gemm<Fc4DgradHWT, 16>(a, s);
+    // (bwd3 stays on plain stores in this mode: 16 404 vs 16 445 steps/s alone, 16 775 vs 16 809 with the others — tools/exp/README.md)
+    if (id == K_BWD2 && (t.wt & 32)) return launch_multi<512, NoProblem, 2, Conv2DgradHWT, 8, Conv2WgradHWWT, 8>(a, true, true, s);
+    if (id == K_BWD1 && (t.wt & 64)) return launch_multi<1024, NoProblem, 2, Conv1WgradHWWT, 16, NoProblem, 2>(a, true, false, s);
+  }
   if (a.B <= 32 && !a.h16 && !a.bn && t.wt && !t.hoist && !t.order && !(id >= 0 && id < 12 && t.nw_override[id] > 0)) {       // write-through epilogues: the default launch forms with the *WT problems
     if (id == K_CONV2_FWD && (t.wt & 1) && !(t.r3 & 16)) return launch_gemm<Conv2FwdWT, 16>(a, s);
     if (id == K_FC4_FWD && (t.wt & 4)) return launch_gemm<Staged<Fc4FwdWT>, 14>(a, s);

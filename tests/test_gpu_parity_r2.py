@@ -718,3 +718,29 @@ def test_profile_modes_packet_timestamps_against_event_markers(sd):
         assert 1.0 < us1 < 40.0, (k, us1)
         assert us1 < us0 + 0.5, (k, us1, us0)
     assert sum(per[1][k][0] for k in step) < sum(per[0][k][0] for k in step) - 5.0
+
+
+@pytest.mark.gpu
+def test_fp16_write_through_epilogues_keep_the_numbers(sd):
+    """float16 mode: the write-through (sc1) epilogue variants of every launch (option wt, default on) store the same values as the
+    plain ones — weights, RMSProp state and half copies bit-identical after five steps from a ring, at A = 6."""
+    A, B, size = 6, 32, 3000
+    args = make_args(batch_size=B, datatype="float16")
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 808, num_actions=A)
+    mem.sync_mirror()
+    nets = []
+    for wt in (511, 0):
+        net = sd.DeepQNetwork(A, args)
+        net.set_weights(xavier_weights(A, 809), 0)
+        net.update_target_network()
+        net.set_option("wt", wt)
+        mt = (C.c_uint32 * 625)(); sd.load().sdqn_mt_seed(mt, 17)
+        net.train_from_memory(mem, 5, mt_state=mt, want_cost=False)
+        net.sync()
+        nets.append(net)
+    for l in range(5):
+        assert np.array_equal(nets[0].get_layer(l, 0), nets[1].get_layer(l, 0)), l
+        assert np.array_equal(nets[0].get_layer(l, 2), nets[1].get_layer(l, 2)), l
+    held = random_minibatch(B, A, 3)[0]
+    assert np.array_equal(nets[0].predict(held), nets[1].predict(held))          # (reads the half copies the epilogues refreshed)
