@@ -90,6 +90,13 @@ int sdqn_replay_sample(sdqn_replay_t h, uint32_t mt[SDQN_MT_WORDS], int64_t* idx
 int sdqn_replay_gather(sdqn_replay_t h, const int64_t* idx_host /*[batch]*/);
 /* replay_memory.py:79: the device minibatch copied into the buffers of sdqn_replay_minibatch_ptrs (sync) */
 int sdqn_replay_minibatch_to_host(sdqn_replay_t h);
+/* One-shot declaration by the caller of sdqn_net_train_host: "the pinned prestates / poststates buffers of this handle
+ * (sdqn_replay_minibatch_ptrs) still hold what the last sdqn_replay_minibatch_to_host wrote — I have not modified them".  If that
+ * call is then made on exactly those buffers and no other gather has run since, the step reads the device copy of the minibatch in
+ * place and uploads only the 10 x batch_size bytes of (rewards, actions, terminals).  Never required for correctness: without it
+ * (C callers that write into the buffers, arrays from elsewhere) the states are uploaded as before.  simple_dqn_amd's
+ * ReplayMemory exposes the two buffers as write-tracking numpy views and declares this only while they are untouched. */
+int sdqn_replay_declare_minibatch_clean(sdqn_replay_t h);
 /* device-side timing of the last n gather launches, for bench.py (HIP events on the library stream) */
 int sdqn_replay_bench_gather(sdqn_replay_t h, const int64_t* idx_host, int iters, float* ms_per_launch);
 /* the same with a different index set per launch (idx_host = nsets x batch_size, cycled): a repeated set is served from L2 / MALL

@@ -28,6 +28,9 @@ struct GenericNet {
                                const uint8_t* term, int epoch) = 0;
   virtual hipError_t train_host(const uint8_t* pre, const uint8_t* act, const int64_t* rew, const uint8_t* post,
                                 const uint8_t* term, int epoch) = 0;
+  // device-resident states (a ReplayMemory's gathered minibatch) + host metadata: only the 10 x B bytes of (r, a, t) are uploaded
+  virtual hipError_t train_dev_host_meta(const uint8_t* pre_dev, const uint8_t* post_dev, const uint8_t* act, const int64_t* rew,
+                                         const uint8_t* term, int epoch) = 0;
   virtual hipError_t read_cost(double* cost) = 0;                        // cost of the last step (synchronises)
   virtual hipError_t reset_cost_sum() = 0;                               // running sum over steps (train_many's mean)
   virtual hipError_t read_cost_sum(double* sum) = 0;

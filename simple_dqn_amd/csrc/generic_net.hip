@@ -363,14 +363,21 @@ class GenericNetT : public GenericNet {
     hipLaunchKernelGGL(update_kernel<T>, dim3(grid_for(NP)), dim3(256), 0, st, u);
     return hipGetLastError();
   }
+  hipError_t upload_meta(const uint8_t* actions, const int64_t* rew, const uint8_t* term) {
+    memcpy(small_host.data(), rew, (size_t)B * 8); memcpy(small_host.data() + (size_t)B * 8, actions, B); memcpy(small_host.data() + (size_t)B * 9, term, B);
+    GCHK(hipMemcpyAsync(st_small, small_host.data(), (size_t)B * 10, hipMemcpyHostToDevice, st));
+    return hipStreamSynchronize(st);                 // the caller's arrays (and small_host) are free once this returns, like the reference's
+  }
   hipError_t train_host(const uint8_t* pre, const uint8_t* actions, const int64_t* rew, const uint8_t* post, const uint8_t* term, int epoch) override {
     const size_t sb = (size_t)B * state_bytes();
     GCHK(hipMemcpyAsync(st_states, pre, sb, hipMemcpyHostToDevice, st));
     GCHK(hipMemcpyAsync(st_states + sb, post, sb, hipMemcpyHostToDevice, st));
-    memcpy(small_host.data(), rew, (size_t)B * 8); memcpy(small_host.data() + (size_t)B * 8, actions, B); memcpy(small_host.data() + (size_t)B * 9, term, B);
-    GCHK(hipMemcpyAsync(st_small, small_host.data(), (size_t)B * 10, hipMemcpyHostToDevice, st));
-    GCHK(hipStreamSynchronize(st));                  // the caller's arrays (and small_host) are free once this returns, like the reference's
+    GCHK(upload_meta(actions, rew, term));
     return train_dev(st_states, st_states + sb, st_small + (size_t)B * 8, reinterpret_cast<const int64_t*>(st_small), st_small + (size_t)B * 9, epoch);
+  }
+  hipError_t train_dev_host_meta(const uint8_t* pre_dev, const uint8_t* post_dev, const uint8_t* actions, const int64_t* rew, const uint8_t* term, int epoch) override {
+    GCHK(upload_meta(actions, rew, term));
+    return train_dev(pre_dev, post_dev, st_small + (size_t)B * 8, reinterpret_cast<const int64_t*>(st_small), st_small + (size_t)B * 9, epoch);
   }
 
   template <typename U> static void conv_out(const std::vector<T>& v, void* host) { U* o = (U*)host; for (size_t i = 0; i < v.size(); ++i) o[i] = (U)v[i]; }

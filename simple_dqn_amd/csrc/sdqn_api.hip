@@ -116,6 +116,11 @@ struct sdqn_replay_s {
   int64_t* h_idx = nullptr; int64_t* d_idx_view = nullptr;      // [NSLOT][B] pinned + its device alias
   hipEvent_t slot_ev[NSLOT]; bool slot_busy[NSLOT]; int next_slot = 0;
   int slot_cover[NSLOT]; int pending[NSLOT]; int npending = 0;   // batched release (train_many): slot s is free once slot_ev[slot_cover[s]] has completed
+  // tuple API: the device copy of the gathered minibatch (d_pre | d_post) stays valid after getMinibatch() has brought it down; a
+  // train(tuple) call on the very same pinned arrays may read it in place instead of uploading 2 x B x state bytes again — when the
+  // host copy is as new as the device copy (generations) AND the caller has declared that it did not write into the host arrays
+  // (sdqn_replay_declare_minibatch_clean: one-shot, consumed by the next sdqn_net_train_host)
+  uint64_t mb_dev_gen = 1, mb_host_gen = 0; bool mb_clean_declared = false;
   hipEvent_t mb_upload_ev = nullptr;      // tuple API: the H2D of h_pre | h_post issued by sdqn_net_train_host (waited for before that call returns)
 };
 
@@ -164,7 +169,7 @@ extern "C" int sdqn_replay_create(sdqn_replay_t* out, int64_t size, int H, int W
   const size_t sb = (size_t)batch * STATE;
   // the gathered minibatch as two blocks — [pre | post] and [rewards 8 B | actions B | terminals B] — on the device and in pinned host
   // memory alike: getMinibatch() brings it down with two copies and the tuple API sends it back up with two (every copy is a stream packet)
-  RCHK(hipMalloc((void**)&r->d_pre, 2 * sb)); r->d_post = r->d_pre + sb;
+  RCHK(hipMalloc((void**)&r->d_pre, 2 * sb + SRC_PAD)); r->d_post = r->d_pre + sb;     // (+ slack: the step may read it in place like a staging buffer)
   RCHK(hipMalloc((void**)&r->d_rew, (size_t)batch * 10));
   r->d_act = reinterpret_cast<uint8_t*>(r->d_rew) + (size_t)batch * 8; r->d_term = r->d_act + batch;
   RCHK(hipHostMalloc((void**)&r->h_pre, 2 * sb, hf)); r->h_post = r->h_pre + sb;
@@ -285,10 +290,12 @@ static int replay_release_idx_batched(sdqn_replay_s* r, int slot, bool flush) {
 }
 
 static GatherArgs gather_args(sdqn_replay_s* r, const int64_t* didx) {
+  r->mb_dev_gen++;                                  // (every launch built from these arguments overwrites the device minibatch)
   GatherArgs g; g.ring = r->d_ring; g.meta = r->d_meta; g.idx = didx; g.pre = r->d_pre; g.post = r->d_post;
   g.actions = r->d_act; g.rewards = r->d_rew; g.terminals = r->d_term; g.B = r->B; return g;
 }
 static int replay_gather_generic(sdqn_replay_s* r, const int64_t* didx) {      // any geometry (generic_net.hip)
+  r->mb_dev_gen++;
   GatherGenericArgs g; g.ring = r->d_ring; g.meta = r->d_meta; g.idx = didx; g.pre = r->d_pre; g.post = r->d_post;
   g.actions = r->d_act; g.rewards = r->d_rew; g.terminals = r->d_term; g.B = r->B; g.hist = r->hist; g.frame = r->frame;
   HIPCHK(launch_gather_generic(g, g_stream));
@@ -317,7 +324,11 @@ extern "C" int sdqn_replay_minibatch_to_host(sdqn_replay_t r) {
   HIPCHK(hipMemcpyAsync(r->h_pre, r->d_pre, 2 * sb, hipMemcpyDeviceToHost, g_stream));                 // [pre | post]
   HIPCHK(hipMemcpyAsync(r->h_rew, r->d_rew, (size_t)r->B * 10, hipMemcpyDeviceToHost, g_stream));      // [rewards | actions | terminals]
   HIPCHK(hipStreamSynchronize(g_stream));
+  r->mb_host_gen = r->mb_dev_gen;
   return SDQN_OK;
+}
+extern "C" int sdqn_replay_declare_minibatch_clean(sdqn_replay_t r) {
+  ARGCHK(r, "NULL handle"); r->mb_clean_declared = true; return SDQN_OK;
 }
 extern "C" int sdqn_replay_bench_gather(sdqn_replay_t r, const int64_t* idx_host, int iters, float* ms_per_launch) {
   ARGCHK(r && idx_host && iters > 0 && ms_per_launch, "bad arguments");
@@ -1211,8 +1222,17 @@ extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8
                                    const uint8_t* post, const uint8_t* terminals, float* cost_out) {
   ARGCHK(h && pre && actions && rewards && post && terminals, "NULL argument");
   for (int i = 0; i < h->B; ++i) ARGCHK(actions[i] < h->A, "action %d out of range at %d", (int)actions[i], i);
+  sdqn_replay_s* owner = nullptr;                               // (handles are created / destroyed / used from ONE host thread: sdqn.h)
+  bool reuse = false;                                           // train on the device copy the last gather left (no state upload)
+  for (sdqn_replay_s* r : g_replays) {
+    if (pre == r->h_pre && post == r->h_post && r->B == h->B) { owner = r; reuse = r->mb_clean_declared && r->mb_host_gen == r->mb_dev_gen; }
+    r->mb_clean_declared = false;                               // one-shot, whoever it was meant for
+  }
+  const bool ours = owner != nullptr;
   if (h->gen) {
-    GENCHK(h->gen->train_host(pre, actions, rewards, post, terminals, h->epoch));
+    ARGCHK(!ours || (size_t)owner->state == h->gen->state_bytes(), "replay geometry differs from the network's");
+    if (reuse) GENCHK(h->gen->train_dev_host_meta(owner->d_pre, owner->d_post, actions, rewards, terminals, h->epoch));
+    else GENCHK(h->gen->train_host(pre, actions, rewards, post, terminals, h->epoch));
     h->train_iterations += 1;
     if (cost_out) { double c; GENCHK(h->gen->read_cost(&c)); *cost_out = (float)c; }
     return SDQN_OK;
@@ -1225,28 +1245,30 @@ extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8
   // stream; a HOST write to them could still race the DMA, so in that case the call returns only after the upload has completed
   // (event wait AFTER every launch of the step is enqueued: the GPU never idles for it, the host waits ~30 us it would otherwise
   // spend ahead of the stream).  Either way: once train() has returned the caller's five arrays are free, like the reference's.
+  // Round 3: when those pinned buffers still hold exactly what the last gather put on the device and the caller says it has not
+  // written into them (`reuse`), nothing is uploaded at all — the step reads the device copy in place.
   const int sl = h->stage_next; h->stage_next ^= 1;
   if (!h->h_stage[sl]) {
     HIPCHK(hipHostMalloc((void**)&h->h_stage[sl], 2 * sb + small, hipHostMallocDefault));
     HIPCHK(hipEventCreateWithFlags(&h->stage_ev[sl], hipEventDisableTiming));
   }
   if (h->stage_busy[sl]) { HIPCHK(hipEventSynchronize(h->stage_ev[sl])); h->stage_busy[sl] = false; }
-  sdqn_replay_s* owner = nullptr;                               // (handles are created / destroyed / used from ONE host thread: sdqn.h)
-  for (sdqn_replay_s* r : g_replays) if (pre == r->h_pre && post == r->h_post && r->B == h->B) owner = r;
-  const bool ours = owner != nullptr;
+  ARGCHK(!ours || owner->tuned_geom, "replay geometry differs from the network's");
   uint8_t* st = h->h_stage[sl];
   if (!ours) { memcpy(st, pre, sb); memcpy(st + sb, post, sb); }
   uint8_t* sm = st + 2 * sb;                                                  // [rewards 8 B | actions B | terminals B], as on the device
   memcpy(sm, rewards, (size_t)h->B * 8); memcpy(sm + (size_t)h->B * 8, actions, h->B); memcpy(sm + (size_t)h->B * 9, terminals, h->B);
-  // every copy is a packet of its own in the stream: 2 instead of 5
-  HIPCHK(hipMemcpyAsync(h->st_states, ours ? pre : st, 2 * sb, hipMemcpyHostToDevice, g_stream));     // (a ReplayMemory's pre | post are one block too)
-  if (ours) { HIPCHK(hipEventRecord(owner->mb_upload_ev, g_stream)); }   // waited for before this call returns
+  // every copy is a packet of its own in the stream: 2 instead of 5 (1 with `reuse`)
+  if (!reuse) {
+    HIPCHK(hipMemcpyAsync(h->st_states, ours ? pre : st, 2 * sb, hipMemcpyHostToDevice, g_stream));     // (a ReplayMemory's pre | post are one block too)
+    if (ours) { HIPCHK(hipEventRecord(owner->mb_upload_ev, g_stream)); }   // waited for before this call returns
+  }
   HIPCHK(hipMemcpyAsync(h->st_rew, sm, small, hipMemcpyHostToDevice, g_stream));
   HIPCHK(hipEventRecord(h->stage_ev[sl], g_stream)); h->stage_busy[sl] = true;
-  StepArgs a = step_args(h); a.from_ring = 0; a.src = h->st_states;
+  StepArgs a = step_args(h); a.from_ring = 0; a.src = reuse ? owner->d_pre : h->st_states;
   HeadArgs hd = head_args(h, 1);
   int rc = run_train(h, a, hd); if (rc) return rc;
-  if (ours) { HIPCHK(hipEventSynchronize(owner->mb_upload_ev)); }
+  if (ours && !reuse) { HIPCHK(hipEventSynchronize(owner->mb_upload_ev)); }
   if (cost_out) return read_cost(h, cost_out);
   return SDQN_OK;
 }

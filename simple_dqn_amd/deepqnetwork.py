@@ -167,6 +167,13 @@ class DeepQNetwork:
         want = self.callback is not None
         if self.optimizer == "adam":
             _lib.check(self._lib.sdqn_net_set_epoch(self._h, int(epoch)))        # optimizer.optimize(.., epoch), :165
+        # the reference's loop body net.train(mem.getMinibatch()): the states are still on the device from the gather; if the two
+        # arrays ARE that memory's buffers and nothing has written into them since, say so and the library skips their upload
+        owner = getattr(prestates, "_owner", None)
+        mem = owner() if owner is not None else None
+        if (mem is not None and prestates is getattr(mem, "prestates", None) and poststates is getattr(mem, "poststates", None)
+                and not getattr(mem, "_mb_dirty", True)):
+            _lib.check(self._lib.sdqn_replay_declare_minibatch_clean(mem._h))
         _lib.check(self._lib.sdqn_net_train_host(self._h, _lib.ptr(pre, C.c_uint8), _lib.ptr(act, C.c_uint8),
                                                  _lib.ptr(rew, C.c_int64), _lib.ptr(post, C.c_uint8),
                                                  _lib.ptr(term, C.c_uint8), C.byref(cost) if want else None))

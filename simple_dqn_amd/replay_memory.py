@@ -46,8 +46,12 @@ class ReplayMemory:
         mp, mq, ma, mr, mt = _lib._u8p(), _lib._u8p(), _lib._u8p(), _lib._i64p(), _lib._u8p()
         _lib.check(self._lib.sdqn_replay_minibatch_ptrs(h, C.byref(mp), C.byref(mq), C.byref(ma), C.byref(mr), C.byref(mt)))
         shp = (self.batch_size, self.history_length) + self.dims
-        self.prestates = np.ctypeslib.as_array(mp, shape=shp)          # :21-22, reused every call (aliased, like the reference)
-        self.poststates = np.ctypeslib.as_array(mq, shape=shp)
+        # :21-22, reused every call (aliased, like the reference).  Tracked too: while nobody has written into them since the last
+        # getMinibatch(), DeepQNetwork.train(minibatch) lets the step read the device copy of the gathered states in place instead of
+        # uploading them again (sdqn_replay_declare_minibatch_clean)
+        self._mb_dirty = True
+        self.prestates = TrackedArray(np.ctypeslib.as_array(mp, shape=shp), self, "mb_pre")
+        self.poststates = TrackedArray(np.ctypeslib.as_array(mq, shape=shp), self, "mb_post")
         self._mb_actions = np.ctypeslib.as_array(ma, shape=(self.batch_size,))
         self._mb_rewards = np.ctypeslib.as_array(mr, shape=(self.batch_size,))
         self._mb_terminals = np.ctypeslib.as_array(mt, shape=(self.batch_size,)).view(np.bool_)
@@ -86,6 +90,9 @@ class ReplayMemory:
     # ---- coherence of the HBM mirror with the numpy views -----------------------------------------------------------
     def _mark_dirty_bytes(self, kind, lo, hi):
         """Called by the tracked views: memory [lo, hi) of ring array `kind` was written in place."""
+        if kind.startswith("mb_"):                      # the minibatch buffers: the host copy no longer equals the device copy
+            self._mb_dirty = True
+            return
         if self._flags == ZERO_COPY:
             return                                      # kernels read the pinned views themselves
         base, bps = self._ring_base[kind]
@@ -145,6 +152,7 @@ class ReplayMemory:
         self._check_mirror()
         _lib.check(self._lib.sdqn_replay_gather(self._h, _lib.ptr(idx, C.c_int64)))
         _lib.check(self._lib.sdqn_replay_minibatch_to_host(self._h))
+        self._mb_dirty = False                          # host and device copies of the minibatch are identical from here on
         self.last_indexes = idx.copy()
         # replay_memory.py:76-79: prestates/poststates are the preallocated (aliased) buffers, the three small arrays are
         # fresh fancy-index copies in the reference — a caller may keep them across calls

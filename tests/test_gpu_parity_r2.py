@@ -744,3 +744,50 @@ def test_fp16_write_through_epilogues_keep_the_numbers(sd):
         assert np.array_equal(nets[0].get_layer(l, 2), nets[1].get_layer(l, 2)), l
     held = random_minibatch(B, A, 3)[0]
     assert np.array_equal(nets[0].predict(held), nets[1].predict(held))          # (reads the half copies the epilogues refreshed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(4, 84, 84, "float32"), (3, 60, 52, "float64")])
+def test_tuple_api_reuses_the_device_minibatch_only_while_it_is_the_same_data(sd, geom):
+    """net.train(mem.getMinibatch()): the gathered states are still on the device, so the step reads them in place instead of uploading
+    them again — but only while the host arrays ARE the memory's buffers, nobody has written into them (tracked views) and no other
+    gather has replaced the device copy.  Every case must train exactly like a network fed plain copies of the same tuple."""
+    hist, H, W, dtype = geom
+    A, B, size = 4, 8, 600
+    args = make_args(batch_size=B, history_length=hist, screen_height=H, screen_width=W, datatype=dtype)
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 901, num_actions=A)
+    mem.sync_mirror()
+    n1, n2 = sd.DeepQNetwork(A, args), sd.DeepQNetwork(A, args)
+    n2.set_weights(n1.get_weights(0), 0); n2.set_weights(n1.get_weights(1), 1)
+
+    def same():
+        return all(np.array_equal(n1.get_layer(i, 0), n2.get_layer(i, 0)) for i in range(5))
+    random.seed(31)
+    mb = mem.getMinibatch()                                       # untouched: device copy reused
+    assert not mem._mb_dirty
+    ref = tuple(np.array(x) for x in mb)
+    n1.train(mb); n2.train(ref)
+    assert same()
+    mb = mem.getMinibatch()                                       # written through the view before train(): must be uploaded
+    mb[0][2, 1] ^= 0x3C
+    mem.poststates[5] = 7
+    assert mem._mb_dirty
+    ref = tuple(np.array(x) for x in mb)
+    n1.train(mb); n2.train(ref)
+    assert same()
+    mb = mem.getMinibatch()                                       # another gather replaces the device copy behind the host arrays' back
+    ref = tuple(np.array(x) for x in mb)
+    other = np.array([mem.sample_indexes().copy()])
+    if (hist, H, W) == (4, 84, 84):
+        mem.bench_gather(other, iters=1)
+    else:
+        sd._lib.check(mem._lib.sdqn_replay_gather(mem._h, sd._lib.ptr(other[0], C.c_int64)))      # device gather without the D2H
+    assert not mem._mb_dirty
+    n1.train(mb); n2.train(ref)
+    assert same()
+    mb = mem.getMinibatch()                                       # small arrays are the caller's copies: edits there always count
+    mb[2][:] = 3
+    ref = tuple(np.array(x) for x in mb)
+    n1.train(mb); n2.train(ref)
+    assert same()
