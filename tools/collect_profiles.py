@@ -47,3 +47,21 @@ for sub, name, what in (("b256", "b256", "--batch-size 256 --num-actions 3 --ste
         print("MISSING", e)
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(CAP, "pmc_FETCH_SIZE"), os.path.join(CAP, "pmc_WRITE_SIZE"), os.path.join(P, tag)])
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_mfma_util.py"), os.path.join(CAP, "pmc_MfmaUtil"), os.path.join(P, tag)])
+
+# plain-text side measurements of the same capture (agent loop on the synthetic environment, tuple-API loop, generic path)
+rows = []
+try:
+    for l in open(os.path.join(CAP, "agent_loop.log")):
+        if "steps_per_second" in l or "num_games" in l or "Epoch" in l or "phase" in l.lower():
+            rows.append(l.rstrip())
+except Exception as e:
+    rows.append("MISSING agent_loop.log " + repr(e)[:80])
+for f in ("tuple_api_rate.txt", "generic_rate.txt"):
+    try:
+        rows += ["--- " + f] + [l.rstrip() for l in open(os.path.join(CAP, f)) if "steps/s" in l]
+    except Exception as e:
+        rows.append("MISSING %s %s" % (f, repr(e)[:80]))
+open(os.path.join(P, tag + "_side_rates.txt"), "w").write(
+    "# tools/final_capture.sh, build %s: python -m simple_dqn_amd.main --replay_size 100000 --random_steps 5000 --train_steps 40000 --test_steps 20000 --epochs 1 (synthetic environment);\n"
+    "# tools/exp/tuple_api_rate.py; tools/generic_rate.py\n" % rev + "\n".join(rows) + "\n")
+print("wrote %s_side_rates.txt (%d lines)" % (tag, len(rows)))

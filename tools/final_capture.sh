@@ -12,6 +12,10 @@ timeout 200 python bench.py --batch-size 256 --num-actions 3 --no-cpu-baseline -
 timeout 200 python bench.py --batch-size 256 --num-actions 6 --no-cpu-baseline --steps 600 --warmup 100 --replay-size 200000 > $O/bench_b256_a6.json 2>/dev/null
 timeout 200 python bench.py --batch-size 256 --num-actions 3 --datatype float16 --no-cpu-baseline --steps 600 --warmup 100 --replay-size 200000 > $O/bench_b256_fp16.json 2>/dev/null
 timeout 200 python bench.py --single-rank-dp --no-cpu-baseline --steps 2000 --warmup 200 --replay-size 200000 > $O/bench_dp1.json 2>/dev/null
+# the whole agent loop on the synthetic environment (README table row) and the reference-style tuple-API loop
+timeout 300 python -m simple_dqn_amd.main --replay_size 100000 --random_steps 5000 --train_steps 40000 --test_steps 20000 --epochs 1 --csv_file $O/agent_loop.csv > $O/agent_loop.log 2>&1
+timeout 200 python tools/exp/tuple_api_rate.py > $O/tuple_api_rate.txt 2>&1
+timeout 200 python tools/generic_rate.py > $O/generic_rate.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 500 --warmup 100 --no-cpu-baseline --profile-run --replay-size 100000 > $O/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do
