@@ -176,3 +176,40 @@ def test_what_stays_refused_says_so(sd):
         net.apply_update(8)
     with pytest.raises((RuntimeError, AssertionError)):
         net.set_option("grad_only", 1)
+
+
+def test_hundred_free_running_steps_against_the_float64_yardstick(sd):
+    """the 1e-4 contract is met on the MAE of teacher-forced steps, while free-running float32 implementations of this
+    algorithm separate through ReLU / clip gate flips.  The honest question for a free-running trajectory is therefore not 'HIP == oracle'
+    but 'is HIP float32 as close to the exact trajectory as the reference-style float32 arithmetic is?'.  The float64 network on the GPU
+    (generic path, itself held to the float64 oracle at 1e-9 over ten free-running steps above) is that exact trajectory, cheap enough for
+    100 steps: the tuned float32 path, the numpy float32 oracle and the float64 network train on the same 100 minibatches (same sampled
+    indexes, target sync every 25 steps) from the same weights; on a held-out batch the tuned path's distance from float64 must not
+    exceed 1.5 x the oracle's (or the 1e-4 contract)."""
+    A, B, size, steps = 4, 32, 6000, 100
+    a32, a64 = make_args(batch_size=B), make_args(batch_size=B, datatype="float64")
+    mem = sd.ReplayMemory(size, a32)
+    synthetic_fill(mem, 5150, num_actions=A)
+    mem.sync_mirror()
+    ws, wt = xavier_weights(A, 5151), xavier_weights(A, 5152)
+    n32, n64 = sd.DeepQNetwork(A, a32), sd.DeepQNetwork(A, a64)
+    for n in (n32, n64):
+        n.set_weights(wt, 1); n.set_weights(ws, 0)
+    o32 = OracleDQN(A, batch_size=B, weights=ws)
+    o32.Wt = [w.copy() for w in wt]
+    held = _minibatch(B, A, 4, 84, 84, 5153)[0]
+    random.seed(5154)
+    worst = []
+    for i in range(steps):
+        if i and i % 25 == 0:
+            n32.update_target_network(); n64.update_target_network(); o32.update_target_network()
+        idx = mem.sample_indexes().copy()
+        mb = tuple(np.array(x) for x in mem.gather(idx))
+        n32.train_indexes(mem, idx); n64.train_indexes(mem, idx); o32.train(mb)
+        if i % 10 == 9:
+            q64 = n64.predict(held)
+            worst.append((float(np.abs(n32.predict(held) - q64).max()), float(np.abs(o32.predict(held) - q64).max())))
+    d_hip, d_orc = worst[-1]
+    print("free-running distance from float64 every 10 steps (hip fp32, oracle fp32):", ["%.1e/%.1e" % w for w in worst])
+    assert d_hip <= max(1.5 * d_orc, 1e-4), worst
+    assert max(w[0] for w in worst) <= max(2.0 * max(w[1] for w in worst), 1e-4), worst

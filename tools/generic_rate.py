@@ -5,12 +5,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import numpy as np
 import simple_dqn_amd as sd
 from util import make_args
-from oracle.replay_numpy import synthetic_fill
 for dtype, hist, H, W, B in (("float64", 4, 84, 84, 32), ("float32", 4, 84, 84, 32), ("float32", 4, 96, 96, 32), ("float64", 4, 84, 84, 256)):
     if (dtype, hist, H, W) == ("float32", 4, 84, 84):
         continue                                     # (that is the tuned path)
     args = make_args(batch_size=B, history_length=hist, screen_height=H, screen_width=W, datatype=dtype)
-    mem = sd.ReplayMemory(20000, args); synthetic_fill(mem, 1, num_actions=4); mem.sync_mirror()
+    mem = sd.ReplayMemory(20000, args)
+    rng = np.random.RandomState(1)
+    mem.screens[:] = rng.randint(0, 256, size=mem.screens.shape, dtype=np.uint8); mem.actions[:] = rng.randint(0, 4, size=mem.size)
+    mem.rewards[:] = rng.randint(-1, 2, size=mem.size); mem.terminals[:] = rng.rand(mem.size) < 0.005
+    mem.count, mem.current = mem.size, mem.size // 3
     net = sd.DeepQNetwork(4, args); net.update_target_network()
     mt = (C.c_uint32 * 625)(); sd.load().sdqn_mt_seed(mt, 5)
     net.train_from_memory(mem, 20, mt_state=mt, want_cost=False); net.sync()
