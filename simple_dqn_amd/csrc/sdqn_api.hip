@@ -472,6 +472,7 @@ struct sdqn_net_s {
   int fuse_dbg = 0;                        // experiment only: 1 = the online conv1 blocks do not wait (WRONG results, timing of the wait)
   bool fuse_upd = false;                   // round 3: inside train_many, update(i) and conv1_fwd(i + 1) are ONE launch (sdqn_kernels_r3.hip: upd_conv1_kernel)
   bool has_pending_upd = false; UpdateArgs pending_upd;      // the deferred optimizer pass of the previous step (never outlives a train_many call)
+  bool head_f4d = false; bool skip_head = false; unsigned hf_epochs = 0;   // head + fc4_dgrad as one launch (w1_ctr[4] counts head-block arrivals, [5] = time-out word)
   unsigned* w1_ctr = nullptr; unsigned w1_epochs = 0;        // [0] W1 blocks counted in (monotonic: 64 per fused launch), [1] sticky time-out word
   int conv1w_bf16 = 1;                 // round 3: conv1_wgrad on packed-bf16 MFMA (bytes x on-the-fly bf16 split of delta1)
   bool conv3_c36 = true;                   // round 3: conv3_fwd on 36-deep K-chunks (one chunk per wave; sdqn_kernels_r3.hip)
@@ -949,7 +950,7 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int
     LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, f3, g_stream, 0, c36)); }
   { int rc = join_comm(h); if (rc) return rc; }                // conv1..3 of this step overlap the previous step's fc4 all-reduce
   LAUNCH(K_FC4_FWD, launch_tuned(h, K_FC4_FWD, fm, g_stream));
-  LAUNCH(K_HEAD, launch_head(a, hd, g_stream));
+  if (!h->skip_head) LAUNCH(K_HEAD, launch_head(a, hd, g_stream));       // (skip_head: run_train launches it together with fc4_dgrad)
   return SDQN_OK;
 }
 static UpdateArgs make_update_args(sdqn_net_s* h, const StepArgs& a) {
@@ -974,7 +975,14 @@ static UpdateArgs make_update_args(sdqn_net_s* h, const StepArgs& a) {
   return u;
 }
 static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const PrepArgs* next = nullptr, int hoist = 0, bool defer_update = false) {
-  int rc = run_forward(h, a, hd, hoist); if (rc) return rc;
+  // round 3: head + fc4_dgrad in ONE launch — the 98 dgrad tiles fetch their W4 panels while the B head workgroups run, then pick up
+  // delta4 through an in-launch hand-off (sdqn_kernels_r3.hip: head_f4d_kernel).  Same arithmetic and summation order: bit-identical.
+  const bool hf = h->head_f4d && hd.train && h->B <= 32 && h->A <= 8 && a.nz == 2 && h->cfg.datatype == 0 && !h->bn && !hoist && !h->f4w_early &&
+                  h->S4 == 7 && h->nw_override[K_FC4_DGRAD] == 0 && h->nw_override[K_HEAD] == 0 && hd.next_B == 0 && h->w1_ctr;
+  h->skip_head = hf;
+  int rc = run_forward(h, a, hd, hoist);
+  h->skip_head = false;
+  if (rc) return rc;
   // Backward.  Critical path on the library stream: fc4_dgrad -> conv3_dgrad -> conv2_dgrad -> conv1_wgrad.
   // The three other weight-gradient kernels only need the delta of their layer, so they run beside it
   // on the side stream (fork after the producer of their delta, join before the update).
@@ -992,7 +1000,11 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   const bool c1w = (h->conv1w_bf16 == 2 || (h->conv1w_bf16 == 1 && h->B < 128)) && h->cfg.datatype == 0 && !h->bn && !hoist && h->nw_override[K_CONV1_WGRAD] == 0;
   const bool f4_early = h->f4w_early && h->B <= 32 && h->cfg.datatype == 0 && !h->bn && h->fused_launches && !h->two_streams &&
                         !dp_ov && !hoist && h->bwd_order == 0 && h->f4_share[0] == 100 && h->f4_share[1] == 0 && h->nw_override[K_FC4_DGRAD] == 0;
-  if (f4_early) { h->handoff_launched = true; LAUNCH(K_F4D_F4W, launch_tuned(h, K_FC4_DGRAD, a, g_stream, 0, 1)); }
+  if (hf) {
+    h->handoff_launched = true; h->hf_epochs += 1;
+    LAUNCH(K_HEAD_F4D, launch_head_f4d(a, hd, h->w1_ctr + 4, (unsigned)h->B * h->hf_epochs, h->w1_ctr + 5, g_stream));
+  }
+  else if (f4_early) { h->handoff_launched = true; LAUNCH(K_F4D_F4W, launch_tuned(h, K_FC4_DGRAD, a, g_stream, 0, 1)); }
   else LAUNCH(K_FC4_DGRAD, launch_tuned(h, K_FC4_DGRAD, a, g_stream));
   BN_BWD(2);
   if (dp_ov) {
@@ -1480,6 +1492,8 @@ extern "C" int sdqn_net_sync(sdqn_net_t h) {
   unsigned timed_out = 0;
   HIPCHK(hipMemcpy(&timed_out, h->f4d_flags + (NIN4 / 32) * 16, 4, hipMemcpyDeviceToHost));
   if (timed_out) { set_error("fc4_wgrad waited for a fc4_dgrad tile that never signalled (in-launch hand-off timed out): results are invalid"); return SDQN_ERR_STATE; }
+  HIPCHK(hipMemcpy(&timed_out, h->w1_ctr + 5, 4, hipMemcpyDeviceToHost));
+  if (timed_out) { set_error("fc4_dgrad waited for head workgroups of its own launch that never signalled (in-launch hand-off timed out): results are invalid"); return SDQN_ERR_STATE; }
   HIPCHK(hipMemcpy(&timed_out, h->w1_ctr + 1, 4, hipMemcpyDeviceToHost));
   if (timed_out) { set_error("conv1 waited for W1 blocks of the fused update that never signalled (in-launch hand-off timed out): results are invalid"); return SDQN_ERR_STATE; }
   return SDQN_OK;
@@ -1543,6 +1557,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "wt")) h->wt = value;
   else if (!strcmp(name, "prep_inline")) h->prep_inline = value != 0;
   else if (!strcmp(name, "r3_xcd")) h->r3_xcd = value;
+  else if (!strcmp(name, "head_f4d")) h->head_f4d = value != 0;         // 1: head + fc4_dgrad in one launch (in-launch hand-off of delta4)
   else if (!strcmp(name, "fuse_upd")) h->fuse_upd = value != 0;         // 0: the optimizer pass is always its own launch
   else if (!strcmp(name, "conv1w_bf16")) h->conv1w_bf16 = value;   // 0: conv1_wgrad on the fp32-MFMA engine (round-2 kernel)
   else if (!strcmp(name, "conv3_c36")) h->conv3_c36 = value != 0;       // 0: conv3_fwd on the engine's 32-deep chunks (round-2 kernel)

@@ -770,3 +770,40 @@ def test_fp16_fused_replay_path(sd):
     n2.train_from_memory(mem, 3)
     for i in range(5):
         assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("A", [4, 6])
+def test_head_and_fc4_dgrad_in_one_launch_is_bit_identical(A):
+    """Option head_f4d: the B head workgroups and the 98 fc4_dgrad tiles share one launch; the tiles fetch their W4 panels while the
+    head runs and pick up delta4 through an in-launch hand-off (write-through stores, arrival counter, sc1 loads).  Same arithmetic and
+    summation order as the two launches: weights, RMSProp state, cost and Q-values bit-identical, from the ring and through the tuple API."""
+    import ctypes as C
+    import simple_dqn_amd as sd
+    from oracle.replay_numpy import synthetic_fill
+    B, size = 32, 3000
+    args = make_args(batch_size=B)
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 4242, num_actions=A)
+    mem.sync_mirror()
+    nets, costs = [], []
+    for on in (1, 0):
+        net = sd.DeepQNetwork(A, args)
+        net.set_weights(xavier_weights(A, 4243), 0)
+        net.update_target_network()
+        net.set_option("head_f4d", on)
+        mt = (C.c_uint32 * 625)(); sd.load().sdqn_mt_seed(mt, 23)
+        c = [net.train_from_memory(mem, 1, mt_state=mt, want_cost=True) for _ in range(3)]
+        c.append(net.train_from_memory(mem, 9, mt_state=mt, want_cost=True))
+        mb = random_minibatch(B, A, 77)
+        net.train(mb)
+        net.sync()
+        nets.append(net); costs.append(c)
+    assert costs[0] == costs[1]
+    for l in range(5):
+        assert np.array_equal(nets[0].get_layer(l, 0), nets[1].get_layer(l, 0)), l
+        assert np.array_equal(nets[0].get_layer(l, 2), nets[1].get_layer(l, 2)), l
+    held = random_minibatch(B, A, 78)[0]
+    assert np.array_equal(nets[0].predict(held), nets[1].predict(held))
+    pre0, mq0 = nets[0].last_q(); pre1, mq1 = nets[1].last_q()
+    assert np.array_equal(pre0, pre1) and np.array_equal(mq0, mq1)
