@@ -52,6 +52,13 @@ template <class P> struct uses_f16_wgrad<P, decltype((void)P::F16_WGRAD)> { stat
 // (every operand load of the tile has returned by then) — round 3's write-after-read hand-off between fc4_dgrad and fc4_wgrad
 template <class P, class = void> struct signals { static constexpr bool value = false; };
 template <class P> struct signals<P, decltype((void)P::SIGNALS)> { static constexpr bool value = P::SIGNALS; };
+// PRELOAD: P::preload(a) runs first thing in the kernel and touches every argument field the problem will read, so that hipcc issues
+// ALL their scalar loads in one batch behind one wait.  Left alone it fetches each field of the 464-byte by-value StepArgs where it is
+// first used: four or five DEPENDENT round trips to a kernel-argument segment that is cold at every launch (round 3, sdqn_kernels_r3.hip)
+template <class P, class = void> struct has_preload { static constexpr bool value = false; };
+template <class P> struct has_preload<P, decltype((void)P::PRELOAD)> { static constexpr bool value = P::PRELOAD; };
+template <class P, class = void> struct has_preload_multi { static constexpr bool value = false; };
+template <class P> struct has_preload_multi<P, decltype((void)P::PRELOAD_MULTI)> { static constexpr bool value = P::PRELOAD_MULTI; };
 template <class P, class = void> struct uses_f16_mfma { static constexpr bool value = false; };
 template <class P> struct uses_f16_mfma<P, decltype((void)P::F16_MFMA)> { static constexpr bool value = P::F16_MFMA; };
 
@@ -581,6 +588,7 @@ __device__ __forceinline__ int xcd_tile_id_range(int b, int s, int n) {
 template <class P, int NW>
 __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {
   __shared__ float smem[tile_lds_any<P, NW>()];
+  if constexpr (has_preload<P>::value) P::preload(a, gridDim.x, gridDim.y, gridDim.z);
   const int gx = gridDim.x, gy = gridDim.y;
   const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
   const int t = (a.xcd_map & 1) ? xcd_tile_id(lin, gx * gy * gridDim.z) : lin;
@@ -621,6 +629,7 @@ __global__ void __launch_bounds__(NT) gemm_multi_kernel(const StepArgs a, const 
                 L2 = tile_lds_any<P2, NW2>() * (NW2 == 1 ? NT / 64 : 1);
   constexpr int L = L0 > L1 ? (L0 > L2 ? L0 : L2) : (L1 > L2 ? L1 : L2);
   __shared__ float smem[L];
+  if constexpr (has_preload_multi<P1>::value) P1::preload_multi(a, d);      // (one statement for the whole launch: every field of all its problems)
   const int b = blockIdx.x;                               // problem choice is workgroup-uniform; XCD-contiguous runs per problem
   const int xm = a.xcd_map;                               // bit i: problem i of the launch uses the XCD-contiguous map
   if (b < d.n[0]) multi_dispatch<P0, NW0, NT>(a, d, 0, (xm & 1) ? xcd_tile_id_range(b, 0, d.n[0]) : b, smem);

@@ -281,6 +281,14 @@ template <bool OVF>
 __global__ void __launch_bounds__(256) update_kernel(const UpdateArgs u) {
   __shared__ float4 part[8][32];
   __shared__ float cost_sh[4096];
+#ifndef SDQN_NO_UPDATE_PRELOAD
+  // every argument field in flight at once (one wait): left alone hipcc fetches the fields of the by-value UpdateArgs where each is first
+  // used — seven dependent round trips to a cold kernel-argument segment before the first vector load of this latency-bound launch
+  asm volatile("" :: "s"(u.theta), "s"(u.state), "s"(u.g), "s"(u.slab[0]), "s"(u.slab[1]), "s"(u.slab[2]), "s"(u.dq), "s"(u.a4), "s"(u.cost_terms),
+               "s"(u.cost_out), "s"(u.cost_accum), "s"(u.w1p), "s"(u.next.meta), "s"(u.next.idx), "s"(u.next.actions), "s"(u.next.rewards),
+               "s"(u.next.terminals), "s"(u.ns[0]), "s"(u.ns[1]), "s"(u.ns[2]), "s"(u.B), "s"(u.A), "s"(u.mode), "s"(u.skip_fc4), "s"(u.next.B),
+               "s"(u.next.idx_in_valid), "s"(u.bsz), "s"(u.rho), "s"(u.one_minus_rho), "s"(u.lr));
+#endif
   update_body<OVF>(u, (int)blockIdx.x, (int)gridDim.x, part, cost_sh);
 }
 

@@ -27,11 +27,29 @@ namespace sdqn {
 #define SDQN_NT_W4 0
 #endif
 constexpr bool NT_W4 = SDQN_NT_W4 != 0;      // experiment: non-temporal loads of the streamed W4 operand
+#ifndef SDQN_PRELOAD
+#define SDQN_PRELOAD 1
+#endif
+#define SDQN_TOUCH(...) asm volatile("" :: __VA_ARGS__)
+// the whole bwd3 / bwd2 launch in ONE statement (an asm statement takes at most 30 operands): every pointer and scalar any of its problems reads
+#define SDQN_PRELOAD_MULTI_DEF \
+  static constexpr bool PRELOAD_MULTI = SDQN_PRELOAD != 0; \
+  __device__ static void preload_multi(const StepArgs& a, const MultiDims& d) { \
+    SDQN_TOUCH("s"(a.d3p), "s"(a.theta[0]), "s"(a.a2), "s"(a.d2p), "s"(a.d2), "s"(a.d3), "s"(a.slab3), "s"(a.a3), "s"(a.d4), "s"(a.theta_w), "s"(a.state), \
+               "s"(a.g), "s"(a.a1), "s"(a.d1), "s"(a.slab2), "s"(a.B), "s"(a.tps2), "s"(a.tps3), "s"(a.fuse_rms), "s"(a.f4w_first), "s"(a.f4w_count), \
+               "s"(a.xcd_map), "s"(a.bsz), "s"(a.rho), "s"(a.one_minus_rho), "s"(a.lr), "s"(a.eps), "s"(d.n[0]), "s"(d.n[1]), "s"(d.gx[1])); \
+  }
 __device__ __forceinline__ void wt_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 struct Conv2FwdWT : Conv2Fwd {
+  static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.a1), "s"(a.a2), "s"(a.theta[0]), "s"(a.theta[1]), "s"(a.B), "s"(a.nz), "s"(a.xcd_map), "s"(g0), "s"(g1), "s"(g2)); }
+
   __device__ static void store(const StepArgs& a, int z, int, int m, int n, float v) { wt_store(&a.a2[((int64_t)z * M(a) + m) * K2 + n], fmaxf(v, 0.0f)); }
 };
 struct Conv3FwdWT : Conv3Fwd {
+  static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.a2), "s"(a.a3), "s"(a.theta[0]), "s"(a.theta[1]), "s"(a.B), "s"(a.nz), "s"(a.xcd_map), "s"(g0), "s"(g1), "s"(g2)); }
+
   __device__ static void store(const StepArgs& a, int z, int, int m, int n, float v) { wt_store(&a.a3[((int64_t)z * M(a) + m) * K3 + n], fmaxf(v, 0.0f)); }
 };
 __device__ __forceinline__ f4 ld4_nt(const float* p) {          // streamed-once operand (W4: every element is read by exactly one workgroup)
@@ -39,10 +57,16 @@ __device__ __forceinline__ f4 ld4_nt(const float* p) {          // streamed-once
   const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p)); f4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; return o;
 }
 struct Fc4FwdWT : Fc4Fwd {
+  static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.a3), "s"(a.slab4), "s"(a.theta[0]), "s"(a.theta[1]), "s"(a.B), "s"(a.nz), "s"(a.S4), "s"(a.xcd_map), "s"(g0), "s"(g1), "s"(g2)); }
+
   __device__ static f4 b_load4(const StepArgs& a, int z, int o) { return NT_W4 ? ld4_nt(a.theta[z] + OFF4 + o) : ld4(a.theta[z] + OFF4 + o); }
   __device__ static void store(const StepArgs& a, int z, int ks, int m, int n, float v) { wt_store(&a.slab4[(((int64_t)ks * 2 + z) * a.B + m) * NFC + n], v); }
 };
 struct Fc4DgradWT : Fc4Dgrad {
+  static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.d4), "s"(a.theta[0]), "s"(a.a3), "s"(a.d3p), "s"(a.d3), "s"(a.B), "s"(a.xcd_map), "s"(g0), "s"(g1), "s"(g2)); }
+
   __device__ static f4 b_load4(const StepArgs& a, int, int o) { return NT_W4 ? ld4_nt(a.theta[0] + OFF4 + o) : ld4(a.theta[0] + OFF4 + o); }
   __device__ static void store(const StepArgs& a, int, int, int m, int n, float v) {
     const int pix = n >> 6, f = n & 63, p = pix / Q3, q = pix - p * Q3;
@@ -52,6 +76,10 @@ struct Fc4DgradWT : Fc4Dgrad {
   }
 };
 struct Conv3DgradWT : Conv3Dgrad {
+  static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
+  SDQN_PRELOAD_MULTI_DEF
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.d3p), "s"(a.theta[0]), "s"(a.a2), "s"(a.d2p), "s"(a.d2), "s"(a.B), "s"(g0), "s"(g1), "s"(g2)); }
+
   __device__ static void store(const StepArgs& a, int, int, int m, int c, float v) {
     const float dv = a.a2[(int64_t)m * K2 + c] > 0.0f ? v : 0.0f;
     wt_store(&a.d2p[prow2(m) + c], dv);
@@ -59,9 +87,17 @@ struct Conv3DgradWT : Conv3Dgrad {
   }
 };
 struct Conv3WgradWT : Conv3Wgrad {
+  static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
+  SDQN_PRELOAD_MULTI_DEF
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.a2), "s"(a.d3), "s"(a.slab3), "s"(a.tps3), "s"(a.B), "s"(g0), "s"(g1), "s"(g2)); }
+
   __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab3[(int64_t)ks * NW3 + m * K3 + n], v); }
 };
 struct Conv2DgradWT : Conv2Dgrad {
+  static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
+  SDQN_PRELOAD_MULTI_DEF
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.d2p), "s"(a.theta[0]), "s"(a.a1), "s"(a.d1), "s"(a.B), "s"(g0), "s"(g1), "s"(g2)); }
+
   __device__ static void store(const StepArgs& a, int z, int, int m, int c, float v) {
     const int py = z >> 1, px = z & 1;
     const int n = m / 100, pix = m - n * 100, i = pix / 10, j = pix - i * 10;
@@ -70,12 +106,17 @@ struct Conv2DgradWT : Conv2Dgrad {
   }
 };
 struct Conv2WgradWT : Conv2Wgrad {
+  static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.a1), "s"(a.d2), "s"(a.slab2), "s"(a.tps2), "s"(a.B), "s"(g0), "s"(g1), "s"(g2)); }
+
   __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab2[(int64_t)ks * NW2 + m * K2 + n], v); }
 };
 struct Conv1WgradWT : Conv1Wgrad {
   __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab1[(int64_t)ks * NW1 + m * K1 + n], v); }
 };
-struct Fc4WgradWT : Fc4Wgrad {          // the 12.8 MB of new W4 + RMSProp state (or the 6.4 MB gradient) leave write-through
+struct Fc4WgradWT : Fc4Wgrad {
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.a3), "s"(a.d4), "s"(a.theta_w), "s"(a.state), "s"(a.g), "s"(a.fuse_rms), "s"(a.f4w_first), "s"(a.f4w_count), "s"(a.B)); SDQN_TOUCH("s"(a.bsz), "s"(a.rho), "s"(a.one_minus_rho), "s"(a.lr), "s"(a.eps), "s"(g0), "s"(g1), "s"(g2)); }
+          // the 12.8 MB of new W4 + RMSProp state (or the 6.4 MB gradient) leave write-through
   __device__ static void store(const StepArgs& a, int, int, int m, int n, float v) {          // K-split form (B > 32)
     const int64_t e = OFF4 + (int64_t)m * NFC + n;
     if (a.fuse_rms) { float st = a.state[e]; const float w = rms_step(a.theta_w[e], st, v, a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps); wt_store(&a.theta_w[e], w); wt_store(&a.state[e], st); }
@@ -108,6 +149,7 @@ struct Fc4WgradWT : Fc4Wgrad {          // the 12.8 MB of new W4 + RMSProp state
 // (train, predict, predict_one), the hoisted / batch-norm / tuning-hook variants keep the old one consistently on both nets.
 template <class P>
 __global__ void __launch_bounds__(1024) gemm36_kernel(const StepArgs a) {
+  if constexpr (has_preload<P>::value) P::preload(a, gridDim.x, gridDim.y, gridDim.z);
   static_assert(P::A_K && !P::B_K && P::B_REG, "36-deep routine: k-contiguous A (own-row loads), row-major B");
   __shared__ float smem[16 * PANEL];
   const int gx = gridDim.x, gy = gridDim.y;
@@ -718,18 +760,33 @@ __device__ __forceinline__ void wt_store_h(half_t* p, half_t v) {
   __hip_atomic_store(reinterpret_cast<unsigned short*>(p), c.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 struct Conv1FwdHWT : Conv1FwdH {
+  static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.src), "s"(a.idx), "s"(a.h_a1), "s"(a.wht[0]), "s"(a.wht[1]), "s"(a.B), "s"(a.nz), "s"(a.from_ring), "s"(a.xcd_map), "s"(g0), "s"(g1), "s"(g2)); }
+
   __device__ static void store(const StepArgs& a, int z, int, int m, int n, float v) { wt_store_h(&a.h_a1[((int64_t)z * M(a) + m) * K1 + n], (half_t)fmaxf(v, 0.0f)); }
 };
 struct Conv2FwdHWT : Conv2FwdH {
+  static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.h_a1), "s"(a.h_a2), "s"(a.wht[0]), "s"(a.wht[1]), "s"(a.B), "s"(a.nz), "s"(a.xcd_map), "s"(g0), "s"(g1), "s"(g2)); }
+
   __device__ static void store(const StepArgs& a, int z, int, int m, int n, float v) { wt_store_h(&a.h_a2[((int64_t)z * M(a) + m) * K2 + n], (half_t)fmaxf(v, 0.0f)); }
 };
 struct Conv3FwdHWT : Conv3FwdH {
+  static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.h_a2), "s"(a.h_a3), "s"(a.wht[0]), "s"(a.wht[1]), "s"(a.B), "s"(a.nz), "s"(a.xcd_map), "s"(g0), "s"(g1), "s"(g2)); }
+
   __device__ static void store(const StepArgs& a, int z, int, int m, int n, float v) { wt_store_h(&a.h_a3[((int64_t)z * M(a) + m) * K3 + n], (half_t)fmaxf(v, 0.0f)); }
 };
 struct Fc4FwdHWT : Fc4FwdH {
+  static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.h_a3), "s"(a.slab4), "s"(a.wht[0]), "s"(a.wht[1]), "s"(a.B), "s"(a.nz), "s"(a.S4), "s"(a.xcd_map), "s"(g0), "s"(g1), "s"(g2)); }
+
   __device__ static void store(const StepArgs& a, int z, int ks, int m, int n, float v) { wt_store(&a.slab4[(((int64_t)ks * 2 + z) * a.B + m) * NFC + n], v); }
 };
 struct Fc4DgradHWT : Fc4DgradH {
+  static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
+  __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.h_d4), "s"(a.wh[0]), "s"(a.h_a3), "s"(a.h_d3p), "s"(a.h_d3), "s"(a.B), "s"(a.xcd_map), "s"(g0), "s"(g1), "s"(g2)); }
+
   __device__ static void store(const StepArgs& a, int, int, int m, int n, float v) {
     int pix = n >> 6, f = n & 63, p = pix / Q3, q = pix - p * Q3;
     const half_t dv = (float)a.h_a3[(int64_t)m * NIN4 + n] > 0.0f ? (half_t)v : (half_t)0.0f;
@@ -738,6 +795,12 @@ struct Fc4DgradHWT : Fc4DgradH {
   }
 };
 struct Conv2DgradHWT : Conv2DgradH {
+  static constexpr bool PRELOAD_MULTI = SDQN_PRELOAD != 0;      // bwd2 of the float16 mode: conv2_dgrad + conv2_wgrad in one statement
+  __device__ static void preload_multi(const StepArgs& a, const MultiDims& d) {
+    SDQN_TOUCH("s"(a.h_d2p), "s"(a.wh[0]), "s"(a.h_a1), "s"(a.h_d1), "s"(a.h_d2), "s"(a.slab2), "s"(a.tps2), "s"(a.inv_loss_scale), "s"(a.B), "s"(a.xcd_map),
+               "s"(d.n[0]), "s"(d.n[1]), "s"(d.gx[1]), "s"(d.gx[2]), "s"(d.gy[1]), "s"(d.gy[2]));
+  }
+
   __device__ static void store(const StepArgs& a, int z, int, int m, int c, float v) {
     int py = z >> 1, px = z & 1;
     int n = m / 100, pix = m - n * 100, i = pix / 10, j = pix - i * 10;
@@ -749,6 +812,12 @@ struct Conv2WgradHWWT : Conv2WgradHW {
   __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab2[(int64_t)ks * NW2 + m * K2 + n], v * a.inv_loss_scale); }
 };
 struct Conv1WgradHWWT : Conv1WgradHW {
+  static constexpr bool PRELOAD_MULTI = SDQN_PRELOAD != 0;      // bwd1 of the float16 mode
+  __device__ static void preload_multi(const StepArgs& a, const MultiDims& d) {
+    SDQN_TOUCH("s"(a.src), "s"(a.idx), "s"(a.h_d1), "s"(a.slab1), "s"(a.tps1), "s"(a.inv_loss_scale), "s"(a.B), "s"(a.from_ring), "s"(a.xcd_map),
+               "s"(d.n[0]), "s"(d.n[1]), "s"(d.gx[1]), "s"(d.gy[1]));
+  }
+
   __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab1[(int64_t)ks * NW1 + m * K1 + n], v * a.inv_loss_scale); }
 };
 hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
