@@ -217,7 +217,13 @@ int sdqn_net_set_epoch(sdqn_net_t h, int epoch);
  * all-reduced and applied on a second communicator + stream), "dp_sync_replicas" (1 default: sdqn_dp_init broadcasts rank 0's online net,
  * target net and optimizer state so every learner starts from — and keeps — the same network; 0 BEFORE sdqn_dp_init: keep own), "profile_every" (N: sdqn_net_profile times every N-th
  * launch), "profile_mode" (1 default: the launch records its own dispatch-packet begin / end timestamps into the event pair through hipExtLaunchKernel —
- * what rocprofv3 --kernel-trace reports, nothing added to the queue; 0: hipEventRecord markers around the launch, ~2.6 us more per launch), "nw:<kernel id>" / "xcd:<kernel id>" / "f4_share3" / "f4_share2" (tuning hooks) */
+ * what rocprofv3 --kernel-trace reports, nothing added to the queue; 0: hipEventRecord markers around the launch, ~2.6 us more per launch), "nw:<kernel id>" / "xcd:<kernel id>" / "f4_share3" / "f4_share2" (tuning hooks).
+ * Round-3 switches of the default fp32 / float16 step, every one bit-identical to its alternative unless noted (tools/exp/README.md has the
+ * measurements): "wt" (bit mask, default 511: write-through epilogue stores per launch), "conv1_bf16" / "conv1w_bf16" (1 default: conv1
+ * forward / weight gradient on packed-bf16 MFMA with an exact 3-way split; 0: the fp32-MFMA engine — last bits differ), "conv3_c36" (1 default:
+ * conv3 forward on 36-deep K-chunks; last bits differ), "r3_xcd" (tile maps of the two conv1 kernels), and three in-launch hand-offs that
+ * measured slower than kernel boundaries and default to 0: "f4w_early" (fc4_wgrad inside the fc4_dgrad launch), "fuse_upd" (update(i) +
+ * conv1(i+1)), "head_f4d" (head + fc4_dgrad).  A float64 / non-84x84x4 network (generic path) accepts and ignores the tuning options. */
 int sdqn_net_set_option(sdqn_net_t h, const char* name, int value);
 
 /* test hook: raw read-back of an internal device buffer ("a1","a2","a3","a4","d4","d3p","d2p","d1","q",
