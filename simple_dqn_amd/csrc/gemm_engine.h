@@ -649,6 +649,8 @@ struct NoProblem {            // placeholder third problem for two-problem launc
   SDQN_HD static int a_row(const StepArgs&, int, int) { return 0; }
   SDQN_HD static int a_col(const StepArgs&, int, int) { return 0; }
   SDQN_HD static float a_load(const StepArgs&, int, int) { return 0.f; }
+  SDQN_HD static f4 a_load4(const StepArgs&, int, int) { f4 o; o.x = o.y = o.z = o.w = 0.f; return o; }
+  SDQN_HD static f4 b_load4(const StepArgs&, int, int) { f4 o; o.x = o.y = o.z = o.w = 0.f; return o; }
   SDQN_HD static int b_row(const StepArgs&, int, int) { return 0; }
   SDQN_HD static int b_col(const StepArgs&, int, int) { return 0; }
   SDQN_HD static float b_load(const StepArgs&, int, int) { return 0.f; }

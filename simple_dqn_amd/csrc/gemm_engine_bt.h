@@ -1,0 +1,280 @@
+// gemm_engine_bt.h — BLOCK-TILE routine of the tile engine: the throughput regime (B >= 128, BASELINE.json configs[2]).
+//
+// gemm_tile (gemm_engine.h) gives every 32 x 32 output tile its own workgroup whose waves split K and fetch their operand
+// fragments straight from L2: right for a launch that is a handful of latency chains (B = 32), wrong for thousands of tiles —
+// every tile re-reads its 32 A rows and 32 B rows (8 FLOP per L2 byte), the fragment-shaped loads touch 32 cache lines per
+// instruction, and the B = 256 step sat at 45 % of the fp32 matrix peak with both fused backward launches at 35 %.
+// Here (maps and layouts: bt_map.h):
+//   * ONE workgroup of 4 waves owns a BM x BN block of C (64 x 64 ... 128 x 128) for the WHOLE K range of its split;
+//   * per 32-deep chunk the workgroup stages one A panel and one B panel in LDS with full-line 16-byte loads (each element
+//     leaves L2 once per workgroup: 16-32 FLOP per L2 byte) through a ring of D register sets: the global loads of chunk c + D
+//     are issued before the MFMAs of chunk c, chunk c + 1 (issued D - 1 chunks ago: landed) is written to the other LDS stage
+//     behind them, ONE barrier per chunk.  Round 1's first cut of this routine (tools/exp/big_tiles.patch) had one chunk in
+//     flight and scalar LDS traffic and lost to the latency engine: a workgroup waited a loaded-L2 round trip per 0.43 us of
+//     matrix work.  D chunks in flight per workgroup x several workgroups per CU (37 KB of LDS at 64 x 64) cover it;
+//   * wave (wm, wn) multiplies its SM x SN sub-tiles out of LDS (ds_read_b128 of its own row for k-contiguous panels,
+//     conflict-free ds_read_b32 for x-contiguous ones) on v_mfma_f32_32x32x2_f32 — exact fp32, one accumulator per sub-tile
+//     over the whole K range (no cross-wave combine: the sum order is k ascending in k-slot order, chunk after chunk);
+//   * same problem structs (problems.h) and the same epilogues (P::store16: ReLU, dgrad masks, padded + dense delta scatter,
+//     split-K slabs, fused RMSProp of W4, write-through variants) as the latency engine.
+// Results differ from gemm_tile's in the last bits only (another partition of the same fp32 sum).
+#pragma once
+#include "gemm_engine.h"
+#include "bt_map.h"
+
+namespace sdqn {
+
+template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 2>
+struct BtCfg {
+  typedef P_ P;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int D = D_;                          // chunks in flight per workgroup: D register sets of (BM + BN) / 32 float4 per thread
+  static_assert(D >= 1 && D <= 4, "prefetch depth");
+  static constexpr int SM = BM / (32 * WM), SN = BN / (32 * WN);
+  static_assert(WM * WN * 64 == bt::NT, "four waves per workgroup");
+  static_assert(SM >= 1 && SN >= 1 && SM * 32 * WM == BM && SN * 32 * WN == BN, "block = wave grid x sub-tiles of 32 x 32");
+  static constexpr int AF = bt::panel_floats(P::A_K, BM), BF = bt::panel_floats(P::B_K, BN);
+  static constexpr int STAGE = AF + BF;                 // floats per LDS stage
+  static constexpr int LDS = 2 * STAGE;                 // double-buffered
+};
+
+template <class P, class = void> struct has_store_tile { static constexpr bool value = false; };
+template <class P> struct has_store_tile<P, decltype((void)P::STORE_TILE)> { static constexpr bool value = P::STORE_TILE; };
+
+__device__ __forceinline__ float4 f4_to_float4(const f4& v) { return make_float4(v.x, v.y, v.z, v.w); }
+
+template <class C>
+__device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int bz, float* smem) {
+  typedef typename C::P P;
+  typedef typename P::aoff_t aoff_t;
+  constexpr int BM = C::BM, BN = C::BN, SM = C::SM, SN = C::SN, WN = C::WN;
+  constexpr bool AK = P::A_K, BKC = P::B_K;
+  constexpr int PA = bt::passes(BM), PB = bt::passes(BN);
+  static_assert(sizeof(typename a_elem<P>::type) == 4 && sizeof(typename b_elem<P>::type) == 4, "fp32 operands (the fp16 mode has its own routine)");
+
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int m0 = bx * BM, n0 = by * BN;
+  int z, ks, kbeg, kend;
+  P::ksplit(a, bz, z, ks, kbeg, kend);
+  const int M = P::M(a), N = P::N(a);
+
+  // ---- loader geometry: the part of every address that does not change from chunk to chunk -------------------------------
+  aoff_t ag[PA]; int bg[PB];
+  if constexpr (AK) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) { const int m = m0 + bt::km_item_row(tid, p); ag[p] = P::a_row(a, z, m < M ? m : M - 1); }
+  } else {
+    const int m = m0 + bt::mk_item_x(BM, tid);
+    ag[0] = P::a_row(a, z, m + 4 <= M ? m : M - 4);
+  }
+  if constexpr (BKC) {
+#pragma unroll
+    for (int p = 0; p < PB; ++p) { const int n = n0 + bt::km_item_row(tid, p); bg[p] = P::b_col(a, z, n < N ? n : N - 1); }
+  } else {
+    const int n = n0 + bt::mk_item_x(BN, tid);
+    bg[0] = P::b_col(a, z, n + 4 <= N ? n : N - 4);
+  }
+
+  // ---- one chunk's panels: global -> registers (ra, rb) -> LDS stage ---------------------------------------------------------
+  // loads are unconditional with clamped k (a conditional load costs a branch and a vmcnt(0) each), out-of-range k is zeroed
+  constexpr int D = C::D;
+  float4 ra[D][PA], rb[D][PB];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto gload = [&](int kc, float4* qa, float4* qb) {
+    if constexpr (AK) {
+      const int k = kc + bt::km_item_k(tid);
+      const aoff_t c = P::a_col(a, z, k < kend ? k : kbeg);
+#pragma unroll
+      for (int p = 0; p < PA; ++p) { qa[p] = f4_to_float4(P::a_load4(a, z, ag[p] + c)); if (k >= kend) qa[p] = zero4; }
+    } else {
+#pragma unroll
+      for (int p = 0; p < PA; ++p) {
+        const int k = kc + bt::mk_item_k(BM, tid, p);
+        qa[p] = f4_to_float4(P::a_load4(a, z, ag[0] + P::a_col(a, z, k < kend ? k : kbeg)));
+        if (k >= kend) qa[p] = zero4;
+      }
+    }
+    if constexpr (BKC) {
+      const int k = kc + bt::km_item_k(tid);
+      const int r = P::b_row(a, z, k < kend ? k : kbeg);
+#pragma unroll
+      for (int p = 0; p < PB; ++p) { qb[p] = f4_to_float4(P::b_load4(a, z, bg[p] + r)); if (k >= kend) qb[p] = zero4; }
+    } else {
+#pragma unroll
+      for (int p = 0; p < PB; ++p) {
+        const int k = kc + bt::mk_item_k(BN, tid, p);
+        qb[p] = f4_to_float4(P::b_load4(a, z, bg[0] + P::b_row(a, z, k < kend ? k : kbeg)));
+        if (k >= kend) qb[p] = zero4;
+      }
+    }
+  };
+  auto lds_store = [&](const float4* qa, const float4* qb, float* As, float* Bs) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int o = AK ? bt::km_off(bt::km_item_row(tid, p), bt::km_item_k(tid)) : bt::mk_off(BM, bt::mk_item_k(BM, tid, p), bt::mk_item_x(BM, tid));
+      *reinterpret_cast<float4*>(As + o) = qa[p];
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int o = BKC ? bt::km_off(bt::km_item_row(tid, p), bt::km_item_k(tid)) : bt::mk_off(BN, bt::mk_item_k(BN, tid, p), bt::mk_item_x(BN, tid));
+      *reinterpret_cast<float4*>(Bs + o) = qb[p];
+    }
+  };
+
+  f32x16 acc[SM][SN];
+#pragma unroll
+  for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+    for (int sn = 0; sn < SN; ++sn)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[sm][sn][q] = 0.0f;
+
+  auto compute = [&](const float* As, const float* Bs) {
+    float fa[SM][16], fb[SN][16];
+#pragma unroll
+    for (int sm = 0; sm < SM; ++sm) {
+      const int x = (wm * SM + sm) * 32 + i;
+      if constexpr (AK) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 v = *reinterpret_cast<const float4*>(As + bt::km_off(x, 8 * j + 4 * h));
+          fa[sm][4 * j] = v.x; fa[sm][4 * j + 1] = v.y; fa[sm][4 * j + 2] = v.z; fa[sm][4 * j + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) fa[sm][t] = As[bt::mk_off(BM, bt::kslot(t, 0), x) + h * (4 * BM)];
+      }
+    }
+#pragma unroll
+    for (int sn = 0; sn < SN; ++sn) {
+      const int x = (wn * SN + sn) * 32 + i;
+      if constexpr (BKC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 v = *reinterpret_cast<const float4*>(Bs + bt::km_off(x, 8 * j + 4 * h));
+          fb[sn][4 * j] = v.x; fb[sn][4 * j + 1] = v.y; fb[sn][4 * j + 2] = v.z; fb[sn][4 * j + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) fb[sn][t] = Bs[bt::mk_off(BN, bt::kslot(t, 0), x) + h * (4 * BN)];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+        for (int sn = 0; sn < SN; ++sn) acc[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sm][t], fb[sn][t], acc[sm][sn], 0, 0, 0);
+  };
+
+  // ---- main loop: register set (c mod D) holds chunk c; two LDS stages; one barrier per chunk ---------------------------------
+  typename P::Epi epi[SM][SN];
+  const int nch = (kend - kbeg + bt::BK - 1) / bt::BK;
+  auto epi_prefetch = [&]() {
+    // whatever the epilogue reads besides the accumulators (W4 / RMSProp state of the fused optimizer) flies under the last chunk
+#pragma unroll
+    for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+      for (int sn = 0; sn < SN; ++sn) P::epi_begin(a, m0 + (wm * SM + sm) * 32, n0 + (wn * SN + sn) * 32, lane, epi[sm][sn]);
+  };
+  if (nch > 0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) if (d < nch) gload(kbeg + d * bt::BK, ra[d], rb[d]);
+    lds_store(ra[0], rb[0], smem, smem + C::AF);
+    __syncthreads();
+    for (int c0 = 0; c0 < nch; c0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int c = c0 + d;                                          // workgroup-uniform control flow throughout
+        if (c < nch) {
+          float* cur = smem + (c & 1) * C::STAGE;
+          float* nxt = smem + ((c + 1) & 1) * C::STAGE;
+          if (c + D < nch) gload(kbeg + (c + D) * bt::BK, ra[d], rb[d]);      // set d is free: chunk c went to LDS one iteration ago
+          if (c + 1 == nch) epi_prefetch();
+          compute(cur, cur + C::AF);
+          if (c + 1 < nch) { lds_store(ra[(d + 1) % D], rb[(d + 1) % D], nxt, nxt + C::AF); __syncthreads(); }
+        }
+      }
+    }
+  } else epi_prefetch();
+
+  // ---- epilogue: every sub-tile through the problem's own 32 x 32 epilogue ----------------------------------------------------
+#pragma unroll
+  for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+    for (int sn = 0; sn < SN; ++sn) {
+      const int ms = m0 + (wm * SM + sm) * 32, ns = n0 + (wn * SN + sn) * 32;
+      if (ms >= M || ns >= N) continue;                               // (wave-uniform) sub-tile entirely outside C
+      if constexpr (has_store_tile<P>::value) {                      // the problem's own 32 x 32 epilogue (fc4_wgrad + fused RMSProp, full tiles)
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = acc[sm][sn][q];
+        P::store_tile(a, ms, ns, lane, v);
+      } else if constexpr (sizeof(typename P::Epi) > 1) {            // an epilogue with prefetched state
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = acc[sm][sn][q];
+        P::store16(a, z, ks, ms, ns, lane, M, N, v, epi[sm][sn]);
+      } else {
+        // P::store of the MOST DERIVED problem (the inherited default store16 would call the base problem's plain stores and lose
+        // a write-through variant); 32 lanes along n: one 128-byte row per accumulator register
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = ms + bt::acc_row(q, h), n = ns + i;
+          if (m < M && n < N) P::store(a, z, ks, m, n, acc[sm][sn][q]);
+        }
+      }
+    }
+}
+
+// workgroups of problem P at block size BM x BN
+template <class C> inline void bt_grid(const StepArgs& a, int& gx, int& gy, int& gz) {
+  typedef typename C::P P;
+  gx = (P::M(a) + C::BM - 1) / C::BM; gy = (P::N(a) + C::BN - 1) / C::BN; gz = P::nbz(a);
+}
+
+template <class C>
+__global__ void __launch_bounds__(bt::NT) bt_kernel(const StepArgs a, const int gx, const int gy) {
+  __shared__ __attribute__((aligned(16))) float smem[C::LDS];
+  if constexpr (has_preload<typename C::P>::value) C::P::preload(a, gridDim.x, (unsigned)gx, (unsigned)gy);
+  const int t = blockIdx.x;
+  const int per_z = gx * gy, bz = t / per_z, r = t - bz * per_z;
+  bt_tile<C>(a, r % gx, r / gx, bz, smem);
+}
+
+template <class C>
+inline hipError_t launch_bt(const StepArgs& a, hipStream_t stream) {
+  int gx, gy, gz; bt_grid<C>(a, gx, gy, gz);
+  if (gx * gy * gz == 0) return hipSuccess;
+  SDQN_LAUNCH((bt_kernel<C>), dim3(gx * gy * gz), dim3(bt::NT), 0, stream, a, gx, gy);
+  return hipGetLastError();
+}
+
+// ---- several independent problems in ONE launch (bwd3 = fc4_wgrad || conv3_dgrad || conv3_wgrad, bwd2 = conv2_dgrad || conv2_wgrad):
+// block-id ranges dispatch to different configurations; the LDS footprint is the largest one's
+template <class C0, class C1, class C2>
+__global__ void __launch_bounds__(bt::NT) bt_multi_kernel(const StepArgs a, const MultiDims d) {
+  constexpr int L01 = C0::LDS > C1::LDS ? C0::LDS : C1::LDS, L = L01 > C2::LDS ? L01 : C2::LDS;
+  __shared__ __attribute__((aligned(16))) float smem[L];
+  if constexpr (has_preload_multi<typename C1::P>::value) C1::P::preload_multi(a, d);
+  const int b = blockIdx.x;
+  if (b < d.n[0]) { const int pz = d.gx[0] * d.gy[0], bz = b / pz, r = b - bz * pz; bt_tile<C0>(a, r % d.gx[0], r / d.gx[0], bz, smem); }
+  else if (b < d.n[0] + d.n[1]) { const int l = b - d.n[0], pz = d.gx[1] * d.gy[1], bz = l / pz, r = l - bz * pz; bt_tile<C1>(a, r % d.gx[1], r / d.gx[1], bz, smem); }
+  else { const int l = b - d.n[0] - d.n[1], pz = d.gx[2] * d.gy[2], bz = l / pz, r = l - bz * pz; bt_tile<C2>(a, r % d.gx[2], r / d.gx[2], bz, smem); }
+}
+
+template <class C0, class C1, class C2>
+inline hipError_t launch_bt_multi(const StepArgs& a, bool has0, bool has1, bool has2, hipStream_t stream) {
+  MultiDims d; memset(&d, 0, sizeof d);
+  int gz;
+  if (has0) { bt_grid<C0>(a, d.gx[0], d.gy[0], gz); d.n[0] = d.gx[0] * d.gy[0] * gz; }
+  if (has1) { bt_grid<C1>(a, d.gx[1], d.gy[1], gz); d.n[1] = d.gx[1] * d.gy[1] * gz; }
+  if (has2) { bt_grid<C2>(a, d.gx[2], d.gy[2], gz); d.n[2] = d.gx[2] * d.gy[2] * gz; }
+  if (d.n[0] + d.n[1] + d.n[2] == 0) return hipSuccess;
+  SDQN_LAUNCH((bt_multi_kernel<C0, C1, C2>), dim3(d.n[0] + d.n[1] + d.n[2]), dim3(bt::NT), 0, stream, a, d);
+  return hipGetLastError();
+}
+
+}  // namespace sdqn

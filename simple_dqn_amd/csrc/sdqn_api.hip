@@ -457,6 +457,7 @@ struct sdqn_net_s {
   int f4_share[2] = {100, 0};               // % of the fc4-wgrad tiles in bwd3 / bwd2 (rest in bwd1)
   int ns_cap[3] = {1, 1, 1};               // slabs the split-K buffers were allocated for (tuning hook "tps:<layer>")
   int rb[12] = {0};                        // B >= 128: register-blocked routine, menu entry per kernel id (0 = unblocked)
+  bool bt_on = true; int bt[K_COUNT] = {0};  // round 4, B >= 128 float32: block-tile engine (sdqn_kernels_bt.hip); per kernel id 0 = built-in block shape, n = menu entry, -1 = latency engine
   int xcd_mask[K_COUNT] = {0};             // tuning hook "xcd:<kernel id>": per-launch problem mask (-1 = built-in)
   bool xcd_map = false;                    // XCD-contiguous tile map for EVERY launch: traffic ~ algorithmic, step ~1 % slower (bwd3);
                                            // built-in: only where it also wins time (fc4_fwd: the 7 K-slabs of a tile's W4 panel share an L2)
@@ -564,7 +565,8 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   h->ns1 = ceil_div(T1, h->tps1); h->ns2 = ceil_div(T2, h->tps2); h->ns3 = ceil_div(T3, h->tps3);
   // fc4 forward K-splits: parallelism at B = 32; at B >= 128 the M x N tiles fill the chip in fp32 (3 620 -> 3 650 steps/s at B = 256),
   // not in float16 where a wave owns a 64 x 64 block (S4 = 1: 4 850 steps/s, 7: 5 770)
-  h->S4 = (B >= 128 && c->datatype == 0) ? 1 : 7;
+  // (round 4: the block-tile engine owns a 64 x 64 block per workgroup — 64 blocks per slab at B = 256 — so it wants the slabs too)
+  h->S4 = 7;
 #define NCHK(x) do { int r_ = (x); if (r_) { net_free(h); return r_; } } while (0)
   NCHK(dalloc(h, (void**)&h->theta, h->NP * 4));
   if (c->target_enabled) NCHK(dalloc(h, (void**)&h->theta_t, h->NP * 4)); else h->theta_t = h->theta;   // deepqnetwork.py:64-73
@@ -895,6 +897,7 @@ static hipError_t launch_tuned(sdqn_net_s* h, int id, StepArgs a, hipStream_t s,
   XCD_TUNE(a, id);
   LaunchTune t;
   for (int i = 0; i < 12; ++i) { t.nw_override[i] = h->nw_override[i]; t.rb[i] = h->rb[i]; }
+  for (int i = 0; i < K_COUNT; ++i) t.bt[i] = h->bt_on ? h->bt[i] : -1;
   t.hoist = hoist; t.order = h->bwd_order; t.r3 = r3; t.host_idx = h->host_idx_cur; t.r3_xcd = h->r3_xcd; t.wt = h->wt;
   return launch_kernel(id, a, t, s);
 }
@@ -1578,6 +1581,12 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
     int id = atoi(name + 3);
     if (id < 0 || id >= 12 || value < 0 || value > 8) { set_error("bad rb override"); return SDQN_ERR_ARG; }
     h->rb[id] = value;
+  }
+  else if (!strcmp(name, "bt")) h->bt_on = value != 0;                  // 0: B >= 128 on the latency engine's launch forms (round 3)
+  else if (!strncmp(name, "bt:", 3)) {                     // block-tile engine: menu entry of kernel id (0 built-in, -1 latency engine)
+    int id = atoi(name + 3);
+    if (id < 0 || id >= K_COUNT || value < -1 || value > 8) { set_error("bad bt override"); return SDQN_ERR_ARG; }
+    h->bt[id] = value;
   }
   else if (!strcmp(name, "bwd_order")) h->bwd_order = value;
   else if (!strcmp(name, "s4")) {                          // tuning: split-K slabs of the fc4 forward (1..7; 7 allocated)

@@ -39,8 +39,14 @@ static hipError_t launch_nw(int nw, const StepArgs& a, hipStream_t s) {
 hipError_t launch_kernel_ext(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled);
 
 hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled);
+hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled);
 
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s) {
+  if (a.B >= 128 && !a.h16) {  // throughput regime: the block-tile engine (round 4; sdqn_kernels_bt.hip) takes what it implements
+    bool handled = false;
+    const hipError_t e = launch_kernel_bt(id, a, t, s, &handled);
+    if (handled) return e;
+  }
   if (t.r3 || t.wt) {          // round-3 launch variants live in their own translation unit (same reason as sdqn_kernels_ext.hip)
     bool handled = false;
     const hipError_t e = launch_kernel_r3(id, a, t, s, &handled);

@@ -8,6 +8,7 @@
 #include <vector>
 #include <algorithm>
 #include "../../simple_dqn_amd/csrc/problems.h"
+#include "../../simple_dqn_amd/csrc/bt_map.h"
 
 using namespace sdqn;
 
@@ -31,6 +32,111 @@ static void run(const StepArgs& a) {
       }
     }
   }
+}
+
+// ---- the block-tile engine's maps (bt_map.h) executed on the host ------------------------------------------------------------
+// Mirrors gemm_engine_bt.h's bt_tile step by step with a simulated workgroup: 256 "threads" fill the two LDS panels through the
+// loader item maps, 4 waves x 64 lanes fetch their MFMA fragments through frag_off(), the MFMA is the documented lane semantics
+// (lane l feeds A[i = l & 31][k-slot l >> 5] and B[k-slot l >> 5][j = l & 31]; register r of lane l is C[acc_row(r, l >> 5)][l & 31]),
+// the epilogue goes through P::store with the engine's sub-tile -> (m, n) map.  Any hole in the loader coverage, any disagreement of
+// the A and B k-slot maps, any wrong panel offset shows up as a wrong gradient against the oracle.
+template <class P, int BM, int BN, int WM, int WN>
+static void run_bt(const StepArgs& a) {
+  using namespace sdqn::bt;
+  constexpr bool AK = P::A_K, BKC = P::B_K;
+  constexpr int SM = BM / (32 * WM), SN = BN / (32 * WN), PA = passes(BM), PB = passes(BN);
+  const int M = P::M(a), N = P::N(a);
+  const int gx = (M + BM - 1) / BM, gy = (N + BN - 1) / BN;
+  std::vector<float> As(panel_floats(AK, BM)), Bs(panel_floats(BKC, BN));
+  for (int bz = 0; bz < P::nbz(a); ++bz) {
+    int z, ks, kbeg, kend; P::ksplit(a, bz, z, ks, kbeg, kend);
+    const int nch = (kend - kbeg + BK - 1) / BK;
+    for (int by = 0; by < gy; ++by) for (int bx = 0; bx < gx; ++bx) {
+      const int m0 = bx * BM, n0 = by * BN;
+      std::vector<float> acc((size_t)4 * SM * SN * 64 * 16, 0.f);          // [wave][sm][sn][lane][r]
+      for (int c = 0; c < nch; ++c) {
+        const int kc = kbeg + c * BK;
+        std::fill(As.begin(), As.end(), -1e30f); std::fill(Bs.begin(), Bs.end(), -1e30f);     // a missed slot poisons the result
+        for (int tid = 0; tid < NT; ++tid) {
+          for (int p = 0; p < PA; ++p) {
+            f4 v; int off;
+            if (AK) {
+              const int m = m0 + km_item_row(tid, p), k = kc + km_item_k(tid);
+              const typename P::aoff_t ar = P::a_row(a, z, m < M ? m : M - 1);
+              v = P::a_load4(a, z, ar + P::a_col(a, z, k < kend ? k : kbeg));
+              if (k >= kend) v.x = v.y = v.z = v.w = 0.f;
+              off = km_off(km_item_row(tid, p), km_item_k(tid));
+            } else {
+              const int m = m0 + mk_item_x(BM, tid), k = kc + mk_item_k(BM, tid, p);
+              const typename P::aoff_t ar = P::a_row(a, z, m + 4 <= M ? m : M - 4);
+              v = P::a_load4(a, z, ar + P::a_col(a, z, k < kend ? k : kbeg));
+              if (k >= kend) v.x = v.y = v.z = v.w = 0.f;
+              off = mk_off(BM, mk_item_k(BM, tid, p), mk_item_x(BM, tid));
+            }
+            As[off] = v.x; As[off + 1] = v.y; As[off + 2] = v.z; As[off + 3] = v.w;
+          }
+          for (int p = 0; p < PB; ++p) {
+            f4 v; int off;
+            if (BKC) {
+              const int n = n0 + km_item_row(tid, p), k = kc + km_item_k(tid);
+              const int bc = P::b_col(a, z, n < N ? n : N - 1);
+              v = P::b_load4(a, z, bc + P::b_row(a, z, k < kend ? k : kbeg));
+              if (k >= kend) v.x = v.y = v.z = v.w = 0.f;
+              off = km_off(km_item_row(tid, p), km_item_k(tid));
+            } else {
+              const int n = n0 + mk_item_x(BN, tid), k = kc + mk_item_k(BN, tid, p);
+              const int bc = P::b_col(a, z, n + 4 <= N ? n : N - 4);
+              v = P::b_load4(a, z, bc + P::b_row(a, z, k < kend ? k : kbeg));
+              if (k >= kend) v.x = v.y = v.z = v.w = 0.f;
+              off = mk_off(BN, mk_item_k(BN, tid, p), mk_item_x(BN, tid));
+            }
+            Bs[off] = v.x; Bs[off + 1] = v.y; Bs[off + 2] = v.z; Bs[off + 3] = v.w;
+          }
+        }
+        for (int wave = 0; wave < 4; ++wave) {
+          const int wm = wave / WN, wn = wave % WN;
+          for (int sm = 0; sm < SM; ++sm) for (int sn = 0; sn < SN; ++sn) {
+            float* ac = &acc[((((size_t)wave * SM + sm) * SN + sn) * 64) * 16];
+            for (int t = 0; t < 16; ++t) {
+              float fa[64], fb[64];
+              for (int l = 0; l < 64; ++l) {
+                const int i = l & 31, h = l >> 5;
+                fa[l] = As[frag_off(AK, BM, (wm * SM + sm) * 32 + i, t, h)];
+                fb[l] = Bs[frag_off(BKC, BN, (wn * SN + sn) * 32 + i, t, h)];
+              }
+              for (int l = 0; l < 64; ++l) for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(r, l >> 5), col = l & 31;
+                float d = ac[l * 16 + r];
+                d += fa[row] * fb[col];                 // k-slot 0
+                d += fa[row + 32] * fb[col + 32];       // k-slot 1
+                ac[l * 16 + r] = d;
+              }
+            }
+          }
+        }
+      }
+      for (int wave = 0; wave < 4; ++wave) {
+        const int wm = wave / WN, wn = wave % WN;
+        for (int sm = 0; sm < SM; ++sm) for (int sn = 0; sn < SN; ++sn) {
+          const int ms = m0 + (wm * SM + sm) * 32, ns = n0 + (wn * SN + sn) * 32;
+          const float* ac = &acc[((((size_t)wave * SM + sm) * SN + sn) * 64) * 16];
+          for (int l = 0; l < 64; ++l) for (int r = 0; r < 16; ++r) {
+            const int m = ms + acc_row(r, l >> 5), n = ns + (l & 31);
+            if (m < M && n < N) P::store(a, z, ks, m, n, ac[l * 16 + r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+static int g_bt_variant = 0;       // 0: naive loops; 1 / 2: the block-tile maps at the built-in / the alternative block shapes
+extern "C" void emul_set_bt(int v) { g_bt_variant = v; }
+template <class P, int BM1, int BN1, int WM1, int WN1, int BM2, int BN2, int WM2, int WN2>
+static void run_any(const StepArgs& a) {
+  if (g_bt_variant == 1) run_bt<P, BM1, BN1, WM1, WN1>(a);
+  else if (g_bt_variant == 2) run_bt<P, BM2, BN2, WM2, WN2>(a);
+  else run<P>(a);
 }
 
 extern "C" void emul_div_bsz(const float* x, float bsz, float* out, int n) { for (int i = 0; i < n; ++i) out[i] = div_bsz(x[i], bsz); }
@@ -61,7 +167,8 @@ extern "C" int emul_step(int B, int A, const float* const* w_online /*5, Neon*/,
   std::vector<float> s1((size_t)ns1 * NW1), s2((size_t)ns2 * NW2), s3((size_t)ns3 * NW3);
   a.a1 = a1.data(); a.a2 = a2.data(); a.a3 = a3.data(); a.slab4 = slab4.data(); a.a4 = a4.data(); a.d4 = d4.data();
   a.d3p = d3p.data(); a.d2p = d2p.data(); a.d3 = d3.data(); a.d2 = d2.data(); a.d1 = d1.data(); a.g = g.data(); a.slab1 = s1.data(); a.slab2 = s2.data(); a.slab3 = s3.data();
-  run<Conv1Fwd>(a); run<Conv2Fwd>(a); run<Conv3Fwd>(a); run<Fc4Fwd>(a);
+  run<Conv1Fwd>(a);
+  run_any<Conv2Fwd, 64, 64, 2, 2, 128, 64, 4, 1>(a); run_any<Conv3Fwd, 64, 64, 2, 2, 128, 64, 2, 2>(a); run_any<Fc4Fwd, 64, 64, 2, 2, 128, 128, 2, 2>(a);
   // head (mirrors head_kernel in sdqn_kernels.hip)
   std::vector<float> dq((size_t)B * A, 0.f);
   double cost = 0;
@@ -87,8 +194,9 @@ extern "C" int emul_step(int B, int A, const float* const* w_online /*5, Neon*/,
     for (int j = 0; j < NFC; ++j) d4[(size_t)n * NFC + j] = a4[(size_t)n * NFC + j] > 0 ? a.theta[0][OFF5 + act[n] * NFC + j] * dc : 0.f;
   }
   *cost_out = (float)(cost / B);
-  run<Fc4Dgrad>(a); run<Fc4Wgrad>(a); run<Conv3Dgrad>(a); run<Conv3Wgrad>(a);
-  run<Conv2Dgrad>(a); run<Conv2Wgrad>(a); run<Conv1Wgrad>(a);
+  run_any<Fc4Dgrad, 64, 64, 2, 2, 32, 128, 1, 4>(a); run_any<Fc4Wgrad, 64, 64, 2, 2, 64, 128, 2, 2>(a);
+  run_any<Conv3Dgrad, 64, 64, 2, 2, 128, 64, 2, 2>(a); run_any<Conv3Wgrad, 64, 64, 2, 2, 128, 64, 2, 2>(a);
+  run_any<Conv2Dgrad, 128, 32, 4, 1, 256, 32, 4, 1>(a); run_any<Conv2Wgrad, 64, 64, 2, 2, 128, 64, 2, 2>(a); run<Conv1Wgrad>(a);
   for (int i = 0; i < NW1; ++i) { float s = 0; for (int k = 0; k < ns1; ++k) s += s1[(size_t)k * NW1 + i]; g[OFF1 + i] = s; }
   for (int i = 0; i < NW2; ++i) { float s = 0; for (int k = 0; k < ns2; ++k) s += s2[(size_t)k * NW2 + i]; g[OFF2 + i] = s; }
   for (int i = 0; i < NW3; ++i) { float s = 0; for (int k = 0; k < ns3; ++k) s += s3[(size_t)k * NW3 + i]; g[OFF3 + i] = s; }

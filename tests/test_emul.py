@@ -19,13 +19,18 @@ def emul():
     so = os.path.join(HERE, "emul", "libsdqn_emul.so")
     src = os.path.join(HERE, "emul", "emul.cpp")
     hdr = os.path.join(HERE, "..", "simple_dqn_amd", "csrc", "problems.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdr2 = os.path.join(HERE, "..", "simple_dqn_amd", "csrc", "bt_map.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)):
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src])
     return C.CDLL(so)
 
 
-@pytest.mark.parametrize("B,A,seed", [(4, 6, 5), (3, 4, 8), (5, 18, 2)])
-def test_problem_index_math(emul, B, A, seed):
+@pytest.mark.parametrize("B,A,seed,bt", [(4, 6, 5, 0), (3, 4, 8, 0), (5, 18, 2, 0), (3, 4, 9, 1), (5, 6, 3, 2)])
+def test_problem_index_math(emul, B, A, seed, bt):
+    """bt = 0: the problem structs with naive loops.  bt = 1 / 2: the same step through the BLOCK-TILE engine's maps (bt_map.h: loader
+    items, the two LDS panel layouts, fragment offsets, accumulator rows) on a simulated workgroup, at the built-in block shapes and at
+    the alternative ones of the menu — small B leaves ragged blocks in every stage (M = 81 B, 49 B, B ...)."""
+    emul.emul_set_bt(bt)
     ws, wt = xavier_weights(A, seed), xavier_weights(A, seed + 1)
     o = OracleDQN(A, batch_size=B, weights=ws)
     o.Wt = [w.copy() for w in wt]
@@ -40,6 +45,7 @@ def test_problem_index_math(emul, B, A, seed):
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
     emul.emul_step(B, A, arr(ws), arr(wt), vp(pre), vp(act), vp(rew), vp(post), vp(t8), C.c_double(0.99),
                    C.c_double(1.0), C.c_double(-1.0), C.c_double(1.0), q.ctypes.data_as(fp), arr(gout), C.byref(cst))
+    emul.emul_set_bt(0)
     assert np.abs(q[0] - preq).max() < 1e-5
     assert abs(cst.value - float(cost)) < 1e-5
     for i in range(5):

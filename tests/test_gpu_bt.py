@@ -1,0 +1,92 @@
+"""The block-tile engine of the throughput regime (B >= 128, float32; simple_dqn_amd/csrc/gemm_engine_bt.h) against the latency
+engine it replaces there, stage by stage, and against itself across launch structures.  Parity of the B >= 128 step with the ORACLE is
+what tests/test_gpu_dqn.py::test_batch256_one_step, tests/test_gpu_parity_r2.py::test_batch256_* and the B = 160 cases of the conv1
+tests assert (they run through this engine by default now); here: the two engines compute the same fp32 sums in different partitions,
+so every intermediate must agree to fp32 round-off, ragged blocks included (B = 160: M = 81 B, 49 B ... are not multiples of 64)."""
+import numpy as np
+import pytest
+
+from oracle.dqn_numpy import OracleDQN, xavier_weights
+from util import make_args, random_minibatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import simple_dqn_amd
+    return simple_dqn_amd
+
+
+def _net(sd, A, B, seed, opts=()):
+    net = sd.DeepQNetwork(A, make_args(batch_size=B))
+    net.set_weights(xavier_weights(A, seed + 1), 1)
+    net.set_weights(xavier_weights(A, seed), 0)
+    for k, v in opts:
+        net.set_option(k, v)
+    return net
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(1e-6, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("A,B", [(3, 256), (6, 160), (4, 128)])
+def test_block_tile_engine_matches_the_latency_engine(sd, A, B):
+    mb = random_minibatch(B, A, 40 + B, reward_range=(-2, 3))
+    new = _net(sd, A, B, 7, [("keep_gradients", 1)])
+    old = _net(sd, A, B, 7, [("keep_gradients", 1), ("bt", 0)])
+    new.train(mb); old.train(mb)
+    sizes = dict(a2=2 * B * 81 * 64, a3=2 * B * 49 * 64, a4=2 * B * 512, d4=B * 512, d3p=B * 121 * 64, d2p=B * 121 * 64, d1=B * 400 * 32)
+    for name, n in sizes.items():
+        x, y = new.debug_read(name, n), old.debug_read(name, n)
+        assert _rel(x, y) < 2e-5, (name, _rel(x, y))
+    assert np.abs(new.last_q()[0] - old.last_q()[0]).max() < 2e-5
+    for i in range(5):
+        assert _rel(new.get_layer(i, 3), old.get_layer(i, 3)) < 2e-5, i
+
+
+@pytest.mark.parametrize("A,B", [(3, 256), (6, 160)])
+def test_block_tile_fused_unfused_and_menu_entries_agree(sd, A, B):
+    """Fused (bwd3 / bwd2 multi-problem launches) and unfused backward launches use the same block shapes: bit-identical.  Every menu
+    entry (other block shapes / prefetch depths: the tuning surface of tools/sweep_bt.py) is the same sum in the same order per output
+    element — k ascending, chunk after chunk — so all entries are bit-identical too."""
+    mb = random_minibatch(B, A, 50 + B, reward_range=(-2, 3))
+    ref = _net(sd, A, B, 9, [("keep_gradients", 1)])
+    ref.train(mb)
+    g0 = [ref.get_layer(i, 3) for i in range(5)]
+    variants = [[("fused_launches", 0)]]
+    variants += [[("bt:1", m), ("bt:2", m), ("bt:3", m), ("bt:5", m), ("bt:16", min(m, 4)), ("bt:17", min(m, 4))] for m in (1, 2, 3, 4, 5)]
+    for opts in variants:
+        net = _net(sd, A, B, 9, [("keep_gradients", 1)] + opts)
+        net.train(mb)
+        assert np.array_equal(net.last_q()[0], ref.last_q()[0]), opts
+        for i in range(5):
+            assert np.array_equal(net.get_layer(i, 3), g0[i]), (opts, i)
+
+
+def test_block_tile_fused_rmsprop_step(sd):
+    """The fc4_wgrad epilogue of the block-tile engine applies RMSProp in place (12.8 MB of W4 + state never leave as a gradient):
+    after one step the weights and the optimizer state equal the materialised-gradient path's (same per-element operations)."""
+    A, B = 3, 256
+    mb = random_minibatch(B, A, 77)
+    fused = _net(sd, A, B, 11)
+    split = _net(sd, A, B, 11, [("keep_gradients", 1)])
+    fused.train(mb); split.train(mb)
+    for which in (0, 2):
+        for i in range(5):
+            assert np.array_equal(fused.get_layer(i, which), split.get_layer(i, which)), (which, i)
+
+
+def test_block_tile_other_slab_counts(sd):
+    """K-slab choices of the weight gradients and of fc4 forward (options tps:<l>, s4) only regroup the fp32 sums."""
+    A, B = 3, 256
+    mb = random_minibatch(B, A, 78)
+    ref = _net(sd, A, B, 13, [("keep_gradients", 1)])
+    ref.train(mb)
+    for opts in ([("tps:2", 8), ("tps:3", 7)], [("s4", 1)], [("s4", 4), ("tps:2", 41)]):
+        net = _net(sd, A, B, 13, [("keep_gradients", 1)] + opts)
+        net.train(mb)
+        assert np.abs(net.last_q()[0] - ref.last_q()[0]).max() < 2e-5, opts
+        for i in range(5):
+            assert _rel(net.get_layer(i, 3), ref.get_layer(i, 3)) < 2e-5, (opts, i)
