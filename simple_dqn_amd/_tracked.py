@@ -8,12 +8,17 @@ owning ReplayMemory (a dirty slot range); the memory uploads exactly that range 
 ever trained on stale frames silently, and no `sync_mirror()` call is needed for correctness any more (it remains as an
 explicit bulk upload).
 
+Every array the class hands out is flagged READ-ONLY for numpy; the tracked write paths below go through a private writable alias
+of the same memory (`_w()`).  So an alias that escapes the tracking — `np.asarray(mem.screens)`, `.view(np.ndarray)`,
+`memoryview(...)`, `torch.from_numpy(...)` — cannot be written at all: `x = np.asarray(mem.screens); x[5] = 7` raises
+"assignment destination is read-only" instead of training on a stale HBM mirror silently.  A caller who
+re-enables writing on such an alias (`x.flags.writeable = True`) or writes through raw pointers owns the `sync_mirror()` call.
+
 Write paths covered: indexing assignment (`a[...] = v`, any index kind), in-place operators and every ufunc / numpy
 function with `out=` (`np.bitwise_xor(x, y, out=a[s:e])`), `np.copyto / put / place / putmask / put_along_axis`, and the
 mutating ndarray methods (`fill`, `put`, `sort`, `partition`, `byteswap(inplace=True)`, `setfield`, `itemset`).  Views of
 views stay tracked (`a[10:20][3] = v`), also after `.view(dtype)` / `.reshape` of the same memory.  NOT covered: writes
-through the raw buffer protocol (`memoryview(a)`, `file.readinto`, ctypes pointers) — those callers own their
-`sync_mirror()` (ReplayMemory.load does).
+through ctypes / raw pointers — those callers own their `sync_mirror()`.
 """
 import weakref
 
@@ -30,7 +35,23 @@ class TrackedArray(np.ndarray):
         obj = np.asarray(base_array).view(cls)
         obj._owner = weakref.ref(owner)
         obj._kind = kind
+        obj.flags.writeable = False             # every view / alias derived from this object inherits the flag
         return obj
+
+    def _w(self):
+        """Writable plain-ndarray alias of exactly this view (same memory, shape, strides) — the only door for writes."""
+        if self.flags.writeable:                # a copy that owns its data (fancy-index result, .copy()): nothing to track
+            return self.view(np.ndarray)
+        ref = self._owner
+        owner = ref() if ref is not None else None
+        raw = owner._raw_bytes.get(self._kind) if owner is not None else None
+        if raw is None or self.size == 0:
+            return self.view(np.ndarray)        # (read-only: a write raises)
+        base = raw.__array_interface__["data"][0]
+        lo, hi = _byte_bounds(self)
+        if lo < base or hi > base + raw.nbytes:
+            return self.view(np.ndarray)
+        return np.ndarray(self.shape, dtype=self.dtype, buffer=raw, offset=self.__array_interface__["data"][0] - base, strides=self.strides)
 
     def __array_finalize__(self, obj):
         self._owner = getattr(obj, "_owner", None)
@@ -49,18 +70,48 @@ class TrackedArray(np.ndarray):
     def __setitem__(self, key, value):
         # an int / slice on the first axis narrows the range to the slots actually written; anything else marks this view's extent
         target = self
+        k0 = key[0] if isinstance(key, tuple) and key else key
         try:
-            if isinstance(key, (int, np.integer, slice)):
-                target = np.ndarray.__getitem__(self, key)
-            elif isinstance(key, tuple) and key and isinstance(key[0], (int, np.integer, slice)):
-                target = np.ndarray.__getitem__(self, key[0])
+            if isinstance(k0, (int, np.integer, slice)):
+                target = np.ndarray.__getitem__(self, k0)
         except Exception:
             target = self
-        np.ndarray.__setitem__(self, key, value)
+        if isinstance(value, TrackedArray):
+            value = value.view(np.ndarray)
+        self._w()[key] = value
+        if self.flags.writeable:                # (an untracked copy)
+            return
+        if isinstance(k0, (list, np.ndarray)) and self.ndim >= 1 and self._touched_rows(k0):
+            return                              # integer-array / boolean-mask key on the first axis: only the rows it names
         if isinstance(target, TrackedArray):
             target._touched()
         else:                                   # a 0-d element (a[i] = v on a 1-d array): one slot
             self._touched_element(key)
+
+    def _touched_rows(self, k0):
+        """Fancy key on axis 0: mark the named rows (each one while they are few, their span otherwise) instead of the
+        whole view — `mem.screens[[i, j, k]] = frames` on a 1 M-frame ring must not schedule a 7 GB upload."""
+        try:
+            idx = np.asarray(k0)
+            if idx.dtype == np.bool_:
+                if idx.ndim != 1 or idx.shape[0] != self.shape[0]:
+                    return False
+                idx = np.flatnonzero(idx)
+            elif not np.issubdtype(idx.dtype, np.integer):
+                return False
+            idx = idx.reshape(-1).astype(np.int64)
+            if idx.size == 0:
+                return True
+            idx = np.where(idx < 0, idx + self.shape[0], idx)
+            rows = np.unique(idx) if idx.size <= 64 else np.array([idx.min(), idx.max()])
+            if idx.size <= 64:
+                for i in rows:
+                    np.ndarray.__getitem__(self, slice(int(i), int(i) + 1))._touched()
+            else:
+                np.ndarray.__getitem__(self, slice(int(rows[0]), int(rows[1]) + 1))._touched()
+            return True
+        except Exception:
+            return False
 
     def _touched_element(self, key):
         ref = self._owner
@@ -87,9 +138,11 @@ class TrackedArray(np.ndarray):
         written = [o for o in outs if isinstance(o, TrackedArray)]
         if method == "at" and inputs and isinstance(inputs[0], TrackedArray):      # np.add.at(a, idx, v) writes its first input
             written.append(inputs[0])
+        if method == "at" and inputs and isinstance(inputs[0], TrackedArray):
+            inputs = (inputs[0]._w(),) + tuple(inputs[1:])
         inputs = tuple(x.view(np.ndarray) if isinstance(x, TrackedArray) else x for x in inputs)
         if outs:
-            kwargs["out"] = tuple(o.view(np.ndarray) if isinstance(o, TrackedArray) else o for o in outs)
+            kwargs["out"] = tuple(o._w() if isinstance(o, TrackedArray) else o for o in outs)
         res = getattr(ufunc, method)(*inputs, **kwargs)
         for w in written:
             w._touched()
@@ -104,42 +157,51 @@ class TrackedArray(np.ndarray):
     def __array_function__(self, func, types, args, kwargs):
         written = []
         name = getattr(func, "__name__", "")
+        args, kwargs = list(args), dict(kwargs)
         if name in _MUTATING_FUNCS:
-            tgt = args[0] if args else kwargs.get(_MUTATING_FUNCS[name])
-            if isinstance(tgt, TrackedArray):
-                written.append(tgt)
+            pname = _MUTATING_FUNCS[name]
+            if args and isinstance(args[0], TrackedArray):
+                written.append(args[0]); args[0] = args[0]._w()
+            elif isinstance(kwargs.get(pname), TrackedArray):
+                written.append(kwargs[pname]); kwargs[pname] = kwargs[pname]._w()
         o = kwargs.get("out")
-        for x in (o if isinstance(o, tuple) else (o,)):
-            if isinstance(x, TrackedArray):
-                written.append(x)
-        res = super().__array_function__(func, types, args, kwargs)
+        if isinstance(o, tuple):
+            written += [x for x in o if isinstance(x, TrackedArray)]
+            kwargs["out"] = tuple(x._w() if isinstance(x, TrackedArray) else x for x in o)
+        elif isinstance(o, TrackedArray):
+            written.append(o); kwargs["out"] = o._w()
+        if not written:
+            return super().__array_function__(func, types, tuple(args), kwargs)
+        # the write targets are plain writable aliases now; the remaining tracked arguments are read-only inputs
+        plain = lambda x: x.view(np.ndarray) if isinstance(x, TrackedArray) else x
+        res = func(*[plain(x) for x in args], **{k: plain(v) for k, v in kwargs.items()})
         for w in written:
             w._touched()
         return res
 
     def fill(self, value):
-        np.ndarray.fill(self, value); self._touched()
+        self._w().fill(value); self._touched()
 
     def put(self, *a, **k):
-        np.ndarray.put(self, *a, **k); self._touched()
+        self._w().put(*a, **k); self._touched()
 
     def sort(self, *a, **k):
-        np.ndarray.sort(self, *a, **k); self._touched()
+        self._w().sort(*a, **k); self._touched()
 
     def partition(self, *a, **k):
-        np.ndarray.partition(self, *a, **k); self._touched()
+        self._w().partition(*a, **k); self._touched()
 
     def setfield(self, *a, **k):
-        np.ndarray.setfield(self, *a, **k); self._touched()
+        self._w().setfield(*a, **k); self._touched()
 
     def byteswap(self, inplace=False):
-        r = np.ndarray.byteswap(self, inplace)
-        if inplace:
-            self._touched()
-        return r
+        if not inplace:
+            return np.ndarray.byteswap(self.view(np.ndarray), False)
+        self._w().byteswap(True); self._touched()
+        return self
 
     def itemset(self, *a):                      # (numpy < 2)
-        np.ndarray.itemset(self, *a); self._touched()
+        self._w().itemset(*a); self._touched()
 
 
 def _byte_bounds(a):

@@ -24,11 +24,19 @@
 
 namespace sdqn {
 
-template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 2>
+// X_ = 0: v_mfma_f32_32x32x2_f32 (exact fp32: an fmaf chain).  X_ = 9 / 6: the same fp32 operands on PACKED-bf16 MFMA through exact
+// three-way splits (problems.h: split_bf16x3 — hi + mid + lo == x exactly): x y = sum_{i,j} x_i y_j with every one of the 9 partial
+// products exact in fp32 (8 x 8 significant bits), accumulated in fp32 by v_mfma_f32_32x32x16_bf16 at 16x the fp32 matrix rate:
+// 9 instructions of 32 cycles per 16 k instead of 8 of 64 (0.56x the matrix-pipe time); X_ = 6 drops the three products below
+// 2^-24 of x y (lo x mid, mid x lo, lo x lo: 0.375x).  The dominant hi x hi products have their own accumulator, the small cross
+// terms a second one, added once in the epilogue (small + main): no cross term is ever rounded against the running main sum.
+template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 2, int X_ = 0>
 struct BtCfg {
   typedef P_ P;
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
   static constexpr int D = D_;                          // chunks in flight per workgroup: D register sets of (BM + BN) / 32 float4 per thread
+  static constexpr int X = X_;
+  static_assert(X == 0 || X == 6 || X == 9, "fp32 MFMA, or 6 / 9 exact bf16 partial products");
   static_assert(D >= 1 && D <= 4, "prefetch depth");
   static constexpr int SM = BM / (32 * WM), SN = BN / (32 * WN);
   static_assert(WM * WN * 64 == bt::NT, "four waves per workgroup");
@@ -42,6 +50,17 @@ template <class P, class = void> struct has_store_tile { static constexpr bool v
 template <class P> struct has_store_tile<P, decltype((void)P::STORE_TILE)> { static constexpr bool value = P::STORE_TILE; };
 
 __device__ __forceinline__ float4 f4_to_float4(const f4& v) { return make_float4(v.x, v.y, v.z, v.w); }
+
+typedef __bf16 bt_bf16x8 __attribute__((ext_vector_type(8)));
+// eight fp32 values -> three bf16 fragments with hi + mid + lo == x exactly (round-to-nearest splits, exact residuals)
+__device__ __forceinline__ void split8_bf16x3(const float* x, bt_bf16x8& hi, bt_bf16x8& mid, bt_bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)x[e]; const float r1 = x[e] - (float)h;
+    const __bf16 m = (__bf16)r1; const float r2 = r1 - (float)m;
+    hi[e] = h; mid[e] = m; lo[e] = (__bf16)r2;
+  }
+}
 
 template <class C>
 __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int bz, float* smem) {
@@ -131,7 +150,77 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[sm][sn][q] = 0.0f;
 
+  constexpr int X = C::X;
+  f32x16 accs[X ? SM : 1][X ? SN : 1];                                  // the small cross terms of the bf16x3 mode
+  if constexpr (X != 0) {
+#pragma unroll
+    for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+      for (int sn = 0; sn < SN; ++sn)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accs[sm][sn][q] = 0.0f;
+  }
+  // packed-bf16 form of one chunk: two 16-deep steps; lane (i, h) feeds k = 16 s + 8 h .. + 7 of row / column i of BOTH operands
+  // (the same slot <-> k assignment for A and B, so the result does not depend on the hardware's k numbering)
+  auto compute_x3 = [&](const float* As, const float* Bs) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      bt_bf16x8 a1[SM], a2[SM], a3[SM], b1[SN], b2[SN], b3[SN];
+#pragma unroll
+      for (int sm = 0; sm < SM; ++sm) {
+        const int x = (wm * SM + sm) * 32 + i;
+        float v[8];
+        if constexpr (AK) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float4 q = *reinterpret_cast<const float4*>(As + bt::km_off(x, 16 * st + 8 * h + 4 * j));
+            v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = As[bt::mk_off(BM, 16 * st + e, x) + h * (8 * BM)];
+        }
+        split8_bf16x3(v, a1[sm], a2[sm], a3[sm]);
+      }
+#pragma unroll
+      for (int sn = 0; sn < SN; ++sn) {
+        const int x = (wn * SN + sn) * 32 + i;
+        float v[8];
+        if constexpr (BKC) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float4 q = *reinterpret_cast<const float4*>(Bs + bt::km_off(x, 16 * st + 8 * h + 4 * j));
+            v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = Bs[bt::mk_off(BN, 16 * st + e, x) + h * (8 * BN)];
+        }
+        split8_bf16x3(v, b1[sn], b2[sn], b3[sn]);
+      }
+#pragma unroll
+      for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+        for (int sn = 0; sn < SN; ++sn) {
+          f32x16 m = acc[sm][sn], q = accs[sm][sn];
+          if constexpr (X == 9) {
+            q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[sm], b3[sn], q, 0, 0, 0);
+            q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[sm], b3[sn], q, 0, 0, 0);
+            q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[sm], b2[sn], q, 0, 0, 0);
+          }
+          q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[sm], b3[sn], q, 0, 0, 0);
+          m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[sm], b1[sn], m, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[sm], b1[sn], q, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[sm], b2[sn], q, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[sm], b2[sn], q, 0, 0, 0);
+          q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[sm], b1[sn], q, 0, 0, 0);
+          acc[sm][sn] = m; accs[sm][sn] = q;
+        }
+    }
+  };
   auto compute = [&](const float* As, const float* Bs) {
+    if constexpr (X != 0) compute_x3(As, Bs);
+    else {
     float fa[SM][16], fb[SN][16];
 #pragma unroll
     for (int sm = 0; sm < SM; ++sm) {
@@ -167,6 +256,7 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
       for (int sm = 0; sm < SM; ++sm)
 #pragma unroll
         for (int sn = 0; sn < SN; ++sn) acc[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sm][t], fb[sn][t], acc[sm][sn], 0, 0, 0);
+    }
   };
 
   // ---- main loop: register set (c mod D) holds chunk c; two LDS stages; one barrier per chunk ---------------------------------
@@ -207,6 +297,10 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
     for (int sn = 0; sn < SN; ++sn) {
       const int ms = m0 + (wm * SM + sm) * 32, ns = n0 + (wn * SN + sn) * 32;
       if (ms >= M || ns >= N) continue;                               // (wave-uniform) sub-tile entirely outside C
+      if constexpr (X != 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[sm][sn][q] = accs[sm][sn][q] + acc[sm][sn][q];
+      }
       if constexpr (has_store_tile<P>::value) {                      // the problem's own 32 x 32 epilogue (fc4_wgrad + fused RMSProp, full tiles)
         float v[16];
 #pragma unroll

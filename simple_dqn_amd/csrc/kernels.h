@@ -147,6 +147,7 @@ struct LaunchTune {
   int r3_xcd;               // round-3 kernels' XCD-contiguous tile maps: bit 0 conv1_fwd (bf16), bit 1 conv1_wgrad (bf16)
   int wt;                   // write-through (sc1) epilogue stores per launch: 1 conv2_fwd, 2 conv3_fwd, 4 fc4_fwd, 8 fc4_dgrad, 16 bwd3, 32 bwd2, 64 conv1_wgrad, 128 conv1_fwd
   int bt[K_COUNT];          // B >= 128, float32: block-tile engine (sdqn_kernels_bt.hip) per kernel id; 0 = built-in block shape, n > 0 = menu entry, < 0 = latency engine
+  int btx[K_COUNT];         // block-tile engine, arithmetic per kernel id: 0 = fp32 MFMA, 9 / 6 = exact bf16x3 splits of both operands on packed-bf16 MFMA (9 / 6 partial products)
   int r3;                   // round-3 launch variants (sdqn_kernels_r3.hip); bit 0: this K_FC4_DGRAD launch also carries the fc4_wgrad tiles; bit 1: conv3_fwd on 36-deep K-chunks; bit 2: conv1_fwd on packed-bf16 MFMA
 };
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s);     // the GEMM-shaped stages (single or multi-problem launches)

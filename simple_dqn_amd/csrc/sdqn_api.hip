@@ -457,6 +457,7 @@ struct sdqn_net_s {
   int f4_share[2] = {100, 0};               // % of the fc4-wgrad tiles in bwd3 / bwd2 (rest in bwd1)
   int ns_cap[3] = {1, 1, 1};               // slabs the split-K buffers were allocated for (tuning hook "tps:<layer>")
   int rb[12] = {0};                        // B >= 128: register-blocked routine, menu entry per kernel id (0 = unblocked)
+  int btx[K_COUNT] = {0};                    // block-tile engine arithmetic per kernel id: 0 fp32 MFMA, 9 / 6 exact bf16x3 operand splits on packed-bf16 MFMA
   bool bt_on = true; int bt[K_COUNT] = {0};  // round 4, B >= 128 float32: block-tile engine (sdqn_kernels_bt.hip); per kernel id 0 = built-in block shape, n = menu entry, -1 = latency engine
   int xcd_mask[K_COUNT] = {0};             // tuning hook "xcd:<kernel id>": per-launch problem mask (-1 = built-in)
   bool xcd_map = false;                    // XCD-contiguous tile map for EVERY launch: traffic ~ algorithmic, step ~1 % slower (bwd3);
@@ -558,6 +559,9 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
     // throughput regime: the chunks per slab stay about what they are at B = 32 and the NUMBER of slabs grows with B
     // (tools/sweep_tps.py at B = 256, steps/s: 64/54/49 chunks per slab 3 430 -> 50/18/20 3 620; float16 5 380 -> 100/18/20 5 790)
     h->tps1 = c->datatype == 1 ? 100 : 50; h->tps2 = 18; h->tps3 = 20;
+    // round 4, float32 on the block-tile engine (one 64 x 64 block of a slab per workgroup, its chunks in sequence): shorter slabs
+    // (tools/sweep_bt.py at B = 256: conv2_wgrad 18 -> 9 chunks per slab, bwd2 49.6 -> 43.8 us; conv3_wgrad 20 -> 14: 41.5 -> 40.7 us)
+    if (c->datatype == 0 && !h->bn) { h->tps2 = 9; h->tps3 = 14; }
     if (h->tps1 > T1) h->tps1 = T1; if (h->tps2 > T2) h->tps2 = T2; if (h->tps3 > T3) h->tps3 = T3;
   }
   // (the register-blocked routine, gemm_engine_rb.h, is available per kernel id through set_option "rb:<id>" / "tps:<l>":
@@ -565,8 +569,7 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   h->ns1 = ceil_div(T1, h->tps1); h->ns2 = ceil_div(T2, h->tps2); h->ns3 = ceil_div(T3, h->tps3);
   // fc4 forward K-splits: parallelism at B = 32; at B >= 128 the M x N tiles fill the chip in fp32 (3 620 -> 3 650 steps/s at B = 256),
   // not in float16 where a wave owns a 64 x 64 block (S4 = 1: 4 850 steps/s, 7: 5 770)
-  // (round 4: the block-tile engine owns a 64 x 64 block per workgroup — 64 blocks per slab at B = 256 — so it wants the slabs too)
-  h->S4 = 7;
+  h->S4 = (B >= 128 && c->datatype == 0) ? 1 : 7;
 #define NCHK(x) do { int r_ = (x); if (r_) { net_free(h); return r_; } } while (0)
   NCHK(dalloc(h, (void**)&h->theta, h->NP * 4));
   if (c->target_enabled) NCHK(dalloc(h, (void**)&h->theta_t, h->NP * 4)); else h->theta_t = h->theta;   // deepqnetwork.py:64-73
@@ -897,7 +900,7 @@ static hipError_t launch_tuned(sdqn_net_s* h, int id, StepArgs a, hipStream_t s,
   XCD_TUNE(a, id);
   LaunchTune t;
   for (int i = 0; i < 12; ++i) { t.nw_override[i] = h->nw_override[i]; t.rb[i] = h->rb[i]; }
-  for (int i = 0; i < K_COUNT; ++i) t.bt[i] = h->bt_on ? h->bt[i] : -1;
+  for (int i = 0; i < K_COUNT; ++i) { t.bt[i] = h->bt_on ? h->bt[i] : -1; t.btx[i] = h->btx[i]; }
   t.hoist = hoist; t.order = h->bwd_order; t.r3 = r3; t.host_idx = h->host_idx_cur; t.r3_xcd = h->r3_xcd; t.wt = h->wt;
   return launch_kernel(id, a, t, s);
 }
@@ -1235,14 +1238,16 @@ extern "C" int sdqn_net_predict_state(sdqn_net_t h, sdqn_statebuf_t sb, float* q
 
 extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8_t* actions, const int64_t* rewards,
                                    const uint8_t* post, const uint8_t* terminals, float* cost_out) {
-  ARGCHK(h && pre && actions && rewards && post && terminals, "NULL argument");
-  for (int i = 0; i < h->B; ++i) ARGCHK(actions[i] < h->A, "action %d out of range at %d", (int)actions[i], i);
+  // the one-shot "minibatch buffers are clean" declarations are consumed FIRST: an argument error below must not leave one armed for a
+  // later call whose buffers were edited in place
   sdqn_replay_s* owner = nullptr;                               // (handles are created / destroyed / used from ONE host thread: sdqn.h)
   bool reuse = false;                                           // train on the device copy the last gather left (no state upload)
   for (sdqn_replay_s* r : g_replays) {
-    if (pre == r->h_pre && post == r->h_post && r->B == h->B) { owner = r; reuse = r->mb_clean_declared && r->mb_host_gen == r->mb_dev_gen; }
+    if (h && pre && post && pre == r->h_pre && post == r->h_post && r->B == h->B) { owner = r; reuse = r->mb_clean_declared && r->mb_host_gen == r->mb_dev_gen; }
     r->mb_clean_declared = false;                               // one-shot, whoever it was meant for
   }
+  ARGCHK(h && pre && actions && rewards && post && terminals, "NULL argument");
+  for (int i = 0; i < h->B; ++i) ARGCHK(actions[i] < h->A, "action %d out of range at %d", (int)actions[i], i);
   const bool ours = owner != nullptr;
   if (h->gen) {
     ARGCHK(!ours || (size_t)owner->state == h->gen->state_bytes(), "replay geometry differs from the network's");
@@ -1583,6 +1588,15 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
     h->rb[id] = value;
   }
   else if (!strcmp(name, "bt")) h->bt_on = value != 0;                  // 0: B >= 128 on the latency engine's launch forms (round 3)
+  else if (!strcmp(name, "bt_x")) {                        // arithmetic of every block-tile launch: 0 fp32 MFMA, 9 / 6 exact bf16x3 splits
+    ARGCHK(value == 0 || value == 6 || value == 9, "bt_x must be 0, 6 or 9");
+    for (int i = 0; i < K_COUNT; ++i) h->btx[i] = value;
+  }
+  else if (!strncmp(name, "btx:", 4)) {
+    int id = atoi(name + 4);
+    ARGCHK(id >= 0 && id < K_COUNT && (value == 0 || value == 6 || value == 9), "bad btx override");
+    h->btx[id] = value;
+  }
   else if (!strncmp(name, "bt:", 3)) {                     // block-tile engine: menu entry of kernel id (0 built-in, -1 latency engine)
     int id = atoi(name + 3);
     if (id < 0 || id >= K_COUNT || value < -1 || value > 8) { set_error("bad bt override"); return SDQN_ERR_ARG; }

@@ -15,6 +15,7 @@
 namespace sdqn {
 
 #define BT(P, BM, BN, WM, WN, D) BtCfg<P, BM, BN, WM, WN, D>
+#define BTX(P, BM, BN, WM, WN, D, X) BtCfg<P, BM, BN, WM, WN, D, X>
 #define BT_CASE(N, P, BM, BN, WM, WN, D) case N: return launch_bt<BT(P, BM, BN, WM, WN, D)>(a, s)
 
 // built-in block shapes (menu entry 0 maps onto these)
@@ -73,6 +74,33 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
   return hipErrorInvalidValue;
 }
 
+// the built-in block shapes on packed-bf16 MFMA through exact three-way splits of both operands (gemm_engine_bt.h: X = 9 / 6 partial products)
+template <int X>
+static hipError_t launch_single_x(int id, const StepArgs& a, hipStream_t s) {
+  switch (id) {
+    case K_CONV2_FWD: return launch_bt<BTX(Conv2FwdWT, 64, 64, 2, 2, 2, X)>(a, s);
+    case K_CONV3_FWD: return launch_bt<BTX(Conv3FwdWT, 64, 64, 2, 2, 2, X)>(a, s);
+    case K_FC4_FWD: return launch_bt<BTX(Fc4FwdWT, 64, 64, 2, 2, 2, X)>(a, s);
+    case K_FC4_DGRAD: return launch_bt<BTX(Fc4DgradWT, 64, 64, 2, 2, 2, X)>(a, s);
+    case K_FC4_WGRAD: return launch_bt<BTX(Fc4WgradBT, 64, 64, 2, 2, 2, X)>(a, s);
+    case K_CONV3_DGRAD: return launch_bt<BTX(Conv3DgradWT, 64, 64, 2, 2, 2, X)>(a, s);
+    case K_CONV3_WGRAD: return launch_bt<BTX(Conv3WgradWT, 64, 64, 2, 2, 2, X)>(a, s);
+    case K_CONV2_DGRAD: return launch_bt<BTX(Conv2DgradWT, 128, 32, 4, 1, 2, X)>(a, s);
+    case K_CONV2_WGRAD: return launch_bt<BTX(Conv2WgradWT, 64, 64, 2, 2, 2, X)>(a, s);
+    default: break;
+  }
+  return hipErrorInvalidValue;
+}
+template <int X>
+static hipError_t launch_fused_x(int id, const StepArgs& a, hipStream_t s) {
+  const bool f4 = a.f4w_count > 0;
+  if (id == K_BWD3)
+    return launch_bt_multi<BTX(Conv3DgradWT, 64, 64, 2, 2, 2, X), BTX(Conv3WgradWT, 64, 64, 2, 2, 2, X), BTX(Fc4WgradBT, 64, 64, 2, 2, 2, X)>(a, true, true, f4, s);
+  if (id == K_BWD2 && !f4)
+    return launch_bt_multi<NOP, BTX(Conv2WgradWT, 64, 64, 2, 2, 2, X), BTX(Conv2DgradWT, 128, 32, 4, 1, 2, X)>(a, false, true, true, s);
+  return hipErrorInvalidValue;
+}
+
 static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t s) {
   const bool f4 = a.f4w_count > 0;         // (B > 32: all of fc4_wgrad rides in bwd3 or none of it, sdqn_api.hip)
   if (id == K_BWD3) {
@@ -87,10 +115,10 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
     }
   } else if (id == K_BWD2 && !f4) {
     switch (menu) {
-      case 0: return launch_bt_multi<NOP, C2D, C2W>(a, false, true, true, s);
+      case 0: return launch_bt_multi<NOP, C2W, C2D>(a, false, true, true, s);      // the long 9-chunk wgrad blocks are dispatched first, the 800 short dgrad blocks fill in (49.6 -> 43.8 us)
       case 1: return launch_bt_multi<NOP, BT(Conv2DgradWT, 128, 32, 4, 1, 3), BT(Conv2WgradWT, 64, 64, 2, 2, 3)>(a, false, true, true, s);
       case 2: return launch_bt_multi<NOP, BT(Conv2DgradWT, 256, 32, 4, 1, 2), C2W>(a, false, true, true, s);
-      case 3: return launch_bt_multi<NOP, C2W, C2D>(a, false, true, true, s);
+      case 3: return launch_bt_multi<NOP, C2D, C2W>(a, false, true, true, s);
       case 4: return launch_bt_multi<NOP, BT(Conv2DgradWT, 128, 32, 4, 1, 2), BT(Conv2WgradWT, 128, 64, 2, 2, 2)>(a, false, true, true, s);
       default: break;
     }
@@ -104,8 +132,15 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
   *handled = false;
   if (a.B < 128 || a.h16 || a.bn || t.hoist || t.order) return hipSuccess;
   if (id < 0 || id >= K_COUNT || t.bt[id] < 0) return hipSuccess;
+  // fc4 forward / dgrad have 64 / 196 blocks of 64 x 64 — one or two per CU, nothing to overlap their waits with — and measured slower
+  // here than on the latency engine (fc4_fwd 23.4 vs 18.7 us, fc4_dgrad 17.0 vs 15.2 at B = 256): block-tile only on request (menu entry > 0)
+  if ((id == K_FC4_FWD || id == K_FC4_DGRAD) && t.bt[id] == 0 && t.btx[id] == 0) return hipSuccess;
   if (id < 12 && (t.nw_override[id] > 0 || t.rb[id] > 0)) return hipSuccess;      // explicit latency-engine tuning hooks win
   hipError_t e = hipErrorInvalidValue;
+  const int x = t.btx[id];
+  if (x == 9 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<9>(id, a, s) : launch_single_x<9>(id, a, s);
+  else if (x == 6 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<6>(id, a, s) : launch_single_x<6>(id, a, s);
+  else
   if (id == K_BWD3 || id == K_BWD2) e = launch_fused(id, t.bt[id], a, s);
   else if (id == K_CONV2_FWD || id == K_CONV3_FWD || id == K_FC4_FWD || id == K_FC4_DGRAD || id == K_FC4_WGRAD || id == K_CONV3_DGRAD ||
            id == K_CONV3_WGRAD || id == K_CONV2_DGRAD || id == K_CONV2_WGRAD) e = launch_single(id, t.bt[id], a, s);

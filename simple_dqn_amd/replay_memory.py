@@ -41,6 +41,10 @@ class ReplayMemory:
                "screens": np.ctypeslib.as_array(ps, shape=(size,) + self.dims),
                "terminals": np.ctypeslib.as_array(pt, shape=(size,)).view(np.bool_)}
         self._ring_base = {k: (v.__array_interface__["data"][0], v.nbytes // size) for k, v in raw.items()}   # (address, bytes per slot)
+        # the public attributes are READ-ONLY for numpy (an alias that escapes the tracking cannot be written); the tracked write
+        # paths go through these private writable byte views of the same memory (_tracked.py: TrackedArray._w)
+        self._raw = raw
+        self._raw_bytes = {k: v.reshape(-1).view(np.uint8) for k, v in raw.items()}
         self.actions, self.rewards = TrackedArray(raw["actions"], self, "actions"), TrackedArray(raw["rewards"], self, "rewards")
         self.screens, self.terminals = TrackedArray(raw["screens"], self, "screens"), TrackedArray(raw["terminals"], self, "terminals")
         mp, mq, ma, mr, mt = _lib._u8p(), _lib._u8p(), _lib._u8p(), _lib._i64p(), _lib._u8p()
@@ -50,8 +54,10 @@ class ReplayMemory:
         # getMinibatch(), DeepQNetwork.train(minibatch) lets the step read the device copy of the gathered states in place instead of
         # uploading them again (sdqn_replay_declare_minibatch_clean)
         self._mb_dirty = True
-        self.prestates = TrackedArray(np.ctypeslib.as_array(mp, shape=shp), self, "mb_pre")
-        self.poststates = TrackedArray(np.ctypeslib.as_array(mq, shape=shp), self, "mb_post")
+        raw_mb = {"mb_pre": np.ctypeslib.as_array(mp, shape=shp), "mb_post": np.ctypeslib.as_array(mq, shape=shp)}
+        self._raw_bytes.update({k: v.reshape(-1).view(np.uint8) for k, v in raw_mb.items()})
+        self.prestates = TrackedArray(raw_mb["mb_pre"], self, "mb_pre")
+        self.poststates = TrackedArray(raw_mb["mb_post"], self, "mb_post")
         self._mb_actions = np.ctypeslib.as_array(ma, shape=(self.batch_size,))
         self._mb_rewards = np.ctypeslib.as_array(mr, shape=(self.batch_size,))
         self._mb_terminals = np.ctypeslib.as_array(mt, shape=(self.batch_size,)).view(np.bool_)
@@ -75,9 +81,20 @@ class ReplayMemory:
     def count(self):
         return self._state()[0]
 
+    # Backstop behind the write tracking: slots that a direct assignment of count / current newly EXPOSES to the sampler
+    # are uploaded before the next device use whether or not a tracked write touched them — a bulk fill through raw pointers followed
+    # by `mem.count = n` trains on what the host holds.  Costs the newly exposed slots only.
+    def _expose(self, first, last):
+        if last > first:
+            if self._flags != ZERO_COPY:
+                self._dirty_frames.mark(first, last)
+            self._dirty_meta.mark(first, last)
+
     @count.setter
     def count(self, v):
-        _lib.check(self._lib.sdqn_replay_set_state(self._h, int(v), self._state()[1]))
+        old, cur = self._state()
+        _lib.check(self._lib.sdqn_replay_set_state(self._h, int(v), cur))
+        self._expose(old, min(int(v), self.size))
 
     @property
     def current(self):
@@ -85,7 +102,13 @@ class ReplayMemory:
 
     @current.setter
     def current(self, v):
-        _lib.check(self._lib.sdqn_replay_set_state(self._h, self._state()[0], int(v)))
+        cnt, old = self._state()
+        _lib.check(self._lib.sdqn_replay_set_state(self._h, cnt, int(v)))
+        v = int(v)
+        if v >= old:
+            self._expose(old, v)
+        else:                                           # moved across the wrap
+            self._expose(old, self.size); self._expose(0, v)
 
     # ---- coherence of the HBM mirror with the numpy views -----------------------------------------------------------
     def _mark_dirty_bytes(self, kind, lo, hi):
@@ -93,8 +116,10 @@ class ReplayMemory:
         if kind.startswith("mb_"):                      # the minibatch buffers: the host copy no longer equals the device copy
             self._mb_dirty = True
             return
-        if self._flags == ZERO_COPY:
-            return                                      # kernels read the pinned views themselves
+        if self._flags == ZERO_COPY and kind == "screens":
+            return                                      # the kernels read the pinned frames themselves ...
+        # ... but NOT the raw actions / rewards / terminals: also a zero-copy ring's kernels read the PACKED MetaRec array, which only
+        # sdqn_replay_upload_meta re-packs from these views (a rewards edit trained on stale metadata there)
         base, bps = self._ring_base[kind]
         first, last = max(0, (lo - base) // bps), min(self.size, -((base - hi) // bps))     # floor / ceil in slots
         if last > first:
@@ -181,10 +206,10 @@ class ReplayMemory:
             assert f.read(len(self._MAGIC)) == self._MAGIC, "not a replay-memory checkpoint"
             size, count, current, h, w, hist = np.fromfile(f, dtype=np.int64, count=6)
             assert (size, h, w, hist) == (self.size, self.dims[0], self.dims[1], self.history_length), "geometry mismatch"
-            self.actions[:count] = np.fromfile(f, dtype=np.uint8, count=count)
-            self.rewards[:count] = np.fromfile(f, dtype=np.int64, count=count)
-            self.terminals[:count] = np.fromfile(f, dtype=np.uint8, count=count).view(np.bool_)
-            f.readinto(memoryview(self.screens[:count]).cast("B"))
+            self._raw["actions"][:count] = np.fromfile(f, dtype=np.uint8, count=count)
+            self._raw["rewards"][:count] = np.fromfile(f, dtype=np.int64, count=count)
+            self._raw["terminals"][:count] = np.fromfile(f, dtype=np.uint8, count=count).view(np.bool_)
+            f.readinto(memoryview(self._raw["screens"][:count]).cast("B"))
         _lib.check(self._lib.sdqn_replay_set_state(self._h, int(count), int(current)))
         self.sync_mirror(0, int(count))
 
