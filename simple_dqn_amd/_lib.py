@@ -17,6 +17,10 @@ class SdqnError(RuntimeError):
 
 
 def lib_path():
+    # SDQN_LIB_VARIANT=experiments: the build with the measured-slower step structures compiled in (`make -C simple_dqn_amd/csrc
+    # experiments`; tests marked `experiments`, tools/exp).  Never the default: the product library has ONE step structure per regime.
+    if os.environ.get("SDQN_LIB_VARIANT") == "experiments":
+        return os.path.join(_HERE, "libsdqn_hip_exp.so")
     return os.path.join(_HERE, "libsdqn_hip.so")
 
 

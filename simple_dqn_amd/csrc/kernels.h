@@ -160,10 +160,12 @@ hipError_t launch_bn_update(const UpdateArgs& u, hipStream_t s);   // optimizer 
 hipError_t launch_prep(const PrepArgs& p, hipStream_t s, double* zero8 = nullptr);   // zero8: an 8-byte accumulator the launch also clears
 hipError_t launch_grad_to_half(const float* g, half_t* gh, int64_t n, int* state, hipStream_t s);       // fp16 DP payload; state = {flag, log2 scale, good steps}
 hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, int* state, hipStream_t s);
+#ifdef SDQN_EXPERIMENTS
 // round 3: update(i) + conv1_fwd(i + 1) as one launch (sdqn_kernels_r3.hip); u.skip_fc4 must be 1, u.w1_ctr == ctr
 hipError_t launch_upd_conv1(const UpdateArgs& u, const StepArgs& a, const int64_t* host_idx, unsigned* ctr, unsigned target, unsigned* timeout, int xcd, hipStream_t s);
 // round 3: head + fc4_dgrad as one launch (sdqn_kernels_r3.hip; B <= 32, A <= 8, fp32, no batch-norm); ctr counts head-block arrivals (monotonic)
 hipError_t launch_head_f4d(const StepArgs& a, const HeadArgs& h, unsigned* ctr, unsigned target, unsigned* timeout, hipStream_t s);
+#endif
 hipError_t launch_w1_planes(const float* theta, unsigned short* w1p, hipStream_t s);   // conv1's three bf16 weight planes of one net (problems.h: split_bf16x3)
 hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s);   // fp16 mode: rebuild both half copies
 

@@ -19,6 +19,19 @@
 using namespace sdqn;
 
 // ------------------------------------------------------------------------------------------------
+// Step structures that were built, tested bit-identical and measured SLOWER than the default (tools/exp/README.md) live behind the
+// compile-time switch SDQN_EXPERIMENTS (`make experiments` -> libsdqn_hip_exp.so, never loaded by the package unless
+// SDQN_LIB_VARIANT=experiments): hoist, f4w_early, fuse_upd, head_f4d, two_streams, fwd_rb, bwd_order, rb:<id>.  In the product build the
+// constant below is false, every branch they guard folds away and their kernels are not compiled: one step structure per
+// (B regime, datatype).
+#ifdef SDQN_EXPERIMENTS
+static constexpr bool EXPERIMENTS = true;
+#else
+static constexpr bool EXPERIMENTS = false;
+#endif
+#define EXP_OPTION_REFUSED(NAME) do { set_error("option %s is an experiment (measured slower than the default step; tools/exp/README.md): " \
+                                                "build the library with `make -C simple_dqn_amd/csrc experiments` and load it with SDQN_LIB_VARIANT=experiments", NAME); \
+                                      return SDQN_ERR_ARG; } while (0)
 static thread_local std::string g_err;
 static void set_error(const char* fmt, ...) {
   char buf[1024];
@@ -899,9 +912,9 @@ static BnArgs bn_args(sdqn_net_s* h, const StepArgs& a, int layer, int train) {
 static hipError_t launch_tuned(sdqn_net_s* h, int id, StepArgs a, hipStream_t s, int hoist = 0, int r3 = 0) {
   XCD_TUNE(a, id);
   LaunchTune t;
-  for (int i = 0; i < 12; ++i) { t.nw_override[i] = h->nw_override[i]; t.rb[i] = h->rb[i]; }
+  for (int i = 0; i < 12; ++i) { t.nw_override[i] = h->nw_override[i]; t.rb[i] = EXPERIMENTS ? h->rb[i] : 0; }
   for (int i = 0; i < K_COUNT; ++i) { t.bt[i] = h->bt_on ? h->bt[i] : -1; t.btx[i] = h->btx[i]; }
-  t.hoist = hoist; t.order = h->bwd_order; t.r3 = r3; t.host_idx = h->host_idx_cur; t.r3_xcd = h->r3_xcd; t.wt = h->wt;
+  t.hoist = EXPERIMENTS ? hoist : 0; t.order = EXPERIMENTS ? h->bwd_order : 0; t.r3 = r3; t.host_idx = h->host_idx_cur; t.r3_xcd = h->r3_xcd; t.wt = h->wt;
   return launch_kernel(id, a, t, s);
 }
 static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int hoist = 0) {
@@ -922,7 +935,7 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int
     LAUNCH(K_HEAD, launch_head(f, hd, g_stream));
     return SDQN_OK;
   }
-  if (hoist & 2) {
+  if (EXPERIMENTS && (hoist & 2)) {
     // hoist, second half: target conv1 / conv2 of THIS step ran inside the previous step's K_BWD2 / K_BWD1; its conv3 and fc4
     // ride in this step's conv1 / conv2 launches, whose own tiles are the online net's only (nz = 1).  The head then finds
     // the split-K slabs of both nets as usual.
@@ -941,6 +954,7 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int
   // XCD-contiguous tile map where it wins time (tools/sweep_xcd.py, tools/ab_options.py): conv1_fwd +0.5 %, conv2_fwd
   // +0.2 %, fc4_fwd +0.6 % of the step rate; slower for conv3_fwd, fc4_dgrad and every backward launch
   StepArgs fm = a; fm.xcd_map = 1; fm.idx_t = nullptr;
+#ifdef SDQN_EXPERIMENTS
   if (h->has_pending_upd) {
     // the previous step's optimizer pass rides in front of this step's conv1 (train_many only): one launch, the online conv1
     // workgroups wait for the 64 W1 blocks of the same launch (upd_conv1_kernel)
@@ -949,14 +963,15 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int
     UpdateArgs pu = h->pending_upd; pu.w1_ctr = h->w1_ctr;
     LAUNCH(K_UPD_CONV1, launch_upd_conv1(pu, fm, h->host_idx_cur, h->w1_ctr, h->fuse_dbg == 1 ? 0u : 64u * h->w1_epochs, h->w1_ctr + 1, h->r3_xcd & 1, g_stream));
   } else
-  LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, fm, g_stream, 0, (h->conv1_bf16 && !h->hoist && h->nw_override[K_CONV1_FWD] == 0) ? 4 : 0));
-  LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, fm, g_stream, 0, (h->fwd_rb & 1) ? 16 : 0));
+#endif
+  LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, fm, g_stream, 0, (h->conv1_bf16 && !(EXPERIMENTS && h->hoist) && h->nw_override[K_CONV1_FWD] == 0) ? 4 : 0));
+  LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, fm, g_stream, 0, (EXPERIMENTS && (h->fwd_rb & 1)) ? 16 : 0));
   { StepArgs f3 = fm; f3.xcd_map = a.xcd_map;
-    const int c36 = (h->fwd_rb & 2) ? 32 : ((h->conv3_c36 && !h->hoist && h->nw_override[K_CONV3_FWD] == 0) ? 2 : 0);      // (hoist: the riding target conv3 uses the 32-deep routine)
+    const int c36 = (EXPERIMENTS && (h->fwd_rb & 2)) ? 32 : ((h->conv3_c36 && !(EXPERIMENTS && h->hoist) && h->nw_override[K_CONV3_FWD] == 0) ? 2 : 0);      // (hoist: the riding target conv3 uses the 32-deep routine)
     LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, f3, g_stream, 0, c36)); }
   { int rc = join_comm(h); if (rc) return rc; }                // conv1..3 of this step overlap the previous step's fc4 all-reduce
   LAUNCH(K_FC4_FWD, launch_tuned(h, K_FC4_FWD, fm, g_stream));
-  if (!h->skip_head) LAUNCH(K_HEAD, launch_head(a, hd, g_stream));       // (skip_head: run_train launches it together with fc4_dgrad)
+  if (!(EXPERIMENTS && h->skip_head)) LAUNCH(K_HEAD, launch_head(a, hd, g_stream));       // (skip_head: run_train launches it together with fc4_dgrad)
   return SDQN_OK;
 }
 static UpdateArgs make_update_args(sdqn_net_s* h, const StepArgs& a) {
@@ -983,7 +998,7 @@ static UpdateArgs make_update_args(sdqn_net_s* h, const StepArgs& a) {
 static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const PrepArgs* next = nullptr, int hoist = 0, bool defer_update = false) {
   // round 3: head + fc4_dgrad in ONE launch — the 98 dgrad tiles fetch their W4 panels while the B head workgroups run, then pick up
   // delta4 through an in-launch hand-off (sdqn_kernels_r3.hip: head_f4d_kernel).  Same arithmetic and summation order: bit-identical.
-  const bool hf = h->head_f4d && hd.train && h->B <= 32 && h->A <= 8 && a.nz == 2 && h->cfg.datatype == 0 && !h->bn && !hoist && !h->f4w_early &&
+  const bool hf = EXPERIMENTS && h->head_f4d && hd.train && h->B <= 32 && h->A <= 8 && a.nz == 2 && h->cfg.datatype == 0 && !h->bn && !hoist && !h->f4w_early &&
                   h->S4 == 7 && h->nw_override[K_FC4_DGRAD] == 0 && h->nw_override[K_HEAD] == 0 && hd.next_B == 0 && h->w1_ctr;
   h->skip_head = hf;
   int rc = run_forward(h, a, hd, hoist);
@@ -992,11 +1007,12 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   // Backward.  Critical path on the library stream: fc4_dgrad -> conv3_dgrad -> conv2_dgrad -> conv1_wgrad.
   // The three other weight-gradient kernels only need the delta of their layer, so they run beside it
   // on the side stream (fork after the producer of their delta, join before the update).
-  hipStream_t ss = h->two_streams ? g_side : g_stream;
+  const bool two_streams = EXPERIMENTS && h->two_streams;
+  hipStream_t ss = two_streams ? g_side : g_stream;
   // --batch_norm: the delta arriving at layer l (masked by its Rectlin) first goes back through BatchNorm l, in place
 #define BN_BWD(L) do { if (h->bn) LAUNCH(K_BN, launch_bn_backward(bn_args(h, a, (L), 1), g_stream)); } while (0)
   BN_BWD(3);
-  const bool dp_ov = h->comm && h->comm2 && h->dp_overlap && h->fused_launches && !h->two_streams;
+  const bool dp_ov = h->comm && h->comm2 && h->dp_overlap && h->fused_launches && !two_streams;
   // round 3: fc4_wgrad (needs delta4 and a3 only) rides in the fc4_dgrad launch, whose 98 workgroups leave 158 CUs idle; with the
   // fused RMSProp its in-place update of W4 is ordered behind the dgrad's reads by per-row-block flags (sdqn_kernels_r3.hip).
   // Same tiles, same K split as the bwd3 form: bit-identical.  Not for the overlapped-DP / two-stream / hoist / fp16 / bn variants.
@@ -1004,13 +1020,16 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   // B < 128 only: in the throughput regime the on-the-fly split of delta1 makes it VALU-bound (measured 3 580 vs 4 063 steps/s at B = 256;
   // option value 2 forces it for experiments)
   const bool c1w = (h->conv1w_bf16 == 2 || (h->conv1w_bf16 == 1 && h->B < 128)) && h->cfg.datatype == 0 && !h->bn && !hoist && h->nw_override[K_CONV1_WGRAD] == 0;
-  const bool f4_early = h->f4w_early && h->B <= 32 && h->cfg.datatype == 0 && !h->bn && h->fused_launches && !h->two_streams &&
+  const bool f4_early = EXPERIMENTS && h->f4w_early && h->B <= 32 && h->cfg.datatype == 0 && !h->bn && h->fused_launches && !two_streams &&
                         !dp_ov && !hoist && h->bwd_order == 0 && h->f4_share[0] == 100 && h->f4_share[1] == 0 && h->nw_override[K_FC4_DGRAD] == 0;
+#ifdef SDQN_EXPERIMENTS
   if (hf) {
     h->handoff_launched = true; h->hf_epochs += 1;
     LAUNCH(K_HEAD_F4D, launch_head_f4d(a, hd, h->w1_ctr + 4, (unsigned)h->B * h->hf_epochs, h->w1_ctr + 5, g_stream));
   }
-  else if (f4_early) { h->handoff_launched = true; LAUNCH(K_F4D_F4W, launch_tuned(h, K_FC4_DGRAD, a, g_stream, 0, 1)); }
+  else
+#endif
+  if (f4_early) { h->handoff_launched = true; LAUNCH(K_F4D_F4W, launch_tuned(h, K_FC4_DGRAD, a, g_stream, 0, 1)); }
   else LAUNCH(K_FC4_DGRAD, launch_tuned(h, K_FC4_DGRAD, a, g_stream));
   BN_BWD(2);
   if (dp_ov) {
@@ -1033,7 +1052,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     BN_BWD(0);
     LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream, 0, c1w ? 8 : 0));
   } else
-  if (h->fused_launches && !h->two_streams) {
+  if (h->fused_launches && !two_streams) {
     // fc4 wgrad (1568 tiles at B <= 32) is spread over the three backward launches as background traffic;
     // for B > 32 (K-split workgroups) it all rides in the first one
     const int f4_tiles = (NIN4 / 32) * (NFC / 32);
@@ -1054,18 +1073,18 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     b1.xcd_map |= 2;
     LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream, hoist & 1, (c1w && b1.f4w_count == 0) ? 8 : 0));
   } else {
-  if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[1], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[1], 0)); }
+  if (two_streams) { HIPCHK(hipEventRecord(g_ev[1], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[1], 0)); }
   // fc4_wgrad may update W4 in place (fused RMSProp): it must not start before fc4_dgrad has read W4
   LAUNCH_ON(ss, K_FC4_WGRAD, launch_tuned(h, K_FC4_WGRAD, a, ss));            // needs d4, a3
   LAUNCH_ON(ss, K_CONV3_WGRAD, launch_tuned(h, K_CONV3_WGRAD, a, ss));        // needs d3p, a2
   LAUNCH(K_CONV3_DGRAD, launch_tuned(h, K_CONV3_DGRAD, a, g_stream));
   BN_BWD(1);
-  if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[2], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[2], 0)); }
+  if (two_streams) { HIPCHK(hipEventRecord(g_ev[2], g_stream)); HIPCHK(hipStreamWaitEvent(ss, g_ev[2], 0)); }
   LAUNCH_ON(ss, K_CONV2_WGRAD, launch_tuned(h, K_CONV2_WGRAD, a, ss));        // needs d2p, a1
   LAUNCH(K_CONV2_DGRAD, launch_tuned(h, K_CONV2_DGRAD, a, g_stream));
   BN_BWD(0);
   LAUNCH(K_CONV1_WGRAD, launch_tuned(h, K_CONV1_WGRAD, a, g_stream, 0, c1w ? 8 : 0));
-  if (h->two_streams) { HIPCHK(hipEventRecord(g_ev[3], ss)); HIPCHK(hipStreamWaitEvent(g_stream, g_ev[3], 0)); }
+  if (two_streams) { HIPCHK(hipEventRecord(g_ev[3], ss)); HIPCHK(hipStreamWaitEvent(g_stream, g_ev[3], 0)); }
   }
   UpdateArgs u = make_update_args(h, a);
   if (next) u.next = *next;                 // (memset above left next.B = 0 otherwise)
@@ -1101,7 +1120,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   } else if (h->grad_only) {
     u.mode = 1; u.bsz = (float)h->B;                                            // local sums -> g, nothing applied
     LAUNCH(K_UPDATE, launch_update(u, g_stream));
-  } else if (defer_update && a.fuse_rms && !h->bn) {
+  } else if (EXPERIMENTS && defer_update && a.fuse_rms && !h->bn) {
     u.mode = 0; u.bsz = (float)h->B;
     h->pending_upd = u; h->has_pending_upd = true;            // launched together with the next step's conv1 (run_forward)
   } else {
@@ -1314,7 +1333,7 @@ static int check_ring_actions(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* id
 // do_prep: launch the standalone prep for THIS step; next_pinned: fold the NEXT step's prep into the update
 // hoist_in: this step's target conv1 / conv2 already ran inside the previous step; hoist_out: this step carries the next one's
 static bool hoist_possible(sdqn_net_s* h) {
-  return h->hoist && h->B <= 32 && !h->bn && h->cfg.datatype == 0 && h->fused_launches && !h->two_streams &&
+  return EXPERIMENTS && h->hoist && h->B <= 32 && !h->bn && h->cfg.datatype == 0 && h->fused_launches && !h->two_streams &&
          !(h->comm && h->comm2 && h->dp_overlap) && h->f4_share[0] == 100 && h->f4_share[1] == 0 && h->theta_t != h->theta;
 }
 static int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pinned_idx, bool do_prep = true,
@@ -1396,7 +1415,7 @@ extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, 
     const bool hoist_out = next_pinned != nullptr && hoist_possible(h);
     // round 3: this step's optimizer pass is launched together with the NEXT step's conv1 (default fp32 single-learner path, B <= 32:
     // the fused kernel takes the next indexes from its arguments); the last step of a call keeps its own update launch
-    const bool defer = next_pinned != nullptr && h->fuse_upd && h->B <= 32 && h->cfg.datatype == 0 && !h->bn && !h->comm && !h->grad_only &&
+    const bool defer = EXPERIMENTS && next_pinned != nullptr && h->fuse_upd && h->B <= 32 && h->cfg.datatype == 0 && !h->bn && !h->comm && !h->grad_only &&
                        !h->keep_grads && !h->hoist && h->conv1_bf16 && h->fused_launches && !h->two_streams && h->nw_override[K_CONV1_FWD] == 0 &&
                        h->theta_t != h->theta && !(r->flags & SDQN_REPLAY_ZERO_COPY);
     int rc = train_replay_slot(h, r, pinned, /*do_prep=*/i == 0, next_pinned, hoisted, hoist_out, i == 0 ? h->cost_accum : nullptr, defer); if (rc) return rc;
@@ -1495,7 +1514,7 @@ extern "C" int sdqn_net_sync(sdqn_net_t h) {
   // in-launch hand-offs are bounded spins: a producer that never ran would show up here, never as a hung GPU.  Only launches of
   // the two opt-in hand-off variants can raise the words, so only calls that enqueued one pay the two small read-backs
   // (~40 us: measured as 6 % of the driver's 20-step timed region when they ran on every sync)
-  if (!h->handoff_launched) return SDQN_OK;
+  if (!EXPERIMENTS || !h->handoff_launched) return SDQN_OK;
   h->handoff_launched = false;
   unsigned timed_out = 0;
   HIPCHK(hipMemcpy(&timed_out, h->f4d_flags + (NIN4 / 32) * 16, 4, hipMemcpyDeviceToHost));
@@ -1541,7 +1560,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   if (!strcmp(name, "keep_gradients")) h->keep_grads = value != 0;
   else if (!strcmp(name, "grad_only")) h->grad_only = value != 0;
   else if (!strcmp(name, "h16_wgrad_mfma")) h->h16_wgrad_mfma = value != 0;
-  else if (!strcmp(name, "hoist")) h->hoist = value != 0;
+  else if (!strcmp(name, "hoist")) { if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name); h->hoist = value != 0; }
   else if (!strcmp(name, "dp_half")) h->dp_half = value != 0;              // fp16 mode: half (1, default) or fp32 (0) all-reduce payload
   else if (!strcmp(name, "dp_half_scale_log2")) {          // -1: dynamic (default); n >= 0: fixed payload scale 2^n
     ARGCHK(value >= -1 && value <= 40 && h->ovf_flag, "bad scale (or not a float16 network)");
@@ -1557,19 +1576,19 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
     const int st0[4] = {0, value, 0, 0};
     HIPCHK(hipMemcpy(h->ovf_flag, st0, 16, hipMemcpyHostToDevice));
   }
-  else if (!strcmp(name, "two_streams")) { ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
+  else if (!strcmp(name, "two_streams")) { if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name); ARGCHK(!(value && h->bn), "two_streams is not available with batch_norm"); h->two_streams = value != 0; }
   else if (!strcmp(name, "fused_launches")) h->fused_launches = value != 0;
   else if (!strcmp(name, "conv1_bf16")) h->conv1_bf16 = value != 0;     // 0: conv1_fwd on the fp32-MFMA engine (round-2 kernel)
-  else if (!strcmp(name, "fuse_dbg")) h->fuse_dbg = value;
-  else if (!strcmp(name, "fwd_rb")) h->fwd_rb = value;
+  else if (!strcmp(name, "fuse_dbg")) { if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name); h->fuse_dbg = value; }
+  else if (!strcmp(name, "fwd_rb")) { if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name); h->fwd_rb = value; }
   else if (!strcmp(name, "wt")) h->wt = value;
   else if (!strcmp(name, "prep_inline")) h->prep_inline = value != 0;
   else if (!strcmp(name, "r3_xcd")) h->r3_xcd = value;
-  else if (!strcmp(name, "head_f4d")) h->head_f4d = value != 0;         // 1: head + fc4_dgrad in one launch (in-launch hand-off of delta4)
-  else if (!strcmp(name, "fuse_upd")) h->fuse_upd = value != 0;         // 0: the optimizer pass is always its own launch
+  else if (!strcmp(name, "head_f4d")) { if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name); h->head_f4d = value != 0; }         // 1: head + fc4_dgrad in one launch (in-launch hand-off of delta4)
+  else if (!strcmp(name, "fuse_upd")) { if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name); h->fuse_upd = value != 0; }         // 0: the optimizer pass is always its own launch
   else if (!strcmp(name, "conv1w_bf16")) h->conv1w_bf16 = value;   // 0: conv1_wgrad on the fp32-MFMA engine (round-2 kernel)
   else if (!strcmp(name, "conv3_c36")) h->conv3_c36 = value != 0;       // 0: conv3_fwd on the engine's 32-deep chunks (round-2 kernel)
-  else if (!strcmp(name, "f4w_early")) h->f4w_early = value != 0;       // 0: fc4_wgrad inside bwd3 (round-2 launch structure)
+  else if (!strcmp(name, "f4w_early")) { if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name); h->f4w_early = value != 0; }       // 0: fc4_wgrad inside bwd3 (round-2 launch structure)
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;
   else if (!strcmp(name, "dp_sync_replicas")) h->dp_sync_replicas = value != 0;   // before dp_init
   else if (!strcmp(name, "dp_overlap")) h->dp_overlap = value != 0;     // before dp_init: 0 = single all-reduce on the library stream
@@ -1585,6 +1604,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strncmp(name, "rb:", 3)) {                     // register-blocked routine (B >= 128): menu entry of kernel id, 0 = unblocked
     int id = atoi(name + 3);
     if (id < 0 || id >= 12 || value < 0 || value > 8) { set_error("bad rb override"); return SDQN_ERR_ARG; }
+    if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name);
     h->rb[id] = value;
   }
   else if (!strcmp(name, "bt")) h->bt_on = value != 0;                  // 0: B >= 128 on the latency engine's launch forms (round 3)
@@ -1602,7 +1622,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
     if (id < 0 || id >= K_COUNT || value < -1 || value > 8) { set_error("bad bt override"); return SDQN_ERR_ARG; }
     h->bt[id] = value;
   }
-  else if (!strcmp(name, "bwd_order")) h->bwd_order = value;
+  else if (!strcmp(name, "bwd_order")) { if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name); h->bwd_order = value; }
   else if (!strcmp(name, "s4")) {                          // tuning: split-K slabs of the fc4 forward (1..7; 7 allocated)
     if (value < 1 || value > h->S4_cap) { set_error("bad s4 (1..%d)", h->S4_cap); return SDQN_ERR_ARG; }
     { int rc_ = join_comm(h); if (rc_) return rc_; } HIPCHK(hipStreamSynchronize(g_stream));
@@ -1735,11 +1755,13 @@ extern "C" int sdqn_debug_time_kernel(sdqn_net_t h, sdqn_replay_t r, const int64
     if (kernel == K_HEAD) { HeadArgs hd = head_args(h, 1); HIPCHK(launch_head(a, hd, g_stream)); }
     else if (kernel == 100 || kernel == 101) { h->host_idx_cur = idx_host; const hipError_t le = launch_tuned(h, K_CONV1_FWD, a, g_stream, 0, 4); h->host_idx_cur = nullptr; HIPCHK(le); }
     else if (kernel == 102) HIPCHK(launch_tuned(h, K_CONV3_FWD, a, g_stream, 0, 2));
+#ifdef SDQN_EXPERIMENTS
     else if (kernel == 103) {              // the fused update + conv1 launch (the update applies whatever the slabs hold: timing only)
       UpdateArgs u = make_update_args(h, a); u.mode = 0; u.bsz = (float)h->B; u.skip_fc4 = 1; u.w1_ctr = h->w1_ctr;
       h->w1_epochs += 1;
       HIPCHK(launch_upd_conv1(u, a, idx_host, h->w1_ctr, 64u * h->w1_epochs, h->w1_ctr + 1, h->r3_xcd & 1, g_stream));
     }
+#endif
     else if (kernel == 104) { UpdateArgs u = make_update_args(h, a); u.mode = 0; u.bsz = (float)h->B; u.skip_fc4 = 1; HIPCHK(launch_update(u, g_stream)); }
     else HIPCHK(launch_tuned(h, kernel, a, g_stream));
   }

@@ -270,12 +270,14 @@ hipError_t set_timing_buffer(unsigned long long* p) {
 #endif
 
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
+#ifdef SDQN_EXPERIMENTS
   if (h.next_B > 0 && !a.bn) {                       // option "hoist": + one workgroup fetching the next step's indexes
     if (a.A <= 4) SDQN_LAUNCH((head_kernel<4, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
     else if (a.A <= 8) SDQN_LAUNCH((head_kernel<8, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
     else SDQN_LAUNCH((head_kernel<MAX_ACTIONS, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
     return hipGetLastError();
   }
+#endif
   if (a.bn) SDQN_LAUNCH((head_kernel<MAX_ACTIONS, true>), dim3(a.B), dim3(512), 0, s, a, h);     // --batch_norm (not tuned per bucket)
   else if (a.A <= 4) SDQN_LAUNCH((head_kernel<4, false>), dim3(a.B), dim3(512), 0, s, a, h);
   else if (a.A <= 8) SDQN_LAUNCH((head_kernel<8, false>), dim3(a.B), dim3(512), 0, s, a, h);

@@ -21,6 +21,7 @@ static hipError_t launch_nw(int nw, const StepArgs& a, hipStream_t s) {
   }
 }
 
+#ifdef SDQN_EXPERIMENTS      // the fp32 register-blocked menus, "hoist" and "bwd_order": built, correct, measured slower (tools/exp/README.md)
 #define RB_CASE(N, P, RM, RN, NW) case N: return launch_gemm<RB<P, RM, RN>, NW>(a, s)
 
 static hipError_t launch_kernel_rb(int id, int menu, const StepArgs& a, hipStream_t s) {
@@ -62,6 +63,7 @@ static hipError_t launch_kernel_rb(int id, int menu, const StepArgs& a, hipStrea
   }
   return hipErrorInvalidValue;
 }
+#endif  // SDQN_EXPERIMENTS
 
 
 // fp16 mode: forward / dgrad on packed-fp16 MFMA (problems_h16.h), wgrad on the fp32 engine with half operands
@@ -160,6 +162,7 @@ static hipError_t launch_kernel_h16(int id, const StepArgs& a, const LaunchTune&
 }
 
 
+#ifdef SDQN_EXPERIMENTS
 static hipError_t launch_kernel_hoist(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = true;
   {
@@ -188,9 +191,12 @@ static hipError_t launch_kernel_hoist(int id, const StepArgs& a, const LaunchTun
   return hipSuccess;
 }
 
+#endif  // SDQN_EXPERIMENTS
+
 hipError_t launch_kernel_ext(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = true;
   if (a.h16) return launch_kernel_h16(id, a, t, s);
+#ifdef SDQN_EXPERIMENTS
   if (!a.bn && a.B >= 128 && id >= 0 && id < 12 && t.rb[id] > 0) return launch_kernel_rb(id, t.rb[id], a, s);     // experiments (tools/sweep_rb.py)
   if (a.B <= 32 && t.hoist && !a.bn) return launch_kernel_hoist(id, a, t, s, handled);
   if (a.B >= 128 && t.order == 3 && !a.bn && a.f4w_count > 0 && id == K_BWD3)       // experiment: the new order in the throughput regime
@@ -201,6 +207,7 @@ hipError_t launch_kernel_ext(int id, const StepArgs& a, const LaunchTune& t, hip
     if (t.order == 1) return launch_multi<512, Fc4Wgrad, 1, Staged<Conv3Dgrad>, 8, Conv3Wgrad, 8>(a, true, true, s);
     if (t.order == 2) return launch_multi<512, Staged<Conv3Dgrad>, 8, Fc4Wgrad, 1, Conv3Wgrad, 8>(a, true, true, s);
   }
+#endif
   *handled = false;
   return hipSuccess;
 }

@@ -293,6 +293,7 @@ __global__ void __launch_bounds__(256) conv1_bf16_kernel(const Conv1Args c, cons
   conv1_bf16_body<IDX_IN, false>(c, my_idx, (int)blockIdx.x, sw, fw);
 }
 
+#ifdef SDQN_EXPERIMENTS      // (measured slower than the update as a launch of its own: not in the product build)
 // ---- update(i) + conv1_fwd(i + 1) in ONE launch (train_many, steps after the first of a call; B <= 32 ring path) ------------
 // The optimizer pass is the last launch of a step and conv1 the first of the next: nothing between them but a kernel boundary.
 // Block order: [update blocks (W1 first) | target-net conv1 | online conv1].  Only the online conv1 workgroups depend on the update,
@@ -312,6 +313,8 @@ __global__ void __launch_bounds__(256) upd_conv1_kernel(const UpdateArgs u, cons
   }
   conv1_bf16_body<true, true>(c, my_idx, (int)blockIdx.x - n_upd, sw, fw);
 }
+
+#endif  // SDQN_EXPERIMENTS
 
 // ---- conv1 weight gradient on packed-bf16 MFMA ---------------------------------------------------------------------------
 // gW1[(c,r,s)][map] = sum over (sample, y, x) of byte(c, 4y + r, 4x + s) / 255 * delta1(sample, y, x, map): the bytes are exact in
@@ -437,6 +440,7 @@ __global__ void __launch_bounds__(1024) conv1_wgrad_bf16_kernel(const C1wArgs c,
   }
 }
 
+#ifdef SDQN_EXPERIMENTS
 hipError_t launch_upd_conv1(const UpdateArgs& u, const StepArgs& a, const int64_t* host_idx, unsigned* ctr, unsigned target, unsigned* timeout, int xcd, hipStream_t s) {
   const int tiles = (a.B * PIX1 + 31) / 32, wgs = (tiles + 3) / 4;
   Conv1Args c; c.src = a.src; c.a1 = a.a1; c.w1p[0] = a.w1p[0]; c.w1p[1] = a.w1p[1]; c.idx = a.idx;
@@ -447,6 +451,8 @@ hipError_t launch_upd_conv1(const UpdateArgs& u, const StepArgs& a, const int64_
   SDQN_LAUNCH(upd_conv1_kernel, dim3(n_upd + 2 * wgs), dim3(256), 0, s, u, c, ix, fw, n_upd);
   return hipGetLastError();
 }
+
+#endif  // SDQN_EXPERIMENTS
 
 // the three planes of one net's W1 from its fp32 weights (after set_weights / replica broadcast; the update kernel writes them itself)
 __global__ void __launch_bounds__(256) w1_planes_kernel(const float* theta, unsigned short* w1p) {
@@ -461,6 +467,7 @@ hipError_t launch_w1_planes(const float* theta, unsigned short* w1p, hipStream_t
   return hipGetLastError();
 }
 
+#ifdef SDQN_EXPERIMENTS      // (measured slower than head and fc4_dgrad as two launches: not in the product build)
 // ---- head + fc4_dgrad in ONE launch (B <= 32, A <= 8, fp32) -------------------------------------------------------------------
 // fc4_dgrad is 98 tiles that each stream a 64 KB panel of W4 — which depends on nothing the head computes — before they need
 // delta4.  As two launches the panel fetch starts only after the head has finished AND a kernel boundary has passed.  Here the
@@ -636,6 +643,8 @@ hipError_t launch_head_f4d(const StepArgs& a, const HeadArgs& h, unsigned* ctr, 
   return hipGetLastError();
 }
 
+#endif  // SDQN_EXPERIMENTS
+
 // ---- float16 mode: the same write-through epilogues (half outputs leave with 2-byte sc1 stores), every launch but bwd3 -----------------------------------
 __device__ __forceinline__ void wt_store_h(half_t* p, half_t v) {
   union { half_t h; unsigned short u; } c; c.h = v;
@@ -704,8 +713,10 @@ struct Conv1WgradHWWT : Conv1WgradHW {
 };
 hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = true;
+#ifdef SDQN_EXPERIMENTS
   if (id == K_FC4_DGRAD && (t.r3 & 1) && a.B <= 32 && !a.h16 && a.f4w_count > 0 && a.f4d_flags)
     return launch_multi<1024, Staged<Fc4DgradSig>, 16, Fc4WgradWait, 1, NoProblem, 2>(a, true, false, s);
+#endif
   if (id == K_CONV1_FWD && (t.r3 & 4) && !a.h16 && !a.bn && a.w1p[0] && a.w1p[a.nz > 1 ? 1 : 0]) {
     const int tiles = (a.B * PIX1 + 31) / 32, tpw = a.B >= 128 ? 4 : 1, wgs = (tiles + 4 * tpw - 1) / (4 * tpw);
     Conv1Args c; c.src = a.src; c.a1 = a.a1; c.w1p[0] = a.w1p[0]; c.w1p[1] = a.w1p[1]; c.idx = a.idx;
@@ -763,8 +774,10 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     if (id == K_BWD2 && (t.wt & 32) && a.f4w_count == 0) return launch_multi<512, NoProblem, 2, Staged<Conv2DgradWT>, 8, Conv2WgradWT, 8>(a, true, true, s);
     if (id == K_BWD1 && (t.wt & 64) && a.f4w_count == 0 && !(t.r3 & 8)) return launch_multi<1024, NoProblem, 2, Conv1WgradWT, 16, NoProblem, 2>(a, true, false, s);
   }
+#ifdef SDQN_EXPERIMENTS
   if (id == K_CONV2_FWD && (t.r3 & 16) && a.B < 128 && !a.h16 && !a.bn) return launch_gemm<RB<Conv2Fwd, 1, 2>, 16>(a, s);
   if (id == K_CONV3_FWD && (t.r3 & 32) && a.B < 128 && !a.h16 && !a.bn) return launch_gemm<RB<Conv3Fwd, 1, 2>, 16>(a, s);
+#endif
   if (id == K_CONV3_FWD && (t.r3 & 2) && a.B < 128 && !a.h16 && !a.bn) {
     static_assert(CRS3 == 16 * 36, "conv3's K is 16 chunks of 36");
     const dim3 grid((Conv3Fwd::M(a) + 31) / 32, (Conv3Fwd::N(a) + 31) / 32, Conv3Fwd::nbz(a));

@@ -343,6 +343,7 @@ def test_fp16_dp_half_payload_and_overflow_skip(sd):
     #     tests/test_gpu_dp_multiproc.py::test_fp16_dynamic_payload_scale_state_machine
 
 
+@pytest.mark.experiments
 def test_hoisted_target_forward_is_bit_identical(sd):
     """Option "hoist" (off by default: measured slower, tools/exp/README.md): train_many runs the target-net forward of step
     i+1 inside launches of step i (it depends on theta- and the sampled
