@@ -561,6 +561,22 @@ def allreduce_model(n, payload_bytes):
                     "scaling limiter at every N and --dp-overlap (fc4's 95 % of the payload under the rest of the step) is the lever"}
 
 
+def expected_dp_rates(B, A, datatype, ms_per_step_1gpu=None):
+    """What the cost model predicts for an N-GPU record, so that a SCALE record can be judged: per-rank step time =
+    1-GPU step + the part of the all-reduce the form cannot hide.  Serial form: the whole all-reduce + ~6 us for the un-fused fc4
+    update; overlapped form: max(0, fc4 all-reduce - the ~55 % of the step it runs under) + ~17 us of cross-stream dependencies."""
+    payload = 4 * (8192 + 32768 + 36864 + 1605632 + 512 * A) // (2 if datatype == "float16" else 1)
+    base_us = (ms_per_step_1gpu * 1e3) if ms_per_step_1gpu else {("float32", 32): 66.0, ("float16", 32): 57.5, ("float32", 256): 227.0, ("float16", 256): 170.0}.get((datatype, B), 66.0)
+    rows = {}
+    for n in (2, 4, 8):
+        ar = allreduce_model(n, payload)["expected_us"]
+        serial = base_us + 6.0 + ar
+        overl = base_us + 17.0 + max(0.0, 0.95 * ar - 0.55 * base_us)
+        rows[str(n)] = {"allreduce_us": ar, "serial_total_steps_per_s": round(n * 1e6 / serial), "overlapped_total_steps_per_s": round(n * 1e6 / overl),
+                        "serial_scaling_efficiency": round(base_us / serial, 3), "overlapped_scaling_efficiency": round(base_us / overl, 3)}
+    return {"base_us_per_step_1gpu": base_us, "per_n": rows, "note": "cost model only (no N > 1 run has been measured on this stack)"}
+
+
 def b256_leg(sd, make_args, seed, steps=300, warmup=100, ring=200000):
     """BASELINE.json configs[2] ("Pong, batch_size=256: stress conv LDS tiling + HBM bandwidth") measured in the SAME process as the
     headline so that the driver's JSON line carries it: the throughput regime, where the north-star's
@@ -675,9 +691,12 @@ def main():
     ap.add_argument("--single-rank-dp", action="store_true",
                     help="N = 1 with a ONE-rank RCCL communicator: times the data-parallel code path (reduce -> all-reduce -> "
                          "apply, fc4 part overlapped on the communication stream) on one GPU; not the headline")
-    ap.add_argument("--dp-overlap", action="store_true",
-                    help="data parallel: all-reduce + apply the fc4 gradient on a second communicator / stream under the rest of "
-                         "the step (opt-in: validated with a 1-rank communicator only; default = one all-reduce on the library stream)")
+    ap.add_argument("--dp-overlap", choices=["auto", "on", "off"], default="auto", nargs="?", const="on",
+                    help="data parallel: all-reduce + apply the fc4 gradient on a second communicator / stream under the rest of the step. "
+                         "auto (default, round 4): on by rule for N >= 2 behind a start-up probe with bounded waits, voted over the gloo control "
+                         "plane — any rank timing out sends ALL ranks to the serial form (one all-reduce on the library stream); the dp block of "
+                         "the JSON line says which form ran.  on: forced (no probe; what --single-rank-dp times).  off: serial form.")
+    ap.add_argument("--inject-dp-probe-timeout", action="store_true", help="tests: rank 0's start-up probe reports a time-out (exercises the fallback vote)")
     ap.add_argument("--batch-norm", action="store_true", help="--batch_norm variant of the network (non-default learner option; not the headline)")
     ap.add_argument("--zero-copy", action="store_true", help="gather from the pinned host ring over PCIe (no HBM mirror)")
     ap.add_argument("--no-fp16-leg", action="store_true", help="skip the BASELINE configs[4] leg (A=6, float16) that the default B=32 fp32 run appends as `config_fp16`")
@@ -718,7 +737,7 @@ def main():
     fill_ring(mem, a.seed + 1000 * rank, A)                            # own experience per learner
     net = sd.DeepQNetwork(A, args)
     net.update_target_network()
-    net.set_option("dp_overlap", 1 if a.dp_overlap else 0)
+    net.set_option("dp_overlap", {"auto": -1, "on": 1, "off": 0}[a.dp_overlap])
     for kv in filter(None, os.environ.get("SDQN_BENCH_OPTS", "").split(",")):      # experiments only, e.g. "xcd:18=3,xcd:17=7"
         k, v = kv.split("="); net.set_option(k, int(v))
     if world == 1 and a.single_rank_dp:
@@ -731,13 +750,17 @@ def main():
         assert isinstance(ids[0], bytes) and len(ids[0]) == 128
         err = None
         if not a.dry_run_dp:
+            def vote(ok):                                              # AND over all ranks on the gloo control plane
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(int(t[0]))
             try:
-                net.dp_init(ids[0], rank, world)
+                net.dp_init(ids[0], rank, world, vote=vote, inject_probe_timeout=(a.inject_dp_probe_timeout and rank == 0))
             except Exception as e:                                     # keep going to the vote below: a rank that raised here
                 err = repr(e)                                          # would otherwise leave the others hanging in barrier()
             flush_c_stdio()                                            # RCCL's version banner leaves the C stdio buffer now
         # every rank learns whether ALL communicators came up; if not, all ranks exit non-zero together
-        info = dict(rank=rank, local_rank=local_rank, torch_device=dev, error=err, **net.dp_info())
+        info = dict(rank=rank, local_rank=local_rank, torch_device=dev, error=err, form=net.dp_form(), **net.dp_info())
         rows = [None] * world
         dist.all_gather_object(rows, info)
         bad = [r for r in rows if r["error"]]
@@ -847,14 +870,18 @@ def main():
                                    ", batch_size=%d, replay_size=%d, num_actions=%d, HIP Q-net + device replay gather fused into conv1" % (B, a.replay_size, A),
                        "global_batch": B * world, "parallelism": ("dp%d (independent learners, RCCL grad all-reduce)" % world) +
                                       (" [1-rank RCCL communicator: DP code path timed on one GPU]" if (world == 1 and a.single_rank_dp) else "") +
-                                      (" [fc4 all-reduce overlapped]" if a.dp_overlap else ""),
+                                      (" [fc4 all-reduce overlapped]" if net.dp_form()["form"] == "overlapped" else ""),
                        "ring": "zero-copy pinned host" if a.zero_copy else "HBM mirror"},
         }
         if dp_rows is not None:
             # what RCCL itself reports per rank (ncclCommCount / UserRank / CuDevice) next to the bound devices: the evidence
             # that the gradient all-reduce spanned N ranks on N devices (all -1 in --dry-run-dp: no communicator is created)
             payload = 4 * (8192 + 32768 + 36864 + 1605632 + 512 * A) // (2 if a.datatype == "float16" else 1)
+            forms = sorted({r["form"]["form"] for r in dp_rows})
             out["dp"] = {"ranks": world, "rccl_ranks_seen": sorted({r["comm_ranks"] for r in dp_rows}),
+                         "form": forms[0] if len(forms) == 1 else "INCONSISTENT: %s" % forms,
+                         "form_rule": "overlapped by rule for N >= 2 when every rank's start-up probe drains in time (voted over gloo); else serial on all ranks",
+                         "expected_steps_per_s_model": expected_dp_rates(B, A, a.datatype, out["ms_per_step"] if world == 1 else None),
                          "allreduce_model": allreduce_model(world, payload),
                          "allreduce_model_all_n": {str(n): allreduce_model(n, payload)["expected_us"] for n in (2, 4, 8)},
                          "devices": [r["bound_device"] for r in dp_rows], "dry_run": bool(a.dry_run_dp), "per_rank": dp_rows}

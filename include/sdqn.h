@@ -213,8 +213,8 @@ int sdqn_net_set_epoch(sdqn_net_t h, int epoch);
 /* options: "grad_only" (see sdqn_net_apply_update), "keep_gradients" (1: the fc4 gradient is materialised and readable with which=3; 0 (default): on one
  * GPU RMSProp of fc4 is fused into the wgrad epilogue), "two_streams" (0 default; 1: wgrad kernels overlap the dgrad chain on a side stream), "fused_launches" (1 default:
  * independent backward stages share one grid), "xcd_map" (0 default = only where it wins time: conv1/conv2/fc4 forward; 1: the
- * XCD-contiguous workgroup->tile map for every launch), "dp_overlap" (0 default; 1 BEFORE sdqn_dp_init: fc4 gradient
- * all-reduced and applied on a second communicator + stream), "dp_sync_replicas" (1 default: sdqn_dp_init broadcasts rank 0's online net,
+ * XCD-contiguous workgroup->tile map for every launch), "dp_overlap" (BEFORE sdqn_dp_init: -1 default = auto — second communicator for
+ * nranks >= 2, activated by sdqn_dp_probe + vote + sdqn_dp_set_overlap; 1 forced on; 0 one all-reduce on the library stream), "dp_sync_replicas" (1 default: sdqn_dp_init broadcasts rank 0's online net,
  * target net and optimizer state so every learner starts from — and keeps — the same network; 0 BEFORE sdqn_dp_init: keep own), "profile_every" (N: sdqn_net_profile times every N-th
  * launch), "profile_mode" (1 default: the launch records its own dispatch-packet begin / end timestamps into the event pair through hipExtLaunchKernel —
  * what rocprofv3 --kernel-trace reports, nothing added to the queue; 0: hipEventRecord markers around the launch, ~2.6 us more per launch), "nw:<kernel id>" / "xcd:<kernel id>" / "f4_share3" / "f4_share2" (tuning hooks).
@@ -245,6 +245,18 @@ int sdqn_dp_shutdown(sdqn_net_t h);
 /* what RCCL reports about the live communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice; -1 without one)
  * and the device the library is bound to: lets a multi-GPU record prove that RCCL spanned N ranks on N devices */
 int sdqn_dp_info(sdqn_net_t h, int* comm_ranks, int* comm_rank, int* comm_device, int* bound_device);
+/* Overlapped form of the step (fc4's 95 % of the gradient all-reduced + applied on a second communicator / stream under the rest of the
+ * step; no reference counterpart, deepqnetwork.py:46-48).  With option "dp_overlap" = -1 (auto, default) sdqn_dp_init creates the second
+ * communicator for nranks >= 2 but leaves the form INACTIVE; the caller then
+ *   1. runs sdqn_dp_probe on every rank (two rounds of the overlapped collectives with bounded waits; *ok = 1: drained in time here),
+ *   2. agrees over its control plane (all ranks' ok AND-ed),
+ *   3. calls sdqn_dp_set_overlap(agreed) on EVERY rank: 1 activates the form, 0 tears the second communicator down (ncclCommAbort on a
+ *      rank whose probe never drained) and the serial form — one all-reduce on the library stream — runs.
+ * sdqn_dp_form reports what runs: 0 no communicator, 1 serial, 2 overlapped; *probe = -1 not probed / 0 timed out / 1 ok;
+ * *second_comm = 1 while the second communicator exists. */
+int sdqn_dp_probe(sdqn_net_t h, int timeout_ms, int inject_timeout, int* ok);
+int sdqn_dp_set_overlap(sdqn_net_t h, int on);
+int sdqn_dp_form(sdqn_net_t h, int* form, int* probe, int* second_comm);
 
 #ifdef __cplusplus
 }

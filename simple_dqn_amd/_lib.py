@@ -104,6 +104,9 @@ SIGNATURES = {
     "sdqn_dp_init": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int]),
     "sdqn_dp_shutdown": (C.c_int, [_vp]),
     "sdqn_dp_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sdqn_dp_probe": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "sdqn_dp_set_overlap": (C.c_int, [_vp, C.c_int]),
+    "sdqn_dp_form": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 
 _lib = None

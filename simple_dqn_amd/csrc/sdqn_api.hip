@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <thread>
 
 #include "../../include/sdqn.h"
 #include "kernels.h"
@@ -398,6 +399,7 @@ struct Rccl {
   int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;   // optional (replica sync at dp_init)
   int (*CommDestroy)(void*) = nullptr;
   int (*CommSplit)(void*, int, int, void**, void*) = nullptr;      // optional (second communicator for the overlapped all-reduce)
+  int (*CommAbort)(void*) = nullptr;                              // optional (tears down a communicator whose collective never completed)
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
@@ -418,6 +420,7 @@ static int rccl_load(const char* path) {
   g_rccl.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
   g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
   g_rccl.CommSplit = (int (*)(void*, int, int, void**, void*))dlsym(lib, "ncclCommSplit");
+  g_rccl.CommAbort = (int (*)(void*))dlsym(lib, "ncclCommAbort");
   g_rccl.GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
   g_rccl.GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
   g_rccl.CommCount = (int (*)(void*, int*))dlsym(lib, "ncclCommCount");
@@ -506,7 +509,14 @@ struct sdqn_net_s {
   // compute stream finishes the backward pass and starts the next forward; ev_w4 = "W4 of the last step is updated"
   void* comm2 = nullptr; hipEvent_t ev_g4 = nullptr, ev_w4 = nullptr; bool w4_pending = false;
   bool dp_sync_replicas = true;   // dp_init broadcasts rank 0's theta / theta_t / optimizer state (set_option "dp_sync_replicas" 0: keep own)
-  bool dp_overlap = false;        // opt-in (set_option "dp_overlap" before dp_init): multi-rank behaviour is unvalidated on 1-GPU boxes
+  // Overlapped form (fc4's 95 % of the payload all-reduced + applied on a second communicator / stream under the rest of the step).
+  // dp_overlap_req: -1 AUTO (default, round 4): sdqn_dp_init creates the second communicator whenever nranks >= 2, but the form only
+  //   becomes ACTIVE (dp_overlap) after sdqn_dp_probe succeeded on EVERY rank (the caller votes over its control plane) and
+  //   sdqn_dp_set_overlap(1) was called; any rank timing out -> sdqn_dp_set_overlap(0) on all ranks: second communicator torn down,
+  //   the serial form (one all-reduce on the library stream) runs.  1: forced on at dp_init (single-rank tests), 0: never.
+  int dp_overlap_req = -1;
+  bool dp_overlap = false;        // the overlapped form is active
+  int dp_probe_result = -1;       // -1 not probed, 0 timed out / failed, 1 ok (sdqn_dp_probe)
   std::vector<void*> allocs;
 };
 
@@ -1552,6 +1562,7 @@ extern "C" int sdqn_net_set_epoch(sdqn_net_t h, int epoch) { ARGCHK(h && epoch >
 extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   ARGCHK(h && name, "NULL argument");
   if (h->gen) {                                   // the generic path has no tuning knobs; the ones that change semantics are refused
+    if (!strcmp(name, "dp_overlap") && value < 0) return SDQN_OK;      // (auto: nothing to overlap without a communicator)
     if (!strcmp(name, "grad_only") || !strcmp(name, "dp_overlap") || !strcmp(name, "keep_gradients")) {
       ARGCHK(value == 0 || !strcmp(name, "keep_gradients"), "option %s is implemented for the 84x84x4 float32 / float16 configurations", name);
     }
@@ -1591,7 +1602,11 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strcmp(name, "f4w_early")) { if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name); h->f4w_early = value != 0; }       // 0: fc4_wgrad inside bwd3 (round-2 launch structure)
   else if (!strcmp(name, "xcd_map")) h->xcd_map = value != 0;
   else if (!strcmp(name, "dp_sync_replicas")) h->dp_sync_replicas = value != 0;   // before dp_init
-  else if (!strcmp(name, "dp_overlap")) h->dp_overlap = value != 0;     // before dp_init: 0 = single all-reduce on the library stream
+  else if (!strcmp(name, "dp_overlap")) {                  // before dp_init: -1 auto (probe + vote, default), 1 forced on, 0 single all-reduce on the library stream
+    ARGCHK(value >= -2 && value <= 1, "dp_overlap must be -1 (auto), 0 or 1 (-2: auto also for a 1-rank communicator, tests)");
+    ARGCHK(!h->comm, "dp_overlap is chosen before sdqn_dp_init (afterwards: sdqn_dp_set_overlap)");
+    h->dp_overlap_req = value; h->dp_overlap = value == 1;
+  }
   else if (!strcmp(name, "f4_share3")) h->f4_share[0] = value;
   else if (!strcmp(name, "f4_share2")) h->f4_share[1] = value;
   else if (!strcmp(name, "profile_mode")) { ARGCHK(value == 0 || value == 1, "profile_mode must be 0 (event markers) or 1 (kernel-packet timestamps)"); h->prof_mode = value; }
@@ -1682,9 +1697,13 @@ extern "C" int sdqn_dp_init(sdqn_net_t h, const char* rccl_path, const char id[1
   // second communicator (same ranks) for the overlapped fc4 all-reduce: two collectives may only be in flight at
   // once on different communicators.  Without ncclCommSplit the step falls back to one all-reduce on the library stream.
   h->comm2 = nullptr;
-  if (g_rccl.CommSplit && h->dp_overlap) {
+  const bool want2 = h->dp_overlap_req == 1 || h->dp_overlap_req == -2 || (h->dp_overlap_req == -1 && nranks >= 2);
+  h->dp_overlap = h->dp_overlap_req == 1;                  // auto: inactive until probed + voted (sdqn_dp_probe / sdqn_dp_set_overlap)
+  h->dp_probe_result = -1;
+  if (g_rccl.CommSplit && want2) {
     if (g_rccl.CommSplit(h->comm, 0, rank, &h->comm2, nullptr) != 0) h->comm2 = nullptr;
   }
+  if (!h->comm2) h->dp_overlap = false;
   if (h->comm2) {
     if (!h->ev_g4) HIPCHK(hipEventCreateWithFlags(&h->ev_g4, hipEventDisableTiming));
     if (!h->ev_w4) HIPCHK(hipEventCreateWithFlags(&h->ev_w4, hipEventDisableTiming));
@@ -1708,6 +1727,75 @@ extern "C" int sdqn_dp_init(sdqn_net_t h, const char* rccl_path, const char id[1
     }
     HIPCHK(hipStreamSynchronize(g_stream));
   }
+  return SDQN_OK;
+}
+// Start-up probe of the overlapped form: two rounds of exactly the collectives an overlapped step issues — the fc4
+// range on the second communicator / communication stream, the conv + fc5 ranges as one group on the first communicator / library stream,
+// concurrently — with BOUNDED waits (hipStreamQuery polling against a deadline: never a blocking wait on a stream that may never drain).
+// *ok = 1: both streams drained in time on THIS rank.  The caller must agree over its control plane (every rank's ok AND-ed) and then call
+// sdqn_dp_set_overlap on every rank with the same answer; ranks that disagree would deadlock in the first real step.  The gradient buffer
+// used as payload is scratch between steps (every step rewrites it).  inject_timeout != 0 (tests): report a time-out after the real
+// completion, so that the fallback path can be exercised on a healthy stack.
+extern "C" int sdqn_dp_probe(sdqn_net_t h, int timeout_ms, int inject_timeout, int* ok) {
+  ARGCHK(h && ok && timeout_ms > 0, "bad arguments");
+  *ok = 0;
+  if (h->gen || !h->comm) { set_error("sdqn_dp_probe needs a data-parallel network (sdqn_dp_init first)"); return SDQN_ERR_STATE; }
+  if (!h->comm2) { h->dp_probe_result = 0; return SDQN_OK; }           // no second communicator: the serial form is the only one
+  HIPCHK(hipStreamSynchronize(g_stream)); HIPCHK(hipStreamSynchronize(g_comm));
+  for (int rep = 0; rep < 2; ++rep) {
+    HIPCHK(hipEventRecord(h->ev_g4, g_stream));
+    HIPCHK(hipStreamWaitEvent(g_comm, h->ev_g4, 0));
+    NCCLCHK(g_rccl.AllReduce(h->g + OFF4, h->g + OFF4, (size_t)NW4, /*ncclFloat32*/ 7, 0, h->comm2, g_comm));
+    HIPCHK(hipEventRecord(h->ev_w4, g_comm));
+    if (g_rccl.GroupStart && g_rccl.GroupEnd) NCCLCHK(g_rccl.GroupStart());
+    NCCLCHK(g_rccl.AllReduce(h->g, h->g, (size_t)OFF4, 7, 0, h->comm, g_stream));
+    NCCLCHK(g_rccl.AllReduce(h->g + OFF5, h->g + OFF5, (size_t)(h->NP - OFF5), 7, 0, h->comm, g_stream));
+    if (g_rccl.GroupStart && g_rccl.GroupEnd) NCCLCHK(g_rccl.GroupEnd());
+    HIPCHK(hipStreamWaitEvent(g_stream, h->ev_w4, 0));
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  bool done = false;
+  while (!done) {
+    const hipError_t a = hipStreamQuery(g_stream), b = hipStreamQuery(g_comm);
+    if (a == hipSuccess && b == hipSuccess) { done = true; break; }
+    if ((a != hipSuccess && a != hipErrorNotReady) || (b != hipSuccess && b != hipErrorNotReady)) break;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) break;
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+  (void)hipGetLastError();
+  if (done) HIPCHK(hipMemsetAsync(h->g, 0, (size_t)h->NP * 4, g_stream));       // (the probe's sums are not a gradient)
+  h->dp_probe_result = (done && !inject_timeout) ? 1 : 0;
+  *ok = h->dp_probe_result;
+  return SDQN_OK;
+}
+// The agreed answer of the vote: on = 1 activates the overlapped form (needs the second communicator), on = 0 tears the second
+// communicator down — ncclCommAbort when this rank's probe never completed (a destroy would wait for the stuck collective), ncclCommDestroy
+// otherwise — and every later step runs the serial form.
+extern "C" int sdqn_dp_set_overlap(sdqn_net_t h, int on) {
+  ARGCHK(h, "NULL handle");
+  if (h->gen || !h->comm) { set_error("sdqn_dp_set_overlap needs a data-parallel network (sdqn_dp_init first)"); return SDQN_ERR_STATE; }
+  if (on) {
+    if (!h->comm2) { set_error("the overlapped form needs the second communicator (ncclCommSplit missing, or dp_overlap was 0 at sdqn_dp_init)"); return SDQN_ERR_STATE; }
+    h->dp_overlap = true;
+    return SDQN_OK;
+  }
+  h->dp_overlap = false;
+  if (h->comm2) {
+    const bool stuck = hipStreamQuery(g_comm) == hipErrorNotReady && h->dp_probe_result == 0;
+    (void)hipGetLastError();
+    if (stuck && g_rccl.CommAbort) { NCCLCHK(g_rccl.CommAbort(h->comm2)); }
+    else { { int rc = join_comm(h); if (rc) return rc; } HIPCHK(hipStreamSynchronize(g_stream)); HIPCHK(hipStreamSynchronize(g_comm)); NCCLCHK(g_rccl.CommDestroy(h->comm2)); }
+    h->comm2 = nullptr; h->w4_pending = false;
+  }
+  return SDQN_OK;
+}
+// which form runs: *form = 0 no communicator, 1 serial (one all-reduce on the library stream), 2 overlapped; *probe = -1 / 0 / 1;
+// *second_comm = 1 while the second communicator exists (auto mode between sdqn_dp_init and the vote: present but inactive)
+extern "C" int sdqn_dp_form(sdqn_net_t h, int* form, int* probe, int* second_comm) {
+  ARGCHK(h, "NULL handle");
+  if (form) *form = !h->comm ? 0 : ((h->comm2 && h->dp_overlap) ? 2 : 1);
+  if (probe) *probe = h->dp_probe_result;
+  if (second_comm) *second_comm = h->comm2 ? 1 : 0;
   return SDQN_OK;
 }
 // What RCCL itself reports about the communicator (not what the caller passed in): ranks it spans, this rank, its device.

@@ -342,9 +342,32 @@ class DeepQNetwork:
         return out
 
     # ---- data parallel -----------------------------------------------------------------------------
-    def dp_init(self, unique_id, rank, nranks, rccl=None):
+    def dp_init(self, unique_id, rank, nranks, rccl=None, vote=None, probe_timeout_ms=5000, inject_probe_timeout=False):
+        """One learner per GPU: RCCL communicator over `nranks` ranks.  With option "dp_overlap" at its default (-1, auto) and
+        nranks >= 2 the OVERLAPPED form (fc4's 95 % of the gradient all-reduced + applied on a second communicator under the rest of
+        the step) is tried by rule: every rank probes it with bounded waits (sdqn_dp_probe), the ranks agree through `vote` — a
+        callable taking this rank's bool and returning the AND over all ranks, e.g. a gloo all-reduce(MIN) of the control plane — and
+        all of them activate it, or all of them tear the second communicator down and run the serial form (one all-reduce on the
+        library stream).  Without a `vote` the ranks cannot agree, so the serial form runs.  dp_form() says which one it is."""
         path = (rccl or _lib.rccl_path()).encode()
         _lib.check(self._lib.sdqn_dp_init(self._h, path, unique_id, rank, nranks))
+        form = self.dp_form()
+        if form["form"] == "serial" and form["second_communicator"] and not form["overlap_forced"]:
+            ok = C.c_int(0)
+            _lib.check(self._lib.sdqn_dp_probe(self._h, int(probe_timeout_ms), int(bool(inject_probe_timeout)), C.byref(ok)))
+            agreed = bool(vote(bool(ok.value))) if vote is not None else False
+            _lib.check(self._lib.sdqn_dp_set_overlap(self._h, int(agreed)))
+            self._dp_vote = dict(local_probe_ok=bool(ok.value), agreed=agreed, voted=vote is not None)
+        return self.dp_form()
+
+    def dp_form(self):
+        """Which data-parallel form runs: 'none' / 'serial' / 'overlapped', the start-up probe's local result and the vote."""
+        f, p, c2 = C.c_int(0), C.c_int(-1), C.c_int(0)
+        _lib.check(self._lib.sdqn_dp_form(self._h, C.byref(f), C.byref(p), C.byref(c2)))
+        d = dict(form=("none", "serial", "overlapped")[f.value], probe={-1: None, 0: False, 1: True}[p.value],
+                 second_communicator=bool(c2.value), overlap_forced=(f.value == 2 and p.value == -1))
+        d.update(getattr(self, "_dp_vote", {}))
+        return d
 
     def overflow_steps(self):
         """float16 mode under data parallel: steps skipped because the all-reduced half gradient overflowed."""

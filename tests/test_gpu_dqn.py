@@ -548,6 +548,39 @@ def test_dp_single_rank_rccl(sd, overlap):
         assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
 
 
+@pytest.mark.parametrize("inject", [False, True])
+def test_dp_overlap_by_rule_probe_vote_and_fallback(sd, inject):
+    """the overlapped data-parallel form is on BY RULE behind a start-up probe with bounded waits and a vote.  On the
+    1-GPU box: a 1-rank communicator in auto mode (option value -2 = auto also for one rank).  Healthy probe + unanimous vote -> the
+    overlapped form runs; an injected probe time-out -> the vote fails, the second communicator is torn down and the serial form runs.
+    Either way the steps are bit-identical to the fused single-GPU update (the all-reduce over one rank is the identity)."""
+    from simple_dqn_amd.deepqnetwork import dp_unique_id
+    A, B = 4, 32
+    n1, _ = _pair(sd, A, B, 171)
+    n2, _ = _pair(sd, A, B, 171)
+    n2.set_option("dp_overlap", -2)
+    votes = []
+    form = n2.dp_init(dp_unique_id(), 0, 1, vote=lambda ok: votes.append(ok) or ok, inject_probe_timeout=inject, probe_timeout_ms=3000)
+    assert votes == [not inject]
+    assert form["form"] == ("serial" if inject else "overlapped") and form["probe"] is (not inject) and form["agreed"] is (not inject)
+    assert form["second_communicator"] is (not inject)                  # torn down after a failed vote
+    for s in range(4):
+        mb = random_minibatch(B, A, 172 + s)
+        n1.train(mb); n2.train(mb)
+        if s == 1:
+            n1.update_target_network(); n2.update_target_network()
+    for i in range(5):
+        assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
+        assert np.array_equal(n1.get_layer(i, 2), n2.get_layer(i, 2)), i
+    # without a vote the ranks cannot agree: serial form, second communicator gone
+    n3, _ = _pair(sd, A, B, 171)
+    n3.set_option("dp_overlap", -2)
+    f3 = n3.dp_init(dp_unique_id(), 0, 1)
+    assert f3["form"] == "serial" and f3["voted"] is False and f3["second_communicator"] is False
+    n3.train(random_minibatch(B, A, 180))
+    n2.dp_shutdown(); n3.dp_shutdown()
+
+
 def test_agent_loop_plumbing(sd):
     """BASELINE.json configs[0] plumbing on the synthetic environment: Agent drives add/predict/train."""
     A, B = 4, 32
