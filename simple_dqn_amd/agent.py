@@ -44,6 +44,8 @@ class Agent:
         self.train_frequency, self.train_repeat, self.target_steps = args.train_frequency, args.train_repeat, args.target_steps
         self.callback = None
         self.fused = fused and hasattr(self.net, "train_from_memory") and hasattr(self.mem, "_h")
+        # one library call per environment transition (state-buffer add [+ ring add] [+ the next acting forward enqueued ahead of its use])
+        self._one_call = hasattr(self.net, "act_step") and hasattr(self.buf, "_h")
 
     # ---- acting ------------------------------------------------------------------------------------------
     def _greedy_action(self):
@@ -65,22 +67,29 @@ class Agent:
                 self.env.restart()
             self.buf.add(self.env.getScreen())
 
-    def _advance(self, exploration_rate):
+    def _advance(self, exploration_rate, store=False):
         explore = random.random() < exploration_rate                  # draw order matters: shared global stream
         action = random.randrange(self.num_actions) if explore else self._greedy_action()
         reward = self.env.act(action)
         screen, terminal = self.env.getScreen(), self.env.isTerminal()
-        self.buf.add(screen)
+        ring = store and hasattr(self.mem, "_h")
+        if self._one_call:
+            # the acting forward of the new state is started now when the next step will most likely want it (greedy with probability
+            # 1 - exploration_rate) and the episode goes on; same Q-values as a forward started at the next step
+            self.net.act_step(self.buf, self.mem if ring else None, screen, action, reward, terminal,
+                              speculate=(exploration_rate < 0.5 and not terminal))
+        else:
+            self.buf.add(screen)
         if terminal:
             self._fresh_episode()
         if self.callback:
             self.callback.on_step(action, reward, terminal, screen, exploration_rate)
+        if store and not (self._one_call and ring):
+            self.mem.add(action, reward, screen, terminal)
         return action, reward, screen, terminal
 
     def _advance_and_store(self, exploration_rate):
-        transition = self._advance(exploration_rate)
-        self.mem.add(*transition)
-        return transition
+        return self._advance(exploration_rate, store=True)
 
     # ---- learning ----------------------------------------------------------------------------------------
     def _learn(self, epoch):

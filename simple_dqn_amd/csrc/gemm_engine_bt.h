@@ -36,7 +36,7 @@ struct BtCfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
   static constexpr int D = D_;                          // chunks in flight per workgroup: D register sets of (BM + BN) / 32 float4 per thread
   static constexpr int X = X_;
-  static_assert(X == 0 || X == 6 || X == 9, "fp32 MFMA, or 6 / 9 exact bf16 partial products");
+  static_assert(X == 0 || X == 6 || X == 9 || X == 19 || X == 16, "fp32 MFMA, or 6 / 9 exact bf16 partial products (19 / 16: TIMING ONLY, no split)");
   static_assert(D >= 1 && D <= 4, "prefetch depth");
   static constexpr int SM = BM / (32 * WM), SN = BN / (32 * WN);
   static_assert(WM * WN * 64 == bt::NT, "four waves per workgroup");
@@ -53,6 +53,16 @@ __device__ __forceinline__ float4 f4_to_float4(const f4& v) { return make_float4
 
 typedef __bf16 bt_bf16x8 __attribute__((ext_vector_type(8)));
 // eight fp32 values -> three bf16 fragments with hi + mid + lo == x exactly (round-to-nearest splits, exact residuals)
+#ifdef SDQN_EXPERIMENTS
+// timing experiment only (X = 19 / 16): the three "planes" are bit casts — WRONG numbers, the MFMA / LDS schedule of a kernel whose
+// operands arrive pre-split (what producer-written bf16 planes would cost in the consumer)
+__device__ __forceinline__ void fake8_bf16x3(const float* x, bt_bf16x8& hi, bt_bf16x8& mid, bt_bf16x8& lo) {
+  union { float f[4]; bt_bf16x8 v; } a, b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { a.f[e] = x[e]; b.f[e] = x[4 + e]; }
+  hi = a.v; mid = b.v; lo = a.v;
+}
+#endif
 __device__ __forceinline__ void split8_bf16x3(const float* x, bt_bf16x8& hi, bt_bf16x8& mid, bt_bf16x8& lo) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -180,6 +190,9 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = As[bt::mk_off(BM, 16 * st + e, x) + h * (8 * BM)];
         }
+#ifdef SDQN_EXPERIMENTS
+        if constexpr (X > 9) fake8_bf16x3(v, a1[sm], a2[sm], a3[sm]); else
+#endif
         split8_bf16x3(v, a1[sm], a2[sm], a3[sm]);
       }
 #pragma unroll
@@ -196,6 +209,9 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = Bs[bt::mk_off(BN, 16 * st + e, x) + h * (8 * BN)];
         }
+#ifdef SDQN_EXPERIMENTS
+        if constexpr (X > 9) fake8_bf16x3(v, b1[sn], b2[sn], b3[sn]); else
+#endif
         split8_bf16x3(v, b1[sn], b2[sn], b3[sn]);
       }
 #pragma unroll
@@ -203,7 +219,7 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
 #pragma unroll
         for (int sn = 0; sn < SN; ++sn) {
           f32x16 m = acc[sm][sn], q = accs[sm][sn];
-          if constexpr (X == 9) {
+          if constexpr (X == 9 || X == 19) {
             q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[sm], b3[sn], q, 0, 0, 0);
             q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[sm], b3[sn], q, 0, 0, 0);
             q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[sm], b2[sn], q, 0, 0, 0);

@@ -151,7 +151,7 @@ struct LaunchTune {
   int r3;                   // round-3 launch variants (sdqn_kernels_r3.hip); bit 0: this K_FC4_DGRAD launch also carries the fc4_wgrad tiles; bit 1: conv3_fwd on 36-deep K-chunks; bit 2: conv1_fwd on packed-bf16 MFMA
 };
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s);     // the GEMM-shaped stages (single or multi-problem launches)
-hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s);
+hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s, bool q_system_scope = false);   // q_system_scope: h.q is mapped host memory (acting path)
 hipError_t launch_update(const UpdateArgs& u, hipStream_t s);
 hipError_t launch_gather(const GatherArgs& g, hipStream_t s, const int64_t* host_idx = nullptr);   // host_idx (B <= 256): indexes inside the kernel arguments
 hipError_t launch_bn_forward(const BnArgs& b, hipStream_t s);      // [partial +] apply

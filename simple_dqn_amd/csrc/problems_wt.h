@@ -26,7 +26,11 @@ constexpr bool NT_W4 = SDQN_NT_W4 != 0;      // experiment: non-temporal loads o
                "s"(a.g), "s"(a.a1), "s"(a.d1), "s"(a.slab2), "s"(a.B), "s"(a.tps2), "s"(a.tps3), "s"(a.fuse_rms), "s"(a.f4w_first), "s"(a.f4w_count), \
                "s"(a.xcd_map), "s"(a.bsz), "s"(a.rho), "s"(a.one_minus_rho), "s"(a.lr), "s"(a.eps), "s"(d.n[0]), "s"(d.n[1]), "s"(d.gx[1])); \
   }
+#ifdef SDQN_WT_PLAIN      // experiment build only: every "write-through" epilogue store is a plain store (what do 4-byte sc1 stores cost at B = 256?)
+__device__ __forceinline__ void wt_store(float* p, float v) { *p = v; }
+#else
 __device__ __forceinline__ void wt_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
 struct Conv2FwdWT : Conv2Fwd {
   static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
   __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.a1), "s"(a.a2), "s"(a.theta[0]), "s"(a.theta[1]), "s"(a.B), "s"(a.nz), "s"(a.xcd_map), "s"(g0), "s"(g1), "s"(g2)); }

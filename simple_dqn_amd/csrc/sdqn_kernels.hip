@@ -138,7 +138,9 @@ hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStre
 // ~3000 cycles here), and the LDS footprint follows the bucket.
 // HOIST (option "hoist" only; compiled out of the default kernel — even this one branch was measurable): one extra workgroup
 // fetches the next step's indexes from their pinned host slot into HBM.
-template <int AMAX, bool BN, bool HOIST = false>
+// QSYS (acting path, round 4): h.q is HOST memory (mapped, pinned) and every Q-value leaves with a system-scope store the moment it is
+// summed, so the host can poll for it instead of paying a D2H copy packet + a stream synchronisation (sdqn_api.hip: predict_state).
+template <int AMAX, bool BN, bool HOIST = false, bool QSYS = false>
 __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadArgs h) {
   SDQN_STAMP(0);
   if constexpr (HOIST) {
@@ -224,7 +226,8 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
     if (lane == 0) {
       const int z = row / A, act = row - z * A;
       sh_q[z][act] = p;
-      h.q[((int64_t)z * a.B + n) * A + act] = p;
+      if constexpr (QSYS) __hip_atomic_store(&h.q[((int64_t)z * a.B + n) * A + act], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      else h.q[((int64_t)z * a.B + n) * A + act] = p;
     }
   }
   if (!h.train) return;
@@ -269,7 +272,13 @@ hipError_t set_timing_buffer(unsigned long long* p) {
 }
 #endif
 
-hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s) {
+hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s, bool q_system_scope) {
+  if (q_system_scope && !a.bn && !h.train) {          // acting path: Q-values straight into mapped host memory
+    if (a.A <= 4) SDQN_LAUNCH((head_kernel<4, false, false, true>), dim3(a.B), dim3(512), 0, s, a, h);
+    else if (a.A <= 8) SDQN_LAUNCH((head_kernel<8, false, false, true>), dim3(a.B), dim3(512), 0, s, a, h);
+    else SDQN_LAUNCH((head_kernel<MAX_ACTIONS, false, false, true>), dim3(a.B), dim3(512), 0, s, a, h);
+    return hipGetLastError();
+  }
 #ifdef SDQN_EXPERIMENTS
   if (h.next_B > 0 && !a.bn) {                       // option "hoist": + one workgroup fetching the next step's indexes
     if (a.A <= 4) SDQN_LAUNCH((head_kernel<4, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);

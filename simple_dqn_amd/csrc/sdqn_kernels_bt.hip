@@ -8,6 +8,7 @@
 //   and every backward problem as a launch of its own (fused_launches = 0 / two_streams): the same block shapes, so fused and
 //   unfused steps stay bit-identical.
 // LaunchTune::bt[id]: 0 = the built-in block shape, n > 0 = menu entry n (tools/sweep_bt.py), < 0 = this launch on the latency engine.
+#include <stdlib.h>
 #include "gemm_engine_bt.h"
 #include "problems_wt.h"
 #include "kernels.h"
@@ -126,6 +127,141 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
   return hipErrorInvalidValue;
 }
 
+// ---- conv1 weight gradient: bytes x (three exact bf16 planes of delta1) on packed-bf16 MFMA, frame rows staged through LDS ------------
+// gW1[(c,r,s)][map] = sum over k = (sample, y, x) of frame byte x delta1[k][map] (deepqnetwork.py:162 for the first Convolution layer; the
+// 1/255 of :100 applied once to each split-K partial, like conv1_wgrad_bf16_kernel of the latency regime, sdqn_kernels_r3.hip).  A byte is
+// exact in bf16 and delta = hi + mid + lo exactly (problems.h: split_bf16x3), so the sum runs as THREE v_mfma_f32_32x32x16_bf16 per 16 k with
+// every product exact and fp32 accumulation — 0.19x the matrix time of the fp32 form.
+// Every earlier form of this stage (the fp32 engine's A_GROUP4 loader, the latency regime's bf16 kernel, a first block-tile cut of this
+// one) fetched a lane's 4 patch bytes with ONE unaligned 16-byte load of its own — and all of them land at ~25 us at B = 256, whatever
+// the matrix work: tools/exp/c1w_dbg.py ablations (same bytes every chunk: no change; no MFMAs: no change; the loads forced to 16-byte
+// alignment: -11 us) put ~150 cycles of address processing on every such fully divergent load instruction.  So here the frame bytes
+// arrive the other way round:
+//   * K runs in chunks of 80 output positions = 4 output rows of ONE sample (400 = 5 x 80: a chunk never straddles samples) = pixel rows
+//     4 y0 .. 4 y0 + 19 of each of the state's 4 frames: 1 680 CONTIGUOUS, 16-byte aligned bytes per frame, staged in LDS with 420 plain
+//     16-byte loads per workgroup; a lane then reads its patch bytes with ds_read_u8 (offsets of the 80 positions are compile-time);
+//   * delta1's [80 k][32 maps] chunk (10 KB, contiguous) is fetched, split into three bf16 planes and written to LDS once per workgroup
+//     in its own (k-major) layout — 8-byte stores, no transpose; a lane gathers its 8 k of a step with conflict-free 2-byte reads;
+//   * one workgroup (4 waves) owns all 256 rows x 32 maps of one K slab: wave w = input frame c of the state, two 32-row sub-tiles
+//     (kernel rows r = 0..3 / 4..7, column s = lane & 7); double-buffered LDS stages, the next chunk's loads in flight under the MFMAs.
+struct C1wBtArgs { const uint8_t* src; const float* d1; float* slab1; const int64_t* idx; int B, from_ring, tps1, Kt; };
+typedef __bf16 c1w_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int C1W_CH = 80;                          // output positions per chunk: 4 output rows of one sample, 5 MFMA steps of 16
+constexpr int C1W_REG = 20 * W0;                    // bytes of one frame's staged rows (pixel rows 4 y0 .. 4 y0 + 19): 1680
+constexpr int C1W_DPITCH = 3 * K1 + 8;              // ushorts per k row of the delta planes: [plane][32 maps] + pad (208 bytes)
+constexpr int C1W_STAGE = C0 * C1W_REG + C1W_CH * C1W_DPITCH * 2;      // bytes per LDS stage: 6720 + 16640
+__host__ __device__ constexpr int c1w_pos_off(int p) { return (p / Q1) * (ST1 * W0) + (p % Q1) * ST1; }     // position p of the chunk -> byte offset of its patch origin in the staged rows
+
+__global__ void __launch_bounds__(256) c1w_bt_kernel(const C1wBtArgs c) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C1W_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ks = blockIdx.x, Kt = c.Kt, kb = ks * c.tps1 * 32;
+  int ke = kb + c.tps1 * 32; if (ke > Kt) ke = Kt;
+  const int nch = (ke - kb) / C1W_CH;               // (the host launches this kernel only with slabs of whole chunks)
+  // loader items: frame rows = 4 x 105 float4 (items 0..419), delta = 640 float4 (k = item >> 3, maps 4 (item & 7) ..)
+  // D chunks in flight (register set ch mod D): a workgroup walks its slab alone on its CU and every chunk touches frame rows and delta
+  // rows nobody has read before — with one chunk in flight it waited a cold round trip per chunk (3.5 us per chunk for 0.8 us of work)
+  // loader items: frame rows = 4 x 105 float4 (items 0..419: two per thread), delta = 640 float4 (k = item >> 3, maps 4 (item & 7) ..: three)
+  struct Stg { uint4 b0, b1; float4 d0, d1, d2; };
+  auto ld_b = [&](int64_t fb, int it) { if (it > 419) it = 419; const int fc = it / 105, q = it - fc * 105;
+                                        return *reinterpret_cast<const uint4*>(c.src + fb + (int64_t)fc * FRAME + 16 * q); };
+  auto ld_d = [&](int k0, int it) { if (it > 639) it = 639; return *reinterpret_cast<const float4*>(c.d1 + (size_t)k0 * K1 + 4 * it); };
+  auto gload = [&](int ch, Stg& g) {
+    const int k0 = kb + ch * C1W_CH, n = k0 / PIX1, y0 = (k0 - n * PIX1) / Q1;
+    const int64_t fb = (c.from_ring ? (c.idx[n] - C0) * (int64_t)FRAME : (int64_t)n * STATE) + (int64_t)y0 * (ST1 * W0);     // problems.h: sbase, z = 0
+    g.b0 = ld_b(fb, tid); g.b1 = ld_b(fb, tid + 256);
+    g.d0 = ld_d(k0, tid); g.d1 = ld_d(k0, tid + 256); g.d2 = ld_d(k0, tid + 512);
+  };
+  auto st_b = [&](unsigned char* st, int it, const uint4& v) { if (it < 420) *reinterpret_cast<uint4*>(st + (it / 105) * C1W_REG + 16 * (it % 105)) = v; };
+  auto st_d = [&](unsigned short* dp, int it, const float4& d) {
+    if (it >= 640) return;
+    const int k = it >> 3, n4 = (it & 7) * 4;
+    uint16_t a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2;
+    split_bf16x3(d.x, a0, a1, a2); split_bf16x3(d.y, b0, b1, b2); split_bf16x3(d.z, c0, c1, c2); split_bf16x3(d.w, e0, e1, e2);
+    auto pk2 = [](uint16_t lo, uint16_t hi) { return (uint32_t)lo | ((uint32_t)hi << 16); };
+    unsigned short* row = dp + k * C1W_DPITCH + n4;
+    *reinterpret_cast<uint2*>(row) = make_uint2(pk2(a0, b0), pk2(c0, e0));
+    *reinterpret_cast<uint2*>(row + K1) = make_uint2(pk2(a1, b1), pk2(c1, e1));
+    *reinterpret_cast<uint2*>(row + 2 * K1) = make_uint2(pk2(a2, b2), pk2(c2, e2));
+  };
+  auto lds_store = [&](const Stg& g, unsigned char* st) {
+    st_b(st, tid, g.b0); st_b(st, tid + 256, g.b1);
+    unsigned short* dp = reinterpret_cast<unsigned short*>(st + C0 * C1W_REG);
+    st_d(dp, tid, g.d0); st_d(dp, tid + 256, g.d1); st_d(dp, tid + 512, g.d2);
+  };
+  f32x16 acc[2];
+#pragma unroll
+  for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[sm][q] = 0.0f;
+  // this lane's patch element: frame c = wave, kernel row r = 4 sm + (i >> 3), column s = i & 7 (problems.h: col1: m = 64 c + 8 r + s)
+  const int lane_off = wave * C1W_REG + (i >> 3) * W0 + (i & 7);
+  if (nch > 0) {
+    Stg g;
+    gload(0, g);
+    lds_store(g, smem);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+      {
+        {
+          const unsigned char* st = smem + (ch & 1) * C1W_STAGE;
+          if (ch + 1 < nch) gload(ch + 1, g);
+          const unsigned char* pa = st + lane_off;
+          const unsigned short* pd = reinterpret_cast<const unsigned short*>(st + C0 * C1W_REG) + i;
+#pragma unroll
+          for (int s5 = 0; s5 < 5; ++s5) {
+            // B fragments: k = 16 s5 + 8 h + e of map i, one per plane (2-byte reads, lanes along the maps: conflict-free)
+            union { uint32_t u[4]; c1w_bf16x8 v; } B0, B1, B2;
+            const unsigned short* pk = pd + (16 * s5 + 8 * h) * C1W_DPITCH;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              B0.u[e >> 1] = (uint32_t)pk[e * C1W_DPITCH] | ((uint32_t)pk[(e + 1) * C1W_DPITCH] << 16);
+              B1.u[e >> 1] = (uint32_t)pk[e * C1W_DPITCH + K1] | ((uint32_t)pk[(e + 1) * C1W_DPITCH + K1] << 16);
+              B2.u[e >> 1] = (uint32_t)pk[e * C1W_DPITCH + 2 * K1] | ((uint32_t)pk[(e + 1) * C1W_DPITCH + 2 * K1] << 16);
+            }
+            // A fragments: the 8 positions' patch bytes (exact in bf16: upper half of the float), both sub-tiles (4 kernel rows apart)
+            int off[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) off[e] = h ? c1w_pos_off(16 * s5 + 8 + e) : c1w_pos_off(16 * s5 + e);
+#pragma unroll
+            for (int sm = 0; sm < 2; ++sm) {
+              union { uint32_t u[4]; c1w_bf16x8 v; } A;
+#pragma unroll
+              for (int e = 0; e < 8; e += 2) {
+                const uint32_t f0 = __float_as_uint((float)pa[off[e] + sm * (4 * W0)]), f1 = __float_as_uint((float)pa[off[e + 1] + sm * (4 * W0)]);
+                A.u[e >> 1] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);
+              }
+              acc[sm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, B2.v, acc[sm], 0, 0, 0);     // small planes first
+              acc[sm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, B1.v, acc[sm], 0, 0, 0);
+              acc[sm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, B0.v, acc[sm], 0, 0, 0);
+            }
+          }
+          if (ch + 1 < nch) { lds_store(g, smem + ((ch + 1) & 1) * C1W_STAGE); __syncthreads(); }
+        }
+      }
+    }
+  }
+  // epilogue: / 255 (deepqnetwork.py:100, once per partial sum), write-through stores of the slab; lanes along the maps: 128-byte rows
+  const float r255 = 1.0f / 255.0f;
+#pragma unroll
+  for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = 64 * wave + 32 * sm + bt::acc_row(q, h);
+      const float sv = acc[sm][q], qv = sv * r255;
+      wt_store(c.slab1 + (int64_t)ks * NW1 + m * K1 + i, fmaf(fmaf(-qv, 255.0f, sv), r255, qv));       // s / 255 to within an ulp (as div255, sdqn_kernels_r3.hip)
+    }
+}
+
+static hipError_t launch_c1w_bt(const StepArgs& a, hipStream_t s) {
+  // slabs of whole 80-position chunks only (tps1 a multiple of 5: 160 positions); other slab sizes stay on the latency engine's kernel
+  if ((a.tps1 * 32) % C1W_CH != 0) return hipErrorInvalidValue;
+  C1wBtArgs c; c.src = a.src; c.d1 = a.d1; c.slab1 = a.slab1; c.idx = a.idx; c.B = a.B; c.from_ring = a.from_ring; c.tps1 = a.tps1; c.Kt = a.B * PIX1;
+  SDQN_LAUNCH(c1w_bt_kernel, dim3(Conv1Wgrad::nbz(a)), dim3(256), 0, s, c);
+  return hipGetLastError();
+}
+
 // every K range of the launch must be whole chunks for the x-contiguous loaders' zero fill to be the only tail handling — it is
 // (the loaders mask any k >= kend), so the routine takes every B >= 128; what it does not take: fp16 mode, batch-norm (raw outputs)
 hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
@@ -137,9 +273,19 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
   if ((id == K_FC4_FWD || id == K_FC4_DGRAD) && t.bt[id] == 0 && t.btx[id] == 0) return hipSuccess;
   if (id < 12 && (t.nw_override[id] > 0 || t.rb[id] > 0)) return hipSuccess;      // explicit latency-engine tuning hooks win
   hipError_t e = hipErrorInvalidValue;
+  if ((id == K_BWD1 && a.f4w_count == 0) || id == K_CONV1_WGRAD) {             // conv1's weight gradient: bytes x three bf16 planes of delta1
+    e = launch_c1w_bt(a, s);
+    if (e == hipErrorInvalidValue) return hipSuccess;
+    *handled = true;
+    return e;
+  }
   const int x = t.btx[id];
   if (x == 9 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<9>(id, a, s) : launch_single_x<9>(id, a, s);
   else if (x == 6 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<6>(id, a, s) : launch_single_x<6>(id, a, s);
+#ifdef SDQN_EXPERIMENTS
+  else if (x == 19 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<19>(id, a, s) : launch_single_x<19>(id, a, s);
+  else if (x == 16 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<16>(id, a, s) : launch_single_x<16>(id, a, s);
+#endif
   else
   if (id == K_BWD3 || id == K_BWD2) e = launch_fused(id, t.bt[id], a, s);
   else if (id == K_CONV2_FWD || id == K_CONV3_FWD || id == K_FC4_FWD || id == K_FC4_DGRAD || id == K_FC4_WGRAD || id == K_CONV3_DGRAD ||

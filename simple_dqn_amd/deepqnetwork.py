@@ -207,6 +207,16 @@ class DeepQNetwork:
         _lib.check(self._lib.sdqn_net_predict_state(self._h, state_buffer._h, _lib.ptr(q, C.c_float)))
         return q
 
+    def act_step(self, state_buffer, mem, screen, action=0, reward=0, terminal=False, speculate=False):
+        """One environment transition in ONE library call: `state_buffer.add(screen)` and — with a device-backed replay memory —
+        `mem.add(action, reward, screen, terminal)` (agent.py:62 / replay_memory.py:26-34); `speculate` also enqueues the acting forward of
+        the new state, so that the next predict_state(state_buffer) only collects Q-values that are already on their way."""
+        assert screen.shape == state_buffer.dims
+        scr = np.ascontiguousarray(screen, dtype=np.uint8)
+        rh = mem._h if mem is not None else None
+        _lib.check(self._lib.sdqn_net_act_step(self._h, state_buffer._h, rh, _lib.ptr(scr, C.c_uint8), int(action), int(reward),
+                                               int(bool(terminal)), int(bool(speculate))))
+
     def load_weights(self, load_path):                             # :188-189
         """Own .npz snapshots, or a Neon pickle (the reference's `model.load_params`, best effort: neon_compat.py)."""
         if not str(load_path).endswith(".npz"):

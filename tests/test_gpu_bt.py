@@ -97,6 +97,32 @@ def test_block_tile_bf16x3_arithmetic_mode(sd, x):
         assert _rel(net.get_layer(i, 3), ref.get_layer(i, 3)) < 2e-6, i
 
 
+@pytest.mark.parametrize("A,B", [(3, 256), (6, 160), (4, 136)])
+def test_conv1_weight_gradient_block_tile_bf16(sd, A, B):
+    """conv1's weight gradient at B >= 128: bytes x three exact bf16 planes of delta1 on packed-bf16 MFMA, one workgroup per K slab
+    (c1w_bt_kernel).  Every product is exact and the accumulation fp32, so gW1 agrees with the fp32-MFMA engine's to fp32 round-off —
+    from the staged minibatch and from the ring (fused gather), ragged slabs and a batch that is not a multiple of 32 included — and
+    with other slab sizes."""
+    from oracle.replay_numpy import synthetic_fill
+    mb = random_minibatch(B, A, 60 + B, reward_range=(-2, 3))
+    new = _net(sd, A, B, 21, [("keep_gradients", 1)])
+    old = _net(sd, A, B, 21, [("keep_gradients", 1), ("bt:18", -1), ("bt:11", -1)])
+    alt = _net(sd, A, B, 21, [("keep_gradients", 1), ("tps:1", 25)])      # 800 positions per slab: whole 80-position chunks too (5 | 25)
+    unf = _net(sd, A, B, 21, [("keep_gradients", 1), ("fused_launches", 0)])
+    for n in (new, old, alt, unf):
+        n.train(mb)
+    g_old = old.get_layer(0, 3)
+    assert _rel(new.get_layer(0, 3), g_old) < 2e-6 and _rel(alt.get_layer(0, 3), g_old) < 2e-6
+    assert np.array_equal(unf.get_layer(0, 3), new.get_layer(0, 3))
+    # the ring path (indexes in device memory, frames gathered from the HBM mirror)
+    args = make_args(batch_size=B)
+    mem = sd.ReplayMemory(3000, args)
+    synthetic_fill(mem, 22, num_actions=A)
+    idx = np.random.RandomState(23).randint(10, 2900, size=B).astype(np.int64)
+    new.train_indexes(mem, idx); old.train_indexes(mem, idx)
+    assert _rel(new.get_layer(0, 3), old.get_layer(0, 3)) < 2e-6
+
+
 def test_block_tile_other_slab_counts(sd):
     """K-slab choices of the weight gradients and of fc4 forward (options tps:<l>, s4) only regroup the fp32 sums."""
     A, B = 3, 256

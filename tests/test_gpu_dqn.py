@@ -581,6 +581,53 @@ def test_dp_overlap_by_rule_probe_vote_and_fallback(sd, inject):
     n2.dp_shutdown(); n3.dp_shutdown()
 
 
+def test_act_step_and_speculative_forward_are_exact(sd):
+    """one library call per environment transition (state-buffer add + ring add + the NEXT acting forward enqueued
+    ahead of its use, its Q-values delivered by system-scope stores into mapped host memory that the host polls).  (1) a collected
+    speculation equals predict_one of the same state bit for bit, and is dropped when the buffer or the parameters change before its
+    use; (2) an Agent on the one-call path leaves the same ring, takes the same actions and trains to the same weights as the
+    call-per-operation path (same global random stream)."""
+    A, B = 6, 32
+    net, _ = _pair(sd, A, B, 191)
+    args = make_args(batch_size=B, replay_size=600, random_steps=50, exploration_rate_start=0.3, exploration_rate_end=0.1,
+                     exploration_decay_steps=200, target_steps=40, train_frequency=4)
+    buf = sd.DeviceStateBuffer(args)
+    rng = np.random.RandomState(192)
+    for i in range(70):                                   # > one lap of the 64-slot device ring
+        scr = rng.randint(0, 256, (84, 84), dtype=np.uint8)
+        net.act_step(buf, None, scr, speculate=(i % 3 != 0))
+        if i % 5 == 1:
+            buf.add(rng.randint(0, 256, (84, 84), dtype=np.uint8))          # the buffer moves on: the speculation must not be used
+        if i % 7 == 2:
+            net.train(random_minibatch(B, A, 300 + i))                      # the parameters move on: same
+        assert np.array_equal(net.predict_state(buf), net.predict_one(buf.getState())), i
+    outs = []
+    for one_call in (True, False):
+        random.seed(args.random_seed)
+        env = sd.SyntheticEnvironment(args, num_actions=A, seed=3)
+        mem = sd.ReplayMemory(args.replay_size, args)
+        n, _ = _pair(sd, A, B, 193)
+        agent = sd.Agent(env, mem, n, args)
+        assert agent._one_call
+        agent._one_call = one_call
+        acts = []
+        class CB:
+            def on_step(self, action, reward, terminal, screen, rate): acts.append((action, reward, bool(terminal)))
+            def on_train(self, cost): pass
+        agent.callback = CB(); n.callback = None
+        agent.play_random(args.random_steps)
+        agent.train(120, 0)
+        agent.test(60, 0)
+        outs.append((acts, np.asarray(mem.screens[:mem.count]).copy(), np.asarray(mem.actions[:mem.count]).copy(),
+                     np.asarray(mem.rewards[:mem.count]).copy(), mem.count, mem.current, n.get_weights(0)))
+    a, b = outs
+    assert a[0] == b[0] and a[4:6] == b[4:6]
+    for x, y in zip(a[1:4], b[1:4]):
+        assert np.array_equal(x, y)
+    for x, y in zip(a[6], b[6]):
+        assert np.array_equal(x, y)
+
+
 def test_agent_loop_plumbing(sd):
     """BASELINE.json configs[0] plumbing on the synthetic environment: Agent drives add/predict/train."""
     A, B = 4, 32
