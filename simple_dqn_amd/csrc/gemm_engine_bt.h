@@ -30,19 +30,26 @@ namespace sdqn {
 // 9 instructions of 32 cycles per 16 k instead of 8 of 64 (0.56x the matrix-pipe time); X_ = 6 drops the three products below
 // 2^-24 of x y (lo x mid, mid x lo, lo x lo: 0.375x).  The dominant hi x hi products have their own accumulator, the small cross
 // terms a second one, added once in the epilogue (small + main): no cross term is ever rounded against the running main sum.
-template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 2, int X_ = 0>
+// CPI_ = chunks per barrier interval (1 or 2): with 2 a stage holds two consecutive 32-deep chunks (a 64-deep slice of K), each wave
+// issues 32 MFMAs per sub-tile between barriers and the per-interval costs — the barrier itself, the LDS-read latency in front of the
+// first MFMA, the staging stores — are paid once per 64 k.  rocprofv3 PMC at B = 256 (tools/exp/pmc_sq_b256.sh): 1.3-2.6 waves per SIMD
+// and the matrix pipe busy 47-63 % of a launch — a lone wave per SIMD pays those costs serially.
+template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 2, int X_ = 0, int CPI_ = 1>
 struct BtCfg {
   typedef P_ P;
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
   static constexpr int D = D_;                          // chunks in flight per workgroup: D register sets of (BM + BN) / 32 float4 per thread
   static constexpr int X = X_;
+  static constexpr int CPI = CPI_;
+  static_assert(CPI == 1 || CPI == 2, "chunks per barrier interval");
   static_assert(X == 0 || X == 6 || X == 9 || X == 19 || X == 16, "fp32 MFMA, or 6 / 9 exact bf16 partial products (19 / 16: TIMING ONLY, no split)");
   static_assert(D >= 1 && D <= 4, "prefetch depth");
   static constexpr int SM = BM / (32 * WM), SN = BN / (32 * WN);
   static_assert(WM * WN * 64 == bt::NT, "four waves per workgroup");
   static_assert(SM >= 1 && SN >= 1 && SM * 32 * WM == BM && SN * 32 * WN == BN, "block = wave grid x sub-tiles of 32 x 32");
   static constexpr int AF = bt::panel_floats(P::A_K, BM), BF = bt::panel_floats(P::B_K, BN);
-  static constexpr int STAGE = AF + BF;                 // floats per LDS stage
+  static constexpr int PANELS = AF + BF;                // floats of one chunk's two panels
+  static constexpr int STAGE = CPI * PANELS;            // floats per LDS stage
   static constexpr int LDS = 2 * STAGE;                 // double-buffered
 };
 
@@ -109,7 +116,8 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
   // ---- one chunk's panels: global -> registers (ra, rb) -> LDS stage ---------------------------------------------------------
   // loads are unconditional with clamped k (a conditional load costs a branch and a vmcnt(0) each), out-of-range k is zeroed
   constexpr int D = C::D;
-  float4 ra[D][PA], rb[D][PB];
+  constexpr int CPI = C::CPI;
+  float4 ra[D][CPI * PA], rb[D][CPI * PB];
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto gload = [&](int kc, float4* qa, float4* qb) {
     if constexpr (AK) {
@@ -275,32 +283,42 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
     }
   };
 
-  // ---- main loop: register set (c mod D) holds chunk c; two LDS stages; one barrier per chunk ---------------------------------
+  // ---- main loop: register set (t mod D) holds interval t = chunks [CPI t, CPI t + CPI); two LDS stages; one barrier per interval ----------
   typename P::Epi epi[SM][SN];
   const int nch = (kend - kbeg + bt::BK - 1) / bt::BK;
+  const int nit = (nch + CPI - 1) / CPI;                           // (an odd tail chunk is zero-filled by the loaders: k >= kend)
   auto epi_prefetch = [&]() {
-    // whatever the epilogue reads besides the accumulators (W4 / RMSProp state of the fused optimizer) flies under the last chunk
+    // whatever the epilogue reads besides the accumulators (W4 / RMSProp state of the fused optimizer) flies under the last interval
 #pragma unroll
     for (int sm = 0; sm < SM; ++sm)
 #pragma unroll
       for (int sn = 0; sn < SN; ++sn) P::epi_begin(a, m0 + (wm * SM + sm) * 32, n0 + (wn * SN + sn) * 32, lane, epi[sm][sn]);
   };
-  if (nch > 0) {
+  auto gload_it = [&](int t, float4* qa, float4* qb) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) if (d < nch) gload(kbeg + d * bt::BK, ra[d], rb[d]);
-    lds_store(ra[0], rb[0], smem, smem + C::AF);
+    for (int cc = 0; cc < CPI; ++cc) gload(kbeg + (t * CPI + cc) * bt::BK, qa + cc * PA, qb + cc * PB);
+  };
+  auto store_it = [&](const float4* qa, const float4* qb, float* st) {
+#pragma unroll
+    for (int cc = 0; cc < CPI; ++cc) lds_store(qa + cc * PA, qb + cc * PB, st + cc * C::PANELS, st + cc * C::PANELS + C::AF);
+  };
+  if (nit > 0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) if (d < nit) gload_it(d, ra[d], rb[d]);
+    store_it(ra[0], rb[0], smem);
     __syncthreads();
-    for (int c0 = 0; c0 < nch; c0 += D) {
+    for (int t0 = 0; t0 < nit; t0 += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
-        const int c = c0 + d;                                          // workgroup-uniform control flow throughout
-        if (c < nch) {
-          float* cur = smem + (c & 1) * C::STAGE;
-          float* nxt = smem + ((c + 1) & 1) * C::STAGE;
-          if (c + D < nch) gload(kbeg + (c + D) * bt::BK, ra[d], rb[d]);      // set d is free: chunk c went to LDS one iteration ago
-          if (c + 1 == nch) epi_prefetch();
-          compute(cur, cur + C::AF);
-          if (c + 1 < nch) { lds_store(ra[(d + 1) % D], rb[(d + 1) % D], nxt, nxt + C::AF); __syncthreads(); }
+        const int t = t0 + d;                                          // workgroup-uniform control flow throughout
+        if (t < nit) {
+          float* cur = smem + (t & 1) * C::STAGE;
+          float* nxt = smem + ((t + 1) & 1) * C::STAGE;
+          if (t + D < nit) gload_it(t + D, ra[d], rb[d]);               // set d is free: interval t went to LDS one iteration ago
+          if (t + 1 == nit) epi_prefetch();
+#pragma unroll
+          for (int cc = 0; cc < CPI; ++cc) compute(cur + cc * C::PANELS, cur + cc * C::PANELS + C::AF);
+          if (t + 1 < nit) { store_it(ra[(d + 1) % D], rb[(d + 1) % D], nxt); __syncthreads(); }
         }
       }
     }

@@ -1684,11 +1684,13 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   }
   else if (!strcmp(name, "bt")) h->bt_on = value != 0;                  // 0: B >= 128 on the latency engine's launch forms (round 3)
   else if (!strcmp(name, "bt_x")) {                        // arithmetic of every block-tile launch: 0 fp32 MFMA, 9 / 6 exact bf16x3 splits
-    ARGCHK(value == 0 || value == 6 || value == 9 || (EXPERIMENTS && (value == 19 || value == 16)), "bt_x must be 0, 6 or 9");
+    if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name);
+    ARGCHK(value == 0 || value == 6 || value == 9 || value == 19 || value == 16, "bt_x must be 0, 6 or 9");
     for (int i = 0; i < K_COUNT; ++i) h->btx[i] = value;
   }
   else if (!strncmp(name, "btx:", 4)) {
     int id = atoi(name + 4);
+    if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name);
     ARGCHK(id >= 0 && id < K_COUNT && (value == 0 || value == 6 || value == 9), "bad btx override");
     h->btx[id] = value;
   }

@@ -17,6 +17,7 @@ namespace sdqn {
 
 #define BT(P, BM, BN, WM, WN, D) BtCfg<P, BM, BN, WM, WN, D>
 #define BTX(P, BM, BN, WM, WN, D, X) BtCfg<P, BM, BN, WM, WN, D, X>
+#define BT2(P, BM, BN, WM, WN, D) BtCfg<P, BM, BN, WM, WN, D, 0, 2>       // two chunks per barrier interval
 #define BT_CASE(N, P, BM, BN, WM, WN, D) case N: return launch_bt<BT(P, BM, BN, WM, WN, D)>(a, s)
 
 // built-in block shapes (menu entry 0 maps onto these)
@@ -38,6 +39,10 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 0: return launch_bt<C2F>(a, s);
         BT_CASE(1, Conv2FwdWT, 64, 64, 2, 2, 3); BT_CASE(2, Conv2FwdWT, 128, 64, 2, 2, 2); BT_CASE(3, Conv2FwdWT, 128, 64, 4, 1, 2);
         BT_CASE(4, Conv2FwdWT, 64, 64, 2, 2, 1); BT_CASE(5, Conv2FwdWT, 128, 64, 2, 2, 3);
+#ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
+        case 6: return launch_bt<BT2(Conv2FwdWT, 64, 64, 2, 2, 2)>(a, s);
+        case 7: return launch_bt<BT2(Conv2FwdWT, 64, 64, 2, 2, 1)>(a, s);
+#endif
         default: break;
       }
       break;
@@ -46,6 +51,10 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 0: return launch_bt<C3F>(a, s);
         BT_CASE(1, Conv3FwdWT, 64, 64, 2, 2, 3); BT_CASE(2, Conv3FwdWT, 128, 64, 2, 2, 2); BT_CASE(3, Conv3FwdWT, 128, 64, 4, 1, 2);
         BT_CASE(4, Conv3FwdWT, 64, 64, 2, 2, 1); BT_CASE(5, Conv3FwdWT, 128, 64, 2, 2, 3);
+#ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
+        case 6: return launch_bt<BT2(Conv3FwdWT, 64, 64, 2, 2, 2)>(a, s);
+        case 7: return launch_bt<BT2(Conv3FwdWT, 64, 64, 2, 2, 1)>(a, s);
+#endif
         default: break;
       }
       break;
@@ -54,6 +63,10 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 0: return launch_bt<F4F>(a, s);
         BT_CASE(1, Fc4FwdWT, 64, 64, 2, 2, 3); BT_CASE(2, Fc4FwdWT, 128, 64, 2, 2, 2); BT_CASE(3, Fc4FwdWT, 128, 128, 2, 2, 2);
         BT_CASE(4, Fc4FwdWT, 64, 128, 2, 2, 2); BT_CASE(5, Fc4FwdWT, 128, 128, 2, 2, 3);
+#ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
+        case 6: return launch_bt<BT2(Fc4FwdWT, 64, 64, 2, 2, 2)>(a, s);
+        case 7: return launch_bt<BT2(Fc4FwdWT, 64, 64, 2, 2, 1)>(a, s);
+#endif
         default: break;
       }
       break;
@@ -62,6 +75,10 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 0: return launch_bt<F4D>(a, s);
         BT_CASE(1, Fc4DgradWT, 64, 64, 2, 2, 3); BT_CASE(2, Fc4DgradWT, 64, 128, 2, 2, 2); BT_CASE(3, Fc4DgradWT, 32, 128, 1, 4, 2);
         BT_CASE(4, Fc4DgradWT, 128, 64, 2, 2, 2); BT_CASE(5, Fc4DgradWT, 32, 128, 1, 4, 3);
+#ifdef SDQN_EXPERIMENTS
+        case 6: return launch_bt<BT2(Fc4DgradWT, 64, 64, 2, 2, 2)>(a, s);
+        case 7: return launch_bt<BT2(Fc4DgradWT, 32, 128, 1, 4, 2)>(a, s);
+#endif
         default: break;
       }
       break;
@@ -75,7 +92,9 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
   return hipErrorInvalidValue;
 }
 
-// the built-in block shapes on packed-bf16 MFMA through exact three-way splits of both operands (gemm_engine_bt.h: X = 9 / 6 partial products)
+#ifdef SDQN_EXPERIMENTS
+// the built-in block shapes on packed-bf16 MFMA through exact three-way splits of both operands (gemm_engine_bt.h: X = 9 / 6 partial products):
+// fp32-class results, measured SLOWER than fp32 MFMA while the split runs per wave at fragment-read time (VALU-bound) — tools/exp/README.md
 template <int X>
 static hipError_t launch_single_x(int id, const StepArgs& a, hipStream_t s) {
   switch (id) {
@@ -102,6 +121,8 @@ static hipError_t launch_fused_x(int id, const StepArgs& a, hipStream_t s) {
   return hipErrorInvalidValue;
 }
 
+#endif  // SDQN_EXPERIMENTS
+
 static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t s) {
   const bool f4 = a.f4w_count > 0;         // (B > 32: all of fc4_wgrad rides in bwd3 or none of it, sdqn_api.hip)
   if (id == K_BWD3) {
@@ -112,6 +133,10 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
       case 2: return launch_bt_multi<BT(Conv3DgradWT, 128, 64, 2, 2, 2), BT(Conv3WgradWT, 64, 64, 2, 2, 2), F4W>(a, true, true, f4, s);
       case 3: return launch_bt_multi<F4W, C3D, C3W>(a, f4, true, true, s);
       case 4: return launch_bt_multi<BT(Conv3DgradWT, 128, 64, 2, 2, 2), BT(Conv3WgradWT, 128, 64, 2, 2, 2), BT(Fc4WgradBT, 64, 128, 2, 2, 2)>(a, true, true, f4, s);
+#ifdef SDQN_EXPERIMENTS
+      case 5: return launch_bt_multi<BT2(Conv3DgradWT, 64, 64, 2, 2, 2), BT2(Conv3WgradWT, 64, 64, 2, 2, 2), BT2(Fc4WgradBT, 64, 64, 2, 2, 2)>(a, true, true, f4, s);
+      case 6: return launch_bt_multi<BT2(Conv3DgradWT, 64, 64, 2, 2, 1), BT2(Conv3WgradWT, 64, 64, 2, 2, 1), BT2(Fc4WgradBT, 64, 64, 2, 2, 1)>(a, true, true, f4, s);
+#endif
       default: break;
     }
   } else if (id == K_BWD2 && !f4) {
@@ -121,6 +146,10 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
       case 2: return launch_bt_multi<NOP, BT(Conv2DgradWT, 256, 32, 4, 1, 2), C2W>(a, false, true, true, s);
       case 3: return launch_bt_multi<NOP, C2D, C2W>(a, false, true, true, s);
       case 4: return launch_bt_multi<NOP, BT(Conv2DgradWT, 128, 32, 4, 1, 2), BT(Conv2WgradWT, 128, 64, 2, 2, 2)>(a, false, true, true, s);
+#ifdef SDQN_EXPERIMENTS
+      case 5: return launch_bt_multi<NOP, BT2(Conv2WgradWT, 64, 64, 2, 2, 2), BT2(Conv2DgradWT, 128, 32, 4, 1, 2)>(a, false, true, true, s);
+      case 6: return launch_bt_multi<NOP, BT2(Conv2WgradWT, 64, 64, 2, 2, 1), BT2(Conv2DgradWT, 128, 32, 4, 1, 1)>(a, false, true, true, s);
+#endif
       default: break;
     }
   }
@@ -270,7 +299,7 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
   if (id < 0 || id >= K_COUNT || t.bt[id] < 0) return hipSuccess;
   // fc4 forward / dgrad have 64 / 196 blocks of 64 x 64 — one or two per CU, nothing to overlap their waits with — and measured slower
   // here than on the latency engine (fc4_fwd 23.4 vs 18.7 us, fc4_dgrad 17.0 vs 15.2 at B = 256): block-tile only on request (menu entry > 0)
-  if ((id == K_FC4_FWD || id == K_FC4_DGRAD) && t.bt[id] == 0 && t.btx[id] == 0) return hipSuccess;
+  if ((id == K_FC4_FWD || id == K_FC4_DGRAD) && t.bt[id] == 0) return hipSuccess;
   if (id < 12 && (t.nw_override[id] > 0 || t.rb[id] > 0)) return hipSuccess;      // explicit latency-engine tuning hooks win
   hipError_t e = hipErrorInvalidValue;
   if ((id == K_BWD1 && a.f4w_count == 0) || id == K_CONV1_WGRAD) {             // conv1's weight gradient: bytes x three bf16 planes of delta1
@@ -279,14 +308,14 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
     *handled = true;
     return e;
   }
+#ifdef SDQN_EXPERIMENTS
   const int x = t.btx[id];
   if (x == 9 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<9>(id, a, s) : launch_single_x<9>(id, a, s);
   else if (x == 6 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<6>(id, a, s) : launch_single_x<6>(id, a, s);
-#ifdef SDQN_EXPERIMENTS
   else if (x == 19 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<19>(id, a, s) : launch_single_x<19>(id, a, s);
   else if (x == 16 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<16>(id, a, s) : launch_single_x<16>(id, a, s);
-#endif
   else
+#endif
   if (id == K_BWD3 || id == K_BWD2) e = launch_fused(id, t.bt[id], a, s);
   else if (id == K_CONV2_FWD || id == K_CONV3_FWD || id == K_FC4_FWD || id == K_FC4_DGRAD || id == K_FC4_WGRAD || id == K_CONV3_DGRAD ||
            id == K_CONV3_WGRAD || id == K_CONV2_DGRAD || id == K_CONV2_WGRAD) e = launch_single(id, t.bt[id], a, s);

@@ -81,9 +81,10 @@ def test_block_tile_fused_rmsprop_step(sd):
             assert np.array_equal(fused.get_layer(i, which), split.get_layer(i, which)), (which, i)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("x", [9, 6])
 def test_block_tile_bf16x3_arithmetic_mode(sd, x):
-    """Option bt_x (experiment, off by default): the same fp32 operands on packed-bf16 MFMA through exact three-way bf16 splits of BOTH
+    """Option bt_x (experiments build only): the same fp32 operands on packed-bf16 MFMA through exact three-way bf16 splits of BOTH
     operands (9 exact partial products, or 6 without the three below 2^-24 of the product).  fp32-class results: every gradient within
     2e-6 of max|g| of the fp32-MFMA result, Q within 1e-6.  (Measured SLOWER than fp32 MFMA when the split runs per wave at fragment-read
     time — VALU-bound, tools/exp/README.md — which is why it is an option and not the product path.)"""

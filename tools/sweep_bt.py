@@ -70,11 +70,16 @@ def trial(tag, opts, ids):
     results[tag] = dict(total=tot, **{NAMES[k]: us.get(k) for k in ids})
 
 for kid in (1, 2, 3, 5):
-    for m in range(1, 6):
+    for m in ((6, 7) if QUICK else range(1, 8)):
         trial("%s menu %d" % (NAMES[kid], m), [("bt:%d" % kid, m)], [kid])
 for kid in (16, 17):
-    for m in range(1, 5):
+    for m in ((5, 6) if QUICK else range(1, 7)):
         trial("%s menu %d" % (NAMES[kid], m), [("bt:%d" % kid, m)], [kid])
+if QUICK:
+    trial("bwd2 menu 5, tps:2 = 8", [("bt:17", 5), ("tps:2", 8)], [17, 12])
+    trial("bwd2 menu 5, tps:2 = 10", [("bt:17", 5), ("tps:2", 10)], [17, 12])
+    trial("all CPI=2", [("bt:1", 6), ("bt:2", 6), ("bt:16", 5), ("bt:17", 5), ("tps:2", 8)], [1, 2, 16, 17])
+    trial("all CPI=2, D=1", [("bt:1", 7), ("bt:2", 7), ("bt:16", 6), ("bt:17", 6), ("tps:2", 8)], [1, 2, 16, 17])
 if not QUICK:
     for t3 in (7, 10, 14, 28, 49):
         trial("tps:3 = %d" % t3, [("tps:3", t3)], [16, 12])
