@@ -33,6 +33,7 @@ static constexpr bool EXPERIMENTS = false;
 #define EXP_OPTION_REFUSED(NAME) do { set_error("option %s is an experiment (measured slower than the default step; tools/exp/README.md): " \
                                                 "build the library with `make -C simple_dqn_amd/csrc experiments` and load it with SDQN_LIB_VARIANT=experiments", NAME); \
                                       return SDQN_ERR_ARG; } while (0)
+static constexpr int Q_SLOTS = 8;       // host-mapped Q-value slots of the acting path (sdqn_net_predict_state)
 static thread_local std::string g_err;
 static void set_error(const char* fmt, ...) {
   char buf[1024];
@@ -460,7 +461,8 @@ struct sdqn_net_s {
   // acting path (round 4): the head kernel of a predict_state forward writes its Q-values straight into mapped host memory (q_host; q_host_dev
   // = its device alias) and the host polls for them.  spec_*: a forward enqueued AHEAD of its use by sdqn_net_act_step (speculation) — valid
   // while the state buffer generation and the parameters are what they were when it was enqueued
-  float *q_host = nullptr, *q_host_dev = nullptr;
+  float *q_host = nullptr, *q_host_dev = nullptr;      // Q_SLOTS slots of 32 floats: every enqueued acting forward gets its OWN slot, so a
+  int q_slot = 0;                                       // speculation that was dropped (still in flight) cannot write into the slot being polled
   bool head_q_system = false;              // (run_forward: this forward's head writes system-scope)
   bool spec_pending = false; const void* spec_sb = nullptr; uint64_t spec_gen = 0;
   uint8_t* h_stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; bool stage_busy[2] = {false, false}; int stage_next = 0;
@@ -682,7 +684,7 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
   NCHK(dalloc(h, (void**)&h->d_idx, (size_t)B * 8));
   NCHK(dalloc(h, (void**)&h->d_idx_t, (size_t)B * 8));
   { hipError_t e = hipHostMalloc((void**)&h->h_f, (size_t)(2 * B * MAX_ACTIONS + B + 64) * 8, hipHostMallocMapped);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->q_host, 256, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->q_host, Q_SLOTS * 32 * sizeof(float), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->q_host_dev, h->q_host, 0);
     if (e != hipSuccess) { set_error("hipHostMalloc -> %s", hipGetErrorString(e)); net_free(h); return SDQN_ERR_HIP; } }
 #undef NCHK
@@ -1273,22 +1275,25 @@ extern "C" int sdqn_statebuf_read_device(sdqn_statebuf_t s, uint8_t* out) {
 // synchronisation — the host polls the A words (bounded; falls back to a blocking wait).  37 -> ~29 us per call on MI355X.
 static const uint32_t Q_SENTINEL = 0xFFFFFFFFu;
 static int predict_state_enqueue(sdqn_net_s* h, sdqn_statebuf_s* sb) {
-  volatile uint32_t* qh = reinterpret_cast<volatile uint32_t*>(h->q_host);
+  // a fresh slot per forward: the stream runs forwards in order, so by the time a slot comes round again (Q_SLOTS forwards later) any
+  // dropped speculation that wrote into it has long finished
+  h->q_slot = (h->q_slot + 1) % Q_SLOTS;
+  volatile uint32_t* qh = reinterpret_cast<volatile uint32_t*>(h->q_host + h->q_slot * 32);
   for (int k = 0; k < h->A; ++k) qh[k] = Q_SENTINEL;
   StepArgs a = step_args(h); a.B = 1; a.nz = 1; a.from_ring = 0; a.src = statebuf_window(sb);   // batch of one, read in place
   HeadArgs hd = head_args(h, 0);
   const bool direct = !h->bn;                                    // (--batch_norm: the plain head + a copy, as before)
-  if (direct) hd.q = h->q_host_dev;
+  if (direct) hd.q = h->q_host_dev + h->q_slot * 32;
   h->head_q_system = direct;
   const int rc = run_forward(h, a, hd);
   h->head_q_system = false;
   if (rc) return rc;
-  if (!direct) HIPCHK(hipMemcpyAsync(h->q_host, h->q, (size_t)h->A * 4, hipMemcpyDeviceToHost, g_stream));
+  if (!direct) HIPCHK(hipMemcpyAsync(h->q_host + h->q_slot * 32, h->q, (size_t)h->A * 4, hipMemcpyDeviceToHost, g_stream));
   h->spec_pending = true; h->spec_sb = sb; h->spec_gen = sb->gen;
   return SDQN_OK;
 }
 static int predict_state_collect(sdqn_net_s* h, float* q_out) {
-  volatile uint32_t* qh = reinterpret_cast<volatile uint32_t*>(h->q_host);
+  volatile uint32_t* qh = reinterpret_cast<volatile uint32_t*>(h->q_host + h->q_slot * 32);
   auto landed = [&]() { for (int k = 0; k < h->A; ++k) if (qh[k] == Q_SENTINEL) return false; return true; };
   const auto t0 = std::chrono::steady_clock::now();
   while (!landed()) {

@@ -672,7 +672,8 @@ def test_dispatch_order_and_slab_options_keep_the_numbers(sd, datatype):
         cost = [n.train_from_memory(mem, s, mt_state=mt, want_cost=True) for s in (1, 2)]
         return n, cost
     base, cb = run([])
-    for order in (1, 2) if datatype == "float32" else (1,):
+    from util import experiments_build
+    for order in ((1, 2) if datatype == "float32" else (1,)) if experiments_build() else ():       # (bwd_order: experiments build only, round 4)
         n, c = run([("bwd_order", order)])
         assert c == cb, order
         for which in (0, 2):
