@@ -73,6 +73,9 @@ def kernel_work(B, A):
         21: dict(bytes=(a3 + w3 + 2 * a2) + (a2 + a3 + w3), flops=2 * B * 49 * 64 * 576 * 2),
         # round 3: update(i) + conv1_fwd(i + 1) in one launch = the sum of the two
         22: dict(bytes=(npar - 1605632) * f * 5 + (25 * w1 + 6 * w2 + 4 * w3) + B * 5 * 7056 + 2 * a1 + 2 * w1, flops=8 * (npar - 1605632) + 2 * 2 * B * 400 * 32 * 256),
+        23: dict(bytes=(2 * a4 * 2 + 2 * 512 * A * f) + (a4 + w4 + 2 * a3), flops=2 * 2 * B * 512 * A + 2 * B * 512 * 3136),     # (experiments build) head + fc4_dgrad
+        # round 4 (float16, B >= 128): fc4_wgrad + fused RMSProp || conv3_wgrad || conv2_wgrad in one launch
+        24: dict(bytes=(a4 + a3 + 4 * w4) + (a2 + a3 + w3) + (a1 + a2 + w2), flops=2 * B * 512 * 3136 + 2 * B * 49 * 64 * 576 + 2 * B * 81 * 64 * 512),
     }
     # (default tile split: the whole fc4 wgrad + fused RMSProp read-modify-write — theta, s read and written — rides in bwd3)
 

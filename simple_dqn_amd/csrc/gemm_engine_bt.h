@@ -357,6 +357,129 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
     }
 }
 
+// ---- the float16 mode's forward / dgrad stages (packed-fp16 MFMA, both operands k-contiguous halves: problems_h16.h) --------------------
+// Same structure with half panels: chunks of 64 k (a 128-byte row chunk = 8 lanes x 16 bytes, like the fp32 chunk), LDS rows of 72 halves
+// (= 36 dwords: the fp32 panel's bank picture), a lane's fragment of a 16-deep step = ONE ds_read_b128, four v_mfma_f32_32x32x16_f16 per
+// sub-tile and chunk.  At B >= 128 these launches were operand-traffic bound on the wave-tile routines (every 64 x 64 wave block fetched
+// its own rows from L2: gemm_engine_rb.h); here a row leaves L2 once per workgroup.
+template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 2>
+struct BtCfgH {
+  typedef P_ P;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, D = D_;
+  static constexpr int SM = BM / (32 * WM), SN = BN / (32 * WN);
+  static_assert(WM * WN * 64 == bt::NT && SM >= 1 && SN >= 1 && SM * 32 * WM == BM && SN * 32 * WN == BN, "block = 4 waves x sub-tiles of 32 x 32");
+  static_assert(uses_f16_mfma<P>::value, "a problems_h16.h forward / dgrad problem: both operands k-contiguous halves (a_load8 / b_load8)");
+  static constexpr int AH = bt::kmh_halves(BM), BH = bt::kmh_halves(BN);
+  static constexpr int STAGE = AH + BH;                 // halves per LDS stage
+  static constexpr int LDS = 2 * STAGE / 2;             // floats (the kernels declare float arrays): double-buffered
+};
+
+template <class C>
+__device__ __forceinline__ void bt_tile_h(const StepArgs& a, int bx, int by, int bz, float* smem_f) {
+  typedef typename C::P P;
+  typedef typename P::aoff_t aoff_t;
+  constexpr int BM = C::BM, BN = C::BN, SM = C::SM, SN = C::SN, WN = C::WN, D = C::D;
+  constexpr int PA = bt::passes(BM), PB = bt::passes(BN);
+  half_t* smem = reinterpret_cast<half_t*>(smem_f);
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int m0 = bx * BM, n0 = by * BN;
+  int z, ks, kbeg, kend;
+  P::ksplit(a, bz, z, ks, kbeg, kend);
+  const int M = P::M(a), N = P::N(a);
+  aoff_t ag[PA]; int bg[PB];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) { const int m = m0 + bt::kmh_item_row(tid, p); ag[p] = P::a_row(a, z, m < M ? m : M - 1); }
+#pragma unroll
+  for (int p = 0; p < PB; ++p) { const int n = n0 + bt::kmh_item_row(tid, p); bg[p] = P::b_col(a, z, n < N ? n : N - 1); }
+  half8 ra[D][PA], rb[D][PB];
+  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto gload = [&](int kc, half8* qa, half8* qb) {
+    const int k = kc + bt::kmh_item_k(tid), kk = k < kend ? k : kbeg;
+    const aoff_t ca = P::a_col(a, z, kk); const int rbk = P::b_row(a, z, kk);
+#pragma unroll
+    for (int p = 0; p < PA; ++p) { qa[p] = P::a_load8(a, z, ag[p] + ca); if (k >= kend) qa[p] = zero8; }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) { qb[p] = P::b_load8(a, z, bg[p] + rbk); if (k >= kend) qb[p] = zero8; }
+  };
+  auto lds_store = [&](const half8* qa, const half8* qb, half_t* As, half_t* Bs) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) *reinterpret_cast<half8*>(As + bt::kmh_off(bt::kmh_item_row(tid, p), bt::kmh_item_k(tid))) = qa[p];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) *reinterpret_cast<half8*>(Bs + bt::kmh_off(bt::kmh_item_row(tid, p), bt::kmh_item_k(tid))) = qb[p];
+  };
+  f32x16 acc[SM][SN];
+#pragma unroll
+  for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+    for (int sn = 0; sn < SN; ++sn)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[sm][sn][q] = 0.0f;
+  auto compute = [&](const half_t* As, const half_t* Bs) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      half8 fa[SM], fb[SN];
+#pragma unroll
+      for (int sm = 0; sm < SM; ++sm) fa[sm] = *reinterpret_cast<const half8*>(As + bt::fragh_off((wm * SM + sm) * 32 + i, st, h));
+#pragma unroll
+      for (int sn = 0; sn < SN; ++sn) fb[sn] = *reinterpret_cast<const half8*>(Bs + bt::fragh_off((wn * SN + sn) * 32 + i, st, h));
+#pragma unroll
+      for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+        for (int sn = 0; sn < SN; ++sn) acc[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sm], fb[sn], acc[sm][sn], 0, 0, 0);
+    }
+  };
+  const int nch = (kend - kbeg + bt::BKH - 1) / bt::BKH;
+  if (nch > 0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) if (d < nch) gload(kbeg + d * bt::BKH, ra[d], rb[d]);
+    lds_store(ra[0], rb[0], smem, smem + C::AH);
+    __syncthreads();
+    for (int c0 = 0; c0 < nch; c0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int c = c0 + d;
+        if (c < nch) {
+          half_t* cur = smem + (c & 1) * C::STAGE;
+          half_t* nxt = smem + ((c + 1) & 1) * C::STAGE;
+          if (c + D < nch) gload(kbeg + (c + D) * bt::BKH, ra[d], rb[d]);
+          compute(cur, cur + C::AH);
+          if (c + 1 < nch) { lds_store(ra[(d + 1) % D], rb[(d + 1) % D], nxt, nxt + C::AH); __syncthreads(); }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+    for (int sn = 0; sn < SN; ++sn) {
+      const int ms = m0 + (wm * SM + sm) * 32, ns = n0 + (wn * SN + sn) * 32;
+      if (ms >= M || ns >= N) continue;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = ms + bt::acc_row(q, h), n = ns + i;
+        if (m < M && n < N) P::store(a, z, ks, m, n, acc[sm][sn][q]);
+      }
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(bt::NT) bt_kernel_h(const StepArgs a, const int gx, const int gy) {
+  __shared__ __attribute__((aligned(16))) float smem[C::LDS];
+  const int t = blockIdx.x;
+  const int per_z = gx * gy, bz = t / per_z, r = t - bz * per_z;
+  bt_tile_h<C>(a, r % gx, r / gx, bz, smem);
+}
+template <class C>
+inline hipError_t launch_bt_h(const StepArgs& a, hipStream_t stream) {
+  typedef typename C::P P;
+  const int gx = (P::M(a) + C::BM - 1) / C::BM, gy = (P::N(a) + C::BN - 1) / C::BN, gz = P::nbz(a);
+  if (gx * gy * gz == 0) return hipSuccess;
+  SDQN_LAUNCH((bt_kernel_h<C>), dim3(gx * gy * gz), dim3(bt::NT), 0, stream, a, gx, gy);
+  return hipGetLastError();
+}
+
 // workgroups of problem P at block size BM x BN
 template <class C> inline void bt_grid(const StepArgs& a, int& gx, int& gy, int& gz) {
   typedef typename C::P P;

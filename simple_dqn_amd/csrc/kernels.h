@@ -19,6 +19,7 @@ enum KernelId {
   K_BWD3_CONV, // round 3: bwd3 without the fc4 share (conv3_dgrad + conv3_wgrad)
   K_UPD_CONV1, // round 3: update(i) + conv1_fwd(i + 1) in one launch
   K_HEAD_F4D,  // round 3: head + fc4_dgrad in one launch (the dgrad tiles fetch their W4 panels while the head runs)
+  K_WGRADS,    // round 4 (float16, B >= 128): fc4_wgrad (+ fused RMSProp) || conv3_wgrad || conv2_wgrad in one launch, after the block-tile dgrad chain
   K_COUNT
 };
 const char* kernel_name(int id);

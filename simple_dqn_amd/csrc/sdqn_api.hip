@@ -1056,6 +1056,12 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   if (f4_early) { h->handoff_launched = true; LAUNCH(K_F4D_F4W, launch_tuned(h, K_FC4_DGRAD, a, g_stream, 0, 1)); }
   else LAUNCH(K_FC4_DGRAD, launch_tuned(h, K_FC4_DGRAD, a, g_stream));
   BN_BWD(2);
+  // round 4, float16 at B >= 128: the two dgrads run on the half block-tile routine as launches of their own (15.6 / 18.1 -> ~7 / 8 us:
+  // operands leave L2 once per workgroup), and every weight gradient that does not need delta1 shares ONE launch behind them (it packs
+  // better than the two fused backward launches did): fc4_dgrad, conv3_dgrad, conv2_dgrad, {fc4_wgrad + RMSProp || conv3_wgrad ||
+  // conv2_wgrad}, conv1_wgrad — five launches where there were four, 19 us less (tools/exp/README.md)
+  const bool h16_bt = h->cfg.datatype == 1 && h->B >= 128 && h->bt_on && !h->bn && h->fused_launches && !two_streams && !dp_ov &&
+                      h->bt[K_CONV3_DGRAD] >= 0 && h->bt[K_CONV2_DGRAD] >= 0 && h->nw_override[K_CONV3_DGRAD] == 0 && h->nw_override[K_CONV2_DGRAD] == 0;
   if (dp_ov) {
     // data parallel, overlapped: ALL of fc4_wgrad rides the first backward launch, so the 6.4 MB fc4 gradient is
     // complete two launches before the step ends; its all-reduce and its optimizer update run on g_comm
@@ -1075,6 +1081,14 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
     LAUNCH(K_BWD2, launch_tuned(h, K_BWD2, b2, g_stream));
     BN_BWD(0);
     LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream, 0, c1w ? 8 : 0));
+  } else
+  if (h16_bt) {
+    StepArgs w = a; w.f4w_first = 0; w.f4w_count = (NIN4 / 32) * (NFC / 32);
+    StepArgs b1 = a; b1.f4w_count = 0; b1.xcd_map |= 2;
+    LAUNCH(K_CONV3_DGRAD, launch_tuned(h, K_CONV3_DGRAD, a, g_stream));
+    LAUNCH(K_CONV2_DGRAD, launch_tuned(h, K_CONV2_DGRAD, a, g_stream));
+    LAUNCH(K_WGRADS, launch_tuned(h, K_WGRADS, w, g_stream));
+    LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream));
   } else
   if (h->fused_launches && !two_streams) {
     // fc4 wgrad (1568 tiles at B <= 32) is spread over the three backward launches as background traffic;

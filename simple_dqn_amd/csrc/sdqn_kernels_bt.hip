@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include "gemm_engine_bt.h"
 #include "problems_wt.h"
+#include "problems_h16.h"
 #include "kernels.h"
 
 namespace sdqn {
@@ -291,12 +292,37 @@ static hipError_t launch_c1w_bt(const StepArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- float16 mode, B >= 128: forward / dgrad launches on the half block-tile routine (menu per kernel id like the fp32 one) ---------------
+#define BTH(P, BM, BN, WM, WN, D) BtCfgH<P, BM, BN, WM, WN, D>
+#define BTH_CASE(N, P, BM, BN, WM, WN, D) case N: return launch_bt_h<BTH(P, BM, BN, WM, WN, D)>(a, s)
+static hipError_t launch_single_h(int id, int menu, const StepArgs& a, hipStream_t s) {
+  switch (id) {
+    // (conv1 forward gathers bytes and converts per lane: 19.4 us here against 17.7 on the register-blocked routine -> only on request)
+    case K_CONV1_FWD: switch (menu) { BTH_CASE(1, Conv1FwdH, 128, 32, 4, 1, 2); BTH_CASE(2, Conv1FwdH, 256, 32, 4, 1, 2); default: break; } break;
+    case K_CONV2_FWD: switch (menu) { BTH_CASE(0, Conv2FwdH, 64, 64, 2, 2, 2); BTH_CASE(1, Conv2FwdH, 128, 64, 2, 2, 2); BTH_CASE(2, Conv2FwdH, 64, 64, 2, 2, 3); default: break; } break;
+    case K_CONV3_FWD: switch (menu) { BTH_CASE(0, Conv3FwdH, 64, 64, 2, 2, 2); BTH_CASE(1, Conv3FwdH, 128, 64, 2, 2, 2); BTH_CASE(2, Conv3FwdH, 64, 64, 2, 2, 3); default: break; } break;
+    case K_FC4_FWD: switch (menu) { BTH_CASE(0, Fc4FwdH, 64, 64, 2, 2, 2); BTH_CASE(1, Fc4FwdH, 128, 128, 2, 2, 2); BTH_CASE(2, Fc4FwdH, 64, 128, 2, 2, 2); default: break; } break;
+    case K_FC4_DGRAD: switch (menu) { BTH_CASE(0, Fc4DgradH, 64, 64, 2, 2, 2); BTH_CASE(1, Fc4DgradH, 128, 128, 2, 2, 2); BTH_CASE(2, Fc4DgradH, 64, 128, 2, 2, 2); default: break; } break;
+    case K_CONV3_DGRAD: switch (menu) { BTH_CASE(0, Conv3DgradH, 64, 64, 2, 2, 2); BTH_CASE(1, Conv3DgradH, 128, 64, 2, 2, 2); BTH_CASE(2, Conv3DgradH, 64, 64, 2, 2, 3); default: break; } break;
+    case K_CONV2_DGRAD: switch (menu) { BTH_CASE(0, Conv2DgradH, 128, 32, 4, 1, 2); BTH_CASE(1, Conv2DgradH, 256, 32, 4, 1, 2); BTH_CASE(2, Conv2DgradH, 128, 32, 4, 1, 3); default: break; } break;
+    default: break;
+  }
+  return hipErrorInvalidValue;
+}
+
 // every K range of the launch must be whole chunks for the x-contiguous loaders' zero fill to be the only tail handling — it is
 // (the loaders mask any k >= kend), so the routine takes every B >= 128; what it does not take: fp16 mode, batch-norm (raw outputs)
 hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = false;
-  if (a.B < 128 || a.h16 || a.bn || t.hoist || t.order) return hipSuccess;
+  if (a.B < 128 || a.bn || t.hoist || t.order) return hipSuccess;
   if (id < 0 || id >= K_COUNT || t.bt[id] < 0) return hipSuccess;
+  if (a.h16) {                             // float16 mode: the forward launches and fc4_dgrad (the fused backward launches stay on the wave-tile routines)
+    if (id >= 12 || t.nw_override[id] > 0 || t.rb[id] > 0) return hipSuccess;
+    const hipError_t eh = launch_single_h(id, t.bt[id], a, s);
+    if (eh == hipErrorInvalidValue) return hipSuccess;
+    *handled = true;
+    return eh;
+  }
   // fc4 forward / dgrad have 64 / 196 blocks of 64 x 64 — one or two per CU, nothing to overlap their waits with — and measured slower
   // here than on the latency engine (fc4_fwd 23.4 vs 18.7 us, fc4_dgrad 17.0 vs 15.2 at B = 256): block-tile only on request (menu entry > 0)
   if ((id == K_FC4_FWD || id == K_FC4_DGRAD) && t.bt[id] == 0) return hipSuccess;
