@@ -80,6 +80,8 @@ struct UpdateArgs {
   half_t* wh;                   // fp16 mode: half copies of theta refreshed by the update (master layout / transposed)
   half_t* wht;
   unsigned short* w1p;          // conv1's three bf16 planes of the ONLINE net, rewritten with W1 (nullptr: not maintained)
+  unsigned short* wpm;          // round 4: bf16 planes of conv2 / conv3 / fc4 weights, master layout (nullptr: not maintained — B < 128)
+  unsigned short* wpt;          //          ... conv2 / conv3 transposed ([n][K])
   int wt;                       // 1: the new parameters / optimizer state leave with write-through (sc1) stores
   unsigned* w1_ctr;             // fused update + conv1 launch only: counts the W1 blocks whose write-through stores are out (monotonic across launches)
   int64_t bn_first;             // --batch_norm: element offset of the [beta|gamma] block (bn_update_kernel); BN_PARAMS elements
@@ -169,5 +171,6 @@ hipError_t launch_head_f4d(const StepArgs& a, const HeadArgs& h, unsigned* ctr, 
 #endif
 hipError_t launch_w1_planes(const float* theta, unsigned short* w1p, hipStream_t s);   // conv1's three bf16 weight planes of one net (problems.h: split_bf16x3)
 hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s);   // fp16 mode: rebuild both half copies
+hipError_t launch_refresh_planes(const float* theta, unsigned short* wpm, unsigned short* wpt, hipStream_t s);   // plane mode: rebuild the bf16 planes of conv2 / conv3 (both layouts) and fc4 (master; wpm may be nullptr: target net)
 
 }  // namespace sdqn

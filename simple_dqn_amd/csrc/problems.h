@@ -121,7 +121,17 @@ struct StepArgs {
   // the fp32 weight exactly, each [32 output maps][256 k] with k contiguous — written by whoever writes W1 (update kernel, set_weights,
   // target sync)
   const unsigned short* w1p[2];
+  // ---- round 4 (appended): bf16 planes of the conv2 / conv3 / fc4 weights for the block-tile engine's plane mode (gemm_engine_bt.h:
+  // bt_tile_xp).  Three planes whose sum is the fp32 weight exactly (split_bf16x3), plane stride XP_PLANE elements, written by whoever
+  // writes the weights (update kernel, fc4_wgrad's fused RMSProp epilogue, set_weights, target sync, DP broadcast):
+  //   wpm    : online net, MASTER layout (same element index as theta): the k-contiguous B operand of the dgrads
+  //   wpt[z] : per net, every layer TRANSPOSED ([n][K], k contiguous: the fp16 mode's wht indexing): the B operand of conv2 / conv3 forward
+  const unsigned short* wpm;
+  const unsigned short* wpt[2];
+  int xp;                   // 0: fp32 MFMA everywhere; 9 / 6: plane mode with 9 / 6 exact partial products per fp32 product
+  int xp_pad_;
 };
+constexpr int XP_PLANE = OFF5;            // elements per weight plane (conv1 .. fc4; fc5 is not a GEMM stage of the engine)
 
 // A9 + A10 in Neon's operation order (the library is built with -ffp-contract=off: one rounding per op)
 // grad / be.bsz (A9), exactly: for a power-of-two divisor (B = 32, 256, ...; R*B under data parallel) the quotient

@@ -154,9 +154,32 @@ struct Fc4WgradBT : Fc4WgradWT {
       rms_step2(w[2], w[3], st[2], st[3], v[4 * g + 2], v[4 * g + 3], a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { stw(a.theta_w, base + epi_row(4 * g + e), w[e]); stw(a.state, base + epi_row(4 * g + e), st[e]); }
+#ifdef SDQN_EXPERIMENTS
+      if (a.wpm) {                                // plane mode: W4's master-layout bf16 planes follow (lanes along n: 64-byte rows per plane)
+        unsigned short* wp = const_cast<unsigned short*>(a.wpm);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint16_t hi, mid, lo; split_bf16x3(w[e], hi, mid, lo);
+          const uint32_t el = (base + epi_row(4 * g + e)) >> 2;
+          wp[el] = hi; wp[XP_PLANE + el] = mid; wp[2 * XP_PLANE + el] = lo;
+        }
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);      // keep the groups apart: hoisting all 32 loads is exactly the register bill this form avoids
     }
   }
+};
+
+// ---- plane mode of the block-tile engine (bt_tile_xp): where a problem's B operand (always a weight matrix here) lives as bf16 planes ----
+template <class P, int OFF, int K> struct XPF : P {       // forward conv: transposed planes [n][K] of net z
+  __device__ static const unsigned short* bp(const StepArgs& a, int z) { return a.wpt[z] + OFF; }
+  __device__ static int bp_col(const StepArgs&, int, int n) { return n * K; }
+  __device__ static int bp_row(const StepArgs&, int, int k) { return k; }
+};
+template <class P, int OFF> struct XPD : P {              // dgrad: master-layout planes, the problem's own k-contiguous B index functions
+  __device__ static const unsigned short* bp(const StepArgs& a, int) { return a.wpm + OFF; }
+  __device__ static int bp_col(const StepArgs& a, int z, int n) { return P::b_col(a, z, n); }
+  __device__ static int bp_row(const StepArgs& a, int z, int k) { return P::b_row(a, z, k); }
 };
 
 }  // namespace sdqn

@@ -481,6 +481,9 @@ struct sdqn_net_s {
   int f4_share[2] = {100, 0};               // % of the fc4-wgrad tiles in bwd3 / bwd2 (rest in bwd1)
   int ns_cap[3] = {1, 1, 1};               // slabs the split-K buffers were allocated for (tuning hook "tps:<layer>")
   int rb[12] = {0};                        // B >= 128: register-blocked routine, menu entry per kernel id (0 = unblocked)
+  // plane mode of the block-tile engine (B >= 128, float32): bf16 planes of the conv2 / conv3 / fc4 weights (problems.h: StepArgs::wpm / wpt),
+  // kept current wherever the weights are written; xp = partial products per fp32 product (9 exact / 6; 0 = fp32 MFMA, no planes used)
+  unsigned short *wpm = nullptr, *wpt[2] = {nullptr, nullptr}; int xp = 0;
   int btx[K_COUNT] = {0};                    // block-tile engine arithmetic per kernel id: 0 fp32 MFMA, 9 / 6 exact bf16x3 operand splits on packed-bf16 MFMA
   bool bt_on = true; int bt[K_COUNT] = {0};  // round 4, B >= 128 float32: block-tile engine (sdqn_kernels_bt.hip); per kernel id 0 = built-in block shape, n = menu entry, -1 = latency engine
   int xcd_mask[K_COUNT] = {0};             // tuning hook "xcd:<kernel id>": per-launch problem mask (-1 = built-in)
@@ -681,6 +684,13 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
     NCHK(dalloc(h, (void**)&h->w1p[0], (size_t)3 * W1P_PLANE * 2));
     if (c->target_enabled) NCHK(dalloc(h, (void**)&h->w1p[1], (size_t)3 * W1P_PLANE * 2)); else h->w1p[1] = h->w1p[0];
   }
+  // plane mode (experiments build only: measured 9 % / 17 % SLOWER than fp32 MFMA with 6 / 9 partial products, tools/exp/README.md)
+  if (EXPERIMENTS && c->datatype == 0 && B >= 128 && !h->bn) {   // its weight planes (3 x bf16 of every conv1..fc4 weight slot: 10 MB each)
+    NCHK(dalloc(h, (void**)&h->wpm, (size_t)3 * XP_PLANE * 2));
+    NCHK(dalloc(h, (void**)&h->wpt[0], (size_t)3 * XP_PLANE * 2));
+    if (c->target_enabled) NCHK(dalloc(h, (void**)&h->wpt[1], (size_t)3 * XP_PLANE * 2)); else h->wpt[1] = h->wpt[0];
+    h->xp = 0;                                                    // (option bt_planes = 6 / 9 turns it on)
+  }
   NCHK(dalloc(h, (void**)&h->d_idx, (size_t)B * 8));
   NCHK(dalloc(h, (void**)&h->d_idx_t, (size_t)B * 8));
   { hipError_t e = hipHostMalloc((void**)&h->h_f, (size_t)(2 * B * MAX_ACTIONS + B + 64) * 8, hipHostMallocMapped);
@@ -780,6 +790,12 @@ extern "C" int sdqn_net_set_weights(sdqn_net_t h, int which, int layer, const fl
   if (h->cfg.datatype == 1 && which <= 1) {      // fp16 mode: the half copies follow the master weights
     const int zz = (which == 1 && h->theta_t != h->theta) ? 1 : 0;
     HIPCHK(launch_refresh16(zz ? h->theta_t : h->theta, h->wh[zz], h->wht[zz], g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+  }
+  if (h->wpm && which <= 1 && layer >= 1 && layer <= 3) {   // plane mode: the bf16 planes of conv2 / conv3 / fc4 follow the weights
+    const int zz = (which == 1 && h->theta_t != h->theta) ? 1 : 0;
+    HIPCHK(launch_refresh_planes(zz ? h->theta_t : h->theta, zz ? nullptr : h->wpm, h->wpt[zz], g_stream));
+    if (!zz && h->theta_t == h->theta) {}        // (no target net: wpt[1] aliases wpt[0])
     HIPCHK(hipStreamSynchronize(g_stream));
   }
   if (h->w1p[0] && which <= 1 && layer == 0) {   // conv1's bf16 planes follow W1
@@ -895,6 +911,7 @@ static StepArgs step_args(sdqn_net_s* h) {
   }
   a.f4w_first = 0; a.f4w_count = (NIN4 / 32) * (NFC / 32);
   a.w1p[0] = h->w1p[0]; a.w1p[1] = h->w1p[1];
+  a.wpm = h->wpm; a.wpt[0] = h->wpt[0]; a.wpt[1] = h->wpt[1]; a.xp = (h->wpm && h->bt_on) ? h->xp : 0;
   a.f4d_flags = h->f4d_flags; a.f4d_epoch = (unsigned)(h->train_iterations + 1);      // (never 0; one train step per value)
   a.fuse_rms = (!h->comm && !h->keep_grads && !h->grad_only && h->cfg.optimizer == 0) ? 1 : 0;
   a.theta_w = h->theta; a.state = h->state; a.bsz = (float)h->B;
@@ -1010,6 +1027,7 @@ static UpdateArgs make_update_args(sdqn_net_s* h, const StepArgs& a) {
   u.opt = h->cfg.optimizer; u.state2 = h->state2;
   if (h->cfg.datatype == 1) { u.wh = h->wh[0]; u.wht = h->wht[0]; }
   u.w1p = h->w1p[0];
+  u.wpm = h->wpm; u.wpt = h->wpt[0];
   u.wt = (h->wt >> 8) & 1;
   u.bn_first = h->bn ? h->NPW : 0;
   if (u.opt == 1) {            // Neon Adam [neon-recalled]: t = epoch + 1, l = lr*sqrt(1-b2^t)/(1-b1^t), math in Python floats
@@ -1528,6 +1546,9 @@ extern "C" int sdqn_net_update_target(sdqn_net_t h) {
     HIPCHK(hipMemcpyAsync(h->theta_t, h->theta, (size_t)h->NP * 4, hipMemcpyDeviceToDevice, g_stream));   // deepqnetwork.py:102-105
     if (h->w1p[0] && h->w1p[1] != h->w1p[0])
       HIPCHK(hipMemcpyAsync(h->w1p[1], h->w1p[0], (size_t)3 * W1P_PLANE * 2, hipMemcpyDeviceToDevice, g_stream));
+    if (h->wpt[0] && h->wpt[1] != h->wpt[0])     // (the transposed conv planes of the three planes only: [OFF2, OFF4) of each)
+      for (int q = 0; q < 3; ++q)
+        HIPCHK(hipMemcpyAsync(h->wpt[1] + (size_t)q * XP_PLANE + OFF2, h->wpt[0] + (size_t)q * XP_PLANE + OFF2, (size_t)(OFF4 - OFF2) * 2, hipMemcpyDeviceToDevice, g_stream));
     if (h->cfg.datatype == 1) {
       HIPCHK(hipMemcpyAsync(h->wh[1], h->wh[0], (size_t)OFF5 * 2, hipMemcpyDeviceToDevice, g_stream));
       HIPCHK(hipMemcpyAsync(h->wht[1], h->wht[0], (size_t)OFF5 * 2, hipMemcpyDeviceToDevice, g_stream));
@@ -1702,6 +1723,12 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
     h->rb[id] = value;
   }
   else if (!strcmp(name, "bt")) h->bt_on = value != 0;                  // 0: B >= 128 on the latency engine's launch forms (round 3)
+  else if (!strcmp(name, "bt_planes")) {                   // plane mode: 9 / 6 partial products, 0 = fp32 MFMA (B >= 128 float32 networks only)
+    ARGCHK(value == 0 || value == 6 || value == 9, "bt_planes must be 0, 6 or 9");
+    if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name);
+    ARGCHK(value == 0 || h->wpm, "bt_planes needs a float32 network with batch_size >= 128 (no batch_norm)");
+    h->xp = value;
+  }
   else if (!strcmp(name, "bt_x")) {                        // arithmetic of every block-tile launch: 0 fp32 MFMA, 9 / 6 exact bf16x3 splits
     if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name);
     ARGCHK(value == 0 || value == 6 || value == 9 || value == 19 || value == 16, "bt_x must be 0, 6 or 9");
@@ -1805,6 +1832,10 @@ extern "C" int sdqn_dp_init(sdqn_net_t h, const char* rccl_path, const char id[1
     if (h->cfg.datatype == 1) {
       HIPCHK(launch_refresh16(h->theta, h->wh[0], h->wht[0], g_stream));
       if (h->theta_t != h->theta) HIPCHK(launch_refresh16(h->theta_t, h->wh[1], h->wht[1], g_stream));
+    }
+    if (h->wpm) {
+      HIPCHK(launch_refresh_planes(h->theta, h->wpm, h->wpt[0], g_stream));
+      if (h->theta_t != h->theta) HIPCHK(launch_refresh_planes(h->theta_t, nullptr, h->wpt[1], g_stream));
     }
     HIPCHK(hipStreamSynchronize(g_stream));
   }

@@ -292,6 +292,51 @@ static hipError_t launch_c1w_bt(const StepArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- plane mode (StepArgs::xp = 9 / 6): conv2 / conv3 forward, the three dgrads on packed-bf16 MFMA with weight planes ------------------
+// EXPERIMENTS BUILD ONLY.  Exact (9 partial products) it ran the B = 256 step in 262.7 us against 224.5 on fp32 MFMA, with 6 products in
+// 244.9 (one box, alternating runs; tools/exp/README.md): the launches are latency- not MFMA-bound there and the split costs VALU time.
+#ifdef SDQN_EXPERIMENTS
+template <int NP>
+static hipError_t launch_xp(int id, const StepArgs& a, hipStream_t s) {
+  typedef BtCfgXP<XPF<Conv2FwdWT, OFF2, CRS2>, 64, 64, 2, 2, 2, NP> XC2F;
+  typedef BtCfgXP<XPF<Conv3FwdWT, OFF3, CRS3>, 64, 64, 2, 2, 2, NP> XC3F;
+  typedef BtCfgXP<XPD<Fc4DgradWT, OFF4>, 64, 64, 2, 2, 2, NP> XF4D;
+  typedef BtCfgXP<XPD<Conv3DgradWT, OFF3>, 64, 64, 2, 2, 2, NP> XC3D;
+  typedef BtCfgXP<XPD<Conv2DgradWT, OFF2>, 128, 32, 4, 1, 2, NP> XC2D;
+  const bool f4 = a.f4w_count > 0;
+  switch (id) {
+    case K_CONV2_FWD: return launch_bt_xp<XC2F>(a, s);
+    case K_CONV3_FWD: return launch_bt_xp<XC3F>(a, s);
+    case K_FC4_DGRAD: return launch_bt_xp<XF4D>(a, s);
+    case K_CONV3_DGRAD: return launch_bt_xp<XC3D>(a, s);
+    case K_CONV2_DGRAD: return launch_bt_xp<XC2D>(a, s);
+    case K_BWD3: return launch_bt_multi<XC3D, C3W, F4W>(a, true, true, f4, s);          // the weight gradients stay on fp32 MFMA (both operands x-contiguous)
+    case K_BWD2: if (!f4) return launch_bt_multi<NOP, C2W, XC2D>(a, false, true, true, s); break;
+    default: break;
+  }
+  return hipErrorInvalidValue;
+}
+
+__global__ void __launch_bounds__(256) refresh_planes_kernel(const float* theta, unsigned short* wpm, unsigned short* wpt) {
+  for (int64_t e = OFF2 + (int64_t)blockIdx.x * 256 + threadIdx.x; e < OFF5; e += (int64_t)gridDim.x * 256) {
+    uint16_t hi, mid, lo; split_bf16x3(theta[e], hi, mid, lo);
+    if (wpm) { wpm[e] = hi; wpm[XP_PLANE + e] = mid; wpm[2 * XP_PLANE + e] = lo; }
+    if (e < OFF4) {
+      const int L = e < OFF3 ? 1 : 2, off = L == 1 ? OFF2 : OFF3, K = L == 1 ? CRS2 : CRS3;
+      const int64_t r = e - off; const int k = (int)(r / 64), n = (int)(r - (int64_t)k * 64);
+      const int64_t t = off + (int64_t)n * K + k;
+      wpt[t] = hi; wpt[XP_PLANE + t] = mid; wpt[2 * XP_PLANE + t] = lo;
+    }
+  }
+}
+hipError_t launch_refresh_planes(const float* theta, unsigned short* wpm, unsigned short* wpt, hipStream_t s) {
+  hipLaunchKernelGGL(refresh_planes_kernel, dim3(1024), dim3(256), 0, s, theta, wpm, wpt);
+  return hipGetLastError();
+}
+#else
+hipError_t launch_refresh_planes(const float*, unsigned short*, unsigned short*, hipStream_t) { return hipErrorInvalidValue; }   // (never called: no planes)
+#endif  // SDQN_EXPERIMENTS
+
 // ---- float16 mode, B >= 128: forward / dgrad launches on the half block-tile routine (menu per kernel id like the fp32 one) ---------------
 #define BTH(P, BM, BN, WM, WN, D) BtCfgH<P, BM, BN, WM, WN, D>
 #define BTH_CASE(N, P, BM, BN, WM, WN, D) case N: return launch_bt_h<BTH(P, BM, BN, WM, WN, D)>(a, s)
@@ -325,9 +370,15 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
   }
   // fc4 forward / dgrad have 64 / 196 blocks of 64 x 64 — one or two per CU, nothing to overlap their waits with — and measured slower
   // here than on the latency engine (fc4_fwd 23.4 vs 18.7 us, fc4_dgrad 17.0 vs 15.2 at B = 256): block-tile only on request (menu entry > 0)
-  if ((id == K_FC4_FWD || id == K_FC4_DGRAD) && t.bt[id] == 0) return hipSuccess;
+  if ((id == K_FC4_FWD || id == K_FC4_DGRAD) && t.bt[id] == 0 && !(id == K_FC4_DGRAD && a.xp && a.wpm)) return hipSuccess;
   if (id < 12 && (t.nw_override[id] > 0 || t.rb[id] > 0)) return hipSuccess;      // explicit latency-engine tuning hooks win
   hipError_t e = hipErrorInvalidValue;
+#ifdef SDQN_EXPERIMENTS
+  if (a.xp && a.wpm && a.wpt[0] && t.bt[id] == 0) {        // plane mode: the stages whose B operand is a weight matrix
+    e = a.xp == 6 ? launch_xp<6>(id, a, s) : launch_xp<9>(id, a, s);
+    if (e != hipErrorInvalidValue) { *handled = true; return e; }
+  }
+#endif
   if ((id == K_BWD1 && a.f4w_count == 0) || id == K_CONV1_WGRAD) {             // conv1's weight gradient: bytes x three bf16 planes of delta1
     e = launch_c1w_bt(a, s);
     if (e == hipErrorInvalidValue) return hipSuccess;

@@ -124,6 +124,61 @@ def test_conv1_weight_gradient_block_tile_bf16(sd, A, B):
     assert _rel(new.get_layer(0, 3), old.get_layer(0, 3)) < 2e-6
 
 
+def _close_but_for_gate_flips(x, y, tol, what):
+    """fp32-class agreement of two buffers downstream of ReLU gates: an activation that is +-1e-8 on the two sides flips its gate and
+    moves the handful of delta elements behind it by their full size — all other elements within tol of max|y|."""
+    d = np.abs(x - y) / max(1e-6, float(np.abs(y).max()))
+    assert float((d > tol).mean()) < 1e-5, (what, float((d > tol).mean()), float(d.max()))
+
+
+@pytest.mark.experiments
+@pytest.mark.parametrize("A,B,np_", [(3, 256, 9), (6, 160, 9), (3, 256, 6)])
+def test_plane_mode_matches_fp32_mfma(sd, A, B, np_):
+    """Plane mode (option bt_planes, experiments build only — measured slower than fp32 MFMA, tools/exp/README.md): the weight operand
+    of conv2 / conv3 forward and the three dgrads as three bf16 planes kept next to the weights, the activation / delta operand split
+    once per workgroup while it is staged — 9 (or 6) exact partial products per fp32 product, fp32 accumulation.  Forward stages within
+    fp32 round-off of the fp32-MFMA result; backward buffers the same except behind a flipped ReLU gate; gradients within 1e-3 rel."""
+    mb = random_minibatch(B, A, 140 + B, reward_range=(-2, 3))
+    ref = _net(sd, A, B, 31, [("keep_gradients", 1)])
+    net = _net(sd, A, B, 31, [("keep_gradients", 1), ("bt_planes", np_)])
+    ref.train(mb); net.train(mb)
+    for name, n in dict(a2=2 * B * 81 * 64, a3=2 * B * 49 * 64).items():
+        assert _rel(net.debug_read(name, n), ref.debug_read(name, n)) < 3e-6, name
+    assert np.abs(net.last_q()[0] - ref.last_q()[0]).max() < 1e-6
+    for name, n in dict(d3p=B * 121 * 64, d2p=B * 121 * 64, d1=B * 400 * 32).items():
+        _close_but_for_gate_flips(net.debug_read(name, n), ref.debug_read(name, n), 3e-6, name)
+    for i in range(5):
+        g, r = net.get_layer(i, 3).astype(np.float64), ref.get_layer(i, 3).astype(np.float64)
+        assert np.linalg.norm(g - r) / max(1e-12, np.linalg.norm(r)) < 1e-3, i
+
+
+@pytest.mark.experiments
+def test_weight_planes_follow_every_writer_of_the_weights(sd):
+    """Plane mode's bf16 planes are written by the update kernel (conv2 / conv3, both layouts), by fc4_wgrad's fused RMSProp epilogue (W4,
+    master layout), by set_weights and by the target sync.  After train steps with a target sync in between, a network built from the
+    trained one's weights through set_weights (which rebuilds every plane from theta) must produce bit-identical Q-values (forward
+    planes of both nets), TD targets and gradients (master-layout planes) — on the fused path and on the materialised-gradient path."""
+    A, B = 3, 256
+    for keep in (0, 1):
+        net = _net(sd, A, B, 41, [("keep_gradients", keep), ("bt_planes", 9)])
+        for s in range(5):
+            net.train(random_minibatch(B, A, 150 + s))
+            if s == 2:
+                net.update_target_network()
+        twin = sd.DeepQNetwork(A, make_args(batch_size=B))
+        twin.set_option("bt_planes", 9)
+        for which in (1, 2, 0):
+            twin.set_weights(net.get_weights(which), which)
+        mb = random_minibatch(B, A, 160)
+        assert np.array_equal(net.predict(mb[0]), twin.predict(mb[0]))
+        for n in (net, twin):
+            n.set_option("keep_gradients", 1)
+            n.train(mb)
+        assert np.array_equal(net.last_q()[0], twin.last_q()[0]) and np.array_equal(net.last_q()[1], twin.last_q()[1])
+        for i in range(5):
+            assert np.array_equal(net.get_layer(i, 3), twin.get_layer(i, 3)), (keep, i)
+
+
 def test_block_tile_other_slab_counts(sd):
     """K-slab choices of the weight gradients and of fc4 forward (options tps:<l>, s4) only regroup the fp32 sums."""
     A, B = 3, 256
