@@ -170,6 +170,10 @@ int sdqn_net_predict_state(sdqn_net_t h, sdqn_statebuf_t s, float* q_out);
  * sdqn_net_predict_state on the same buffer collects without launching anything (dropped if the buffer or the parameters change first). */
 int sdqn_net_act_step(sdqn_net_t h, sdqn_statebuf_t sb, sdqn_replay_t r, const uint8_t* screen, int action, int64_t reward,
                       int terminal, int speculate);
+/* Test / measurement hook of the one-launch acting forward (float32, no batch_norm, standard geometry; option "act_kernel"): one blocking
+ * forward of the buffered state with per-workgroup phase stamps.  q_out float[A], stamps_out uint64[256][80] ({kind, clock} pairs; the last
+ * word of a workgroup's row = its XCC id); either may be NULL. */
+int sdqn_net_debug_act(sdqn_net_t h, sdqn_statebuf_t sb, float* q_out, unsigned long long* stamps_out);
 /* DeepQNetwork.train, deepqnetwork.py:107-172, minibatch given as host arrays.
  * cost_out nullable: NULL -> the step itself is not waited for.  Buffer contract: when the call returns, all five arrays
  * are free to be overwritten — pageable arrays were copied into a pinned double buffer; pre / post that ARE a
@@ -185,6 +189,14 @@ int sdqn_net_train_replay(sdqn_net_t h, sdqn_replay_t r, const int64_t* idx_host
  * the loop body of Agent.train, src/agent.py:108-114 */
 int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t mt[SDQN_MT_WORDS], int n_steps,
                         float* mean_cost /*nullable*/);
+/* The same without waiting for the cost (deepqnetwork.py:168-172 when the stats callback can take the cost later): the stream copies the
+ * call's cost sum into a pinned ring slot; sdqn_net_cost_collect(ticket) polls it (bounded) and returns the mean cost of the call's steps.
+ * A ticket stays valid for 64 further deferred calls. */
+int sdqn_net_train_many_deferred(sdqn_net_t h, sdqn_replay_t r, uint32_t mt[SDQN_MT_WORDS], int n_steps, int64_t* ticket);
+int sdqn_net_cost_collect(sdqn_net_t h, int64_t ticket, float* mean_cost);
+/* 32-bit MT19937 outputs the library has drawn since it was loaded: a caller that handed over a COPY of random.getstate()[1] advances its
+ * own generator by the difference (random.getrandbits(32 * words)) instead of importing the 625 words back */
+int sdqn_mt_words(uint64_t* words);
 /* DeepQNetwork.update_target_network, deepqnetwork.py:102-105 */
 int sdqn_net_update_target(sdqn_net_t h);
 int sdqn_net_sync(sdqn_net_t h);

@@ -20,6 +20,7 @@ enum KernelId {
   K_UPD_CONV1, // round 3: update(i) + conv1_fwd(i + 1) in one launch
   K_HEAD_F4D,  // round 3: head + fc4_dgrad in one launch (the dgrad tiles fetch their W4 panels while the head runs)
   K_WGRADS,    // round 4 (float16, B >= 128): fc4_wgrad (+ fused RMSProp) || conv3_wgrad || conv2_wgrad in one launch, after the block-tile dgrad chain
+  K_ACT,       // round 4: the acting forward (batch of one) as ONE launch (sdqn_act.hip)
   K_COUNT
 };
 const char* kernel_name(int id);
@@ -169,6 +170,24 @@ hipError_t launch_upd_conv1(const UpdateArgs& u, const StepArgs& a, const int64_
 // round 3: head + fc4_dgrad as one launch (sdqn_kernels_r3.hip; B <= 32, A <= 8, fp32, no batch-norm); ctr counts head-block arrivals (monotonic)
 hipError_t launch_head_f4d(const StepArgs& a, const HeadArgs& h, unsigned* ctr, unsigned target, unsigned* timeout, hipStream_t s);
 #endif
+// ---- the acting forward as ONE launch (sdqn_act.hip): float32, standard geometry, no batch-norm ---------------------------------------
+constexpr int ACT_GRID = 256;                     // workgroups of 256 threads (one per CU when the chip is idle; any placement is correct)
+constexpr int ACT_XCC_FLOATS = 21248 + 8 * 32 * 64;  // one XCC's scratch: a1 [400][32] | a2 [81][64] | a3 [49][64] (+ pad) | fc4 partials [8 stripes][32 chunks][64]
+constexpr int ACT_KCH = 32;                       // fc4 K-chunks per stripe of 64 hidden units
+constexpr int ACT_Q_STRIDE = 32;                  // the launch delivers 8 stripe partials of the Q-vector: q[stripe * 32 + action]; the host adds them in stripe order
+constexpr int ACT_CTL_WORDS = 832;                // control block of one launch; 4 rotate (a launch clears the one after next)
+constexpr int ACT_STAMPS = 40;                    // (timing build of the kernel: {kind, clock64} pairs per workgroup)
+struct ActArgs {
+  const uint8_t* state;       // [4][84*84] bytes, oldest frame first (the device state buffer's window)
+  const float* theta;         // online parameters
+  float* scratch;             // [8][ACT_XCC_FLOATS]
+  unsigned* ctl;              // [4][ACT_CTL_WORDS], zero before the first launch
+  float* q;                   // [8][ACT_Q_STRIDE] destination: stripe partials
+  unsigned long long* stamps; // nullptr, or [ACT_GRID][2 * ACT_STAMPS] (tools/exp/act_stamps.py)
+  int A;
+  unsigned seq;               // launch number (selects the control block / partial slot)
+};
+hipError_t launch_act(const ActArgs& a, bool q_system_scope, hipStream_t s);
 hipError_t launch_w1_planes(const float* theta, unsigned short* w1p, hipStream_t s);   // conv1's three bf16 weight planes of one net (problems.h: split_bf16x3)
 hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s);   // fp16 mode: rebuild both half copies
 hipError_t launch_refresh_planes(const float* theta, unsigned short* wpm, unsigned short* wpt, hipStream_t s);   // plane mode: rebuild the bf16 planes of conv2 / conv3 (both layouts) and fc4 (master; wpm may be nullptr: target net)

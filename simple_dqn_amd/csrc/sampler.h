@@ -7,6 +7,10 @@
 
 namespace sdqn {
 
+// 32-bit outputs drawn by this library since it was loaded (host-side, one thread): lets a caller that handed over a COPY of its generator
+// state advance its own generator by exactly the words a call consumed (random.getrandbits(32 * words)) instead of re-importing 625 words
+inline uint64_t& mt_words_drawn() { static uint64_t w = 0; return w; }
+
 struct MT {
   uint32_t* s;   // 624 words + position
   explicit MT(uint32_t* st) : s(st) {}
@@ -54,6 +58,7 @@ struct MT {
       s[624] = 0;
     }
     uint32_t y = mt[s[624]++];
+    ++mt_words_drawn();
     y ^= y >> 11;
     y ^= (y << 7) & 0x9D2C5680u;
     y ^= (y << 15) & 0xEFC60000u;

@@ -33,6 +33,8 @@ static constexpr bool EXPERIMENTS = false;
 #define EXP_OPTION_REFUSED(NAME) do { set_error("option %s is an experiment (measured slower than the default step; tools/exp/README.md): " \
                                                 "build the library with `make -C simple_dqn_amd/csrc experiments` and load it with SDQN_LIB_VARIANT=experiments", NAME); \
                                       return SDQN_ERR_ARG; } while (0)
+static constexpr int Q_SLOT_FLOATS = 8 * ACT_Q_STRIDE;   // one slot: [A] Q-values (head kernel) or 8 stripe partials [8][ACT_Q_STRIDE] (one-launch forward)
+static constexpr int COST_RING = 64;
 static constexpr int Q_SLOTS = 8;       // host-mapped Q-value slots of the acting path (sdqn_net_predict_state)
 static thread_local std::string g_err;
 static void set_error(const char* fmt, ...) {
@@ -464,6 +466,11 @@ struct sdqn_net_s {
   float *q_host = nullptr, *q_host_dev = nullptr;      // Q_SLOTS slots of 32 floats: every enqueued acting forward gets its OWN slot, so a
   int q_slot = 0;                                       // speculation that was dropped (still in flight) cannot write into the slot being polled
   bool head_q_system = false;              // (run_forward: this forward's head writes system-scope)
+  // the acting forward as ONE launch (sdqn_act.hip; float32, no batch-norm): per-XCC scratch copies, fc4 partial slots, control blocks
+  float *act_scratch = nullptr, *act_q = nullptr; unsigned* act_ctl = nullptr; unsigned act_seq = 0;
+  bool act_on = false, act_last = false; int act_fallbacks = 0;     // act_last: the forward being collected came from that launch
+  // deferred cost read-back (sdqn_net_train_many_deferred): pinned ring of cost sums the stream copies into
+  double* cost_ring = nullptr; int cost_steps[64] = {0}; int64_t cost_ticket = 0;
   bool spec_pending = false; const void* spec_sb = nullptr; uint64_t spec_gen = 0;
   uint8_t* h_stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; bool stage_busy[2] = {false, false}; int stage_next = 0;
                                            // tuple API (sdqn_net_train_host): pinned double buffer for the caller's pageable minibatch
@@ -549,6 +556,7 @@ static int net_free(sdqn_net_s* h) {
   for (void* p : h->allocs) hipFree(p);
   hipHostFree(h->h_f);
   if (h->q_host) hipHostFree(h->q_host);
+  if (h->cost_ring) hipHostFree(h->cost_ring);
   for (int i = 0; i < 2; ++i) { if (h->h_stage[i]) hipHostFree(h->h_stage[i]); if (h->stage_ev[i]) hipEventDestroy(h->stage_ev[i]); }
   for (auto& pp : h->prof_pending) { hipEventDestroy(pp.a); hipEventDestroy(pp.b); }
   for (auto e : h->prof_free) hipEventDestroy(e);
@@ -691,10 +699,16 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
     if (c->target_enabled) NCHK(dalloc(h, (void**)&h->wpt[1], (size_t)3 * XP_PLANE * 2)); else h->wpt[1] = h->wpt[0];
     h->xp = 0;                                                    // (option bt_planes = 6 / 9 turns it on)
   }
+  if (c->datatype == 0 && !h->bn) {
+    NCHK(dalloc(h, (void**)&h->act_scratch, (size_t)8 * ACT_XCC_FLOATS * 4));
+    NCHK(dalloc(h, (void**)&h->act_q, (size_t)Q_SLOT_FLOATS * 4));
+    NCHK(dalloc(h, (void**)&h->act_ctl, (size_t)4 * ACT_CTL_WORDS * 4));
+    h->act_on = true;
+  }
   NCHK(dalloc(h, (void**)&h->d_idx, (size_t)B * 8));
   NCHK(dalloc(h, (void**)&h->d_idx_t, (size_t)B * 8));
-  { hipError_t e = hipHostMalloc((void**)&h->h_f, (size_t)(2 * B * MAX_ACTIONS + B + 64) * 8, hipHostMallocMapped);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->q_host, Q_SLOTS * 32 * sizeof(float), hipHostMallocMapped);
+  { hipError_t e = hipHostMalloc((void**)&h->h_f, (size_t)(2 * B * MAX_ACTIONS + B + 64 + Q_SLOT_FLOATS) * 8, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->q_host, Q_SLOTS * Q_SLOT_FLOATS * sizeof(float), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&h->q_host_dev, h->q_host, 0);
     if (e != hipSuccess) { set_error("hipHostMalloc -> %s", hipGetErrorString(e)); net_free(h); return SDQN_ERR_HIP; } }
 #undef NCHK
@@ -1216,10 +1230,35 @@ extern "C" int sdqn_net_predict(sdqn_net_t h, const uint8_t* states, float* q_ou
   return SDQN_OK;
 }
 
+// the one-launch forward's 8 stripe partials [8][ACT_Q_STRIDE] -> Q-values, added in stripe order; false if a stripe never arrived
+static bool act_sum_partials(const float* part, int A, float* q_out) {
+  for (int k = 0; k < A; ++k) {
+    float qv = 0.0f;
+    for (int sp = 0; sp < 8; ++sp) {
+      uint32_t w; memcpy(&w, part + sp * ACT_Q_STRIDE + k, 4);
+      if (w == 0xFFFFFFFFu) return false;
+      qv = sp ? qv + part[sp * ACT_Q_STRIDE + k] : part[sp * ACT_Q_STRIDE + k];
+    }
+    q_out[k] = qv;
+  }
+  return true;
+}
 extern "C" int sdqn_net_predict_one(sdqn_net_t h, const uint8_t* state, float* q_out) {
   ARGCHK(h && state && q_out, "NULL argument");
   if (h->gen) { GENCHK(h->gen->predict_host(state, 1, q_out, false)); return SDQN_OK; }
   HIPCHK(hipMemcpyAsync(h->st_states, state, (size_t)STATE, hipMemcpyHostToDevice, g_stream));
+  if (h->act_on && !h->prof_on) {            // the one-launch forward (sdqn_act.hip): the same kernel predict_state runs, the same numbers
+    ActArgs aa; memset(&aa, 0, sizeof aa);
+    aa.state = h->st_states; aa.theta = h->theta; aa.scratch = h->act_scratch; aa.ctl = h->act_ctl;
+    aa.q = h->act_q; aa.A = h->A; aa.seq = h->act_seq++;
+    HIPCHK(hipMemsetAsync(h->act_q, 0xFF, (size_t)Q_SLOT_FLOATS * 4, g_stream));          // (an abandoned launch leaves NaNs, checked below)
+    LAUNCH(K_ACT, launch_act(aa, false, g_stream));
+    HIPCHK(hipMemcpyAsync(h->h_f, h->act_q, (size_t)Q_SLOT_FLOATS * 4, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    if (act_sum_partials(h->h_f, h->A, q_out)) return SDQN_OK;
+    h->act_on = false; h->act_fallbacks += 1;
+    fprintf(stderr, "simple_dqn_amd: the one-launch acting forward did not complete; using the five-launch forward from now on\n");
+  }
   StepArgs a = step_args(h); a.B = 1; a.nz = 1; a.from_ring = 0; a.src = h->st_states;   // same buffers, batch of one
   HeadArgs hd = head_args(h, 0);
   int rc = run_forward(h, a, hd); if (rc) return rc;
@@ -1310,33 +1349,65 @@ static int predict_state_enqueue(sdqn_net_s* h, sdqn_statebuf_s* sb) {
   // a fresh slot per forward: the stream runs forwards in order, so by the time a slot comes round again (Q_SLOTS forwards later) any
   // dropped speculation that wrote into it has long finished
   h->q_slot = (h->q_slot + 1) % Q_SLOTS;
-  volatile uint32_t* qh = reinterpret_cast<volatile uint32_t*>(h->q_host + h->q_slot * 32);
+  volatile uint32_t* qh = reinterpret_cast<volatile uint32_t*>(h->q_host + h->q_slot * Q_SLOT_FLOATS);
   for (int k = 0; k < h->A; ++k) qh[k] = Q_SENTINEL;
+  h->act_last = false;
+  if (h->act_on && !h->prof_on) {                                // one launch: conv1 .. fc5 (sdqn_act.hip); 8 stripe partials come back
+    for (int sp = 1; sp < 8; ++sp) for (int k = 0; k < h->A; ++k) qh[sp * ACT_Q_STRIDE + k] = Q_SENTINEL;
+    ActArgs aa; memset(&aa, 0, sizeof aa);
+    aa.state = statebuf_window(sb); aa.theta = h->theta; aa.scratch = h->act_scratch; aa.ctl = h->act_ctl;
+    aa.q = h->q_host_dev + h->q_slot * Q_SLOT_FLOATS; aa.A = h->A; aa.seq = h->act_seq++;
+    LAUNCH(K_ACT, launch_act(aa, true, g_stream));
+    h->act_last = true;
+    h->spec_pending = true; h->spec_sb = sb; h->spec_gen = sb->gen;
+    return SDQN_OK;
+  }
   StepArgs a = step_args(h); a.B = 1; a.nz = 1; a.from_ring = 0; a.src = statebuf_window(sb);   // batch of one, read in place
   HeadArgs hd = head_args(h, 0);
   const bool direct = !h->bn;                                    // (--batch_norm: the plain head + a copy, as before)
-  if (direct) hd.q = h->q_host_dev + h->q_slot * 32;
+  if (direct) hd.q = h->q_host_dev + h->q_slot * Q_SLOT_FLOATS;
   h->head_q_system = direct;
   const int rc = run_forward(h, a, hd);
   h->head_q_system = false;
   if (rc) return rc;
-  if (!direct) HIPCHK(hipMemcpyAsync(h->q_host + h->q_slot * 32, h->q, (size_t)h->A * 4, hipMemcpyDeviceToHost, g_stream));
+  if (!direct) HIPCHK(hipMemcpyAsync(h->q_host + h->q_slot * Q_SLOT_FLOATS, h->q, (size_t)h->A * 4, hipMemcpyDeviceToHost, g_stream));
   h->spec_pending = true; h->spec_sb = sb; h->spec_gen = sb->gen;
   return SDQN_OK;
 }
+// SDQN_ACT_TRACE=1: host-side segments of the acting path on stderr every 1000 calls (enqueue = sentinel fill + launch; wait = poll)
+static bool act_trace() { static const bool on = getenv("SDQN_ACT_TRACE") != nullptr; return on; }
+static double g_act_enq_ns = 0, g_act_wait_ns = 0; static long g_act_calls = 0;
 static int predict_state_collect(sdqn_net_s* h, float* q_out) {
-  volatile uint32_t* qh = reinterpret_cast<volatile uint32_t*>(h->q_host + h->q_slot * 32);
-  auto landed = [&]() { for (int k = 0; k < h->A; ++k) if (qh[k] == Q_SENTINEL) return false; return true; };
+  volatile uint32_t* qh = reinterpret_cast<volatile uint32_t*>(h->q_host + h->q_slot * Q_SLOT_FLOATS);
+  const int nparts = h->act_last ? 8 : 1;                       // (one-launch forward: 8 stripe partials, added here in stripe order)
+  auto landed = [&]() { for (int sp = 0; sp < nparts; ++sp) for (int k = 0; k < h->A; ++k) if (qh[sp * ACT_Q_STRIDE + k] == Q_SENTINEL) return false; return true; };
   const auto t0 = std::chrono::steady_clock::now();
   while (!landed()) {
     if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {        // never an unbounded spin
       HIPCHK(hipStreamSynchronize(g_stream));
+      if (!landed() && h->act_last && h->spec_sb) {
+        // the one-launch forward gave up on a hand-off (its polls are bounded): never again in this process — the five-launch forward
+        // of the same state instead, said once on stderr
+        h->act_on = false; h->act_fallbacks += 1;
+        fprintf(stderr, "simple_dqn_amd: the one-launch acting forward did not complete; using the five-launch forward from now on\n");
+        sdqn_statebuf_s* sb = (sdqn_statebuf_s*)h->spec_sb;
+        int rc = predict_state_enqueue(h, sb); if (rc) return rc;
+        return predict_state_collect(h, q_out);
+      }
       if (!landed()) { set_error("predict_state: the head kernel finished without delivering its Q-values"); return SDQN_ERR_STATE; }
       break;
     }
   }
-  for (int k = 0; k < h->A; ++k) { uint32_t w = qh[k]; memcpy(q_out + k, &w, 4); }
+  for (int k = 0; k < h->A; ++k) {
+    float qv = 0.0f;
+    for (int sp = 0; sp < nparts; ++sp) { uint32_t w = qh[sp * ACT_Q_STRIDE + k]; float f; memcpy(&f, &w, 4); qv = sp ? qv + f : f; }
+    q_out[k] = qv;
+  }
   h->spec_pending = false;
+  if (act_trace()) {
+    g_act_wait_ns += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (++g_act_calls % 1000 == 0) { fprintf(stderr, "act trace: enqueue %.2f us, wait %.2f us per call\n", g_act_enq_ns / 1e6, g_act_wait_ns / 1e6); g_act_enq_ns = g_act_wait_ns = 0; }
+  }
   return SDQN_OK;
 }
 extern "C" int sdqn_net_predict_state(sdqn_net_t h, sdqn_statebuf_t sb, float* q_out) {
@@ -1344,7 +1415,11 @@ extern "C" int sdqn_net_predict_state(sdqn_net_t h, sdqn_statebuf_t sb, float* q
   ARGCHK((size_t)sb->hist * sb->frame == (h->gen ? h->gen->state_bytes() : (size_t)STATE), "state buffer geometry differs from the network's");
   if (h->gen) { GENCHK(h->gen->predict_dev(statebuf_window(sb), 1, q_out, false)); return SDQN_OK; }
   // a forward enqueued ahead by sdqn_net_act_step for exactly this state and these parameters: only collect it
-  if (!(h->spec_pending && h->spec_sb == sb && h->spec_gen == sb->gen)) { int rc = predict_state_enqueue(h, sb); if (rc) return rc; }
+  if (!(h->spec_pending && h->spec_sb == sb && h->spec_gen == sb->gen)) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = predict_state_enqueue(h, sb); if (rc) return rc;
+    if (act_trace()) g_act_enq_ns += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  }
   return predict_state_collect(h, q_out);
 }
 // One environment transition in ONE call (agent.py:48-85 + :62: `buf.add(screen)`, optionally `mem.add(action, reward, screen, terminal)`):
@@ -1358,6 +1433,30 @@ extern "C" int sdqn_net_act_step(sdqn_net_t h, sdqn_statebuf_t sb, sdqn_replay_t
   int rc = sdqn_statebuf_add(sb, screen); if (rc) return rc;
   if (r) { rc = sdqn_replay_add(r, action, reward, screen, terminal); if (rc) return rc; }
   if (speculate && !h->gen && (size_t)sb->hist * sb->frame == (size_t)STATE) return predict_state_enqueue(h, sb);
+  return SDQN_OK;
+}
+
+// Test / measurement hook: ONE one-launch acting forward of the buffered state with per-workgroup phase stamps ({kind, clock64} pairs,
+// sdqn_act.hip) — blocking; q_out [A], stamps_out [ACT_GRID][2 * ACT_STAMPS] (either may be NULL).  tools/exp/act_stamps.py reads them.
+extern "C" int sdqn_net_debug_act(sdqn_net_t h, sdqn_statebuf_t sb, float* q_out, unsigned long long* stamps_out) {
+  ARGCHK(h && sb, "NULL argument");
+  ARGCHK(h->act_scratch && (size_t)sb->hist * sb->frame == (size_t)STATE, "the one-launch acting forward needs a float32 network without batch_norm and the standard geometry");
+  const size_t nst = (size_t)ACT_GRID * 2 * ACT_STAMPS;
+  unsigned long long* d_st = nullptr;
+  if (stamps_out) { HIPCHK(hipMalloc((void**)&d_st, nst * 8)); HIPCHK(hipMemsetAsync(d_st, 0, nst * 8, g_stream)); }
+  ActArgs aa; memset(&aa, 0, sizeof aa);
+  aa.state = statebuf_window(sb); aa.theta = h->theta; aa.scratch = h->act_scratch; aa.ctl = h->act_ctl;
+  aa.q = h->act_q; aa.A = h->A; aa.seq = h->act_seq++; aa.stamps = d_st;
+  HIPCHK(hipMemsetAsync(h->act_q, 0xFF, (size_t)Q_SLOT_FLOATS * 4, g_stream));
+  hipError_t e = launch_act(aa, false, g_stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h->h_f, h->act_q, (size_t)Q_SLOT_FLOATS * 4, hipMemcpyDeviceToHost, g_stream);
+  if (e == hipSuccess && stamps_out) e = hipMemcpyAsync(stamps_out, d_st, nst * 8, hipMemcpyDeviceToHost, g_stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+  if (d_st) hipFree(d_st);
+  HIPCHK(e);
+  float qv[MAX_ACTIONS];
+  if (!act_sum_partials(h->h_f, h->A, qv)) { set_error("the one-launch acting forward did not deliver every stripe"); return SDQN_ERR_STATE; }
+  if (q_out) memcpy(q_out, qv, (size_t)h->A * 4);
   return SDQN_OK;
 }
 
@@ -1538,6 +1637,41 @@ extern "C" int sdqn_net_train_many(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, 
   }
   return SDQN_OK;
 }
+// ---- train_many without waiting for the cost (agent.py:108-114 + deepqnetwork.py:168-172 when the callback can take the cost later) ----------
+// The mean cost of the call's steps is copied into a pinned ring slot by the stream itself; sdqn_net_cost_collect polls the slot (bounded).
+// A ticket is valid until COST_RING further deferred calls have been made.
+extern "C" int sdqn_net_train_many_deferred(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, int n_steps, int64_t* ticket) {
+  ARGCHK(h && ticket && n_steps >= 1, "bad arguments");
+  if (!h->cost_ring) HIPCHK(hipHostMalloc((void**)&h->cost_ring, COST_RING * sizeof(double), hipHostMallocDefault));
+  const int slot = (int)(h->cost_ticket % COST_RING);
+  if (h->gen) {
+    float c = 0.0f; int rc = sdqn_net_train_many(h, r, mt, n_steps, &c); if (rc) return rc;
+    h->cost_ring[slot] = (double)c * n_steps;
+  } else {
+    int rc = sdqn_net_train_many(h, r, mt, n_steps, nullptr); if (rc) return rc;
+    uint64_t s1 = ~0ull; memcpy(&h->cost_ring[slot], &s1, 8);                          // sentinel: a NaN no cost sum produces
+    HIPCHK(hipMemcpyAsync(&h->cost_ring[slot], h->cost_accum, 8, hipMemcpyDeviceToHost, g_stream));
+  }
+  h->cost_steps[slot] = n_steps;
+  *ticket = h->cost_ticket++;
+  return SDQN_OK;
+}
+extern "C" int sdqn_net_cost_collect(sdqn_net_t h, int64_t ticket, float* mean_cost) {
+  ARGCHK(h && mean_cost, "NULL argument");
+  ARGCHK(h->cost_ring && ticket >= 0 && ticket < h->cost_ticket && ticket + COST_RING > h->cost_ticket, "stale or unknown cost ticket");
+  const int slot = (int)(ticket % COST_RING);
+  volatile uint64_t* w = reinterpret_cast<volatile uint64_t*>(&h->cost_ring[slot]);
+  const auto t0 = std::chrono::steady_clock::now();
+  while (*w == ~0ull) {
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) { HIPCHK(hipStreamSynchronize(g_stream)); break; }
+  }
+  ARGCHK(*w != ~0ull, "the cost of ticket %lld was never delivered", (long long)ticket);
+  uint64_t bits = *w; double sum; memcpy(&sum, &bits, 8);
+  *mean_cost = (float)(sum / h->cost_steps[slot]);
+  return SDQN_OK;
+}
+extern "C" int sdqn_mt_words(uint64_t* words) { ARGCHK(words, "NULL argument"); *words = mt_words_drawn(); return SDQN_OK; }
+
 extern "C" int sdqn_net_update_target(sdqn_net_t h) {
   ARGCHK(h, "NULL handle");
   if (h->gen) { GENCHK(h->gen->update_target()); return SDQN_OK; }
@@ -1721,6 +1855,10 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
     if (id < 0 || id >= 12 || value < 0 || value > 8) { set_error("bad rb override"); return SDQN_ERR_ARG; }
     if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name);
     h->rb[id] = value;
+  }
+  else if (!strcmp(name, "act_kernel")) {                  // 1: acting forward as one launch (default where available), 0: the five forward launches
+    ARGCHK(value == 0 || h->act_scratch, "act_kernel needs a float32 network without batch_norm");
+    h->act_on = value != 0; h->spec_pending = false;
   }
   else if (!strcmp(name, "bt")) h->bt_on = value != 0;                  // 0: B >= 128 on the latency engine's launch forms (round 3)
   else if (!strcmp(name, "bt_planes")) {                   // plane mode: 9 / 6 partial products, 0 = fp32 MFMA (B >= 128 float32 networks only)

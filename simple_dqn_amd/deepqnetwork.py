@@ -5,6 +5,7 @@ load_weights / save_weights) and attributes (train_iterations, callback, batch_s
 The whole step — target forward, online forward, TD target, clipped error, backward, RMSProp —
 runs in libsdqn_hip.so on the device with zero host round trips (the reference does six, :119-171).
 """
+import array
 import ctypes as C
 import logging
 
@@ -281,28 +282,58 @@ class DeepQNetwork:
         import random
         mem._check_mirror()
         if mt_state is None:
+            # Python's generator state goes in as a copy (array('I') of the 625 words: 6 us; a ctypes slice assignment took 25); afterwards
+            # Python's own generator is advanced by exactly the 32-bit words the library drew — one getrandbits call instead of
+            # rebuilding a 625-tuple and random.setstate (another 40 us per call)
             st = random.getstate()
-            mt = self._mt_buf                                     # persistent buffer + slice copies: 25 us instead of 78 us
-            mt[:] = st[1]                                          # per call for marshalling the 625-word generator state
+            arr = array.array("I", st[1])
+            mt = (C.c_uint32 * _lib.MT_WORDS).from_buffer(arr)
+            w0 = C.c_uint64(); self._lib.sdqn_mt_words(C.byref(w0))
         else:
             mt = mt_state
+
+        def resync():
+            if mt_state is None:
+                w1 = C.c_uint64(); self._lib.sdqn_mt_words(C.byref(w1))
+                n = w1.value - w0.value
+                if n:
+                    random.getrandbits(32 * n)                     # ceil(k / 32) genrand_uint32 calls: the same n words (Modules/_randommodule.c)
+
         want = (self.callback is not None) if want_cost is None else want_cost
         cost = C.c_float()
         if self.callback is not None and n_steps > 1:
             # the reference reports every step to the callback (deepqnetwork.py:168-172: train_iterations, then
             # on_train(cost)): step by step, so Statistics' running mean sees the same sequence; no callback -> one call
             total = 0.0
-            for _ in range(int(n_steps)):
-                _lib.check(self._lib.sdqn_net_train_many(self._h, mem._h, mt, 1, C.byref(cost)))
-                self.train_iterations += 1
-                self.callback.on_train(cost.value)
-                total += cost.value
-            if mt_state is None:
-                random.setstate((st[0], tuple(mt[:]), st[2]))
+            try:
+                for _ in range(int(n_steps)):
+                    _lib.check(self._lib.sdqn_net_train_many(self._h, mem._h, mt, 1, C.byref(cost)))
+                    self.train_iterations += 1
+                    self.callback.on_train(cost.value)
+                    total += cost.value
+            finally:
+                resync()
             return total / n_steps if want else None
-        _lib.check(self._lib.sdqn_net_train_many(self._h, mem._h, mt, int(n_steps), C.byref(cost) if want else None))
-        if mt_state is None:
-            random.setstate((st[0], tuple(mt[:]), st[2]))
+        if self.callback is not None and n_steps == 1 and want_cost is None and hasattr(self.callback, "on_train_deferred"):
+            # the callback can take the cost later: enqueue the step, hand it a collector (deepqnetwork.py:168-172, order kept)
+            ticket = C.c_int64()
+            try:
+                _lib.check(self._lib.sdqn_net_train_many_deferred(self._h, mem._h, mt, 1, C.byref(ticket)))
+            finally:
+                resync()
+            self.train_iterations += 1
+            tk = ticket.value
+
+            def collect(tk=tk):
+                c = C.c_float()
+                _lib.check(self._lib.sdqn_net_cost_collect(self._h, tk, C.byref(c)))
+                return c.value
+            self.callback.on_train_deferred(collect, self.train_iterations)
+            return None
+        try:
+            _lib.check(self._lib.sdqn_net_train_many(self._h, mem._h, mt, int(n_steps), C.byref(cost) if want else None))
+        finally:
+            resync()
         self.train_iterations += n_steps
         if self.callback and n_steps:
             self.callback.on_train(cost.value)

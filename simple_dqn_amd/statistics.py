@@ -86,10 +86,13 @@ class Statistics:
     # the tally's fields are part of the reference's public surface (st.num_games, st.average_cost, ...)
     def __getattr__(self, name):
         if name in _TALLY_FIELDS:
+            if name == "average_cost" and self.__dict__.get("_pending"):
+                self._resolve_pending()
             return getattr(self.__dict__["_tally"], name)
         raise AttributeError(name)
 
     def reset(self):
+        self._resolve_pending()                                         # (costs of the phase that ends belong to its tally)
         self._tally = _PhaseTally()
         self.epoch_start_time = self._tally.began
 
@@ -97,8 +100,28 @@ class Statistics:
         self._tally.step(reward, terminal, exploration_rate)
 
     def on_train(self, cost):
+        self._resolve_pending()
         t = self._tally
         t.average_cost += (cost - t.average_cost) / self.net.train_iterations
+
+    # Deferred form of on_train (simple_dqn_amd.DeepQNetwork.train_from_memory offers it to callbacks that have this method): the train
+    # step has been ENQUEUED, its cost is collected later — when the next one is announced, or when average_cost is read / the phase
+    # ends.  The running mean is updated with exactly the (cost, train_iterations) pairs and in exactly the order the immediate form
+    # would have used (statistics.py:70-71 of the reference), so the tally is bit-identical; the host just no longer waits 65 us for
+    # the GPU after every fourth environment step.
+    def on_train_deferred(self, collect, train_iterations):
+        self._resolve_pending()
+        self._pending.append((collect, train_iterations))
+
+    def _resolve_pending(self):
+        pend = self.__dict__.get("_pending")
+        if pend is None:
+            self._pending = []
+            return
+        while pend:
+            collect, iters = pend.pop(0)
+            t = self._tally
+            t.average_cost += (collect() - t.average_cost) / iters
 
     def _mean_max_q(self):
         if self.validation_states is None:

@@ -66,6 +66,30 @@ def test_native_sampler_matches_reference_kats(golden_dir):
             assert idx.tolist() == call["indexes"] and draws.value == call["draws"]
 
 
+def test_generator_resync_by_words_drawn():
+    """train_from_memory hands the library a COPY of random.getstate()[1] and afterwards advances Python's own generator by the number
+    of 32-bit words the library drew (sdqn_mt_words): random.getrandbits(32 * n) consumes exactly n words (ceil(k / 32) genrand_uint32
+    calls), so Python's state equals the library's copy — for ring sizes below and above 2^32 / with rejections, across a twist."""
+    import array
+    lib = sd.load()
+    term = np.zeros(50000, np.uint8); term[::97] = 1
+    idx = np.empty(32, np.int64)
+    random.seed(77)
+    for rep in range(60):
+        random.random(); random.randrange(6)                         # the agent's own draws in between (agent.py:50-51)
+        st = random.getstate()
+        arr = array.array("I", st[1])
+        mt = (C.c_uint32 * 625).from_buffer(arr)
+        w0, w1 = C.c_uint64(), C.c_uint64()
+        _lib.check(lib.sdqn_mt_words(C.byref(w0)))
+        _lib.check(lib.sdqn_sample_indices(mt, _lib.ptr(term, C.c_uint8), 50000 - rep, 1234, 4, 32, _lib.ptr(idx, C.c_int64), None))
+        _lib.check(lib.sdqn_mt_words(C.byref(w1)))
+        n = w1.value - w0.value
+        assert n >= 32
+        random.getrandbits(32 * n)
+        assert random.getstate()[1] == tuple(arr)
+
+
 def test_sampler_preconditions():
     lib = sd.load()
     mt = (C.c_uint32 * 625)()
