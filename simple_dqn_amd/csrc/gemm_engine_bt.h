@@ -680,6 +680,167 @@ inline hipError_t launch_bt_h(const StepArgs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// ---- the float16 mode's WEIGHT GRADIENTS (problems_h16.h: *WgradH): G[m][n] = sum_k A[k][m] * D[k][n], both operands k-major halves ------
+// (k = sample / output position: the long axis; a row of A is the im2col patch of one position, contiguous along m in runs of >= 32).
+// Packed-fp16 MFMA wants 8 consecutive k per lane for BOTH operands — a transpose of what memory holds.  The wave-tile routine
+// (gemm_tile_hw) transposes every 32 x 32 tile through wave-private LDS with 2-byte accesses; here a workgroup stages ONE k-major image
+// [64 k][BM] / [64 k][BN] per chunk with 16-byte loads and stores exactly as memory has it, and the fragments come out of LDS through
+// gfx950's transpose read: ds_read_b64_tr_b16 hands lane 16 g + t the 4 halves in[16 g + 4 j + (t >> 2)][t & 3], j = 0..3, of the
+// 8-byte pieces the 16 lanes of its group address (tools/exp/tr16_probe.hip) — lanes 4 j .. 4 j + 3 point at the four 4-column pieces
+// of k-row j, and lane t receives column t of a [4 k][16] block: 4 consecutive k of ONE m.  Two reads = the 8-k fragment of a
+// v_mfma_f32_32x32x16_f16.  Row pitch BM + 16 halves: the four 32-byte row pieces a 16-lane group touches fall in disjoint banks.
+template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 4>
+struct BtCfgHW {
+  typedef P_ P;
+  static constexpr int KIND = 3;                        // bt_run_tile: bt_tile_hw
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = 64, D = D_;     // D chunks of global loads in flight per thread
+  static constexpr int SM = BM / (32 * WM), SN = BN / (32 * WN);
+  static_assert(WM * WN * 64 == bt::NT && SM >= 1 && SN >= 1 && SM * 32 * WM == BM && SN * 32 * WN == BN, "block = 4 waves x sub-tiles of 32 x 32");
+  static_assert(!P::A_K && !P::B_K && sizeof(typename a_elem<P>::type) == 2 && sizeof(typename b_elem<P>::type) == 2, "a *WgradH problem: k-major half operands");
+  static constexpr int PITA = BM + 16, PITB = BN + 16;                // halves
+  static constexpr int AH = BK * PITA, BH = BK * PITB, STAGE = AH + BH;
+  static constexpr int LDS = 2 * STAGE / 2;             // floats: double-buffered
+  static constexpr int IA = BK * (BM / 8) / bt::NT, IB = BK * (BN / 8) / bt::NT;     // 16-byte pieces per thread and chunk
+  static_assert(IA * bt::NT == BK * (BM / 8) && IB * bt::NT == BK * (BN / 8), "whole pieces per thread");
+};
+
+typedef __fp16 bt_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ half8 bt_tr_frag(const half_t* p0, const half_t* p1) {      // two transpose reads -> the 8 consecutive k of one lane
+  const bt_fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) bt_fp16x4*)p0);
+  const bt_fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) bt_fp16x4*)p1);
+  half8 f;
+  f[0] = (half_t)lo[0]; f[1] = (half_t)lo[1]; f[2] = (half_t)lo[2]; f[3] = (half_t)lo[3];
+  f[4] = (half_t)hi[0]; f[5] = (half_t)hi[1]; f[6] = (half_t)hi[2]; f[7] = (half_t)hi[3];
+  return f;
+}
+
+template <class C>
+__device__ __forceinline__ void bt_tile_hw(const StepArgs& a, int bx, int by, int bz, float* smem_f) {
+  typedef typename C::P P;
+  typedef typename P::aoff_t aoff_t;
+  constexpr int BM = C::BM, BN = C::BN, SM = C::SM, SN = C::SN, WN = C::WN, BK = C::BK, IA = C::IA, IB = C::IB, D = C::D;
+  half_t* smem = reinterpret_cast<half_t*>(smem_f);
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int m0 = bx * BM, n0 = by * BN;
+  int z, ks, kbeg, kend;
+  P::ksplit(a, bz, z, ks, kbeg, kend);
+  const int M = P::M(a), N = P::N(a);
+  const half_t* abase = P::a_ptr(a, z);
+  const half_t* bbase = P::b_ptr(a, z);
+  // staging pieces of this thread: piece q = tid + NT * p -> k-row q / (BM / 8), 8 columns from 8 * (q % (BM / 8))
+  aoff_t ag[IA]; int bg[IB]; int ak[IA], bk[IB], alds[IA], blds[IB];
+#pragma unroll
+  for (int p = 0; p < IA; ++p) {
+    const int q = tid + bt::NT * p; ak[p] = q / (BM / 8); const int c8 = 8 * (q - ak[p] * (BM / 8)), m = m0 + c8;
+    ag[p] = P::a_row(a, z, m < M ? m : M - 8); alds[p] = ak[p] * C::PITA + c8;
+  }
+#pragma unroll
+  for (int p = 0; p < IB; ++p) {
+    const int q = tid + bt::NT * p; bk[p] = q / (BN / 8); const int c8 = 8 * (q - bk[p] * (BN / 8)), n = n0 + c8;
+    bg[p] = P::b_col(a, z, n < N ? n : N - 8); blds[p] = bk[p] * C::PITB + c8;
+  }
+  half8 ra[D][IA], rb[D][IB];
+  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto gload = [&](int kc, half8* qa, half8* qb) {
+#pragma unroll
+    for (int p = 0; p < IA; ++p) {
+      const int k = kc + ak[p], kk = k < kend ? k : kbeg;
+      qa[p] = ld_half8(abase + (ag[p] + P::a_col(a, z, kk)));
+      if (k >= kend) qa[p] = zero8;
+    }
+#pragma unroll
+    for (int p = 0; p < IB; ++p) {
+      const int k = kc + bk[p], kk = k < kend ? k : kbeg;
+      qb[p] = ld_half8(bbase + (bg[p] + P::b_row(a, z, kk)));
+      if (k >= kend) qb[p] = zero8;
+    }
+  };
+  auto lds_store = [&](const half8* qa, const half8* qb, half_t* As, half_t* Bs) {
+#pragma unroll
+    for (int p = 0; p < IA; ++p) *reinterpret_cast<half8*>(As + alds[p]) = qa[p];
+#pragma unroll
+    for (int p = 0; p < IB; ++p) *reinterpret_cast<half8*>(Bs + blds[p]) = qb[p];
+  };
+  typename P::Epi epi;
+  constexpr bool EPI = sizeof(typename P::Epi) > 1;
+  if constexpr (EPI) { static_assert(SM == 1 && SN == 1, "one epilogue state per wave"); P::epi_begin(a, m0 + wm * 32, n0 + wn * 32, lane, epi); }
+  f32x16 acc[SM][SN];
+#pragma unroll
+  for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+    for (int sn = 0; sn < SN; ++sn)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[sm][sn][q] = 0.0f;
+  // fragment addresses: 16-lane group G = lane >> 4 covers columns 16 (G & 1) .. + 15 and k 8 (G >> 1) .. + 7 of a step; lane t of the
+  // group points at k-row (t >> 2) (+ 4 for the second read), columns 4 (t & 3) .. + 3
+  const int t = lane & 15, G = lane >> 4;
+  const int frow = 8 * (G >> 1) + (t >> 2), fcol = 16 * (G & 1) + 4 * (t & 3);
+  auto compute = [&](const half_t* As, const half_t* Bs) {
+#pragma unroll
+    for (int st = 0; st < BK / 16; ++st) {
+      half8 fa[SM], fb[SN];
+#pragma unroll
+      for (int sm = 0; sm < SM; ++sm) {
+        const half_t* p = As + (16 * st + frow) * C::PITA + (wm * SM + sm) * 32 + fcol;
+        fa[sm] = bt_tr_frag(p, p + 4 * C::PITA);
+      }
+#pragma unroll
+      for (int sn = 0; sn < SN; ++sn) {
+        const half_t* p = Bs + (16 * st + frow) * C::PITB + (wn * SN + sn) * 32 + fcol;
+        fb[sn] = bt_tr_frag(p, p + 4 * C::PITB);
+      }
+#pragma unroll
+      for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+        for (int sn = 0; sn < SN; ++sn) acc[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sm], fb[sn], acc[sm][sn], 0, 0, 0);
+    }
+  };
+  const int nch = (kend - kbeg + BK - 1) / BK;
+  if (nch > 0) {
+    // every load is issued UNCONDITIONALLY (a chunk index past the end re-reads the last chunk and is never stored): the number of loads
+    // in flight at each LDS store is then a compile-time constant and the compiler waits for exactly the oldest set (vmcnt = 4 (D - 1)),
+    // not for everything — with guarded loads it emitted vmcnt(0) and every iteration paid a full round trip
+    const int klast = kbeg + (nch - 1) * BK;
+    auto chunk_k = [&](int c) { const int k = kbeg + c * BK; return k < klast ? k : klast; };
+#pragma unroll
+    for (int d = 0; d < D; ++d) gload(chunk_k(d), ra[d], rb[d]);
+    lds_store(ra[0], rb[0], smem, smem + C::AH);
+    __syncthreads();
+    for (int c0 = 0; c0 < nch; c0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int c = c0 + d;
+        half_t* cur = smem + (c & 1) * C::STAGE;
+        half_t* nxt = smem + ((c + 1) & 1) * C::STAGE;
+        gload(chunk_k(c + D), ra[d], rb[d]);                                   // (set d held chunk c: in LDS since the last iteration)
+        if (c < nch) compute(cur, cur + C::AH);
+        if (c + 1 < nch) { lds_store(ra[(d + 1) % D], rb[(d + 1) % D], nxt, nxt + C::AH); __syncthreads(); }
+      }
+    }
+  }
+#pragma unroll
+  for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+    for (int sn = 0; sn < SN; ++sn) {
+      const int ms = m0 + (wm * SM + sm) * 32, ns = n0 + (wn * SN + sn) * 32;
+      if (ms >= M || ns >= N) continue;
+      if constexpr (EPI) {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = acc[sm][sn][q];
+        P::store16(a, z, ks, ms, ns, lane, M, N, v, epi);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = ms + bt::acc_row(q, h), n = ns + i;
+          if (m < M && n < N) P::store(a, z, ks, m, n, acc[sm][sn][q]);
+        }
+      }
+    }
+}
+
 // workgroups of problem P at block size BM x BN
 template <class C> inline void bt_grid(const StepArgs& a, int& gx, int& gy, int& gz) {
   typedef typename C::P P;
@@ -710,6 +871,7 @@ __device__ __forceinline__ void bt_run_tile(const StepArgs& a, int bx, int by, i
 #ifdef SDQN_EXPERIMENTS
   if constexpr (C::KIND == 1) bt_tile_xp<C>(a, bx, by, bz, smem); else
 #endif
+  if constexpr (C::KIND == 3) bt_tile_hw<C>(a, bx, by, bz, smem); else
   bt_tile<C>(a, bx, by, bz, smem);
 }
 template <class C0, class C1, class C2>

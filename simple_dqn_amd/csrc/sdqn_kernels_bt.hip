@@ -361,7 +361,18 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
   *handled = false;
   if (a.B < 128 || a.bn || t.hoist || t.order) return hipSuccess;
   if (id < 0 || id >= K_COUNT || t.bt[id] < 0) return hipSuccess;
-  if (a.h16) {                             // float16 mode: the forward launches and fc4_dgrad (the fused backward launches stay on the wave-tile routines)
+  if (a.h16) {                             // float16 mode: forward launches, dgrads, and the weight gradients behind them
+    if (id == K_WGRADS && a.h16 == 2) {    // fc4_wgrad (+ fused RMSProp) || conv3_wgrad || conv2_wgrad: k-major half panels, transpose reads
+      // (2 chunks of loads in flight per thread: 20.5 us at B = 256 against 22.4 / 22.0 with 3 / 4 — the launch is not load-latency bound)
+      typedef BtCfgHW<Fc4WgradH, 64, 64, 2, 2, 2> HF4W;
+      typedef BtCfgHW<Conv3WgradH, 64, 64, 2, 2, 2> HC3W;
+      typedef BtCfgHW<Conv2WgradH, 64, 64, 2, 2, 2> HC2W;
+      *handled = true;
+      if (t.bt[id] == 1) return launch_bt_multi<BtCfgHW<Fc4WgradH, 64, 64, 2, 2, 4>, BtCfgHW<Conv3WgradH, 64, 64, 2, 2, 4>, BtCfgHW<Conv2WgradH, 64, 64, 2, 2, 4>>(a, true, true, true, s);
+      if (t.bt[id] == 2) return launch_bt_multi<BtCfgHW<Fc4WgradH, 64, 64, 2, 2, 3>, BtCfgHW<Conv3WgradH, 64, 64, 2, 2, 3>, BtCfgHW<Conv2WgradH, 64, 64, 2, 2, 3>>(a, true, true, true, s);
+      const int m = t.bt[id];             // (menu 6 / 7 / 8: ONE of the three problems only — timing experiments, incomplete gradients)
+      return launch_bt_multi<HF4W, HC3W, HC2W>(a, m == 0 || m == 6, m == 0 || m == 7, m == 0 || m == 8, s);
+    }
     if (id >= 12 || t.nw_override[id] > 0 || t.rb[id] > 0) return hipSuccess;
     const hipError_t eh = launch_single_h(id, t.bt[id], a, s);
     if (eh == hipErrorInvalidValue) return hipSuccess;

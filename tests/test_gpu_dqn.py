@@ -58,7 +58,7 @@ def test_predict_parity(sd, A, B):
 
 def test_device_state_buffer_matches_reference_semantics(sd):
     """DeviceStateBuffer (last 4 screens resident in HBM) behaves like src/state_buffer.py:3-27, its device
-    window always equals the host state, and predict_state() is bit-identical to predict_one(getState())."""
+    window always equals the host state, and predict_state() is bit-identical to predict_one(getState()) (and to predict() on the five-launch forward)."""
     import ctypes as C
     A, B = 6, 32
     net, _ = _pair(sd, A, B, 71)
@@ -78,13 +78,20 @@ def test_device_state_buffer_matches_reference_semantics(sd):
         assert np.array_equal(win, ref.getState()), i
         q_dev = net.predict_state(dev)
         assert np.array_equal(q_dev, net.predict_one(ref.getState()))
-    assert np.array_equal(q_dev, net.predict(ref.getStateMinibatch())[0])
+    # (the acting forward is its own one-launch kernel since round 4, sdqn_act.hip: the same fp32 sums in another order than the batched
+    #  forward of predict() — equal to fp32 round-off; with option act_kernel = 0 it IS the batched kernels at B = 1 and equal bit for bit)
+    q_b = net.predict(ref.getStateMinibatch())[0]
+    assert np.abs(q_dev - q_b).max() <= 2e-6 * max(1e-3, float(np.abs(q_b).max())) + 1e-7
+    net.set_option("act_kernel", 0)
+    assert np.array_equal(net.predict_state(dev), q_b) and np.array_equal(net.predict_one(ref.getState()), q_b)
 
 
 def test_predict_one_equals_padded_batch(sd):
-    """Acting path: predict_one(state) is bit-identical to predict(StateBuffer batch)[0]."""
+    """Acting path on the batched forward kernels (option act_kernel = 0; the default one-launch acting forward has its own tests in
+    tests/test_gpu_act.py): predict_one(state) is bit-identical to predict(StateBuffer batch)[0]."""
     A, B = 6, 32
     net, o = _pair(sd, A, B, 13)
+    net.set_option("act_kernel", 0)
     buf = sd.StateBuffer(make_args(batch_size=B))
     rng = np.random.RandomState(3)
     for _ in range(6):
@@ -321,6 +328,7 @@ def test_conv1_on_bf16_mfma_against_the_fp32_engine(sd, A, B):
     nets = []
     for bf in (1, 0):
         n, o = _pair(sd, A, B, 310)
+        n.set_option("act_kernel", 0)                                 # (predict_one on the batched kernels: what this test compares)
         n.set_option("conv1_bf16", bf)
         nets.append(n)
     n1, n0 = nets
@@ -395,6 +403,7 @@ def test_conv3_36_deep_chunks_against_the_32_deep_routine(sd):
         outs = []
         for c36 in (1, 0):
             n, o = _pair(sd, A, B, 300)
+            n.set_option("act_kernel", 0)
             n.set_option("conv3_c36", c36)
             q = n.predict(mb[0])
             a3 = n.debug_read("a3", B * 49 * 64)
