@@ -19,6 +19,7 @@
 //     split-K slabs, fused RMSProp of W4, write-through variants) as the latency engine.
 // Results differ from gemm_tile's in the last bits only (another partition of the same fp32 sum).
 #pragma once
+#include <type_traits>
 #include "gemm_engine.h"
 #include "bt_map.h"
 
@@ -696,7 +697,7 @@ struct BtCfgHW {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = 64, D = D_;     // D chunks of global loads in flight per thread
   static constexpr int SM = BM / (32 * WM), SN = BN / (32 * WN);
   static_assert(WM * WN * 64 == bt::NT && SM >= 1 && SN >= 1 && SM * 32 * WM == BM && SN * 32 * WN == BN, "block = 4 waves x sub-tiles of 32 x 32");
-  static_assert(!P::A_K && !P::B_K && sizeof(typename a_elem<P>::type) == 2 && sizeof(typename b_elem<P>::type) == 2, "a *WgradH problem: k-major half operands");
+  static_assert(!P::A_K && !P::B_K && (P::A_U8 || sizeof(typename a_elem<P>::type) == 2) && sizeof(typename b_elem<P>::type) == 2, "a *WgradH problem: k-major half operands (conv1: A from the bytes)");
   static constexpr int PITA = BM + 16, PITB = BN + 16;                // halves
   static constexpr int AH = BK * PITA, BH = BK * PITB, STAGE = AH + BH;
   static constexpr int LDS = 2 * STAGE / 2;             // floats: double-buffered
@@ -727,8 +728,27 @@ __device__ __forceinline__ void bt_tile_hw(const StepArgs& a, int bx, int by, in
   int z, ks, kbeg, kend;
   P::ksplit(a, bz, z, ks, kbeg, kend);
   const int M = P::M(a), N = P::N(a);
-  const half_t* abase = P::a_ptr(a, z);
   const half_t* bbase = P::b_ptr(a, z);
+  // A pieces: 8 halves — or, for conv1 (A_U8), the 8 BYTES of a patch row (converted to half(x / 255), as the forward pass does, when the
+  // piece is stored to LDS)
+  struct APiece { half8 v; };
+  struct UPiece { uint32_t lo, hi; };
+  typedef typename std::conditional<P::A_U8, UPiece, APiece>::type piece_t;
+  auto a_fetch = [&](aoff_t off) {
+    piece_t r;
+    if constexpr (P::A_U8) { const uint32_t* q = reinterpret_cast<const uint32_t*>(a.src + off); r.lo = q[0]; r.hi = q[1]; }
+    else r.v = ld_half8(reinterpret_cast<const half_t*>(P::a_ptr(a, z)) + off);
+    return r;
+  };
+  auto a_zero = [&]() { piece_t r; if constexpr (P::A_U8) { r.lo = 0u; r.hi = 0u; } else { r.v = half8{0, 0, 0, 0, 0, 0, 0, 0}; } return r; };
+  auto a_halves = [&](const piece_t& r) {
+    if constexpr (P::A_U8) {
+      half8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = (half_t)norm_u8((r.lo >> (8 * e)) & 255u); o[4 + e] = (half_t)norm_u8((r.hi >> (8 * e)) & 255u); }
+      return o;
+    } else return r.v;
+  };
   // staging pieces of this thread: piece q = tid + NT * p -> k-row q / (BM / 8), 8 columns from 8 * (q % (BM / 8))
   aoff_t ag[IA]; int bg[IB]; int ak[IA], bk[IB], alds[IA], blds[IB];
 #pragma unroll
@@ -741,14 +761,14 @@ __device__ __forceinline__ void bt_tile_hw(const StepArgs& a, int bx, int by, in
     const int q = tid + bt::NT * p; bk[p] = q / (BN / 8); const int c8 = 8 * (q - bk[p] * (BN / 8)), n = n0 + c8;
     bg[p] = P::b_col(a, z, n < N ? n : N - 8); blds[p] = bk[p] * C::PITB + c8;
   }
-  half8 ra[D][IA], rb[D][IB];
+  piece_t ra[D][IA]; half8 rb[D][IB];
   const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto gload = [&](int kc, half8* qa, half8* qb) {
+  auto gload = [&](int kc, piece_t* qa, half8* qb) {
 #pragma unroll
     for (int p = 0; p < IA; ++p) {
       const int k = kc + ak[p], kk = k < kend ? k : kbeg;
-      qa[p] = ld_half8(abase + (ag[p] + P::a_col(a, z, kk)));
-      if (k >= kend) qa[p] = zero8;
+      qa[p] = a_fetch(ag[p] + P::a_col(a, z, kk));
+      if (k >= kend) qa[p] = a_zero();
     }
 #pragma unroll
     for (int p = 0; p < IB; ++p) {
@@ -757,9 +777,9 @@ __device__ __forceinline__ void bt_tile_hw(const StepArgs& a, int bx, int by, in
       if (k >= kend) qb[p] = zero8;
     }
   };
-  auto lds_store = [&](const half8* qa, const half8* qb, half_t* As, half_t* Bs) {
+  auto lds_store = [&](const piece_t* qa, const half8* qb, half_t* As, half_t* Bs) {
 #pragma unroll
-    for (int p = 0; p < IA; ++p) *reinterpret_cast<half8*>(As + alds[p]) = qa[p];
+    for (int p = 0; p < IA; ++p) *reinterpret_cast<half8*>(As + alds[p]) = a_halves(qa[p]);
 #pragma unroll
     for (int p = 0; p < IB; ++p) *reinterpret_cast<half8*>(Bs + blds[p]) = qb[p];
   };

@@ -607,6 +607,8 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
     // conv1's weight gradient (c1w_bt_kernel: one workgroup per slab of whole 80-position chunks, all 256 x 32 outputs): 10 x 32 = 320
     // positions per slab = 4 chunks, 320 workgroups at B = 256
     if (c->datatype == 0 && !h->bn) { h->tps2 = 9; h->tps3 = 14; h->tps1 = 10; }
+    // float16: conv1's weight gradient is one workgroup per slab of whole 80-position chunks too (c1w_h_kernel): 10 x 32 = 320 positions
+    if (c->datatype == 1 && !h->bn) h->tps1 = 10;
     if (h->tps1 > T1) h->tps1 = T1; if (h->tps2 > T2) h->tps2 = T2; if (h->tps3 > T3) h->tps3 = T3;
   }
   // (the register-blocked routine, gemm_engine_rb.h, is available per kernel id through set_option "rb:<id>" / "tps:<l>":

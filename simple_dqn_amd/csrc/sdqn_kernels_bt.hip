@@ -292,6 +292,187 @@ static hipError_t launch_c1w_bt(const StepArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- float16 mode: conv1's weight gradient, one workgroup per K slab of whole 80-position chunks ------------------------------------------
+// Same plan as c1w_bt_kernel (the frame rows a chunk's patches come from are staged ONCE, coalesced; a patch element is never fetched
+// from memory per position) with half operands: the staged rows hold half(x / 255) — the forward pass's conv1 input values — converted
+// when they are stored, delta1 is the half copy as it lies in memory ([k][32 maps]), and both fragments come out of LDS through the
+// transpose read (ds_read_b64_tr_b16: 4 consecutive k of one m / n per read; a lane addresses 4 consecutive kernel columns of ONE
+// position's patch row, which are contiguous in the staged frame row).  One v_mfma_f32_32x32x16_f16 per step and sub-tile.
+struct C1wHArgs { const uint8_t* src; const half_t* d1; float* slab1; const int64_t* idx; int B, from_ring, tps1, Kt; float inv_loss_scale; };
+constexpr int C1H_PITCH = W0 + 4;                   // halves per staged frame row (176 bytes)
+constexpr int C1H_FR = 20 * C1H_PITCH;              // halves per frame: pixel rows 4 y0 .. 4 y0 + 19
+constexpr int C1H_DPITCH = K1 + 16;                 // halves per k row of delta1 (96 bytes)
+constexpr int C1H_STAGE = C0 * C1H_FR + C1W_CH * C1H_DPITCH;      // halves per LDS stage: 7040 + 3840
+typedef unsigned int c1h_u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) c1w_h_kernel(const C1wHArgs c) {
+  __shared__ __attribute__((aligned(16))) half_t smem[2 * C1H_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ks = blockIdx.x, Kt = c.Kt, kb = ks * c.tps1 * 32;
+  int ke = kb + c.tps1 * 32; if (ke > Kt) ke = Kt;
+  const int nch = (ke - kb) / C1W_CH;               // (the host launches this kernel only with slabs of whole chunks)
+  // loader items: frame rows = 4 frames x 20 rows x 21 dwords = 1680 dwords (7 per thread, the last partly), delta = 320 x 16 bytes (2, partly)
+  struct Stg { uint32_t b[7]; c1h_u32x4 d0, d1; };
+  auto gload = [&](int ch, Stg& g) {
+    const int k0 = kb + ch * C1W_CH, n = k0 / PIX1, y0 = (k0 - n * PIX1) / Q1;
+    const int64_t fb = (c.from_ring ? (c.idx[n] - C0) * (int64_t)FRAME : (int64_t)n * STATE) + (int64_t)y0 * (ST1 * W0);     // problems.h: sbase, z = 0
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      int it = tid + 256 * j; if (it > 1679) it = 1679;
+      const int fc = it / 420, q = it - fc * 420;                             // 420 dwords = 20 rows x 84 bytes, contiguous in the frame
+      g.b[j] = *reinterpret_cast<const uint32_t*>(c.src + fb + (int64_t)fc * FRAME + 4 * q);
+    }
+    const c1h_u32x4* dp = reinterpret_cast<const c1h_u32x4*>(c.d1 + (size_t)k0 * K1);
+    g.d0 = dp[tid]; g.d1 = dp[tid + 256 < 320 ? tid + 256 : 319];
+  };
+  auto lds_store = [&](const Stg& g, half_t* st) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int it = tid + 256 * j;
+      if (it < 1680) {
+        const int fc = it / 420, q = it - fc * 420, row = q / 21, col = 4 * (q - row * 21);
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 v; const uint32_t w = g.b[j];
+        v[0] = (half_t)norm_u8(w & 255u); v[1] = (half_t)norm_u8((w >> 8) & 255u); v[2] = (half_t)norm_u8((w >> 16) & 255u); v[3] = (half_t)norm_u8(w >> 24);
+        *reinterpret_cast<h4*>(st + fc * C1H_FR + row * C1H_PITCH + col) = v;
+      }
+    }
+    half_t* dl = st + C0 * C1H_FR;
+    *reinterpret_cast<c1h_u32x4*>(dl + (tid >> 2) * C1H_DPITCH + 8 * (tid & 3)) = g.d0;
+    if (tid + 256 < 320) *reinterpret_cast<c1h_u32x4*>(dl + ((tid + 256) >> 2) * C1H_DPITCH + 8 * (tid & 3)) = g.d1;
+  };
+  f32x16 acc[2];
+#pragma unroll
+  for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[sm][q] = 0.0f;
+  // transpose-read geometry (gemm_engine_bt.h: bt_tile_hw): 16-lane group G covers m / n columns 16 (G & 1) .. + 15 and k 8 (G >> 1) .. + 7 of
+  // a step; lane t of the group addresses k-row (t >> 2) (+ 4: second read), columns 4 (t & 3) .. + 3.  A: m = 64 c + 8 r + s (problems.h:
+  // col1) — the wave is frame c, sub-tile sm holds kernel rows 4 sm .. + 3, a 16-column group two kernel rows, a lane's 4 columns s = 0..3 / 4..7
+  const int t = lane & 15, G = lane >> 4;
+  const int a_m = wave * C1H_FR + (2 * (G & 1) + ((t & 3) >> 1)) * C1H_PITCH + 4 * (t & 1);
+  int a_pos[10];                                    // staged-row offset of position 16 s5 + 8 (G >> 1) + 4 r + (t >> 2) (chunk-invariant)
+#pragma unroll
+  for (int q = 0; q < 10; ++q) { const int pos = 16 * (q >> 1) + 8 * (G >> 1) + 4 * (q & 1) + (t >> 2); a_pos[q] = (pos / Q1) * (ST1 * C1H_PITCH) + (pos % Q1) * ST1; }
+  const int b_lane = (8 * (G >> 1) + (t >> 2)) * C1H_DPITCH + 16 * (G & 1) + 4 * (t & 3);
+  if (nch > 0) {
+    Stg g;
+    gload(0, g);
+    lds_store(g, smem);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+      const half_t* st = smem + (ch & 1) * C1H_STAGE;
+      if (ch + 1 < nch) gload(ch + 1, g);
+      const half_t* pa = st + a_m;
+      const half_t* pd = st + C0 * C1H_FR + b_lane;
+#pragma unroll
+      for (int s5 = 0; s5 < 5; ++s5) {
+        const half8 fb = bt_tr_frag(pd + 16 * s5 * C1H_DPITCH, pd + (16 * s5 + 4) * C1H_DPITCH);
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) {
+          const half8 fa = bt_tr_frag(pa + a_pos[2 * s5] + sm * (4 * C1H_PITCH), pa + a_pos[2 * s5 + 1] + sm * (4 * C1H_PITCH));
+          acc[sm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[sm], 0, 0, 0);
+        }
+      }
+      if (ch + 1 < nch) { lds_store(g, smem + ((ch + 1) & 1) * C1H_STAGE); __syncthreads(); }
+    }
+  }
+  // epilogue: the loss scale divided out (problems_h16.h: Conv1WgradH::store); lanes along the maps: 128-byte rows of the slab
+#pragma unroll
+  for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = 64 * wave + 32 * sm + bt::acc_row(q, h);
+      c.slab1[(int64_t)ks * NW1 + m * K1 + i] = acc[sm][q] * c.inv_loss_scale;
+    }
+}
+
+static hipError_t launch_c1w_h(const StepArgs& a, hipStream_t s) {
+  if ((a.tps1 * 32) % C1W_CH != 0) return hipErrorInvalidValue;       // slabs of whole 80-position chunks only
+  C1wHArgs c; c.src = a.src; c.d1 = a.h_d1; c.slab1 = a.slab1; c.idx = a.idx; c.B = a.B; c.from_ring = a.from_ring; c.tps1 = a.tps1; c.Kt = a.B * PIX1;
+  c.inv_loss_scale = a.inv_loss_scale;
+  SDQN_LAUNCH(c1w_h_kernel, dim3(Conv1Wgrad::nbz(a)), dim3(256), 0, s, c);
+  return hipGetLastError();
+}
+
+// ---- float16 mode: conv1 forward (fused gather + / 255 + conv + Rectlin), one workgroup per (net, sample) --------------------------------
+// The generic half routines fetch every patch row (8 bytes) of every output position straight from memory: 16 divergent loads per lane
+// and 32 x 32 tile, 17.9 us at B = 256 for 3.4 GFLOP and 27 MB.  Here the sample's four frames (28 KB, contiguous in the ring) are read
+// ONCE with coalesced 16-byte loads, converted to half(x / 255) (problems_h16.h: ldh8_u8) into an LDS image [frame][84 rows][88], W1's
+// transposed half copy ([32 maps][256 k]) beside it, and all 400 x 32 outputs come from v_mfma_f32_16x16x32_f16 steps whose A fragment
+// is two 8-byte LDS reads (the 8 consecutive kernel columns of a patch row are contiguous in the image) and whose B fragment is one
+// 16-byte read.  25 row tiles of 16 positions over the 4 waves, both 16-map column tiles per A fragment.
+struct Conv1HArgs { const uint8_t* src; const int64_t* idx; const half_t* wht[2]; half_t* h_a1; int B, from_ring; };
+constexpr int C1F_PITCH = W0 + 4;                    // halves per image row (176 bytes)
+constexpr int C1F_FR = H0 * C1F_PITCH;               // halves per frame
+constexpr int C1F_WPITCH = CRS1 + 8;                 // halves per map row of W1 (528 bytes)
+constexpr int C1F_LDS = C0 * C1F_FR + K1 * C1F_WPITCH;      // 29 568 + 8 448 halves = 76 032 bytes: two workgroups per CU
+typedef _Float16 c1f_h4 __attribute__((ext_vector_type(4)));
+typedef float c1f_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) conv1_h_kernel(const Conv1HArgs c) {
+  __shared__ __attribute__((aligned(16))) half_t smem[C1F_LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int z = blockIdx.x / c.B, n = blockIdx.x - z * c.B;
+  const int64_t fb = c.from_ring ? (c.idx[n] - C0 + z) * (int64_t)FRAME : ((int64_t)z * c.B + n) * (int64_t)STATE;      // problems.h: sbase
+  // ---- stage: 1764 x 16 bytes of frames (7 per thread, the last partly), 1024 x 16 bytes of weights (4 per thread) -------------------------
+  const c1h_u32x4* fp = reinterpret_cast<const c1h_u32x4*>(c.src + fb);
+  const c1h_u32x4* wp = reinterpret_cast<const c1h_u32x4*>(c.wht[z] + OFF1);
+  c1h_u32x4 fv[7], wv[4];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) { const int it = tid + 256 * j; fv[j] = fp[it < STATE / 16 ? it : STATE / 16 - 1]; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wv[j] = wp[tid + 256 * j];
+  half_t* wl = smem + C0 * C1F_FR;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int it = tid + 256 * j, nn = it >> 5, k8 = it & 31; *reinterpret_cast<c1h_u32x4*>(wl + nn * C1F_WPITCH + 8 * k8) = wv[j]; }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int it = tid + 256 * j;
+    if (it < STATE / 16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = 4 * it + e;                    // dword of the state: frame q / 1764, row (q % 1764) / 21, columns 4 (q % 21) .. + 3
+        const int fc = q / (FRAME / 4), r = q - fc * (FRAME / 4), row = r / (W0 / 4), col = 4 * (r - row * (W0 / 4));
+        const uint32_t w = fv[j][e];
+        c1f_h4 v;
+        v[0] = (half_t)norm_u8(w & 255u); v[1] = (half_t)norm_u8((w >> 8) & 255u); v[2] = (half_t)norm_u8((w >> 16) & 255u); v[3] = (half_t)norm_u8(w >> 24);
+        *reinterpret_cast<c1f_h4*>(smem + fc * C1F_FR + row * C1F_PITCH + col) = v;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- compute: lane = (row r = lane & 15 of the 16-position tile, k-group kg = lane >> 4: kernel row 4 (s & 1) + kg of frame s >> 1) -----------
+  const int r = lane & 15, kg = lane >> 4;
+  const half_t* wb0 = wl + r * C1F_WPITCH + 8 * kg;                     // B: map r (and 16 + r), k = 32 s + 8 kg ..
+  for (int rt = wave; rt < PIX1 / 16; rt += 4) {
+    const int pos = 16 * rt + r, p = pos / Q1, q = pos - p * Q1;
+    const half_t* pa = smem + (ST1 * p + kg) * C1F_PITCH + ST1 * q;
+    c1f_f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const half_t* ap = pa + (st >> 1) * C1F_FR + 4 * (st & 1) * C1F_PITCH;
+      const c1f_h4 a_lo = *reinterpret_cast<const c1f_h4*>(ap), a_hi = *reinterpret_cast<const c1f_h4*>(ap + 4);
+      half8 fa; fa[0] = a_lo[0]; fa[1] = a_lo[1]; fa[2] = a_lo[2]; fa[3] = a_lo[3]; fa[4] = a_hi[0]; fa[5] = a_hi[1]; fa[6] = a_hi[2]; fa[7] = a_hi[3];
+      const half8 fb0 = *reinterpret_cast<const half8*>(wb0 + 32 * st), fb1 = *reinterpret_cast<const half8*>(wb0 + 16 * C1F_WPITCH + 32 * st);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb1, acc1, 0, 0, 0);
+    }
+    // C/D map of the 16 x 16 shapes: element e of lane l = (row 4 (l >> 4) + e, column l & 15); Rectlin, half store (Conv1FwdH::store)
+    half_t* out = c.h_a1 + (((int64_t)z * c.B + n) * PIX1 + 16 * rt + 4 * kg) * K1 + r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { out[e * K1] = (half_t)fmaxf(acc0[e], 0.0f); out[e * K1 + 16] = (half_t)fmaxf(acc1[e], 0.0f); }
+  }
+}
+
+static hipError_t launch_conv1_h(const StepArgs& a, hipStream_t s) {
+  Conv1HArgs c; c.src = a.src; c.idx = a.idx; c.wht[0] = a.wht[0]; c.wht[1] = a.wht[1]; c.h_a1 = a.h_a1; c.B = a.B; c.from_ring = a.from_ring;
+  SDQN_LAUNCH(conv1_h_kernel, dim3(a.nz * a.B), dim3(256), 0, s, c);
+  return hipGetLastError();
+}
+
 // ---- plane mode (StepArgs::xp = 9 / 6): conv2 / conv3 forward, the three dgrads on packed-bf16 MFMA with weight planes ------------------
 // EXPERIMENTS BUILD ONLY.  Exact (9 partial products) it ran the B = 256 step in 262.7 us against 224.5 on fp32 MFMA, with 6 products in
 // 244.9 (one box, alternating runs; tools/exp/README.md): the launches are latency- not MFMA-bound there and the split costs VALU time.
@@ -372,6 +553,18 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
       if (t.bt[id] == 2) return launch_bt_multi<BtCfgHW<Fc4WgradH, 64, 64, 2, 2, 3>, BtCfgHW<Conv3WgradH, 64, 64, 2, 2, 3>, BtCfgHW<Conv2WgradH, 64, 64, 2, 2, 3>>(a, true, true, true, s);
       const int m = t.bt[id];             // (menu 6 / 7 / 8: ONE of the three problems only — timing experiments, incomplete gradients)
       return launch_bt_multi<HF4W, HC3W, HC2W>(a, m == 0 || m == 6, m == 0 || m == 7, m == 0 || m == 8, s);
+    }
+    if (id == K_CONV1_FWD && t.bt[id] == 0 && t.nw_override[id] == 0 && t.rb[id] == 0 && a.idx_t == nullptr) {   // one workgroup per (net, sample)
+      *handled = true;
+      return launch_conv1_h(a, s);
+    }
+    if (id == K_BWD1 && a.h16 == 2 && a.f4w_count == 0) {    // conv1's weight gradient: all 256 x 32 outputs of a K slab per workgroup, A from the bytes
+      // (the generic half routine with A from the bytes — BtCfgHW<Conv1WgradH, 256, 32, 4, 1> — fetches 8-byte patch-row pieces straight
+      //  from memory: 16 divergent loads per thread and chunk, 18.9 us at B = 256, no better than the wave-tile routine's 18.7)
+      const hipError_t e1 = launch_c1w_h(a, s);
+      if (e1 == hipErrorInvalidValue) return hipSuccess;
+      *handled = true;
+      return e1;
     }
     if (id >= 12 || t.nw_override[id] > 0 || t.rb[id] > 0) return hipSuccess;
     const hipError_t eh = launch_single_h(id, t.bt[id], a, s);
