@@ -473,6 +473,118 @@ static hipError_t launch_conv1_h(const StepArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- float32 mode: conv1's weight gradient with transpose-read fragments (second form of c1w_bt_kernel) --------------------------------------
+// c1w_bt_kernel builds a lane's A fragment from 8 single-byte LDS reads + conversions and its three B fragments from 24 two-byte reads per
+// step.  Here the staged frame rows hold the bytes as bf16 (exact: a byte is an 8-bit integer) and every fragment is two
+// ds_read_b64_tr_b16 (tools/exp/tr16_probe.hip; the geometry of c1w_h_kernel).  Same products (byte x bf16 plane of delta1, exact), the
+// same three MFMAs per step and sub-tile in the same order, the same epilogue: bit-identical to c1w_bt_kernel.
+constexpr int C1B_STAGE = C0 * C1H_FR + C1W_CH * C1W_DPITCH;        // ushorts per LDS stage: 7040 + 8320
+__global__ void __launch_bounds__(256) c1w_bt2_kernel(const C1wBtArgs c) {
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * C1B_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ks = blockIdx.x, Kt = c.Kt, kb = ks * c.tps1 * 32;
+  int ke = kb + c.tps1 * 32; if (ke > Kt) ke = Kt;
+  const int nch = (ke - kb) / C1W_CH;
+  typedef float c1b_f4 __attribute__((ext_vector_type(4)));
+  struct Stg { uint32_t b[7]; c1b_f4 d0, d1, d2; };
+  auto gload = [&](int ch, Stg& g) {
+    const int k0 = kb + ch * C1W_CH, n = k0 / PIX1, y0 = (k0 - n * PIX1) / Q1;
+    const int64_t fb = (c.from_ring ? (c.idx[n] - C0) * (int64_t)FRAME : (int64_t)n * STATE) + (int64_t)y0 * (ST1 * W0);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      int it = tid + 256 * j; if (it > 1679) it = 1679;
+      const int fc = it / 420, q = it - fc * 420;
+      g.b[j] = *reinterpret_cast<const uint32_t*>(c.src + fb + (int64_t)fc * FRAME + 4 * q);
+    }
+    const c1b_f4* dp = reinterpret_cast<const c1b_f4*>(c.d1 + (size_t)k0 * K1);
+    g.d0 = dp[tid]; g.d1 = dp[tid + 256]; g.d2 = dp[tid + 512 < 640 ? tid + 512 : 639];
+  };
+  auto st_d = [&](unsigned short* dp, int it, const c1b_f4& d) {
+    if (it >= 640) return;
+    const int k = it >> 3, n4 = (it & 7) * 4;
+    uint16_t a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2;
+    split_bf16x3(d.x, a0, a1, a2); split_bf16x3(d.y, b0, b1, b2); split_bf16x3(d.z, c0, c1, c2); split_bf16x3(d.w, e0, e1, e2);
+    auto pk2 = [](uint16_t lo, uint16_t hi) { return (uint32_t)lo | ((uint32_t)hi << 16); };
+    unsigned short* row = dp + k * C1W_DPITCH + n4;
+    *reinterpret_cast<uint2*>(row) = make_uint2(pk2(a0, b0), pk2(c0, e0));
+    *reinterpret_cast<uint2*>(row + K1) = make_uint2(pk2(a1, b1), pk2(c1, e1));
+    *reinterpret_cast<uint2*>(row + 2 * K1) = make_uint2(pk2(a2, b2), pk2(c2, e2));
+  };
+  auto lds_store = [&](const Stg& g, unsigned short* st) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int it = tid + 256 * j;
+      if (it < 1680) {
+        const int fc = it / 420, q = it - fc * 420, row = q / 21, col = 4 * (q - row * 21);
+        const uint32_t w = g.b[j];
+        const uint32_t f0 = __float_as_uint((float)(w & 255u)), f1 = __float_as_uint((float)((w >> 8) & 255u));
+        const uint32_t f2 = __float_as_uint((float)((w >> 16) & 255u)), f3 = __float_as_uint((float)(w >> 24));
+        *reinterpret_cast<uint2*>(st + fc * C1H_FR + row * C1H_PITCH + col) =
+            make_uint2(__builtin_amdgcn_perm(f1, f0, 0x07060302u), __builtin_amdgcn_perm(f3, f2, 0x07060302u));      // bf16 = upper half of the float
+      }
+    }
+    unsigned short* dp = st + C0 * C1H_FR;
+    st_d(dp, tid, g.d0); st_d(dp, tid + 256, g.d1); st_d(dp, tid + 512, g.d2);
+  };
+  f32x16 acc[2];
+#pragma unroll
+  for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[sm][q] = 0.0f;
+  const int t = lane & 15, G = lane >> 4;
+  const int a_m = wave * C1H_FR + (2 * (G & 1) + ((t & 3) >> 1)) * C1H_PITCH + 4 * (t & 1);
+  int a_pos[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) { const int pos = 16 * (q >> 1) + 8 * (G >> 1) + 4 * (q & 1) + (t >> 2); a_pos[q] = (pos / Q1) * (ST1 * C1H_PITCH) + (pos % Q1) * ST1; }
+  const int b_lane = (8 * (G >> 1) + (t >> 2)) * C1W_DPITCH + 16 * (G & 1) + 4 * (t & 3);
+  auto frag = [](const unsigned short* p0, const unsigned short* p1) {
+    const half8 f = bt_tr_frag(reinterpret_cast<const half_t*>(p0), reinterpret_cast<const half_t*>(p1));
+    union { half8 h; c1w_bf16x8 b; } u; u.h = f; return u.b;                   // (bits are bits: the transpose read moves 16-bit elements)
+  };
+  if (nch > 0) {
+    Stg g;
+    gload(0, g);
+    lds_store(g, smem);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+      const unsigned short* st = smem + (ch & 1) * C1B_STAGE;
+      if (ch + 1 < nch) gload(ch + 1, g);
+      const unsigned short* pa = st + a_m;
+      const unsigned short* pd = st + C0 * C1H_FR + b_lane;
+#pragma unroll
+      for (int s5 = 0; s5 < 5; ++s5) {
+        const unsigned short* pk = pd + 16 * s5 * C1W_DPITCH;
+        const c1w_bf16x8 B0 = frag(pk, pk + 4 * C1W_DPITCH), B1 = frag(pk + K1, pk + K1 + 4 * C1W_DPITCH), B2 = frag(pk + 2 * K1, pk + 2 * K1 + 4 * C1W_DPITCH);
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) {
+          const c1w_bf16x8 A = frag(pa + a_pos[2 * s5] + sm * (4 * C1H_PITCH), pa + a_pos[2 * s5 + 1] + sm * (4 * C1H_PITCH));
+          acc[sm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B2, acc[sm], 0, 0, 0);     // small planes first (as c1w_bt_kernel)
+          acc[sm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B1, acc[sm], 0, 0, 0);
+          acc[sm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B0, acc[sm], 0, 0, 0);
+        }
+      }
+      if (ch + 1 < nch) { lds_store(g, smem + ((ch + 1) & 1) * C1B_STAGE); __syncthreads(); }
+    }
+  }
+  const float r255 = 1.0f / 255.0f;
+#pragma unroll
+  for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = 64 * wave + 32 * sm + bt::acc_row(q, h);
+      const float sv = acc[sm][q], qv = sv * r255;
+      wt_store(c.slab1 + (int64_t)ks * NW1 + m * K1 + i, fmaf(fmaf(-qv, 255.0f, sv), r255, qv));
+    }
+}
+
+static hipError_t launch_c1w_bt2(const StepArgs& a, hipStream_t s) {
+  if ((a.tps1 * 32) % C1W_CH != 0) return hipErrorInvalidValue;
+  C1wBtArgs c; c.src = a.src; c.d1 = a.d1; c.slab1 = a.slab1; c.idx = a.idx; c.B = a.B; c.from_ring = a.from_ring; c.tps1 = a.tps1; c.Kt = a.B * PIX1;
+  SDQN_LAUNCH(c1w_bt2_kernel, dim3(Conv1Wgrad::nbz(a)), dim3(256), 0, s, c);
+  return hipGetLastError();
+}
+
 // ---- plane mode (StepArgs::xp = 9 / 6): conv2 / conv3 forward, the three dgrads on packed-bf16 MFMA with weight planes ------------------
 // EXPERIMENTS BUILD ONLY.  Exact (9 partial products) it ran the B = 256 step in 262.7 us against 224.5 on fp32 MFMA, with 6 products in
 // 244.9 (one box, alternating runs; tools/exp/README.md): the launches are latency- not MFMA-bound there and the split costs VALU time.
@@ -584,7 +696,7 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
   }
 #endif
   if ((id == K_BWD1 && a.f4w_count == 0) || id == K_CONV1_WGRAD) {             // conv1's weight gradient: bytes x three bf16 planes of delta1
-    e = launch_c1w_bt(a, s);
+    e = t.bt[id] == 1 ? launch_c1w_bt(a, s) : launch_c1w_bt2(a, s);      // (menu 1: the first form, fragments from single-byte / two-byte LDS reads)
     if (e == hipErrorInvalidValue) return hipSuccess;
     *handled = true;
     return e;

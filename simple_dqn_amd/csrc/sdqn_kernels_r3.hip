@@ -293,6 +293,83 @@ __global__ void __launch_bounds__(256) conv1_bf16_kernel(const Conv1Args c, cons
   conv1_bf16_body<IDX_IN, false>(c, my_idx, (int)blockIdx.x, sw, fw);
 }
 
+// ---- the same conv1 forward for B >= 128: one workgroup per (net, sample), the sample's four frames staged ONCE in LDS -------------------
+// conv1_bf16_body fetches every patch row (8 bytes) of every output position straight from memory — 16 divergent loads per lane and
+// tile, which the texture path serialises: 18.6 us at B = 256 for 0.84 GFLOP and 41 MB.  Here the 28 KB of a sample (contiguous in the
+// ring) arrive with coalesced 16-byte loads beside the 50 KB of weight planes (2 workgroups per CU), and a lane's 16 patch rows are 32
+// LDS dword reads.  Same fragments, same three MFMA chains in the same k order, same epilogue: bit-identical to conv1_bf16_body.
+__global__ void __launch_bounds__(256) conv1_bf16_staged_kernel(const Conv1Args c) {
+  __shared__ __attribute__((aligned(16))) unsigned short sw[3 * K1 * W1P_PITCH];          // 50 688 B
+  __shared__ __attribute__((aligned(16))) unsigned char img[STATE];                       // 28 224 B
+  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int z = blockIdx.x / c.B, n = blockIdx.x - z * c.B;
+  const int64_t org = c.from_ring ? (c.idx[n] - C0 + z) * (int64_t)FRAME : ((int64_t)z * c.B + n) * (int64_t)STATE;       // problems.h: sbase
+  {
+    const uint4* fp = reinterpret_cast<const uint4*>(c.src + org);
+    const uint4* wp = reinterpret_cast<const uint4*>(c.w1p[z]);
+    uint4 fv[7], v[12];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) { const int it = threadIdx.x + 256 * u; fv[u] = fp[it < STATE / 16 ? it : STATE / 16 - 1]; }
+#pragma unroll
+    for (int u = 0; u < 12; ++u) v[u] = wp[threadIdx.x + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) { const int it = threadIdx.x + 256 * u; if (it < STATE / 16) *reinterpret_cast<uint4*>(img + 16 * it) = fv[u]; }
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int cc = threadIdx.x + 256 * u, row = cc >> 5, col = cc & 31;
+      *reinterpret_cast<uint4*>(sw + row * W1P_PITCH + col * 8) = v[u];
+    }
+  }
+  __syncthreads();
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned short* bw = sw + i * W1P_PITCH + 8 * h;
+  auto cvt = [](const u32x2& r, bf16x8_t& out) {                                              // 8 bytes -> 8 exact bf16 (as conv1_bf16_body)
+    union { uint32_t u[4]; bf16x8_t v; } A;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const uint32_t w = d ? r.y : r.x;
+      const uint32_t f0 = __float_as_uint((float)(w & 255u)), f1 = __float_as_uint((float)((w >> 8) & 255u));
+      const uint32_t f2 = __float_as_uint((float)((w >> 16) & 255u)), f3 = __float_as_uint((float)(w >> 24));
+      A.u[2 * d] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);
+      A.u[2 * d + 1] = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
+    }
+    out = A.v;
+  };
+  const int M = c.B * PIX1;
+  for (int tile = wave; tile < (PIX1 + 31) / 32; tile += 4) {
+    const int pos = 32 * tile + i, pc = pos < PIX1 ? pos : PIX1 - 1, p = pc / Q1, q = pc - p * Q1;
+    const unsigned char* src = img + (p * ST1 + h) * W0 + q * ST1;
+    u32x2 raw[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const uint32_t* q32 = reinterpret_cast<const uint32_t*>(src + (t >> 2) * FRAME + 2 * (t & 3) * W0);
+      raw[t].x = q32[0]; raw[t].y = q32[1];
+    }
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; acc2[r] = 0.0f; }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      bf16x8_t Ac; cvt(raw[t], Ac);
+      const bf16x8_t B0 = *reinterpret_cast<const bf16x8_t*>(bw + 16 * t), B1 = *reinterpret_cast<const bf16x8_t*>(bw + K1 * W1P_PITCH + 16 * t),
+                     B2 = *reinterpret_cast<const bf16x8_t*>(bw + 2 * K1 * W1P_PITCH + 16 * t);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac, B0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac, B1, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac, B2, acc2, 0, 0, 0);
+    }
+    float* out = c.a1 + ((int64_t)z * M + (int64_t)n * PIX1 + 32 * tile + 4 * h) * K1 + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = (r & 3) + 8 * (r >> 2);
+      if (32 * tile + 4 * h + ml < PIX1) {
+        const float v = fmaxf(div255((acc0[r] + acc1[r]) + acc2[r]), 0.0f);
+        if (c.pad_) wt_store(out + ml * K1, v); else out[ml * K1] = v;
+      }
+    }
+  }
+}
+
 #ifdef SDQN_EXPERIMENTS      // (measured slower than the update as a launch of its own: not in the product build)
 // ---- update(i) + conv1_fwd(i + 1) in ONE launch (train_many, steps after the first of a call; B <= 32 ring path) ------------
 // The optimizer pass is the last launch of a step and conv1 the first of the next: nothing between them but a kernel boundary.
@@ -722,6 +799,10 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     Conv1Args c; c.src = a.src; c.a1 = a.a1; c.w1p[0] = a.w1p[0]; c.w1p[1] = a.w1p[1]; c.idx = a.idx;
     c.B = a.B; c.nz = a.nz; c.from_ring = a.from_ring; c.tiles_per_net = tiles; c.wgs_per_net = wgs; c.tpw = tpw; c.xcd = t.r3_xcd & 1; c.pad_ = (t.wt >> 7) & 1;
     static_assert(sizeof(Conv1Args) == 72, "the index block follows 8-byte aligned at byte 72");
+    if (a.B >= 128 && t.bt[K_CONV1_FWD] >= 0) {           // throughput regime: frames staged per (net, sample)  (option bt:0 = -1: the per-tile kernel)
+      SDQN_LAUNCH(conv1_bf16_staged_kernel, dim3(a.nz * a.B), dim3(256), 0, s, c);
+      return hipGetLastError();
+    }
     IdxIn ix;
     if (t.host_idx && a.from_ring && a.B <= 32) {
       memset(ix.v, 0, sizeof ix.v);
