@@ -165,6 +165,8 @@ int sdqn_statebuf_get(sdqn_statebuf_t s, uint8_t* state_out);       /* host mirr
 int sdqn_statebuf_read_device(sdqn_statebuf_t s, uint8_t* state_out);   /* test hook: D2H of the device window (sync) */
 /* Q-values of the buffered state -> float[A] (sync): sdqn_net_predict_one without the state upload */
 int sdqn_net_predict_state(sdqn_net_t h, sdqn_statebuf_t s, float* q_out);
+/* agent.py:55-59: greedy action of the buffered state = first index of the maximal Q-value (np.argmax); q_out float[A] nullable */
+int sdqn_net_act_greedy(sdqn_net_t h, sdqn_statebuf_t s, int* action, float* q_out);
 /* One environment transition in one call (agent.py:48-85: `self.buf.add(screen)` [+ `self.mem.add(action, reward, screen, terminal)`,
  * replay_memory.py:26-34, when `r` is not NULL]); speculate != 0 also enqueues the acting forward of the NEW state, whose Q-values the next
  * sdqn_net_predict_state on the same buffer collects without launching anything (dropped if the buffer or the parameters change first). */

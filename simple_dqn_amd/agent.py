@@ -49,6 +49,10 @@ class Agent:
 
     # ---- acting ------------------------------------------------------------------------------------------
     def _greedy_action(self):
+        if self._one_call and hasattr(self.net, "act_greedy"):
+            a = self.net.act_greedy(self.buf)                         # predict_state + argmax inside the library
+            assert 0 <= a < self.num_actions
+            return a
         if hasattr(self.buf, "_h") and hasattr(self.net, "predict_state"):
             q = self.net.predict_state(self.buf)                      # state already in HBM: one 7 KB upload per env step
         elif hasattr(self.net, "predict_one"):

@@ -1424,6 +1424,18 @@ extern "C" int sdqn_net_predict_state(sdqn_net_t h, sdqn_statebuf_t sb, float* q
   }
   return predict_state_collect(h, q_out);
 }
+// agent.py:55-59: the greedy action of the buffered state (first index of the maximum, as np.argmax) — predict_state + argmax in one call
+extern "C" int sdqn_net_act_greedy(sdqn_net_t h, sdqn_statebuf_t sb, int* action, float* q_out) {
+  ARGCHK(h && sb && action, "NULL argument");
+  float q[MAX_ACTIONS];
+  int rc = sdqn_net_predict_state(h, sb, q); if (rc) return rc;
+  const int A = h->A;
+  int best = 0;
+  for (int k = 1; k < A; ++k) if (q[k] > q[best]) best = k;         // (np.argmax: NaN handling aside, the first maximum)
+  *action = best;
+  if (q_out) memcpy(q_out, q, (size_t)A * 4);
+  return SDQN_OK;
+}
 // One environment transition in ONE call (agent.py:48-85 + :62: `buf.add(screen)`, optionally `mem.add(action, reward, screen, terminal)`):
 // the frame goes to the device-resident state buffer and, with a replay handle, into the ring; with `speculate` the acting forward of the
 // NEW state is enqueued right away — the next step's sdqn_net_predict_state then finds its Q-values already on the host (or on their way)

@@ -89,6 +89,7 @@ class DeepQNetwork:
             _lib.check(self._lib.sdqn_net_set_option(h, b"f4_share3", s3))
             _lib.check(self._lib.sdqn_net_set_option(h, b"f4_share2", s2))
         self._mt_buf = (C.c_uint32 * _lib.MT_WORDS)()
+        self._act_out = C.c_int(); self._act_greedy = self._lib.sdqn_net_act_greedy
         self.train_iterations = 0
         self.callback = None
         self.save_weights_prefix = getattr(args, "save_weights_prefix", None)
@@ -207,6 +208,12 @@ class DeepQNetwork:
         q = np.empty((self.num_actions,), dtype=np.float32)
         _lib.check(self._lib.sdqn_net_predict_state(self._h, state_buffer._h, _lib.ptr(q, C.c_float)))
         return q
+
+    def act_greedy(self, state_buffer):
+        """agent.py:55-59 in one call: int(np.argmax(predict_state(state_buffer)))."""
+        a = self._act_out
+        _lib.check(self._act_greedy(self._h, state_buffer._h, C.byref(a), None))
+        return a.value
 
     def act_step(self, state_buffer, mem, screen, action=0, reward=0, terminal=False, speculate=False):
         """One environment transition in ONE library call: `state_buffer.add(screen)` and — with a device-backed replay memory —

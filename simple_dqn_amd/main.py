@@ -17,6 +17,7 @@ _OPTIONS = {
     "Environment": [
         ("--environment", str, "synthetic", dict(choices=["synthetic", "ale", "gym"])),
         ("--num_actions", int, 4, dict(help="Action-set size of the synthetic environment.")),
+        ("--synthetic_frame_pool", int, 256, dict(help="Synthetic environment: serve frames from a pool of this many pre-generated frames (0: generate 7 KB of random bytes every step).")),
         ("--screen_width", int, 84), ("--screen_height", int, 84),
     ],
     "Replay memory": [("--replay_size", int, 1000000), ("--history_length", int, 4)],
@@ -75,7 +76,7 @@ def run(args):
         from .environment import GymEnvironment                    # needs gymnasium (or gym); not part of this image
         env = GymEnvironment(args.game, args)
     else:
-        env = SyntheticEnvironment(args, num_actions=args.num_actions, seed=args.random_seed or 0)
+        env = SyntheticEnvironment(args, num_actions=args.num_actions, seed=args.random_seed or 0, frame_pool=args.synthetic_frame_pool)
     mem = ReplayMemory(args.replay_size, args)                       # main.py:103-106
     net = DeepQNetwork(env.numActions(), args)
     agent = Agent(env, mem, net, args)
