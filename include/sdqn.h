@@ -176,6 +176,9 @@ int sdqn_net_act_step(sdqn_net_t h, sdqn_statebuf_t sb, sdqn_replay_t r, const u
  * forward of the buffered state with per-workgroup phase stamps.  q_out float[A], stamps_out uint64[256][80] ({kind, clock} pairs; the last
  * word of a workgroup's row = its XCC id); either may be NULL. */
 int sdqn_net_debug_act(sdqn_net_t h, sdqn_statebuf_t sb, float* q_out, unsigned long long* stamps_out);
+/* Experiments build only (returns SDQN_ERR_ARG otherwise): timing probe of the training forward conv chain as one XCC-local launch, ns (state, net)
+ * pairs per XCC (tools/exp/chain_probe.py).  stamps_out uint64[grid][80] nullable. */
+int sdqn_exp_chain_probe(sdqn_net_t h, int ns, int grid, int reps, float* us_per_launch, unsigned long long* stamps_out);
 /* DeepQNetwork.train, deepqnetwork.py:107-172, minibatch given as host arrays.
  * cost_out nullable: NULL -> the step itself is not waited for.  Buffer contract: when the call returns, all five arrays
  * are free to be overwritten — pageable arrays were copied into a pinned double buffer; pre / post that ARE a

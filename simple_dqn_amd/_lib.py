@@ -83,6 +83,7 @@ SIGNATURES = {
     "sdqn_net_predict_state": (C.c_int, [_vp, _vp, _f32p]),
     "sdqn_net_act_step": (C.c_int, [_vp, _vp, _vp, _u8p, C.c_int, C.c_int64, C.c_int, C.c_int]),
     "sdqn_net_act_greedy": (C.c_int, [_vp, _vp, C.POINTER(C.c_int), _f32p]),
+    "sdqn_exp_chain_probe": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _f32p, C.POINTER(C.c_uint64)]),
     "sdqn_net_debug_act": (C.c_int, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "sdqn_net_train_host": (C.c_int, [_vp, _u8p, _u8p, _i64p, _u8p, _u8p, _f32p]),
     "sdqn_net_train_replay": (C.c_int, [_vp, _vp, _i64p, _f32p]),

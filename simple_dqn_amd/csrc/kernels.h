@@ -188,6 +188,9 @@ struct ActArgs {
   unsigned seq;               // launch number (selects the control block / partial slot)
 };
 hipError_t launch_act(const ActArgs& a, bool q_system_scope, hipStream_t s);
+#ifdef SDQN_EXPERIMENTS
+hipError_t launch_chain_probe(const ActArgs& a, int ns, int grid, hipEvent_t e0, hipEvent_t e1, hipStream_t s);     // tools/exp/chain_probe.py
+#endif
 hipError_t launch_w1_planes(const float* theta, unsigned short* w1p, hipStream_t s);   // conv1's three bf16 weight planes of one net (problems.h: split_bf16x3)
 hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s);   // fp16 mode: rebuild both half copies
 hipError_t launch_refresh_planes(const float* theta, unsigned short* wpm, unsigned short* wpt, hipStream_t s);   // plane mode: rebuild the bf16 planes of conv2 / conv3 (both layouts) and fc4 (master; wpm may be nullptr: target net)

@@ -1474,6 +1474,47 @@ extern "C" int sdqn_net_debug_act(sdqn_net_t h, sdqn_statebuf_t sb, float* q_out
   return SDQN_OK;
 }
 
+// Experiments build: the training forward conv chain (conv1 -> conv2 -> conv3 of ns (state, net) pairs per XCC) as ONE XCC-local launch in the
+// acting kernel's arithmetic — a timing probe, outputs unused (sdqn_act.hip: chain_probe_kernel; tools/exp/chain_probe.py).
+// us_per_launch: mean over `reps` launches of the dispatch packet's own begin -> end time (hipExtLaunchKernel events: the duration rocprofv3's
+// kernel trace reports; the control block is re-zeroed by a memset before each launch, outside it).
+extern "C" int sdqn_exp_chain_probe(sdqn_net_t h, int ns, int grid, int reps, float* us_per_launch, unsigned long long* stamps_out) {
+#ifdef SDQN_EXPERIMENTS
+  ARGCHK(h && h->act_scratch && ns != 0 && ns >= -8 && ns <= 8 && grid >= 8 && grid <= 4096 && reps >= 1 && us_per_launch, "bad arguments");
+  uint8_t* st = nullptr; float* scr = nullptr; unsigned* ctl = nullptr; unsigned long long* d_st = nullptr;
+  const int nsa = ns < 0 ? -ns : ns;
+  const size_t nstate = (size_t)8 * nsa * STATE, nscr = (size_t)8 * nsa * ACT_XCC_FLOATS * 4, nctl = (size_t)(8 * 16 + 8 * 8 * 3 * 16 + 64) * 4;
+  const size_t nst = (size_t)grid * 2 * ACT_STAMPS;
+  HIPCHK(hipMalloc((void**)&st, nstate)); HIPCHK(hipMalloc((void**)&scr, nscr)); HIPCHK(hipMalloc((void**)&ctl, nctl));
+  if (stamps_out) HIPCHK(hipMalloc((void**)&d_st, nst * 8));
+  { std::vector<uint8_t> hs(nstate); uint32_t v = 12345u; for (auto& b : hs) { v = v * 1664525u + 1013904223u; b = (uint8_t)(v >> 24); }
+    HIPCHK(hipMemcpy(st, hs.data(), nstate, hipMemcpyHostToDevice)); }
+  hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  ActArgs aa; memset(&aa, 0, sizeof aa);
+  aa.state = st; aa.theta = h->theta; aa.scratch = scr; aa.ctl = ctl; aa.q = h->act_q; aa.A = ns < 0 ? 1 : 0; aa.seq = 0;      // (ns < 0: static tickets)
+  if (ns < 0) ns = -ns;
+  double total = 0; hipError_t e = hipSuccess;
+  for (int r = 0; r < reps + 3 && e == hipSuccess; ++r) {
+    const bool last = r == reps + 2;
+    aa.stamps = last ? d_st : nullptr;
+    if (last && d_st) HIPCHK(hipMemsetAsync(d_st, 0, nst * 8, g_stream));
+    HIPCHK(hipMemsetAsync(ctl, 0, nctl, g_stream));
+    e = launch_chain_probe(aa, ns, grid, e0, e1, g_stream);
+    HIPCHK(hipStreamSynchronize(g_stream));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (r >= 3 && !last) total += ms; else if (r >= 3 && last && reps == 1) total += ms;
+  }
+  *us_per_launch = (float)(total / (reps > 1 ? reps - 1 : 1) * 1e3);
+  if (e == hipSuccess && stamps_out) e = hipMemcpy(stamps_out, d_st, nst * 8, hipMemcpyDeviceToHost);
+  hipEventDestroy(e0); hipEventDestroy(e1); hipFree(st); hipFree(scr); hipFree(ctl); if (d_st) hipFree(d_st);
+  HIPCHK(e);
+  return SDQN_OK;
+#else
+  (void)h; (void)ns; (void)grid; (void)reps; (void)us_per_launch; (void)stamps_out;
+  set_error("sdqn_exp_chain_probe is part of the experiments build (make -C simple_dqn_amd/csrc experiments)"); return SDQN_ERR_ARG;
+#endif
+}
+
 extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8_t* actions, const int64_t* rewards,
                                    const uint8_t* post, const uint8_t* terminals, float* cost_out) {
   // the one-shot "minibatch buffers are clean" declarations are consumed FIRST: an argument error below must not leave one armed for a
