@@ -56,6 +56,17 @@ try:
             rows.append(l.rstrip())
 except Exception as e:
     rows.append("MISSING agent_loop.log " + repr(e)[:80])
+try:
+    rows.append("--- the same with --synthetic_frame_pool 0 (a new 7 KB random frame generated per environment step, as in rounds 1-3)")
+    for l in open(os.path.join(CAP, "agent_loop_pool0.log")):
+        if "steps_per_second" in l:
+            rows.append(l.rstrip())
+except Exception as e:
+    rows.append("MISSING agent_loop_pool0.log " + repr(e)[:80])
+try:
+    rows += ["--- tools/exp/act_stamps.py (one-launch acting forward: phase stamps, predict_state latencies)"] + [l.rstrip() for l in open(os.path.join(CAP, "act_stamps.txt"))][-34:]
+except Exception as e:
+    rows.append("MISSING act_stamps.txt " + repr(e)[:80])
 for f in ("tuple_api_rate.txt", "generic_rate.txt"):
     try:
         rows += ["--- " + f] + [l.rstrip() for l in open(os.path.join(CAP, f)) if "steps/s" in l]

@@ -14,6 +14,8 @@ timeout 200 python bench.py --batch-size 256 --num-actions 3 --datatype float16 
 timeout 200 python bench.py --single-rank-dp --no-cpu-baseline --steps 2000 --warmup 200 --replay-size 200000 > $O/bench_dp1.json 2>/dev/null
 # the whole agent loop on the synthetic environment (README table row) and the reference-style tuple-API loop
 timeout 300 python -m simple_dqn_amd.main --replay_size 100000 --random_steps 5000 --train_steps 40000 --test_steps 20000 --epochs 1 --csv_file $O/agent_loop.csv > $O/agent_loop.log 2>&1
+timeout 300 python -m simple_dqn_amd.main --synthetic_frame_pool 0 --replay_size 100000 --random_steps 5000 --train_steps 40000 --test_steps 20000 --epochs 1 > $O/agent_loop_pool0.log 2>&1
+timeout 200 python tools/exp/act_stamps.py > $O/act_stamps.txt 2>&1
 timeout 200 python tools/exp/tuple_api_rate.py > $O/tuple_api_rate.txt 2>&1
 timeout 200 python tools/generic_rate.py > $O/generic_rate.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
