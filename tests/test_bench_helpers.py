@@ -41,7 +41,7 @@ KERNEL_NAMES = [
     "conv1_wgrad", "update(reduce+fc5wgrad+rmsprop)", "rccl_allreduce", "replay_gather_u8", "prep(idx+meta)",
     "bwd3(conv3_dgrad+conv3_wgrad+fc4_wgrad)", "bwd2(conv2_dgrad+conv2_wgrad+fc4_wgrad)", "bwd1(conv1_wgrad+fc4_wgrad)",
     "batchnorm(layer fwd/bwd)", "fc4_dgrad+fc4_wgrad(+rmsprop W4)", "bwd3(conv3_dgrad+conv3_wgrad)", "update(i)+conv1_fwd(i+1)",
-    "head+fc4_dgrad", "wgrads(fc4+conv3+conv2)"]
+    "head+fc4_dgrad", "wgrads(fc4+conv3+conv2)", "act(conv1..fc5, one state)"]
 
 
 def test_kernel_work_matches_survey_figures():
