@@ -245,7 +245,14 @@ int sdqn_net_set_epoch(sdqn_net_t h, int epoch);
  * forward / weight gradient on packed-bf16 MFMA with an exact 3-way split; 0: the fp32-MFMA engine — last bits differ), "conv3_c36" (1 default:
  * conv3 forward on 36-deep K-chunks; last bits differ), "r3_xcd" (tile maps of the two conv1 kernels), and three in-launch hand-offs that
  * measured slower than kernel boundaries and default to 0: "f4w_early" (fc4_wgrad inside the fc4_dgrad launch), "fuse_upd" (update(i) +
- * conv1(i+1)), "head_f4d" (head + fc4_dgrad).  A float64 / non-84x84x4 network (generic path) accepts and ignores the tuning options. */
+ * conv1(i+1)), "head_f4d" (head + fc4_dgrad).  A float64 / non-84x84x4 network (generic path) accepts and ignores the tuning options.
+ * Round 4: "bt" (1 default: batch_size >= 128 runs on the block-tile engine, gemm_engine_bt.h; 0: the latency engine's launch forms),
+ * "bt:<kernel id>" (menu entry of that launch: 0 built-in block shape, -1 latency engine / previous kernel, n > 0 other shapes — tuning
+ * surface of tools/sweep_bt.py), "tps:<layer>" (K chunks per weight-gradient slab), "act_kernel" (1 default where available — float32, no
+ * batch_norm, 84x84x4: the acting forward of sdqn_net_predict_state / _predict_one is ONE launch, sdqn_act.hip; 0: the five batched
+ * forward kernels at batch 1).  The step structures that were built, tested and measured SLOWER — "hoist", "f4w_early", "fuse_upd",
+ * "head_f4d", "two_streams", "fwd_rb", "bwd_order", "rb:<id>", "bt_x", "btx:<id>", "bt_planes" — exist only in the experiments build
+ * (make -C simple_dqn_amd/csrc experiments -> libsdqn_hip_exp.so); this library refuses a non-zero value for them with SDQN_ERR_ARG. */
 int sdqn_net_set_option(sdqn_net_t h, const char* name, int value);
 
 /* test hook: raw read-back of an internal device buffer ("a1","a2","a3","a4","d4","d3p","d2p","d1","q",
