@@ -118,6 +118,18 @@ __device__ __forceinline__ void update_body(const UpdateArgs& u, const int bid, 
       // slabs sg, sg + 8, sg + 16, ... in increasing order (the order IS the result: fixed).  Four loads are issued together whatever ns
       // (clamped index + select instead of a data-dependent loop: a 25-slab reduction was three dependent memory round trips for seven
       // of the eight slab groups)
+      if (ns > 32) {
+        // many slabs (B >= 128: conv1 has 320 at B = 256): SIXTEEN loads in flight per round trip — with four, a slab group walked its 40
+        // slabs in ten dependent round trips and the whole launch took 10 us.  Same ascending order sg, sg + 8, ...: same bits.
+        for (int s = sg; s < ns; s += 128) {
+          float4 v[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { const int sj = s + 8 * j; v[j] = *reinterpret_cast<const float4*>(sp + (int64_t)(sj < ns ? sj : ns - 1) * nw); }
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (s + 8 * j < ns) { gs.x += v[j].x; gs.y += v[j].y; gs.z += v[j].z; gs.w += v[j].w; }
+        }
+      } else
       for (int s = sg; s < ns; s += 32) {
         float4 v[4];
 #pragma unroll
