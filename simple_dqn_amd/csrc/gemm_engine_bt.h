@@ -309,6 +309,8 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
     for (int d = 0; d < D; ++d) if (d < nit) gload_it(d, ra[d], rb[d]);
     store_it(ra[0], rb[0], smem);
     __syncthreads();
+    // (unconditional ring loads with a clamped interval index — what the half routines below use — measured 1 % SLOWER here: 217.5 vs
+    //  215.4 us per step at B = 256; the fp32 forward problems have compile-time chunk counts and exact waits already)
     for (int t0 = 0; t0 < nit; t0 += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
@@ -633,21 +635,23 @@ __device__ __forceinline__ void bt_tile_h(const StepArgs& a, int bx, int by, int
   };
   const int nch = (kend - kbeg + bt::BKH - 1) / bt::BKH;
   if (nch > 0) {
+    // loads are issued UNCONDITIONALLY (a chunk index past the end re-reads the last chunk and is never stored): with a guarded load and
+    // a run-time chunk count (fc4 forward's K split) the compiler waited for every load in flight before each LDS store (bt_tile_hw)
+    const int klast = kbeg + (nch - 1) * bt::BKH;
+    auto chunk_k = [&](int c) { const int k = kbeg + c * bt::BKH; return k < klast ? k : klast; };
 #pragma unroll
-    for (int d = 0; d < D; ++d) if (d < nch) gload(kbeg + d * bt::BKH, ra[d], rb[d]);
+    for (int d = 0; d < D; ++d) gload(chunk_k(d), ra[d], rb[d]);
     lds_store(ra[0], rb[0], smem, smem + C::AH);
     __syncthreads();
     for (int c0 = 0; c0 < nch; c0 += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const int c = c0 + d;
-        if (c < nch) {
-          half_t* cur = smem + (c & 1) * C::STAGE;
-          half_t* nxt = smem + ((c + 1) & 1) * C::STAGE;
-          if (c + D < nch) gload(kbeg + (c + D) * bt::BKH, ra[d], rb[d]);
-          compute(cur, cur + C::AH);
-          if (c + 1 < nch) { lds_store(ra[(d + 1) % D], rb[(d + 1) % D], nxt, nxt + C::AH); __syncthreads(); }
-        }
+        half_t* cur = smem + (c & 1) * C::STAGE;
+        half_t* nxt = smem + ((c + 1) & 1) * C::STAGE;
+        gload(chunk_k(c + D), ra[d], rb[d]);
+        if (c < nch) compute(cur, cur + C::AH);
+        if (c + 1 < nch) { lds_store(ra[(d + 1) % D], rb[(d + 1) % D], nxt, nxt + C::AH); __syncthreads(); }
       }
     }
   }
