@@ -47,3 +47,25 @@ def test_statistics_csv_columns_and_running_means(tmp_path):
     assert tuple(rows[0]) == COLUMNS and len(rows[0]) == 16
     assert rows[1][:4] == ["1", "train", "5", "2"] and float(rows[1][10]) == 3.0 and rows[1][8] == "42"
     assert st.validation_states is mem.prestates       # the reference's aliasing (:85-86)
+
+
+def test_deferred_cost_protocol_keeps_the_running_mean_bit_identical(tmp_path):
+    """on_train_deferred(collect, train_iterations): the cost is collected when the next step is announced, when average_cost is read, or
+    when the phase ends — with the (cost, train_iterations) pairs and the order the immediate on_train would have used."""
+    rng = np.random.RandomState(3)
+    costs = rng.rand(50).astype(np.float32).tolist()
+    a = Statistics(_Agent(), _Net(), _Mem(), None, make_args(csv_file=None))
+    b = Statistics(_Agent(), _Net(), _Mem(), None, make_args(csv_file=None))
+    collected = []
+    for i, c in enumerate(costs):
+        a.net.train_iterations = b.net.train_iterations = i + 1
+        a.on_train(c)
+        b.on_train_deferred(lambda c=c, i=i: (collected.append(i), c)[1], i + 1)
+        assert len(collected) == i                     # only the PREVIOUS step's cost has been asked for
+        if i == 20:
+            assert b.average_cost == a.average_cost and len(collected) == 21      # reading it resolves what is pending
+    b.net.train_iterations = 999                        # (a later value must not leak into the pending update)
+    assert b.average_cost == a.average_cost and collected == list(range(50))
+    b.on_train_deferred(lambda: 7.0, 51); a.net.train_iterations = 51; a.on_train(7.0)
+    b.reset(); a.reset()                                # a phase end collects before the tally is replaced
+    assert b.average_cost == a.average_cost == 0 and not b._pending
