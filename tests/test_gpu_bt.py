@@ -124,11 +124,12 @@ def test_conv1_weight_gradient_block_tile_bf16(sd, A, B):
     assert _rel(new.get_layer(0, 3), old.get_layer(0, 3)) < 2e-6
 
 
-def _close_but_for_gate_flips(x, y, tol, what):
+def _close_but_for_gate_flips(x, y, tol, what, frac=1e-5):
     """fp32-class agreement of two buffers downstream of ReLU gates: an activation that is +-1e-8 on the two sides flips its gate and
-    moves the handful of delta elements behind it by their full size — all other elements within tol of max|y|."""
+    moves the delta elements behind it by their full size (one flipped conv2 gate reaches up to 4 x 4 x 32 elements of delta1) — all
+    other elements within tol of max|y|."""
     d = np.abs(x - y) / max(1e-6, float(np.abs(y).max()))
-    assert float((d > tol).mean()) < 1e-5, (what, float((d > tol).mean()), float(d.max()))
+    assert float((d > tol).mean()) < frac, (what, float((d > tol).mean()), float(d.max()))
 
 
 @pytest.mark.experiments
@@ -145,8 +146,8 @@ def test_plane_mode_matches_fp32_mfma(sd, A, B, np_):
     for name, n in dict(a2=2 * B * 81 * 64, a3=2 * B * 49 * 64).items():
         assert _rel(net.debug_read(name, n), ref.debug_read(name, n)) < 3e-6, name
     assert np.abs(net.last_q()[0] - ref.last_q()[0]).max() < 1e-6
-    for name, n in dict(d3p=B * 121 * 64, d2p=B * 121 * 64, d1=B * 400 * 32).items():
-        _close_but_for_gate_flips(net.debug_read(name, n), ref.debug_read(name, n), 3e-6, name)
+    for name, n, frac in (("d3p", B * 121 * 64, 1e-5), ("d2p", B * 121 * 64, 1e-4), ("d1", B * 400 * 32, 1e-3)):
+        _close_but_for_gate_flips(net.debug_read(name, n), ref.debug_read(name, n), 3e-6, name, frac)
     for i in range(5):
         g, r = net.get_layer(i, 3).astype(np.float64), ref.get_layer(i, 3).astype(np.float64)
         assert np.linalg.norm(g - r) / max(1e-12, np.linalg.norm(r)) < 1e-3, i
