@@ -565,14 +565,20 @@ inline hipError_t launch_bt_xp(const StepArgs& a, hipStream_t stream) {
 // (= 36 dwords: the fp32 panel's bank picture), a lane's fragment of a 16-deep step = ONE ds_read_b128, four v_mfma_f32_32x32x16_f16 per
 // sub-tile and chunk.  At B >= 128 these launches were operand-traffic bound on the wave-tile routines (every 64 x 64 wave block fetched
 // its own rows from L2: gemm_engine_rb.h); here a row leaves L2 once per workgroup.
-template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 2>
+template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 2, int BK_ = 64>
 struct BtCfgH {
   typedef P_ P;
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, D = D_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, D = D_, BK = BK_;       // BK halves of k per chunk (64 or 128)
   static constexpr int SM = BM / (32 * WM), SN = BN / (32 * WN);
   static_assert(WM * WN * 64 == bt::NT && SM >= 1 && SN >= 1 && SM * 32 * WM == BM && SN * 32 * WN == BN, "block = 4 waves x sub-tiles of 32 x 32");
   static_assert(uses_f16_mfma<P>::value, "a problems_h16.h forward / dgrad problem: both operands k-contiguous halves (a_load8 / b_load8)");
-  static constexpr int AH = bt::kmh_halves(BM), BH = bt::kmh_halves(BN);
+  static_assert(BK == 64 || BK == 128, "chunk depth");
+  // a row of a chunk = BK / 8 pieces of 8 halves; thread -> (row tid / (BK / 8) + rows-per-pass * p, piece tid % (BK / 8)); row pitch BK + 8
+  // halves (36 or 68 dwords: consecutive rows shift by 36 / 4 banks: conflict-free 16-byte fragment reads either way)
+  static constexpr int PPR = BK / 8, RPP = bt::NT / PPR, PITCH = BK + 8;
+  static constexpr int PA = BM / RPP, PB = BN / RPP;
+  static_assert(PA * RPP == BM && PB * RPP == BN, "whole passes");
+  static constexpr int AH = BM * PITCH, BH = BN * PITCH;
   static constexpr int STAGE = AH + BH;                 // halves per LDS stage
   static constexpr int LDS = 2 * STAGE / 2;             // floats (the kernels declare float arrays): double-buffered
 };
@@ -581,8 +587,8 @@ template <class C>
 __device__ __forceinline__ void bt_tile_h(const StepArgs& a, int bx, int by, int bz, float* smem_f) {
   typedef typename C::P P;
   typedef typename P::aoff_t aoff_t;
-  constexpr int BM = C::BM, BN = C::BN, SM = C::SM, SN = C::SN, WN = C::WN, D = C::D;
-  constexpr int PA = bt::passes(BM), PB = bt::passes(BN);
+  constexpr int BM = C::BM, BN = C::BN, SM = C::SM, SN = C::SN, WN = C::WN, D = C::D, BK = C::BK;
+  constexpr int PA = C::PA, PB = C::PB, PPR = C::PPR, RPP = C::RPP, PITCH = C::PITCH;
   half_t* smem = reinterpret_cast<half_t*>(smem_f);
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -591,15 +597,16 @@ __device__ __forceinline__ void bt_tile_h(const StepArgs& a, int bx, int by, int
   int z, ks, kbeg, kend;
   P::ksplit(a, bz, z, ks, kbeg, kend);
   const int M = P::M(a), N = P::N(a);
+  const int irow = tid / PPR, ik = (tid - irow * PPR) * 8;           // this thread's piece: rows irow + RPP p, halves ik .. ik + 7
   aoff_t ag[PA]; int bg[PB];
 #pragma unroll
-  for (int p = 0; p < PA; ++p) { const int m = m0 + bt::kmh_item_row(tid, p); ag[p] = P::a_row(a, z, m < M ? m : M - 1); }
+  for (int p = 0; p < PA; ++p) { const int m = m0 + irow + RPP * p; ag[p] = P::a_row(a, z, m < M ? m : M - 1); }
 #pragma unroll
-  for (int p = 0; p < PB; ++p) { const int n = n0 + bt::kmh_item_row(tid, p); bg[p] = P::b_col(a, z, n < N ? n : N - 1); }
+  for (int p = 0; p < PB; ++p) { const int n = n0 + irow + RPP * p; bg[p] = P::b_col(a, z, n < N ? n : N - 1); }
   half8 ra[D][PA], rb[D][PB];
   const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   auto gload = [&](int kc, half8* qa, half8* qb) {
-    const int k = kc + bt::kmh_item_k(tid), kk = k < kend ? k : kbeg;
+    const int k = kc + ik, kk = k < kend ? k : kbeg;
     const aoff_t ca = P::a_col(a, z, kk); const int rbk = P::b_row(a, z, kk);
 #pragma unroll
     for (int p = 0; p < PA; ++p) { qa[p] = P::a_load8(a, z, ag[p] + ca); if (k >= kend) qa[p] = zero8; }
@@ -608,9 +615,9 @@ __device__ __forceinline__ void bt_tile_h(const StepArgs& a, int bx, int by, int
   };
   auto lds_store = [&](const half8* qa, const half8* qb, half_t* As, half_t* Bs) {
 #pragma unroll
-    for (int p = 0; p < PA; ++p) *reinterpret_cast<half8*>(As + bt::kmh_off(bt::kmh_item_row(tid, p), bt::kmh_item_k(tid))) = qa[p];
+    for (int p = 0; p < PA; ++p) *reinterpret_cast<half8*>(As + (irow + RPP * p) * PITCH + ik) = qa[p];
 #pragma unroll
-    for (int p = 0; p < PB; ++p) *reinterpret_cast<half8*>(Bs + bt::kmh_off(bt::kmh_item_row(tid, p), bt::kmh_item_k(tid))) = qb[p];
+    for (int p = 0; p < PB; ++p) *reinterpret_cast<half8*>(Bs + (irow + RPP * p) * PITCH + ik) = qb[p];
   };
   f32x16 acc[SM][SN];
 #pragma unroll
@@ -621,24 +628,24 @@ __device__ __forceinline__ void bt_tile_h(const StepArgs& a, int bx, int by, int
       for (int q = 0; q < 16; ++q) acc[sm][sn][q] = 0.0f;
   auto compute = [&](const half_t* As, const half_t* Bs) {
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    for (int st = 0; st < BK / 16; ++st) {
       half8 fa[SM], fb[SN];
 #pragma unroll
-      for (int sm = 0; sm < SM; ++sm) fa[sm] = *reinterpret_cast<const half8*>(As + bt::fragh_off((wm * SM + sm) * 32 + i, st, h));
+      for (int sm = 0; sm < SM; ++sm) fa[sm] = *reinterpret_cast<const half8*>(As + ((wm * SM + sm) * 32 + i) * PITCH + 16 * st + 8 * h);
 #pragma unroll
-      for (int sn = 0; sn < SN; ++sn) fb[sn] = *reinterpret_cast<const half8*>(Bs + bt::fragh_off((wn * SN + sn) * 32 + i, st, h));
+      for (int sn = 0; sn < SN; ++sn) fb[sn] = *reinterpret_cast<const half8*>(Bs + ((wn * SN + sn) * 32 + i) * PITCH + 16 * st + 8 * h);
 #pragma unroll
       for (int sm = 0; sm < SM; ++sm)
 #pragma unroll
         for (int sn = 0; sn < SN; ++sn) acc[sm][sn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[sm], fb[sn], acc[sm][sn], 0, 0, 0);
     }
   };
-  const int nch = (kend - kbeg + bt::BKH - 1) / bt::BKH;
+  const int nch = (kend - kbeg + BK - 1) / BK;
   if (nch > 0) {
     // loads are issued UNCONDITIONALLY (a chunk index past the end re-reads the last chunk and is never stored): with a guarded load and
     // a run-time chunk count (fc4 forward's K split) the compiler waited for every load in flight before each LDS store (bt_tile_hw)
-    const int klast = kbeg + (nch - 1) * bt::BKH;
-    auto chunk_k = [&](int c) { const int k = kbeg + c * bt::BKH; return k < klast ? k : klast; };
+    const int klast = kbeg + (nch - 1) * BK;
+    auto chunk_k = [&](int c) { const int k = kbeg + c * BK; return k < klast ? k : klast; };
 #pragma unroll
     for (int d = 0; d < D; ++d) gload(chunk_k(d), ra[d], rb[d]);
     lds_store(ra[0], rb[0], smem, smem + C::AH);
