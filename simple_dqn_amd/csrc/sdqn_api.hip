@@ -1250,6 +1250,7 @@ extern "C" int sdqn_net_predict_one(sdqn_net_t h, const uint8_t* state, float* q
   if (h->gen) { GENCHK(h->gen->predict_host(state, 1, q_out, false)); return SDQN_OK; }
   HIPCHK(hipMemcpyAsync(h->st_states, state, (size_t)STATE, hipMemcpyHostToDevice, g_stream));
   if (h->act_on && !h->prof_on) {            // the one-launch forward (sdqn_act.hip): the same kernel predict_state runs, the same numbers
+    { int rcj = join_comm(h); if (rcj) return rcj; }
     ActArgs aa; memset(&aa, 0, sizeof aa);
     aa.state = h->st_states; aa.theta = h->theta; aa.scratch = h->act_scratch; aa.ctl = h->act_ctl;
     aa.q = h->act_q; aa.A = h->A; aa.seq = h->act_seq++;
@@ -1355,6 +1356,7 @@ static int predict_state_enqueue(sdqn_net_s* h, sdqn_statebuf_s* sb) {
   for (int k = 0; k < h->A; ++k) qh[k] = Q_SENTINEL;
   h->act_last = false;
   if (h->act_on && !h->prof_on) {                                // one launch: conv1 .. fc5 (sdqn_act.hip); 8 stripe partials come back
+    { int rcj = join_comm(h); if (rcj) return rcj; }            // (data parallel, overlapped form: W4's update runs on the second stream)
     for (int sp = 1; sp < 8; ++sp) for (int k = 0; k < h->A; ++k) qh[sp * ACT_Q_STRIDE + k] = Q_SENTINEL;
     ActArgs aa; memset(&aa, 0, sizeof aa);
     aa.state = statebuf_window(sb); aa.theta = h->theta; aa.scratch = h->act_scratch; aa.ctl = h->act_ctl;
@@ -1457,6 +1459,7 @@ extern "C" int sdqn_net_debug_act(sdqn_net_t h, sdqn_statebuf_t sb, float* q_out
   ARGCHK(h->act_scratch && (size_t)sb->hist * sb->frame == (size_t)STATE, "the one-launch acting forward needs a float32 network without batch_norm and the standard geometry");
   const size_t nst = (size_t)ACT_GRID * 2 * ACT_STAMPS;
   unsigned long long* d_st = nullptr;
+  { int rcj = join_comm(h); if (rcj) return rcj; }
   if (stamps_out) { HIPCHK(hipMalloc((void**)&d_st, nst * 8)); HIPCHK(hipMemsetAsync(d_st, 0, nst * 8, g_stream)); }
   ActArgs aa; memset(&aa, 0, sizeof aa);
   aa.state = statebuf_window(sb); aa.theta = h->theta; aa.scratch = h->act_scratch; aa.ctl = h->act_ctl;
