@@ -136,3 +136,16 @@ def test_deferred_cost_gives_the_same_statistics_and_random_stream(sd):
     assert a[0] == b[0] and a[0] > 0 and a[1] == b[1] == 100 and a[3] == b[3] and a[4:] == b[4:]
     for x, y in zip(a[2], b[2]):
         assert np.array_equal(x, y)
+
+
+def test_chain_probe_exists_only_in_the_experiments_build(sd):
+    """sdqn_exp_chain_probe (tools/exp/chain_probe.py) is exported by both libraries (one header), but only the experiments build contains
+    the kernel: the product library refuses by name."""
+    import os
+    net = _net(sd, 4, 621)
+    t = C.c_float()
+    rc = sd.load().sdqn_exp_chain_probe(net._h, 1, 256, 2, C.byref(t), None)
+    if os.environ.get("SDQN_LIB_VARIANT") == "experiments":
+        assert rc == 0 and 2.0 < t.value < 200.0
+    else:
+        assert rc != 0 and b"experiments build" in sd.load().sdqn_last_error()
