@@ -250,7 +250,8 @@ int sdqn_net_set_epoch(sdqn_net_t h, int epoch);
  * "bt:<kernel id>" (menu entry of that launch: 0 built-in block shape, -1 latency engine / previous kernel, n > 0 other shapes — tuning
  * surface of tools/sweep_bt.py), "tps:<layer>" (K chunks per weight-gradient slab), "act_kernel" (1 default where available — float32, no
  * batch_norm, 84x84x4: the acting forward of sdqn_net_predict_state / _predict_one is ONE launch, sdqn_act.hip; 0: the five batched
- * forward kernels at batch 1).  The step structures that were built, tested and measured SLOWER — "hoist", "f4w_early", "fuse_upd",
+ * forward kernels at batch 1; test hook "act_inject_failure": the next such launch delivers nothing, which exercises the host's fall-back to the
+ * five launches).  The step structures that were built, tested and measured SLOWER — "hoist", "f4w_early", "fuse_upd",
  * "head_f4d", "two_streams", "fwd_rb", "bwd_order", "rb:<id>", "bt_x", "btx:<id>", "bt_planes" — exist only in the experiments build
  * (make -C simple_dqn_amd/csrc experiments -> libsdqn_hip_exp.so); this library refuses a non-zero value for them with SDQN_ERR_ARG. */
 int sdqn_net_set_option(sdqn_net_t h, const char* name, int value);

@@ -468,7 +468,7 @@ struct sdqn_net_s {
   bool head_q_system = false;              // (run_forward: this forward's head writes system-scope)
   // the acting forward as ONE launch (sdqn_act.hip; float32, no batch-norm): per-XCC scratch copies, fc4 partial slots, control blocks
   float *act_scratch = nullptr, *act_q = nullptr; unsigned* act_ctl = nullptr; unsigned act_seq = 0;
-  bool act_on = false, act_last = false; int act_fallbacks = 0;     // act_last: the forward being collected came from that launch
+  bool act_on = false, act_last = false, act_inject = false; int act_fallbacks = 0;     // act_inject (tests): the next one-launch forward finds its work already claimed and delivers nothing     // act_last: the forward being collected came from that launch
   // deferred cost read-back (sdqn_net_train_many_deferred): pinned ring of cost sums the stream copies into
   double* cost_ring = nullptr; int cost_steps[64] = {0}; int64_t cost_ticket = 0;
   bool spec_pending = false; const void* spec_sb = nullptr; uint64_t spec_gen = 0;
@@ -1361,6 +1361,10 @@ static int predict_state_enqueue(sdqn_net_s* h, sdqn_statebuf_s* sb) {
     ActArgs aa; memset(&aa, 0, sizeof aa);
     aa.state = statebuf_window(sb); aa.theta = h->theta; aa.scratch = h->act_scratch; aa.ctl = h->act_ctl;
     aa.q = h->q_host_dev + h->q_slot * Q_SLOT_FLOATS; aa.A = h->A; aa.seq = h->act_seq++;
+    if (h->act_inject) {            // every ticket counter of this launch's control block far beyond the item count: all workgroups leave at once
+      h->act_inject = false;
+      HIPCHK(hipMemsetAsync(h->act_ctl + (size_t)(aa.seq & 3u) * ACT_CTL_WORDS, 0x7F, (size_t)ACT_CTL_WORDS * 4, g_stream));
+    }
     LAUNCH(K_ACT, launch_act(aa, true, g_stream));
     h->act_last = true;
     h->spec_pending = true; h->spec_sb = sb; h->spec_gen = sb->gen;
@@ -1913,6 +1917,10 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
     if (id < 0 || id >= 12 || value < 0 || value > 8) { set_error("bad rb override"); return SDQN_ERR_ARG; }
     if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name);
     h->rb[id] = value;
+  }
+  else if (!strcmp(name, "act_inject_failure")) {         // tests: the next one-launch acting forward delivers nothing (exercises the host's fallback)
+    ARGCHK(h->act_scratch, "act_inject_failure needs a network with the one-launch acting forward");
+    h->act_inject = value != 0;
   }
   else if (!strcmp(name, "act_kernel")) {                  // 1: acting forward as one launch (default where available), 0: the five forward launches
     ARGCHK(value == 0 || h->act_scratch, "act_kernel needs a float32 network without batch_norm");

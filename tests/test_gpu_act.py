@@ -149,3 +149,24 @@ def test_chain_probe_exists_only_in_the_experiments_build(sd):
         assert rc == 0 and 2.0 < t.value < 200.0
     else:
         assert rc != 0 and b"experiments build" in sd.load().sdqn_last_error()
+
+
+def test_a_launch_that_delivers_nothing_falls_back_to_the_five_launch_forward(sd, capfd):
+    """Every poll inside the one-launch forward is bounded, and the host's wait for the Q partials is too (2 ms, then a stream
+    synchronisation): a launch that delivers nothing (injected: its work appears claimed already) makes the library fall back to the
+    five-launch forward for THIS call and every later one, with one line on stderr — same Q-values as act_kernel = 0."""
+    A = 4
+    net = _net(sd, A, 631)
+    buf = sd.DeviceStateBuffer(make_args(batch_size=32))
+    rng = np.random.RandomState(632)
+    for _ in range(5):
+        buf.add(rng.randint(0, 256, (84, 84), dtype=np.uint8))
+    q_ok = net.predict_state(buf)
+    net.set_option("act_inject_failure", 1)
+    q_fb = net.predict_state(buf)                       # injected failure -> fallback inside this call
+    q_after = net.predict_state(buf)                    # stays on the five launches
+    net.set_option("act_kernel", 0)
+    q5 = net.predict_state(buf)
+    assert np.array_equal(q_fb, q5) and np.array_equal(q_after, q5)
+    assert np.abs(q_ok - q5).max() <= 2e-6 * max(1e-3, float(np.abs(q5).max())) + 1e-7
+    assert "did not complete" in capfd.readouterr().err
