@@ -634,6 +634,40 @@ def b256_leg(sd, make_args, seed, steps=300, warmup=100, ring=200000):
                                   "fused_gather_conv1": fused, "frac_hbm": round(best, 4), "met": bool(best >= 0.40)}}
 
 
+def fp16_b256_leg(sd, make_args, seed, steps=300, warmup=140, ring=200000):
+    """The throughput regime in float16 (batch_size 256, A = 3: configs[2]'s shape in configs[4]'s precision), in the same process as the
+    headline so that the driver's JSON line carries it (VERDICT r3 item 1 names this number): half block-tile routines, weight gradients
+    through transpose reads, conv1 from frames staged in LDS."""
+    import ctypes as C
+    from simple_dqn_amd import _lib
+    B, A = 256, 3
+    args = make_args(batch_size=B, random_seed=seed + 1, datatype="float16")
+    mem = sd.ReplayMemory(ring, args)
+    fill_ring(mem, seed + 79, A)
+    net = sd.DeepQNetwork(A, args)
+    net.update_target_network()
+    mt = (C.c_uint32 * 625)()
+    _lib.check(sd.load().sdqn_mt_seed(mt, seed + 7))
+    net.train_from_memory(mem, warmup - 40, mt_state=mt, want_cost=False)
+    net.profile(True, -1); net.profile_reset()
+    net.train_from_memory(mem, 40, mt_state=mt, want_cost=False)
+    prof = [p for p in net.profile_read() if p["launches"] >= 40]
+    net.profile(False)
+    net.sync()
+    t0 = time.perf_counter()
+    net.train_from_memory(mem, steps, mt_state=mt, want_cost=False)
+    net.sync()
+    el = time.perf_counter() - t0
+    w = kernel_work(B, A)
+    flops = sum(w[i]["flops"] for i in (0, 1, 2, 3, 4, 5, 16, 17, 18))
+    return {"workload": "batch_size=256, num_actions=3, --datatype float16, replay_size=%d (NOT the headline; same process, after the headline's "
+                        "timed region)" % ring,
+            "value": round(steps / el, 2), "unit": "train_steps/sec", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "warmup": warmup,
+            "frac_fp16_peak_whole_step": round(flops / (el / steps) / BF16_PEAK, 4), "flops_per_step": flops,
+            "kernels_us": {p["name"]: round(p["total_ms"] / p["launches"] * 1e3, 2) for p in prof},
+            "dtype": "f16 activations/deltas/MFMA operands, f32 accumulate + master weights + RMSProp"}
+
+
 def fp16_leg(sd, make_args, seed, steps=1500, warmup=300, ring=200000):
     """BASELINE.json configs[4] ("Space Invaders, fp16 activations with fp32 RMSProp accumulators") on ONE GPU, in the same process as
     the headline so that the driver's JSON line carries it (VERDICT r2 "missing" 5): B = 32, A = 6, --datatype float16.  The 8-GPU half
@@ -914,6 +948,11 @@ def main():
                     out["config_b256"] = b256_leg(sd, make_args, a.seed)
                 except Exception as e:                         # never let the side leg break the headline line
                     out["config_b256"] = {"error": repr(e)[:300]}
+                if not a.no_fp16_leg:
+                    try:
+                        out["config_fp16_b256"] = fp16_b256_leg(sd, make_args, a.seed)
+                    except Exception as e:
+                        out["config_fp16_b256"] = {"error": repr(e)[:300]}
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(B, A, a.seed, a.cpu_baseline_seconds)
                 try:
