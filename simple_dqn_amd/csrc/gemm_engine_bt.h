@@ -35,6 +35,10 @@ namespace sdqn {
 // issues 32 MFMAs per sub-tile between barriers and the per-interval costs — the barrier itself, the LDS-read latency in front of the
 // first MFMA, the staging stores — are paid once per 64 k.  rocprofv3 PMC at B = 256 (tools/exp/pmc_sq_b256.sh): 1.3-2.6 waves per SIMD
 // and the matrix pipe busy 47-63 % of a launch — a lone wave per SIMD pays those costs serially.
+// problems whose epilogue gates the result with a stored activation (the dgrads) say so: P::GATED, P::gate_load, P::store_gated
+template <class P, class = void> struct bt_gated { static constexpr bool value = false; };
+template <class P> struct bt_gated<P, decltype((void)P::GATED)> { static constexpr bool value = P::GATED; };
+
 template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 2, int X_ = 0, int CPI_ = 1>
 struct BtCfg {
   typedef P_ P;
@@ -285,6 +289,22 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
     }
   };
 
+  // a dgrad's gating activations (delta = (W^T delta') . 1[a > 0]): fetched now, under the K loop, not as dependent loads in the epilogue
+  constexpr bool GATED = bt_gated<P>::value;
+  float gate[GATED ? SM : 1][GATED ? SN : 1][16];
+  if constexpr (GATED) {
+#pragma unroll
+    for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+      for (int sn = 0; sn < SN; ++sn)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = m0 + (wm * SM + sm) * 32 + bt::acc_row(q, h), n = n0 + (wn * SN + sn) * 32 + i;
+          gate[sm][sn][q] = P::gate_load(a, z, m < M ? m : M - 1, n < N ? n : N - 1);
+        }
+  }
+  (void)gate;
+
   // ---- main loop: register set (t mod D) holds interval t = chunks [CPI t, CPI t + CPI); two LDS stages; one barrier per interval ----------
   typename P::Epi epi[SM][SN];
   const int nch = (kend - kbeg + bt::BK - 1) / bt::BK;
@@ -355,7 +375,10 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int m = ms + bt::acc_row(q, h), n = ns + i;
-          if (m < M && n < N) P::store(a, z, ks, m, n, acc[sm][sn][q]);
+          if (m < M && n < N) {
+            if constexpr (GATED) P::store_gated(a, z, ks, m, n, acc[sm][sn][q], gate[sm][sn][q]);
+            else P::store(a, z, ks, m, n, acc[sm][sn][q]);
+          }
         }
       }
     }
@@ -626,6 +649,21 @@ __device__ __forceinline__ void bt_tile_h(const StepArgs& a, int bx, int by, int
     for (int sn = 0; sn < SN; ++sn)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[sm][sn][q] = 0.0f;
+  // a dgrad's gating activations (delta = (W^T delta') . 1[a > 0]): fetched now, under the K loop, not as dependent loads in the epilogue
+  constexpr bool GATED = bt_gated<P>::value;
+  float gate[GATED ? SM : 1][GATED ? SN : 1][16];
+  if constexpr (GATED) {
+#pragma unroll
+    for (int sm = 0; sm < SM; ++sm)
+#pragma unroll
+      for (int sn = 0; sn < SN; ++sn)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int m = m0 + (wm * SM + sm) * 32 + bt::acc_row(q, h), n = n0 + (wn * SN + sn) * 32 + i;
+          gate[sm][sn][q] = P::gate_load(a, z, m < M ? m : M - 1, n < N ? n : N - 1);
+        }
+  }
+  (void)gate;
   auto compute = [&](const half_t* As, const half_t* Bs) {
 #pragma unroll
     for (int st = 0; st < BK / 16; ++st) {
@@ -671,7 +709,10 @@ __device__ __forceinline__ void bt_tile_h(const StepArgs& a, int bx, int by, int
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int m = ms + bt::acc_row(q, h), n = ns + i;
-        if (m < M && n < N) P::store(a, z, ks, m, n, acc[sm][sn][q]);
+        if (m < M && n < N) {
+          if constexpr (GATED) P::store_gated(a, z, ks, m, n, acc[sm][sn][q], gate[sm][sn][q]);
+          else P::store(a, z, ks, m, n, acc[sm][sn][q]);
+        }
       }
     }
 }

@@ -70,33 +70,44 @@ struct Fc4DgradH : Fc4Dgrad {
   static constexpr bool F16_MFMA = true;
   __device__ static half8 a_load8(const StepArgs& a, int, aoff_t o) { return ldh8(a.h_d4 + o); }
   __device__ static half8 b_load8(const StepArgs& a, int, int o) { return ldh8(a.wh[0] + OFF4 + o); }
-  __device__ static void store(const StepArgs& a, int, int, int m, int n, float v) {
+  // GATED (block-tile routines): the activation whose sign gates the delta is fetched BEFORE the K loop (it does not depend on it) instead of
+  // as a dependent load per element in the epilogue
+  static constexpr bool GATED = true;
+  __device__ static float gate_load(const StepArgs& a, int, int m, int n) { return (float)a.h_a3[(int64_t)m * NIN4 + n]; }
+  __device__ static void store_gated(const StepArgs& a, int, int, int m, int n, float v, float g) {
     int pix = n >> 6, f = n & 63, p = pix / Q3, q = pix - p * Q3;
-    const half_t dv = (float)a.h_a3[(int64_t)m * NIN4 + n] > 0.0f ? (half_t)v : (half_t)0.0f;
+    const half_t dv = g > 0.0f ? (half_t)v : (half_t)0.0f;
     a.h_d3p[((m * PD3 + p + 2) * PD3 + q + 2) * K3 + f] = dv;
     a.h_d3[(int64_t)m * NIN4 + n] = dv;
   }
+  __device__ static void store(const StepArgs& a, int z, int ks, int m, int n, float v) { store_gated(a, z, ks, m, n, v, gate_load(a, z, m, n)); }
 };
 struct Conv3DgradH : Conv3Dgrad {
   static constexpr bool F16_MFMA = true;
   __device__ static half8 a_load8(const StepArgs& a, int, aoff_t o) { return ldh8(a.h_d3p + o); }
   __device__ static half8 b_load8(const StepArgs& a, int, int o) { return ldh8(a.wh[0] + OFF3 + o); }
-  __device__ static void store(const StepArgs& a, int, int, int m, int c, float v) {
-    const half_t dv = (float)a.h_a2[(int64_t)m * K2 + c] > 0.0f ? (half_t)v : (half_t)0.0f;
+  static constexpr bool GATED = true;
+  __device__ static float gate_load(const StepArgs& a, int, int m, int c) { return (float)a.h_a2[(int64_t)m * K2 + c]; }
+  __device__ static void store_gated(const StepArgs& a, int, int, int m, int c, float v, float g) {
+    const half_t dv = g > 0.0f ? (half_t)v : (half_t)0.0f;
     a.h_d2p[prow2(m) + c] = dv;
     a.h_d2[(int64_t)m * K2 + c] = dv;
   }
+  __device__ static void store(const StepArgs& a, int z, int ks, int m, int c, float v) { store_gated(a, z, ks, m, c, v, gate_load(a, z, m, c)); }
 };
 struct Conv2DgradH : Conv2Dgrad {
   static constexpr bool F16_MFMA = true;
   __device__ static half8 a_load8(const StepArgs& a, int, aoff_t o) { return ldh8(a.h_d2p + o); }
   __device__ static half8 b_load8(const StepArgs& a, int, int o) { return ldh8(a.wh[0] + OFF2 + o); }
-  __device__ static void store(const StepArgs& a, int z, int, int m, int c, float v) {
+  static constexpr bool GATED = true;
+  __device__ static int out_off(int z, int m, int c) {
     int py = z >> 1, px = z & 1;
     int n = m / 100, pix = m - n * 100, i = pix / 10, j = pix - i * 10;
-    int o = ((n * P1 + 2 * i + py) * Q1 + 2 * j + px) * K1 + c;
-    a.h_d1[o] = (float)a.h_a1[o] > 0.0f ? (half_t)v : (half_t)0.0f;
+    return ((n * P1 + 2 * i + py) * Q1 + 2 * j + px) * K1 + c;
   }
+  __device__ static float gate_load(const StepArgs& a, int z, int m, int c) { return (float)a.h_a1[out_off(z, m, c)]; }
+  __device__ static void store_gated(const StepArgs& a, int z, int, int m, int c, float v, float g) { a.h_d1[out_off(z, m, c)] = g > 0.0f ? (half_t)v : (half_t)0.0f; }
+  __device__ static void store(const StepArgs& a, int z, int ks, int m, int c, float v) { store_gated(a, z, ks, m, c, v, gate_load(a, z, m, c)); }
 };
 
 // ---- wgrad: fp32 MFMA engine, half operands, loss scale divided out in the epilogue ---------------------------------

@@ -71,11 +71,15 @@ struct Conv3DgradWT : Conv3Dgrad {
   SDQN_PRELOAD_MULTI_DEF
   __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.d3p), "s"(a.theta[0]), "s"(a.a2), "s"(a.d2p), "s"(a.d2), "s"(a.B), "s"(g0), "s"(g1), "s"(g2)); }
 
-  __device__ static void store(const StepArgs& a, int, int, int m, int c, float v) {
-    const float dv = a.a2[(int64_t)m * K2 + c] > 0.0f ? v : 0.0f;
+  // GATED (block-tile routine): the gating activation is fetched before the K loop instead of as a dependent load per element in the epilogue
+  static constexpr bool GATED = true;
+  __device__ static float gate_load(const StepArgs& a, int, int m, int c) { return a.a2[(int64_t)m * K2 + c]; }
+  __device__ static void store_gated(const StepArgs& a, int, int, int m, int c, float v, float g) {
+    const float dv = g > 0.0f ? v : 0.0f;
     wt_store(&a.d2p[prow2(m) + c], dv);
     wt_store(&a.d2[(int64_t)m * K2 + c], dv);
   }
+  __device__ static void store(const StepArgs& a, int z, int ks, int m, int c, float v) { store_gated(a, z, ks, m, c, v, gate_load(a, z, m, c)); }
 };
 struct Conv3WgradWT : Conv3Wgrad {
   static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
@@ -89,12 +93,15 @@ struct Conv2DgradWT : Conv2Dgrad {
   SDQN_PRELOAD_MULTI_DEF
   __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.d2p), "s"(a.theta[0]), "s"(a.a1), "s"(a.d1), "s"(a.B), "s"(g0), "s"(g1), "s"(g2)); }
 
-  __device__ static void store(const StepArgs& a, int z, int, int m, int c, float v) {
+  static constexpr bool GATED = true;
+  __device__ static int out_off(int z, int m, int c) {
     const int py = z >> 1, px = z & 1;
     const int n = m / 100, pix = m - n * 100, i = pix / 10, j = pix - i * 10;
-    const int o = ((n * P1 + 2 * i + py) * Q1 + 2 * j + px) * K1 + c;
-    wt_store(&a.d1[o], a.a1[o] > 0.0f ? v : 0.0f);
+    return ((n * P1 + 2 * i + py) * Q1 + 2 * j + px) * K1 + c;
   }
+  __device__ static float gate_load(const StepArgs& a, int z, int m, int c) { return a.a1[out_off(z, m, c)]; }
+  __device__ static void store_gated(const StepArgs& a, int z, int, int m, int c, float v, float g) { wt_store(&a.d1[out_off(z, m, c)], g > 0.0f ? v : 0.0f); }
+  __device__ static void store(const StepArgs& a, int z, int ks, int m, int c, float v) { store_gated(a, z, ks, m, c, v, gate_load(a, z, m, c)); }
 };
 struct Conv2WgradWT : Conv2Wgrad {
   static constexpr bool PRELOAD = SDQN_PRELOAD != 0;
