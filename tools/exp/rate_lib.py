@@ -8,7 +8,7 @@ import simple_dqn_amd as sd
 from util import make_args
 from bench import fill_ring
 B, A = int(os.environ.get("B", 32)), 4
-args = make_args(batch_size=B)
+args = make_args(batch_size=B, datatype=os.environ.get("DATATYPE", "float32"))
 mem = sd.ReplayMemory(100000, args); fill_ring(mem, 1, A)
 net = sd.DeepQNetwork(A, args); net.update_target_network()
 mt = (C.c_uint32 * 625)(); sd.load().sdqn_mt_seed(mt, 5)
@@ -17,4 +17,4 @@ net.train_from_memory(mem, 300, mt_state=mt, want_cost=False); net.sync()
 r = []
 for _ in range(4):
     t = time.perf_counter(); net.train_from_memory(mem, N, mt_state=mt, want_cost=False); net.sync(); r.append(N / (time.perf_counter() - t))
-print(os.environ.get("LIB", "default"), "steps/s:", " ".join("%.0f" % x for x in r))
+print(os.environ.get("LIB", "default"), "B", B, os.environ.get("DATATYPE", "float32"), "steps/s:", " ".join("%.0f" % x for x in r))
