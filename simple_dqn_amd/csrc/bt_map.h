@@ -40,6 +40,17 @@ SDQN_HD constexpr int mk_floats(int BX) { return BK * BX; }
 
 SDQN_HD constexpr int panel_floats(bool kcontig, int BX) { return kcontig ? km_floats(BX) : mk_floats(BX); }
 
+// ---- ping-pong routine (gemm_engine_pp.h): 512 threads = two groups of 4 waves, ALL of them loaders.  A panel is BX x 8 float4 items;
+// item -> (row, k4) for KM panels, (k, x4) for MK panels; a 32-wide panel has 256 items: threads t and t + 256 carry the same one
+constexpr int NT2 = 512;
+SDQN_HD constexpr int pp_items(int BX) { return BX * 8; }
+SDQN_HD constexpr int pp_passes(int BX) { return (pp_items(BX) + NT2 - 1) / NT2; }
+SDQN_HD constexpr int pp_item(int BX, int tid, int p) { return (tid + NT2 * p) % pp_items(BX); }
+SDQN_HD constexpr int pp_km_row(int it) { return it >> 3; }
+SDQN_HD constexpr int pp_km_k(int it) { return (it & 7) * 4; }
+SDQN_HD constexpr int pp_mk_k(int BX, int it) { return it / (BX / 4); }
+SDQN_HD constexpr int pp_mk_x(int BX, int it) { return (it % (BX / 4)) * 4; }
+
 // ---- fragment of lane (i = l & 31, h = l >> 5) for sub-tile row/column x0 + i, MFMA step t ------------------------------
 SDQN_HD constexpr int frag_off(bool kcontig, int BX, int x, int t, int h) {
   return kcontig ? km_off(x, kslot(t, h)) : mk_off(BX, kslot(t, h), x);

@@ -94,6 +94,7 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
   constexpr int PA = bt::passes(BM), PB = bt::passes(BN);
   static_assert(sizeof(typename a_elem<P>::type) == 4 && sizeof(typename b_elem<P>::type) == 4, "fp32 operands (the fp16 mode has its own routine)");
 
+  SDQN_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
@@ -329,6 +330,7 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
     for (int d = 0; d < D; ++d) if (d < nit) gload_it(d, ra[d], rb[d]);
     store_it(ra[0], rb[0], smem);
     __syncthreads();
+    SDQN_STAMP(1);
     // (unconditional ring loads with a clamped interval index — what the half routines below use — measured 1 % SLOWER here: 217.5 vs
     //  215.4 us per step at B = 256; the fp32 forward problems have compile-time chunk counts and exact waits already)
     for (int t0 = 0; t0 < nit; t0 += D) {
@@ -343,9 +345,15 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
 #pragma unroll
           for (int cc = 0; cc < CPI; ++cc) compute(cur + cc * C::PANELS, cur + cc * C::PANELS + C::AF);
           if (t + 1 < nit) { store_it(ra[(d + 1) % D], rb[(d + 1) % D], nxt); __syncthreads(); }
+#ifdef SDQN_TIMING
+          if (t == 3) SDQN_STAMP(2);
+          if (t == 7) SDQN_STAMP(3);
+          if (t == 11) SDQN_STAMP(4);
+#endif
         }
       }
     }
+    SDQN_STAMP(5);
   } else epi_prefetch();
 
   // ---- epilogue: every sub-tile through the problem's own 32 x 32 epilogue ----------------------------------------------------
@@ -923,7 +931,9 @@ template <class C>
 __global__ void __launch_bounds__(bt::NT) bt_kernel(const StepArgs a, const int gx, const int gy) {
   __shared__ __attribute__((aligned(16))) float smem[C::LDS];
   if constexpr (has_preload<typename C::P>::value) C::P::preload(a, gridDim.x, (unsigned)gx, (unsigned)gy);
-  const int t = blockIdx.x;
+  // XCD-contiguous block map (StepArgs::xcd_map bit 0): workgroup b runs on XCD b % 8; every XCD gets ONE contiguous run of block ids
+  // (m-fastest), so the blocks that share a B panel (and neighbouring A rows) share an L2 instead of fetching it into eight
+  const int t = (a.xcd_map & 1) ? xcd_tile_id((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
   const int per_z = gx * gy, bz = t / per_z, r = t - bz * per_z;
   bt_tile<C>(a, r % gx, r / gx, bz, smem);
 }
@@ -951,10 +961,10 @@ __global__ void __launch_bounds__(bt::NT) bt_multi_kernel(const StepArgs a, cons
   constexpr int L01 = C0::LDS > C1::LDS ? C0::LDS : C1::LDS, L = L01 > C2::LDS ? L01 : C2::LDS;
   __shared__ __attribute__((aligned(16))) float smem[L];
   if constexpr (has_preload_multi<typename C1::P>::value) C1::P::preload_multi(a, d);
-  const int b = blockIdx.x;
-  if (b < d.n[0]) { const int pz = d.gx[0] * d.gy[0], bz = b / pz, r = b - bz * pz; bt_run_tile<C0>(a, r % d.gx[0], r / d.gx[0], bz, smem); }
-  else if (b < d.n[0] + d.n[1]) { const int l = b - d.n[0], pz = d.gx[1] * d.gy[1], bz = l / pz, r = l - bz * pz; bt_run_tile<C1>(a, r % d.gx[1], r / d.gx[1], bz, smem); }
-  else { const int l = b - d.n[0] - d.n[1], pz = d.gx[2] * d.gy[2], bz = l / pz, r = l - bz * pz; bt_run_tile<C2>(a, r % d.gx[2], r / d.gx[2], bz, smem); }
+  const int b = blockIdx.x, xm = a.xcd_map;              // bit i: problem i on the XCD-contiguous block map
+  if (b < d.n[0]) { const int l = (xm & 1) ? xcd_tile_id_range(b, 0, d.n[0]) : b, pz = d.gx[0] * d.gy[0], bz = l / pz, r = l - bz * pz; bt_run_tile<C0>(a, r % d.gx[0], r / d.gx[0], bz, smem); }
+  else if (b < d.n[0] + d.n[1]) { const int l = (xm & 2) ? xcd_tile_id_range(b, d.n[0], d.n[1]) : b - d.n[0], pz = d.gx[1] * d.gy[1], bz = l / pz, r = l - bz * pz; bt_run_tile<C1>(a, r % d.gx[1], r / d.gx[1], bz, smem); }
+  else { const int l = (xm & 4) ? xcd_tile_id_range(b, d.n[0] + d.n[1], d.n[2]) : b - d.n[0] - d.n[1], pz = d.gx[2] * d.gy[2], bz = l / pz, r = l - bz * pz; bt_run_tile<C2>(a, r % d.gx[2], r / d.gx[2], bz, smem); }
 }
 
 template <class C0, class C1, class C2>

@@ -492,6 +492,7 @@ struct sdqn_net_s {
   // kept current wherever the weights are written; xp = partial products per fp32 product (9 exact / 6; 0 = fp32 MFMA, no planes used)
   unsigned short *wpm = nullptr, *wpt[2] = {nullptr, nullptr}; int xp = 0;
   int btx[K_COUNT] = {0};                    // block-tile engine arithmetic per kernel id: 0 fp32 MFMA, 9 / 6 exact bf16x3 operand splits on packed-bf16 MFMA
+  bool bt_xcd = true;                      // round 4, B >= 128 float32: XCD-contiguous maps for fc4_dgrad / bwd3 / bwd2 (option "bt_xcd")
   bool bt_on = true; int bt[K_COUNT] = {0};  // round 4, B >= 128 float32: block-tile engine (sdqn_kernels_bt.hip); per kernel id 0 = built-in block shape, n = menu entry, -1 = latency engine
   int xcd_mask[K_COUNT] = {0};             // tuning hook "xcd:<kernel id>": per-launch problem mask (-1 = built-in)
   bool xcd_map = false;                    // XCD-contiguous tile map for EVERY launch: traffic ~ algorithmic, step ~1 % slower (bwd3);
@@ -1078,6 +1079,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   // B < 128 only: in the throughput regime the on-the-fly split of delta1 makes it VALU-bound (measured 3 580 vs 4 063 steps/s at B = 256;
   // option value 2 forces it for experiments)
   const bool c1w = (h->conv1w_bf16 == 2 || (h->conv1w_bf16 == 1 && h->B < 128)) && h->cfg.datatype == 0 && !h->bn && !hoist && h->nw_override[K_CONV1_WGRAD] == 0;
+  const bool bt_xcd = h->B >= 128 && h->cfg.datatype == 0 && h->bt_on && !h->bn && h->bt_xcd;
   const bool f4_early = EXPERIMENTS && h->f4w_early && h->B <= 32 && h->cfg.datatype == 0 && !h->bn && h->fused_launches && !two_streams &&
                         !dp_ov && !hoist && h->bwd_order == 0 && h->f4_share[0] == 100 && h->f4_share[1] == 0 && h->nw_override[K_FC4_DGRAD] == 0;
 #ifdef SDQN_EXPERIMENTS
@@ -1088,7 +1090,12 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   else
 #endif
   if (f4_early) { h->handoff_launched = true; LAUNCH(K_F4D_F4W, launch_tuned(h, K_FC4_DGRAD, a, g_stream, 0, 1)); }
-  else LAUNCH(K_FC4_DGRAD, launch_tuned(h, K_FC4_DGRAD, a, g_stream));
+  else {
+    // round 4, B >= 128 float32: the backward launches on the XCD-contiguous block / tile maps (the blocks that share a weight panel share an L2):
+    // fc4_dgrad 15.1 -> 14.4 us, bwd2 38.9 -> 37.5, bwd3 39.7 -> 39.2; 4 802 -> 4 867 steps/s at B = 256 (placement only: same bits)
+    StepArgs fd = a; if (bt_xcd) fd.xcd_map |= 1;
+    LAUNCH(K_FC4_DGRAD, launch_tuned(h, K_FC4_DGRAD, fd, g_stream));
+  }
   BN_BWD(2);
   // round 4, float16 at B >= 128: the two dgrads run on the half block-tile routine as launches of their own (15.6 / 18.1 -> ~7 / 8 us:
   // operands leave L2 once per workgroup), and every weight gradient that does not need delta1 shares ONE launch behind them (it packs
@@ -1136,6 +1143,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
       b2.f4w_first = s3; b2.f4w_count = s2;
       b1.f4w_first = s3 + s2; b1.f4w_count = f4_tiles - s3 - s2;
     } else { b3.f4w_first = 0; b3.f4w_count = f4_tiles; b2.f4w_count = b1.f4w_count = 0; }
+    if (bt_xcd) { b3.xcd_map |= 7; b2.xcd_map |= 7; }
     if (f4_early) LAUNCH(K_BWD3_CONV, launch_tuned(h, K_BWD3, b3, g_stream)); else LAUNCH(K_BWD3, launch_tuned(h, K_BWD3, b3, g_stream));
     BN_BWD(1);
     LAUNCH(K_BWD2, launch_tuned(h, K_BWD2, b2, g_stream, hoist & 1));
@@ -1926,6 +1934,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
     ARGCHK(value == 0 || h->act_scratch, "act_kernel needs a float32 network without batch_norm");
     h->act_on = value != 0; h->spec_pending = false;
   }
+  else if (!strcmp(name, "bt_xcd")) h->bt_xcd = value != 0;             // 0: round-robin block placement in the B >= 128 backward launches
   else if (!strcmp(name, "bt")) h->bt_on = value != 0;                  // 0: B >= 128 on the latency engine's launch forms (round 3)
   else if (!strcmp(name, "bt_planes")) {                   // plane mode: 9 / 6 partial products, 0 = fp32 MFMA (B >= 128 float32 networks only)
     ARGCHK(value == 0 || value == 6 || value == 9, "bt_planes must be 0, 6 or 9");
@@ -1946,7 +1955,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   }
   else if (!strncmp(name, "bt:", 3)) {                     // block-tile engine: menu entry of kernel id (0 built-in, -1 latency engine)
     int id = atoi(name + 3);
-    if (id < 0 || id >= K_COUNT || value < -1 || value > 8) { set_error("bad bt override"); return SDQN_ERR_ARG; }
+    if (id < 0 || id >= K_COUNT || value < -1 || value > (EXPERIMENTS ? 12 : 8)) { set_error("bad bt override"); return SDQN_ERR_ARG; }
     h->bt[id] = value;
   }
   else if (!strcmp(name, "bwd_order")) { if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name); h->bwd_order = value; }

@@ -265,9 +265,11 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
 #ifdef SDQN_TIMING
 hipError_t set_timing_buffer_rb(unsigned long long* p);
 hipError_t set_timing_buffer_r3(unsigned long long* p);
+hipError_t set_timing_buffer_bt(unsigned long long* p);
 hipError_t set_timing_buffer(unsigned long long* p) {
   hipError_t e = set_timing_buffer_rb(p);
   if (e == hipSuccess) e = set_timing_buffer_r3(p);
+  if (e == hipSuccess) e = set_timing_buffer_bt(p);
   return e != hipSuccess ? e : hipMemcpyToSymbol(HIP_SYMBOL(g_sdqn_dbg), &p, sizeof p);
 }
 #endif

@@ -10,6 +10,9 @@
 // LaunchTune::bt[id]: 0 = the built-in block shape, n > 0 = menu entry n (tools/sweep_bt.py), < 0 = this launch on the latency engine.
 #include <stdlib.h>
 #include "gemm_engine_bt.h"
+#ifdef SDQN_EXPERIMENTS
+#include "gemm_engine_pp.h"      // ping-pong form (8 waves, two per SIMD): built, correct, measured SLOWER than bt_tile everywhere — tools/exp/README.md
+#endif
 #include "problems_wt.h"
 #include "problems_h16.h"
 #include "kernels.h"
@@ -20,6 +23,10 @@ namespace sdqn {
 #define BTX(P, BM, BN, WM, WN, D, X) BtCfg<P, BM, BN, WM, WN, D, X>
 #define BT2(P, BM, BN, WM, WN, D) BtCfg<P, BM, BN, WM, WN, D, 0, 2>       // two chunks per barrier interval
 #define BT_CASE(N, P, BM, BN, WM, WN, D) case N: return launch_bt<BT(P, BM, BN, WM, WN, D)>(a, s)
+#ifdef SDQN_EXPERIMENTS
+#define PP(P, BM, BN, WM, WN, D) PpCfg<P, BM, BN, WM, WN, D>                // ping-pong routine (gemm_engine_pp.h): 8 waves, two per SIMD
+#define PP_CASE(N, P, BM, BN, WM, WN, D) case N: return launch_pp<PP(P, BM, BN, WM, WN, D)>(a, s)
+#endif
 
 // built-in block shapes (menu entry 0 maps onto these)
 typedef BT(Conv2FwdWT, 64, 64, 2, 2, 2) C2F;
@@ -40,6 +47,9 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 0: return launch_bt<C2F>(a, s);
         BT_CASE(1, Conv2FwdWT, 64, 64, 2, 2, 3); BT_CASE(2, Conv2FwdWT, 128, 64, 2, 2, 2); BT_CASE(3, Conv2FwdWT, 128, 64, 4, 1, 2);
         BT_CASE(4, Conv2FwdWT, 64, 64, 2, 2, 1); BT_CASE(5, Conv2FwdWT, 128, 64, 2, 2, 3);
+#ifdef SDQN_EXPERIMENTS
+        PP_CASE(10, Conv2FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Conv2FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Conv2FwdWT, 128, 64, 2, 2, 2);
+#endif
 #ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
         case 6: return launch_bt<BT2(Conv2FwdWT, 64, 64, 2, 2, 2)>(a, s);
         case 7: return launch_bt<BT2(Conv2FwdWT, 64, 64, 2, 2, 1)>(a, s);
@@ -52,6 +62,9 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 0: return launch_bt<C3F>(a, s);
         BT_CASE(1, Conv3FwdWT, 64, 64, 2, 2, 3); BT_CASE(2, Conv3FwdWT, 128, 64, 2, 2, 2); BT_CASE(3, Conv3FwdWT, 128, 64, 4, 1, 2);
         BT_CASE(4, Conv3FwdWT, 64, 64, 2, 2, 1); BT_CASE(5, Conv3FwdWT, 128, 64, 2, 2, 3);
+#ifdef SDQN_EXPERIMENTS
+        PP_CASE(10, Conv3FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Conv3FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Conv3FwdWT, 128, 64, 2, 2, 2);
+#endif
 #ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
         case 6: return launch_bt<BT2(Conv3FwdWT, 64, 64, 2, 2, 2)>(a, s);
         case 7: return launch_bt<BT2(Conv3FwdWT, 64, 64, 2, 2, 1)>(a, s);
@@ -64,6 +77,9 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 0: return launch_bt<F4F>(a, s);
         BT_CASE(1, Fc4FwdWT, 64, 64, 2, 2, 3); BT_CASE(2, Fc4FwdWT, 128, 64, 2, 2, 2); BT_CASE(3, Fc4FwdWT, 128, 128, 2, 2, 2);
         BT_CASE(4, Fc4FwdWT, 64, 128, 2, 2, 2); BT_CASE(5, Fc4FwdWT, 128, 128, 2, 2, 3);
+#ifdef SDQN_EXPERIMENTS
+        PP_CASE(10, Fc4FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Fc4FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Fc4FwdWT, 128, 64, 2, 2, 2);
+#endif
 #ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
         case 6: return launch_bt<BT2(Fc4FwdWT, 64, 64, 2, 2, 2)>(a, s);
         case 7: return launch_bt<BT2(Fc4FwdWT, 64, 64, 2, 2, 1)>(a, s);
@@ -77,6 +93,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         BT_CASE(1, Fc4DgradWT, 64, 64, 2, 2, 3); BT_CASE(2, Fc4DgradWT, 64, 128, 2, 2, 2); BT_CASE(3, Fc4DgradWT, 32, 128, 1, 4, 2);
         BT_CASE(4, Fc4DgradWT, 128, 64, 2, 2, 2); BT_CASE(5, Fc4DgradWT, 32, 128, 1, 4, 3);
 #ifdef SDQN_EXPERIMENTS
+        PP_CASE(10, Fc4DgradWT, 64, 64, 2, 2, 2); PP_CASE(11, Fc4DgradWT, 64, 64, 2, 2, 3); PP_CASE(12, Fc4DgradWT, 32, 128, 1, 4, 2);
         case 6: return launch_bt<BT2(Fc4DgradWT, 64, 64, 2, 2, 2)>(a, s);
         case 7: return launch_bt<BT2(Fc4DgradWT, 32, 128, 1, 4, 2)>(a, s);
 #endif
@@ -135,6 +152,8 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
       case 3: return launch_bt_multi<F4W, C3D, C3W>(a, f4, true, true, s);
       case 4: return launch_bt_multi<BT(Conv3DgradWT, 128, 64, 2, 2, 2), BT(Conv3WgradWT, 128, 64, 2, 2, 2), BT(Fc4WgradBT, 64, 128, 2, 2, 2)>(a, true, true, f4, s);
 #ifdef SDQN_EXPERIMENTS
+      case 10: return launch_pp_multi<PP(Conv3DgradWT, 64, 64, 2, 2, 2), PP(Conv3WgradWT, 64, 64, 2, 2, 2), PP(Fc4WgradBT, 64, 64, 2, 2, 2)>(a, true, true, f4, s);
+      case 11: return launch_pp_multi<PP(Conv3DgradWT, 64, 64, 2, 2, 3), PP(Conv3WgradWT, 64, 64, 2, 2, 3), PP(Fc4WgradBT, 64, 64, 2, 2, 3)>(a, true, true, f4, s);
       case 5: return launch_bt_multi<BT2(Conv3DgradWT, 64, 64, 2, 2, 2), BT2(Conv3WgradWT, 64, 64, 2, 2, 2), BT2(Fc4WgradBT, 64, 64, 2, 2, 2)>(a, true, true, f4, s);
       case 6: return launch_bt_multi<BT2(Conv3DgradWT, 64, 64, 2, 2, 1), BT2(Conv3WgradWT, 64, 64, 2, 2, 1), BT2(Fc4WgradBT, 64, 64, 2, 2, 1)>(a, true, true, f4, s);
 #endif
@@ -148,6 +167,8 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
       case 3: return launch_bt_multi<NOP, C2D, C2W>(a, false, true, true, s);
       case 4: return launch_bt_multi<NOP, BT(Conv2DgradWT, 128, 32, 4, 1, 2), BT(Conv2WgradWT, 128, 64, 2, 2, 2)>(a, false, true, true, s);
 #ifdef SDQN_EXPERIMENTS
+      case 10: return launch_pp_multi<PP(NoProblem, 64, 64, 2, 2, 2), PP(Conv2WgradWT, 64, 64, 2, 2, 2), PP(Conv2DgradWT, 128, 32, 4, 1, 2)>(a, false, true, true, s);
+      case 11: return launch_pp_multi<PP(NoProblem, 64, 64, 2, 2, 2), PP(Conv2WgradWT, 64, 64, 2, 2, 3), PP(Conv2DgradWT, 128, 32, 4, 1, 3)>(a, false, true, true, s);
       case 5: return launch_bt_multi<NOP, BT2(Conv2WgradWT, 64, 64, 2, 2, 2), BT2(Conv2DgradWT, 128, 32, 4, 1, 2)>(a, false, true, true, s);
       case 6: return launch_bt_multi<NOP, BT2(Conv2WgradWT, 64, 64, 2, 2, 1), BT2(Conv2DgradWT, 128, 32, 4, 1, 1)>(a, false, true, true, s);
 #endif
@@ -717,5 +738,9 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
   *handled = true;
   return e;
 }
+
+#ifdef SDQN_TIMING
+hipError_t set_timing_buffer_bt(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sdqn_dbg), &p, sizeof p); }
+#endif
 
 }  // namespace sdqn

@@ -192,3 +192,35 @@ def test_block_tile_other_slab_counts(sd):
         assert np.abs(net.last_q()[0] - ref.last_q()[0]).max() < 2e-5, opts
         for i in range(5):
             assert _rel(net.get_layer(i, 3), ref.get_layer(i, 3)) < 2e-5, (opts, i)
+
+
+@pytest.mark.parametrize("A,B", [(3, 256), (6, 160)])
+def test_xcd_contiguous_block_maps_are_placement_only(sd, A, B):
+    """Round 4: fc4_dgrad / bwd3 / bwd2 of the B >= 128 float32 step run on XCD-contiguous block maps (option bt_xcd, on by default): which
+    workgroup computes which block changes, nothing else — every gradient, delta and Q-value is bit-identical with the round-robin maps,
+    ragged grids included (B = 160: block counts that are not multiples of 8)."""
+    mb = random_minibatch(B, A, 70 + B, reward_range=(-2, 3))
+    on = _net(sd, A, B, 11, [("keep_gradients", 1)])
+    off = _net(sd, A, B, 11, [("keep_gradients", 1), ("bt_xcd", 0)])
+    on.train(mb); off.train(mb)
+    for name, n in dict(d3p=B * 121 * 64, d2p=B * 121 * 64, d1=B * 400 * 32).items():
+        assert np.array_equal(on.debug_read(name, n), off.debug_read(name, n)), name
+    for i in range(5):
+        assert np.array_equal(on.get_layer(i, 3), off.get_layer(i, 3)), i
+    assert np.array_equal(on.last_q()[0], off.last_q()[0])
+
+
+@pytest.mark.experiments
+@pytest.mark.parametrize("A,B", [(3, 256), (6, 160)])
+def test_ping_pong_routine_matches_the_block_tile_routine(sd, A, B):
+    """gemm_engine_pp.h (experiments build: 8 waves per workgroup, the two groups of four alternate compute and fragment-read phases; measured
+    slower, tools/exp/README.md): the same sums as bt_tile in another partition (even chunks + odd chunks), every launch, ragged blocks too."""
+    mb = random_minibatch(B, A, 80 + B, reward_range=(-2, 3))
+    ref = _net(sd, A, B, 13, [("keep_gradients", 1), ("bt:3", 1), ("bt:5", 1), ("s4", 7)])
+    pp = _net(sd, A, B, 13, [("keep_gradients", 1), ("s4", 7)] + [("bt:%d" % k, 10) for k in (1, 2, 3, 5, 16, 17)])
+    ref.train(mb); pp.train(mb)
+    for name, n in dict(a2=2 * B * 81 * 64, a3=2 * B * 49 * 64, a4=2 * B * 512, d3p=B * 121 * 64, d2p=B * 121 * 64, d1=B * 400 * 32).items():
+        assert _rel(pp.debug_read(name, n), ref.debug_read(name, n)) < 2e-5, name
+    for i in range(5):
+        assert _rel(pp.get_layer(i, 3), ref.get_layer(i, 3)) < 2e-5, i
+
