@@ -728,7 +728,7 @@ __device__ __forceinline__ void bt_tile_h(const StepArgs& a, int bx, int by, int
 template <class C>
 __global__ void __launch_bounds__(bt::NT) bt_kernel_h(const StepArgs a, const int gx, const int gy) {
   __shared__ __attribute__((aligned(16))) float smem[C::LDS];
-  const int t = blockIdx.x;
+  const int t = (a.xcd_map & 1) ? xcd_tile_id((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;       // (bt_kernel)
   const int per_z = gx * gy, bz = t / per_z, r = t - bz * per_z;
   bt_tile_h<C>(a, r % gx, r / gx, bz, smem);
 }

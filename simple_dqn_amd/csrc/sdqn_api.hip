@@ -1023,7 +1023,8 @@ static int run_forward(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, int
   } else
 #endif
   LAUNCH(K_CONV1_FWD, launch_tuned(h, K_CONV1_FWD, fm, g_stream, 0, (h->conv1_bf16 && !(EXPERIMENTS && h->hoist) && h->nw_override[K_CONV1_FWD] == 0) ? 4 : 0));
-  LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, fm, g_stream, 0, (EXPERIMENTS && (h->fwd_rb & 1)) ? 16 : 0));
+  { StepArgs f2 = fm; if (h->B >= 128) f2.xcd_map = a.xcd_map;          // block-tile routines (B >= 128): conv2_fwd 28.8 / 8.8 us round-robin, 28.9 / 9.0 on the map (fp32 / float16)
+    LAUNCH(K_CONV2_FWD, launch_tuned(h, K_CONV2_FWD, f2, g_stream, 0, (EXPERIMENTS && (h->fwd_rb & 1)) ? 16 : 0)); }
   { StepArgs f3 = fm; f3.xcd_map = a.xcd_map;
     const int c36 = (EXPERIMENTS && (h->fwd_rb & 2)) ? 32 : ((h->conv3_c36 && !(EXPERIMENTS && h->hoist) && h->nw_override[K_CONV3_FWD] == 0) ? 2 : 0);      // (hoist: the riding target conv3 uses the 32-deep routine)
     LAUNCH(K_CONV3_FWD, launch_tuned(h, K_CONV3_FWD, f3, g_stream, 0, c36)); }
