@@ -492,7 +492,7 @@ struct sdqn_net_s {
   // kept current wherever the weights are written; xp = partial products per fp32 product (9 exact / 6; 0 = fp32 MFMA, no planes used)
   unsigned short *wpm = nullptr, *wpt[2] = {nullptr, nullptr}; int xp = 0;
   int btx[K_COUNT] = {0};                    // block-tile engine arithmetic per kernel id: 0 fp32 MFMA, 9 / 6 exact bf16x3 operand splits on packed-bf16 MFMA
-  bool bt_xcd = true;                      // round 4, B >= 128 float32: XCD-contiguous maps for fc4_dgrad / bwd3 / bwd2 (option "bt_xcd")
+  bool bt_xcd = true;                      // round 4, B >= 128: XCD-contiguous block maps for fc4_dgrad / bwd3 / bwd2 (float32) and the weight-gradient launch (float16); option "bt_xcd"
   bool bt_on = true; int bt[K_COUNT] = {0};  // round 4, B >= 128 float32: block-tile engine (sdqn_kernels_bt.hip); per kernel id 0 = built-in block shape, n = menu entry, -1 = latency engine
   int xcd_mask[K_COUNT] = {0};             // tuning hook "xcd:<kernel id>": per-launch problem mask (-1 = built-in)
   bool xcd_map = false;                    // XCD-contiguous tile map for EVERY launch: traffic ~ algorithmic, step ~1 % slower (bwd3);
@@ -1126,6 +1126,7 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
   } else
   if (h16_bt) {
     StepArgs w = a; w.f4w_first = 0; w.f4w_count = (NIN4 / 32) * (NFC / 32);
+    if (h->bt_xcd) w.xcd_map |= 7;          // the weight-gradient launch on XCD-contiguous block maps (the blocks of a K slab share their operand rows): 20.1 -> 17.0 us at B = 256
     StepArgs b1 = a; b1.f4w_count = 0; b1.xcd_map |= 2;
     LAUNCH(K_CONV3_DGRAD, launch_tuned(h, K_CONV3_DGRAD, a, g_stream));
     LAUNCH(K_CONV2_DGRAD, launch_tuned(h, K_CONV2_DGRAD, a, g_stream));
