@@ -1146,6 +1146,9 @@ static int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const
       b1.f4w_first = s3 + s2; b1.f4w_count = f4_tiles - s3 - s2;
     } else { b3.f4w_first = 0; b3.f4w_count = f4_tiles; b2.f4w_count = b1.f4w_count = 0; }
     if (bt_xcd) { b3.xcd_map |= 7; b2.xcd_map |= 7; }
+    // B <= 32: the fc4_wgrad tiles of bwd3 (third problem of the launch) on the XCD-contiguous map — a tile row's 16 tiles share a3's columns
+    // (10.29 -> 10.10 us, 15 315 -> 15 345 steps/s in alternating rate loops; the conv3 problems are slower on it: round-robin as before)
+    if (h->B <= 32 && h->cfg.datatype == 0 && !h->bn && h->bt_xcd) b3.xcd_map |= 4;
     if (f4_early) LAUNCH(K_BWD3_CONV, launch_tuned(h, K_BWD3, b3, g_stream)); else LAUNCH(K_BWD3, launch_tuned(h, K_BWD3, b3, g_stream));
     BN_BWD(1);
     LAUNCH(K_BWD2, launch_tuned(h, K_BWD2, b2, g_stream, hoist & 1));
