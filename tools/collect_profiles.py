@@ -72,6 +72,8 @@ for f in ("tuple_api_rate.txt", "generic_rate.txt"):
         rows += ["--- " + f] + [l.rstrip() for l in open(os.path.join(CAP, f)) if "steps/s" in l]
     except Exception as e:
         rows.append("MISSING %s %s" % (f, repr(e)[:80]))
+if not os.path.exists(os.path.join(CAP, "agent_loop.log")):
+    print("no agent_loop.log in this capture: %s_side_rates.txt left as it is" % tag); sys.exit(0)
 open(os.path.join(P, tag + "_side_rates.txt"), "w").write(
     "# tools/final_capture.sh, build %s: python -m simple_dqn_amd.main --replay_size 100000 --random_steps 5000 --train_steps 40000 --test_steps 20000 --epochs 1 (synthetic environment);\n"
     "# tools/exp/tuple_api_rate.py; tools/generic_rate.py\n" % rev + "\n".join(rows) + "\n")
