@@ -569,7 +569,7 @@ def expected_dp_rates(B, A, datatype, ms_per_step_1gpu=None):
     1-GPU step + the part of the all-reduce the form cannot hide.  Serial form: the whole all-reduce + ~6 us for the un-fused fc4
     update; overlapped form: max(0, fc4 all-reduce - the ~55 % of the step it runs under) + ~17 us of cross-stream dependencies."""
     payload = 4 * (8192 + 32768 + 36864 + 1605632 + 512 * A) // (2 if datatype == "float16" else 1)
-    base_us = (ms_per_step_1gpu * 1e3) if ms_per_step_1gpu else {("float32", 32): 66.0, ("float16", 32): 57.5, ("float32", 256): 227.0, ("float16", 256): 170.0}.get((datatype, B), 66.0)
+    base_us = (ms_per_step_1gpu * 1e3) if ms_per_step_1gpu else {("float32", 32): 66.0, ("float16", 32): 57.5, ("float32", 256): 202.5, ("float16", 256): 105.6}.get((datatype, B), 66.0)
     rows = {}
     for n in (2, 4, 8):
         ar = allreduce_model(n, payload)["expected_us"]
