@@ -558,32 +558,7 @@ constexpr int tile_lds_any() {
 template <class P> constexpr int tile_m() { return 32 * rb_m<P>::value; }
 template <class P> constexpr int tile_n() { return 32 * rb_n<P>::value; }
 
-// XCD-aware workgroup -> tile map (guide T1).  The dispatcher places workgroup b on XCD b % 8, each XCD with its
-// own L2.  Tiles are numbered x-fastest (then y, then split/net z), so NEIGHBOURING tile ids share operands
-// (adjacent im2col rows and halos; the same K-range of activations for all (crs, f) tiles of a wgrad split).
-// Giving every XCD one CONTIGUOUS run of tile ids keeps those re-reads in one L2 instead of eight.  Bijective
-// for any workgroup count; placement only changes speed, never results.  Measured (profiles/README.md): fabric
-// traffic drops to ~1.0-1.7x algorithmic (bwd1 15.0 -> 3.8 MB) but the step gets 3-4 % SLOWER at B=32 and B=256 —
-// these launches are latency-bound and eight L2s fetching a tile's neighbourhood in parallel beat one — so the
-// map is an option (StepArgs::xcd_map, sdqn_net_set_option "xcd_map"), off by default.
-__device__ __forceinline__ int xcd_tile_id(int b, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, i = b >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-}
-// the same for a sub-range [s, s + n) of a grid (one problem of a multi-problem launch): workgroup b's XCD is
-// still b % 8; the range's workgroups on XCD x get one contiguous run of the range's n tile ids
-__device__ __forceinline__ int xcd_tile_id_range(int b, int s, int n) {
-  const int x = b & 7;
-  int before = 0, mine_first = 0;
-#pragma unroll
-  for (int y = 0; y < 8; ++y) {
-    const int first = s + ((y - (s & 7) + 8) & 7);              // first workgroup of the range on XCD y
-    const int cnt = first < s + n ? (s + n - first + 7) >> 3 : 0;
-    if (y < x) before += cnt;
-    if (y == x) mine_first = first;
-  }
-  return before + ((b - mine_first) >> 3);
-}
+// (xcd_tile_id / xcd_tile_id_range, the XCD-aware workgroup -> tile maps: problems.h — host + device, tests/emul executes them)
 
 template <class P, int NW>
 __global__ void __launch_bounds__(NW * 64) gemm_kernel(const StepArgs a) {

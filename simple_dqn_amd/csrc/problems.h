@@ -231,6 +231,33 @@ SDQN_HD f4 ld4_u8(const uint8_t* p) {       // 4 consecutive bytes (4-byte align
 
 SDQN_HD int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// XCD-aware workgroup -> tile map (guide T1).  The dispatcher places workgroup b on XCD b % 8, each XCD with its
+// own L2.  Tiles are numbered x-fastest (then y, then split/net z), so NEIGHBOURING tile ids share operands
+// (adjacent im2col rows and halos; the same K-range of activations for all (crs, f) tiles of a wgrad split).
+// Giving every XCD one CONTIGUOUS run of tile ids keeps those re-reads in one L2 instead of eight.  Bijective
+// for any workgroup count; placement only changes speed, never results.  Measured (profiles/README.md): fabric
+// traffic drops to ~1.0-1.7x algorithmic (bwd1 15.0 -> 3.8 MB) but the step gets 3-4 % SLOWER at B=32 and B=256 —
+// these launches are latency-bound and eight L2s fetching a tile's neighbourhood in parallel beat one — so the
+// map is an option (StepArgs::xcd_map, sdqn_net_set_option "xcd_map"), off by default.
+SDQN_HD int xcd_tile_id(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, i = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+// the same for a sub-range [s, s + n) of a grid (one problem of a multi-problem launch): workgroup b's XCD is
+// still b % 8; the range's workgroups on XCD x get one contiguous run of the range's n tile ids
+SDQN_HD int xcd_tile_id_range(int b, int s, int n) {
+  const int x = b & 7;
+  int before = 0, mine_first = 0;
+  for (int y = 0; y < 8; ++y) {
+    const int first = s + ((y - (s & 7) + 8) & 7);              // first workgroup of the range on XCD y
+    const int cnt = first < s + n ? (s + n - first + 7) >> 3 : 0;
+    if (y < x) before += cnt;
+    if (y == x) mine_first = first;
+  }
+  return before + ((b - mine_first) >> 3);
+}
+
+
 // ---- im2col index helpers -------------------------------------------------------------
 SDQN_HD int64_t row1(const StepArgs& a, int z, int m) {      // conv1 patch origin in the byte source
   int n = m / PIX1, pix = m - n * PIX1, p = pix / Q1, q = pix - p * Q1;

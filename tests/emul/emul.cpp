@@ -139,6 +139,9 @@ static void run_any(const StepArgs& a) {
   else run<P>(a);
 }
 
+// XCD-contiguous workgroup -> tile maps (problems.h): both must be bijections for every grid size / every sub-range of a multi-problem launch
+extern "C" int emul_xcd_tile_id(int b, int nwg) { return xcd_tile_id(b, nwg); }
+extern "C" int emul_xcd_tile_id_range(int b, int s, int n) { return xcd_tile_id_range(b, s, n); }
 extern "C" void emul_div_bsz(const float* x, float bsz, float* out, int n) { for (int i = 0; i < n; ++i) out[i] = div_bsz(x[i], bsz); }
 extern "C" void emul_norm_u8(float* out256) { for (int i = 0; i < 256; ++i) out256[i] = norm_u8((uint32_t)i); }
 

@@ -72,3 +72,23 @@ def test_batch_size_division_is_exact(emul):
         with np.errstate(all="ignore"):
             ref = x / np.float32(bsz)
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), bsz
+
+
+def test_xcd_contiguous_maps_are_bijections_with_contiguous_runs(emul):
+    """problems.h: xcd_tile_id / xcd_tile_id_range (the placement maps of every launch that shares operands inside an XCD's L2 — round 4:
+    the B >= 128 backward launches, the fc4_wgrad tiles of bwd3).  Workgroup b runs on XCD b mod 8: for every grid size, and for every
+    sub-range [s, s + n) of a multi-problem launch, the map must hit every tile exactly once and give each XCD one contiguous run."""
+    for nwg in list(range(1, 70)) + [98, 162, 196, 200, 324, 392, 502, 648, 800, 1568, 4016]:
+        t = [emul.emul_xcd_tile_id(b, nwg) for b in range(nwg)]
+        assert sorted(t) == list(range(nwg)), nwg
+        for x in range(8):
+            run = sorted(t[b] for b in range(x, nwg, 8))
+            assert run == list(range(run[0], run[0] + len(run))) if run else True, (nwg, x)
+    for s0 in (0, 1, 3, 7, 8, 13, 162, 306, 324):
+        for n in list(range(1, 40)) + [98, 144, 196, 352, 400, 800]:
+            t = [emul.emul_xcd_tile_id_range(b, s0, n) for b in range(s0, s0 + n)]
+            assert sorted(t) == list(range(n)), (s0, n)
+            for x in range(8):
+                run = sorted(t[b - s0] for b in range(s0, s0 + n) if b % 8 == x)
+                assert (not run) or run == list(range(run[0], run[0] + len(run))), (s0, n, x)
+
