@@ -39,9 +39,14 @@ namespace sdqn {
 template <class P, class = void> struct bt_gated { static constexpr bool value = false; };
 template <class P> struct bt_gated<P, decltype((void)P::GATED)> { static constexpr bool value = P::GATED; };
 
-template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 2, int X_ = 0, int CPI_ = 1>
+template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 2, int X_ = 0, int CPI_ = 1, int UNC_ = 0>
 struct BtCfg {
   typedef P_ P;
+  // UNC: the ring loads are UNCONDITIONAL (interval index clamped to the last one) — for problems whose chunk count is a run-time value
+  // (the weight gradients' K slabs, fc4 forward's K split).  With the guarded form `if (t + D < nit) gload(...)` hipcc has to cover the path
+  // WITHOUT new loads and waits with vmcnt(3 .. 0) in front of the LDS stores — on the path with loads that drains the loads just issued:
+  // one exposed memory round trip per chunk (conv3_wgrad: 2 640 cycles per chunk for 1 024 of matrix time, tools/exp/bt_stamps.py)
+  static constexpr bool UNC = UNC_ != 0;
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
   static constexpr int KIND = 0;                        // bt_run_tile: fp32 panels (bt_tile)
   static constexpr int D = D_;                          // chunks in flight per workgroup: D register sets of (BM + BN) / 32 float4 per thread
@@ -327,7 +332,7 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
   };
   if (nit > 0) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) if (d < nit) gload_it(d, ra[d], rb[d]);
+    for (int d = 0; d < D; ++d) { if constexpr (C::UNC) gload_it(d < nit ? d : nit - 1, ra[d], rb[d]); else if (d < nit) gload_it(d, ra[d], rb[d]); }
     store_it(ra[0], rb[0], smem);
     __syncthreads();
     SDQN_STAMP(1);
@@ -340,7 +345,8 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
         if (t < nit) {
           float* cur = smem + (t & 1) * C::STAGE;
           float* nxt = smem + ((t + 1) & 1) * C::STAGE;
-          if (t + D < nit) gload_it(t + D, ra[d], rb[d]);               // set d is free: interval t went to LDS one iteration ago
+          if constexpr (C::UNC) gload_it(t + D < nit ? t + D : nit - 1, ra[d], rb[d]);       // (clamped: a re-fetch of the last interval that nobody stores)
+          else if (t + D < nit) gload_it(t + D, ra[d], rb[d]);          // set d is free: interval t went to LDS one iteration ago
           if (t + 1 == nit) epi_prefetch();
 #pragma unroll
           for (int cc = 0; cc < CPI; ++cc) compute(cur + cc * C::PANELS, cur + cc * C::PANELS + C::AF);

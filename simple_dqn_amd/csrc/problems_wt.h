@@ -59,12 +59,16 @@ struct Fc4DgradWT : Fc4Dgrad {
   __device__ static void preload(const StepArgs& a, unsigned g0, unsigned g1, unsigned g2) { SDQN_TOUCH("s"(a.d4), "s"(a.theta[0]), "s"(a.a3), "s"(a.d3p), "s"(a.d3), "s"(a.B), "s"(a.xcd_map), "s"(g0), "s"(g1), "s"(g2)); }
 
   __device__ static f4 b_load4(const StepArgs& a, int, int o) { return NT_W4 ? ld4_nt(a.theta[0] + OFF4 + o) : ld4(a.theta[0] + OFF4 + o); }
-  __device__ static void store(const StepArgs& a, int, int, int m, int n, float v) {
+  // GATED (block-tile routine; the latency engine calls store): the gating activation is fetched before the K loop
+  static constexpr bool GATED = true;
+  __device__ static float gate_load(const StepArgs& a, int, int m, int n) { return a.a3[(int64_t)m * NIN4 + n]; }
+  __device__ static void store_gated(const StepArgs& a, int, int, int m, int n, float v, float g) {
     const int pix = n >> 6, f = n & 63, p = pix / Q3, q = pix - p * Q3;
-    const float dv = a.a3[(int64_t)m * NIN4 + n] > 0.0f ? v : 0.0f;
+    const float dv = g > 0.0f ? v : 0.0f;
     wt_store(&a.d3p[((m * PD3 + p + 2) * PD3 + q + 2) * K3 + f], dv);
     wt_store(&a.d3[(int64_t)m * NIN4 + n], dv);
   }
+  __device__ static void store(const StepArgs& a, int z, int ks, int m, int n, float v) { store_gated(a, z, ks, m, n, v, gate_load(a, z, m, n)); }
 };
 struct Conv3DgradWT : Conv3Dgrad {
   static constexpr bool PRELOAD = SDQN_PRELOAD != 0;

@@ -20,6 +20,7 @@
 namespace sdqn {
 
 #define BT(P, BM, BN, WM, WN, D) BtCfg<P, BM, BN, WM, WN, D>
+#define BTU(P, BM, BN, WM, WN, D) BtCfg<P, BM, BN, WM, WN, D, 0, 1, 1>        // unconditional ring loads (run-time chunk counts)
 #define BTX(P, BM, BN, WM, WN, D, X) BtCfg<P, BM, BN, WM, WN, D, X>
 #define BT2(P, BM, BN, WM, WN, D) BtCfg<P, BM, BN, WM, WN, D, 0, 2>       // two chunks per barrier interval
 #define BT_CASE(N, P, BM, BN, WM, WN, D) case N: return launch_bt<BT(P, BM, BN, WM, WN, D)>(a, s)
@@ -32,12 +33,12 @@ namespace sdqn {
 typedef BT(Conv2FwdWT, 64, 64, 2, 2, 2) C2F;
 typedef BT(Conv3FwdWT, 64, 64, 2, 2, 2) C3F;
 typedef BT(Fc4FwdWT, 64, 64, 2, 2, 2) F4F;
-typedef BT(Fc4DgradWT, 64, 64, 2, 2, 2) F4D;
-typedef BT(Fc4WgradBT, 64, 64, 2, 2, 2) F4W;
+typedef BT(Fc4DgradWT, 64, 64, 2, 2, 3) F4D;          // (three chunks in flight: W4 streams from memory; 12.4 us at B = 256, the latency engine 14.4)
+typedef BTU(Fc4WgradBT, 64, 64, 2, 2, 2) F4W;          // the weight gradients' K slabs are run-time chunk counts: unconditional ring loads
 typedef BT(Conv3DgradWT, 64, 64, 2, 2, 2) C3D;
-typedef BT(Conv3WgradWT, 64, 64, 2, 2, 2) C3W;
+typedef BTU(Conv3WgradWT, 64, 64, 2, 2, 2) C3W;
 typedef BT(Conv2DgradWT, 128, 32, 4, 1, 2) C2D;
-typedef BT(Conv2WgradWT, 64, 64, 2, 2, 2) C2W;
+typedef BTU(Conv2WgradWT, 64, 64, 2, 2, 2) C2W;
 typedef BT(NoProblem, 64, 64, 2, 2, 1) NOP;
 
 static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t s) {
@@ -77,6 +78,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 0: return launch_bt<F4F>(a, s);
         BT_CASE(1, Fc4FwdWT, 64, 64, 2, 2, 3); BT_CASE(2, Fc4FwdWT, 128, 64, 2, 2, 2); BT_CASE(3, Fc4FwdWT, 128, 128, 2, 2, 2);
         BT_CASE(4, Fc4FwdWT, 64, 128, 2, 2, 2); BT_CASE(5, Fc4FwdWT, 128, 128, 2, 2, 3);
+        case 8: return launch_bt<BTU(Fc4FwdWT, 64, 64, 2, 2, 2)>(a, s);        // unconditional ring loads (run-time K split): 21.0 us at S4 = 7, the latency engine 18.1
 #ifdef SDQN_EXPERIMENTS
         PP_CASE(10, Fc4FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Fc4FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Fc4FwdWT, 128, 64, 2, 2, 2);
 #endif
@@ -151,6 +153,7 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
       case 2: return launch_bt_multi<BT(Conv3DgradWT, 128, 64, 2, 2, 2), BT(Conv3WgradWT, 64, 64, 2, 2, 2), F4W>(a, true, true, f4, s);
       case 3: return launch_bt_multi<F4W, C3D, C3W>(a, f4, true, true, s);
       case 4: return launch_bt_multi<BT(Conv3DgradWT, 128, 64, 2, 2, 2), BT(Conv3WgradWT, 128, 64, 2, 2, 2), BT(Fc4WgradBT, 64, 128, 2, 2, 2)>(a, true, true, f4, s);
+      case 7: return launch_bt_multi<C3D, BT(Conv3WgradWT, 64, 64, 2, 2, 2), BT(Fc4WgradBT, 64, 64, 2, 2, 2)>(a, true, true, f4, s);     // guarded ring loads (until round 4's second session: 39.2 vs 38.1 us)
 #ifdef SDQN_EXPERIMENTS
       case 10: return launch_pp_multi<PP(Conv3DgradWT, 64, 64, 2, 2, 2), PP(Conv3WgradWT, 64, 64, 2, 2, 2), PP(Fc4WgradBT, 64, 64, 2, 2, 2)>(a, true, true, f4, s);
       case 11: return launch_pp_multi<PP(Conv3DgradWT, 64, 64, 2, 2, 3), PP(Conv3WgradWT, 64, 64, 2, 2, 3), PP(Fc4WgradBT, 64, 64, 2, 2, 3)>(a, true, true, f4, s);
@@ -166,6 +169,7 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
       case 2: return launch_bt_multi<NOP, BT(Conv2DgradWT, 256, 32, 4, 1, 2), C2W>(a, false, true, true, s);
       case 3: return launch_bt_multi<NOP, C2D, C2W>(a, false, true, true, s);
       case 4: return launch_bt_multi<NOP, BT(Conv2DgradWT, 128, 32, 4, 1, 2), BT(Conv2WgradWT, 128, 64, 2, 2, 2)>(a, false, true, true, s);
+      case 7: return launch_bt_multi<NOP, BT(Conv2WgradWT, 64, 64, 2, 2, 2), C2D>(a, false, true, true, s);      // guarded ring loads
 #ifdef SDQN_EXPERIMENTS
       case 10: return launch_pp_multi<PP(NoProblem, 64, 64, 2, 2, 2), PP(Conv2WgradWT, 64, 64, 2, 2, 2), PP(Conv2DgradWT, 128, 32, 4, 1, 2)>(a, false, true, true, s);
       case 11: return launch_pp_multi<PP(NoProblem, 64, 64, 2, 2, 2), PP(Conv2WgradWT, 64, 64, 2, 2, 3), PP(Conv2DgradWT, 128, 32, 4, 1, 3)>(a, false, true, true, s);
@@ -706,9 +710,10 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
     *handled = true;
     return eh;
   }
-  // fc4 forward / dgrad have 64 / 196 blocks of 64 x 64 — one or two per CU, nothing to overlap their waits with — and measured slower
-  // here than on the latency engine (fc4_fwd 23.4 vs 18.7 us, fc4_dgrad 17.0 vs 15.2 at B = 256): block-tile only on request (menu entry > 0)
-  if ((id == K_FC4_FWD || id == K_FC4_DGRAD) && t.bt[id] == 0 && !(id == K_FC4_DGRAD && a.xp && a.wpm)) return hipSuccess;
+  // fc4 forward has 64 blocks of 64 x 64 per K slab and measured slower here than on the latency engine (21.0 vs 18.1 us at B = 256 with 7
+  // slabs and unconditional ring loads): block-tile only on request (menu entry > 0).  fc4_dgrad (196 blocks) moved here in round 4's second
+  // session: 12.4 us against 14.4 once its gating activations are fetched before the K loop (17.0 with the dependent loads in the epilogue)
+  if (id == K_FC4_FWD && t.bt[id] == 0) return hipSuccess;
   if (id < 12 && (t.nw_override[id] > 0 || t.rb[id] > 0)) return hipSuccess;      // explicit latency-engine tuning hooks win
   hipError_t e = hipErrorInvalidValue;
 #ifdef SDQN_EXPERIMENTS

@@ -7,7 +7,7 @@ import simple_dqn_amd as sd
 from util import make_args, random_minibatch
 from oracle.dqn_numpy import xavier_weights
 B, A = int(os.environ.get("B", 32)), int(os.environ.get("A", 4))
-NAMES = {0: "conv1_fwd", 1: "conv2_fwd", 2: "conv3_fwd", 3: "fc4_fwd", 4: "head", 5: "fc4_dgrad", 7: "c3d", 9: "c2d", 12: "update", 16: "bwd3", 17: "bwd2", 18: "bwd1", 24: "wgrads"}
+NAMES = {0: "conv1_fwd", 1: "conv2_fwd", 2: "conv3_fwd", 3: "fc4_fwd", 4: "head", 5: "fc4_dgrad", 6: "f4w", 7: "c3d", 8: "c3w", 9: "c2d", 10: "c2w", 11: "c1w", 12: "update", 16: "bwd3", 17: "bwd2", 18: "bwd1", 24: "wgrads"}
 ws, wt = xavier_weights(A, 1), xavier_weights(A, 2)
 mb = random_minibatch(B, A, 3, reward_range=(-2, 3))
 args = make_args(batch_size=B, datatype=os.environ.get("DATATYPE", "float32"))
