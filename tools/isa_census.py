@@ -19,10 +19,11 @@ def demangle(names):
         return {n: n for n in names}
 
 
-def census(src, key=None):
+def census_rows(src, extra_flags=()):
+    """Per-kernel records of one translation unit: name (mangled), vgpr, agpr, lds, scratch, occ, loads, mfma, barriers, vmcnt (Counter)."""
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "k.s")
-        subprocess.check_call([HIPCC] + FLAGS + ["-o", asm, os.path.join(CSRC, src)], stderr=subprocess.DEVNULL)
+        subprocess.check_call([HIPCC] + FLAGS + list(extra_flags) + ["-o", asm, os.path.join(CSRC, src)], stderr=subprocess.DEVNULL)
         txt = open(asm).read()
     rows = []
     # "; -- Begin function <name>" ... code ... "; -- End function" ... "; Kernel info:" comments, up to the next Begin marker
@@ -32,9 +33,14 @@ def census(src, key=None):
         if not v or "; Kernel info:" not in tail:
             continue
         g = lambda pat: int(re.search(pat, tail).group(1))
-        rows.append(dict(name=name, vgpr=int(v.group(1)) , agpr=g(r"; NumAgprs: (\d+)"), lds=g(r"; LDSByteSize: (\d+)"), scratch=g(r"; ScratchSize: (\d+)"), occ=g(r"; Occupancy: (\d+)"),
+        rows.append(dict(name=name, vgpr=int(v.group(1)), agpr=g(r"; NumAgprs: (\d+)"), lds=g(r"; LDSByteSize: (\d+)"), scratch=g(r"; ScratchSize: (\d+)"), occ=g(r"; Occupancy: (\d+)"),
                          loads=len(re.findall(r"\bglobal_load|\bbuffer_load", body)), mfma=len(re.findall(r"\bv_mfma", body)),
                          barriers=len(re.findall(r"\bs_barrier", body)), vmcnt=Counter(int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body))))
+    return rows
+
+
+def census(src, key=None):
+    rows = census_rows(src)
     names = demangle([r["name"] for r in rows])
     for r in rows:
         nm = names[r["name"]].replace("sdqn::", "")
