@@ -105,8 +105,8 @@ __device__ __forceinline__ void sk_piece(const StepArgs& a, int bx, int by, int 
       *reinterpret_cast<float4*>(Bs + o) = qb[p];
     }
   };
-  auto compute = [&](const float* As, const float* Bs) {
-    float fa[16], fb[16];
+  float fa[16], fb[16];
+  auto read_frags = [&](const float* As, const float* Bs) {
     { const int x = wm * 32 + i;
       if constexpr (AK) {
 #pragma unroll
@@ -129,6 +129,8 @@ __device__ __forceinline__ void sk_piece(const StepArgs& a, int bx, int by, int 
 #pragma unroll
         for (int t = 0; t < 16; ++t) fb[t] = Bs[bt::mk_off(BN, bt::kslot(t, 0), x) + h * (4 * BN)];
       } }
+  };
+  auto mma = [&]() {
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
   };
@@ -147,8 +149,12 @@ __device__ __forceinline__ void sk_piece(const StepArgs& a, int bx, int by, int 
       if (t < nit) {
         float* cur = smem + (t & 1) * C::STAGE;
         float* nxt = smem + ((t + 1) & 1) * C::STAGE;
+        // fragment reads FIRST, the new ring loads behind them: in this rolled loop hipcc gives the fragments registers of the ring — a read
+        // issued behind the new loads had to wait for every load in flight (first GPU run: one exposed memory round trip per chunk)
+        read_frags(cur, cur + C::AF);
+        asm volatile("" ::: "memory");
         gload(kbeg + (t + D < nit ? t + D : nit - 1) * bt::BK, ra[d], rb[d]);
-        compute(cur, cur + C::AF);
+        mma();
         if (t + 1 < nit) { lds_store(ra[(d + 1) % D], rb[(d + 1) % D], nxt, nxt + C::AF); __syncthreads(); }
       }
     }
