@@ -17,12 +17,13 @@
 // Results: a whole block is bit-identical to bt_tile's; a split block sums the same chunks in the same order but in two or three partial
 // accumulators (last-bit differences).
 //
-// STATUS (last GPU minutes of round 4; experiments build, menu entry 9 of bt:1 / bt:2): the hand-off works — conv2_fwd and conv3_fwd each
-// alone reproduce bt_tile's gradients to 5e-7 on the first run (tools/exp/README.md) — but the launches are SLOWER than bt_tile (conv3_fwd
-// 26.3 vs 23.6 us, conv2_fwd 37.0 vs 30.1 on the same box): in this rolled loop hipcc reuses the ring's registers for the fragments and waits
-// for every load in flight behind each barrier (the per-chunk drain of DESIGN.md 11.7 again, here from register aliasing; the census shows
-// vmcnt(3 / 1 / 0) in front of the fragment reads).  Both launches in ONE step gave wrong numbers in that run: they shared the flag words and
-// the step's epoch — fixed since (a flag region per launch), not re-run.  Next: the pieces on bt_tile's own unrolled loop.
+// STATUS (last GPU minutes of round 4; experiments build, menu entry 9 of bt:1 / bt:2): the hand-off WORKS — conv2_fwd and conv3_fwd, alone and
+// together (one flag region per launch of the step), reproduce bt_tile's gradients to 5e-7 ... 9e-7 — but the launches are still slower than
+// bt_tile: first run conv3_fwd 26.3 vs 23.6 us and conv2_fwd 37.0 vs 30.1 (hipcc gave the ring loads the registers of the fragments just
+// multiplied: every fragment read behind a barrier waited for the loads issued two MFMAs earlier); with the fragments read ahead of the
+// loads and kept live across their issue (census: no wait in front of the reads any more, the previous set drained early in the chunk
+// instead) 24.2 vs 22.8 and 33.0 vs 29.4 (same box).  The balance is there, the per-chunk efficiency of bt_tile's fully unrolled loop is
+// not: next, the pieces on that loop (chunk counts as template arguments of a few instantiations) or on hand-scheduled waits.
 #pragma once
 #include "gemm_engine_bt.h"
 #include "problems_wt.h"      // wt_store
@@ -154,6 +155,12 @@ __device__ __forceinline__ void sk_piece(const StepArgs& a, int bx, int by, int 
         read_frags(cur, cur + C::AF);
         asm volatile("" ::: "memory");
         gload(kbeg + (t + D < nit ? t + D : nit - 1) * bt::BK, ra[d], rb[d]);
+        // ... and the fragments stay LIVE across the issue of those loads (the register allocator otherwise hands the loads the registers of
+        // the half-chunk that has just been multiplied: write-after-write against the next chunk's fragment reads)
+        asm volatile("" :: "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]), "v"(fa[4]), "v"(fa[5]), "v"(fa[6]), "v"(fa[7]), "v"(fa[8]), "v"(fa[9]), "v"(fa[10]),
+                     "v"(fa[11]), "v"(fa[12]), "v"(fa[13]), "v"(fa[14]), "v"(fa[15]) : "memory");
+        asm volatile("" :: "v"(fb[0]), "v"(fb[1]), "v"(fb[2]), "v"(fb[3]), "v"(fb[4]), "v"(fb[5]), "v"(fb[6]), "v"(fb[7]), "v"(fb[8]), "v"(fb[9]), "v"(fb[10]),
+                     "v"(fb[11]), "v"(fb[12]), "v"(fb[13]), "v"(fb[14]), "v"(fb[15]) : "memory");
         mma();
         if (t + 1 < nit) { lds_store(ra[(d + 1) % D], rb[(d + 1) % D], nxt, nxt + C::AF); __syncthreads(); }
       }
