@@ -22,8 +22,11 @@
 // bt_tile: first run conv3_fwd 26.3 vs 23.6 us and conv2_fwd 37.0 vs 30.1 (hipcc gave the ring loads the registers of the fragments just
 // multiplied: every fragment read behind a barrier waited for the loads issued two MFMAs earlier); with the fragments read ahead of the
 // loads and kept live across their issue (census: no wait in front of the reads any more, the previous set drained early in the chunk
-// instead) 24.2 vs 22.8 and 33.0 vs 29.4 (same box).  The balance is there, the per-chunk efficiency of bt_tile's fully unrolled loop is
-// not: next, the pieces on that loop (chunk counts as template arguments of a few instantiations) or on hand-scheduled waits.
+// instead) 24.2 vs 22.8 and 33.0 vs 29.4 (same box); third run, the piece loop instantiated for every chunk count 1 .. MAXCH and inlined
+// (straight-line code with bt_tile's exact vmcnt(4 / 5) ladder, 73-93 KB of code per kernel, no scratch): 23.1 vs 22.6 and 32.3 vs 28.9 —
+// correct, balanced, bt_tile-quality loops, and STILL not faster.  Two workgroups per CU with 13.8 chunks each need 28.2 k matrix cycles per
+// SIMD (11.8 us); the launch takes ~20: a SIMD reaches ~60 % matrix utilisation whether it holds one, two or three of these waves.  The
+// balance was not the bound; what keeps two ready-looking waves from filling one matrix pipe is the open question for round 5.
 #pragma once
 #include "gemm_engine_bt.h"
 #include "problems_wt.h"      // wt_store
@@ -33,15 +36,18 @@ namespace sdqn {
 constexpr int SK_GROUPS = 512;                          // workgroups per launch: two per CU
 constexpr int SK_PART = 64 * 64;                        // floats of one partial block
 
-template <class P_, int D_ = 2>
-struct SkCfg : BtCfg<P_, 64, 64, 2, 2, D_> {};
+template <class P_, int MAXCH_, int D_ = 2>       // MAXCH_: chunks of a whole block (K / 32)
+struct SkCfg : BtCfg<P_, 64, 64, 2, 2, D_> { static constexpr int MAXCH = MAXCH_; };
 
 __device__ __forceinline__ float sk_ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // chunks [c0, c1) of block (bx, by, bz) -> this wave's 32 x 32 accumulator (bt_tile's loop, SM = SN = 1, unconditional ring loads)
-template <class C>
-__device__ __forceinline__ void sk_piece(const StepArgs& a, int bx, int by, int bz, int c0, int c1, float* smem, f32x16& acc,
-                                         int& z_out, int& ks_out) {
+// NIT: the piece's chunk count as a COMPILE-TIME value (sk_kernel dispatches over 1 .. MAXCH): the loop below is then straight-line code with
+// exact wait counts, like bt_tile's — the rolled form lost them at its back edge and drained the ring every chunk (tools/exp/README.md)
+template <class C, int NIT>
+__device__ __forceinline__ void sk_piece(const StepArgs& a, int bx, int by, int bz, int c0, float* smem, f32x16& acc,
+                                      int& z_out, int& ks_out) {
+  const int c1 = c0 + NIT;
   typedef typename C::P P;
   typedef typename P::aoff_t aoff_t;
   constexpr int BM = C::BM, BN = C::BN, WN = C::WN, D = C::D;
@@ -137,34 +143,29 @@ __device__ __forceinline__ void sk_piece(const StepArgs& a, int bx, int by, int 
   };
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-  const int nit = (kend - kbeg + bt::BK - 1) / bt::BK;
-  if (nit <= 0) return;
+  constexpr int nit = NIT;
 #pragma unroll
   for (int d = 0; d < D; ++d) gload(kbeg + (d < nit ? d : nit - 1) * bt::BK, ra[d], rb[d]);
   lds_store(ra[0], rb[0], smem, smem + C::AF);
   __syncthreads();
-  for (int t0 = 0; t0 < nit; t0 += D) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int t = t0 + d;
-      if (t < nit) {
-        float* cur = smem + (t & 1) * C::STAGE;
-        float* nxt = smem + ((t + 1) & 1) * C::STAGE;
-        // fragment reads FIRST, the new ring loads behind them: in this rolled loop hipcc gives the fragments registers of the ring — a read
-        // issued behind the new loads had to wait for every load in flight (first GPU run: one exposed memory round trip per chunk)
-        read_frags(cur, cur + C::AF);
-        asm volatile("" ::: "memory");
-        gload(kbeg + (t + D < nit ? t + D : nit - 1) * bt::BK, ra[d], rb[d]);
-        // ... and the fragments stay LIVE across the issue of those loads (the register allocator otherwise hands the loads the registers of
-        // the half-chunk that has just been multiplied: write-after-write against the next chunk's fragment reads)
-        asm volatile("" :: "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]), "v"(fa[4]), "v"(fa[5]), "v"(fa[6]), "v"(fa[7]), "v"(fa[8]), "v"(fa[9]), "v"(fa[10]),
-                     "v"(fa[11]), "v"(fa[12]), "v"(fa[13]), "v"(fa[14]), "v"(fa[15]) : "memory");
-        asm volatile("" :: "v"(fb[0]), "v"(fb[1]), "v"(fb[2]), "v"(fb[3]), "v"(fb[4]), "v"(fb[5]), "v"(fb[6]), "v"(fb[7]), "v"(fb[8]), "v"(fb[9]), "v"(fb[10]),
-                     "v"(fb[11]), "v"(fb[12]), "v"(fb[13]), "v"(fb[14]), "v"(fb[15]) : "memory");
-        mma();
-        if (t + 1 < nit) { lds_store(ra[(d + 1) % D], rb[(d + 1) % D], nxt, nxt + C::AF); __syncthreads(); }
-      }
-    }
+  for (int t = 0; t < nit; ++t) {
+    const int d = t % D;
+    float* cur = smem + (t & 1) * C::STAGE;
+    float* nxt = smem + ((t + 1) & 1) * C::STAGE;
+    if (t + D < nit) gload(kbeg + (t + D) * bt::BK, ra[d], rb[d]);           // (compile-time condition after unrolling)
+    read_frags(cur, cur + C::AF);
+    mma();
+    if (t + 1 < nit) { lds_store(ra[(d + 1) % D], rb[(d + 1) % D], nxt, nxt + C::AF); __syncthreads(); }
+  }
+}
+
+// piece length -> instantiation
+template <class C, int N>
+__device__ __forceinline__ void sk_piece_dispatch(int len, const StepArgs& a, int bx, int by, int bz, int c0, float* smem, f32x16& acc, int& z, int& ks) {
+  if constexpr (N >= 1) {
+    if (len == N) sk_piece<C, N>(a, bx, by, bz, c0, smem, acc, z, ks);
+    else sk_piece_dispatch<C, N - 1>(len, a, bx, by, bz, c0, smem, acc, z, ks);
   }
 }
 
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(bt::NT) sk_kernel(const StepArgs a, const int 
     const int len = (nch - c0 < u1 - u0) ? nch - c0 : u1 - u0, c1 = c0 + len;
     const int per_z = gx * gy, bz = tile / per_z, r = tile - bz * per_z, bx = r % gx, by = r / gx;
     f32x16 acc; int z, ks;
-    sk_piece<C>(a, bx, by, bz, c0, c1, smem, acc, z, ks);
+    sk_piece_dispatch<C, C::MAXCH>(len, a, bx, by, bz, c0, smem, acc, z, ks);
     if (c0 > 0) {
       // not the head of its block (always this workgroup's FIRST piece): partial -> slot g, then the flag
       float* slot = part + (size_t)g * SK_PART + wave * 1024 + lane;
@@ -248,6 +249,7 @@ inline hipError_t launch_sk(const StepArgs& a, hipStream_t stream, int flag_regi
   int z, ks, kb, ke; P::ksplit(a, 0, z, ks, kb, ke);
   if ((ke - kb) % bt::BK != 0) return hipErrorInvalidValue;          // whole chunks only
   const int nch = (ke - kb) / bt::BK;
+  if (nch > C::MAXCH) return hipErrorInvalidValue;
   if (flag_region < 0 || flag_region > 2) return hipErrorInvalidValue;
   SDQN_LAUNCH((sk_kernel<C>), dim3(SK_GROUPS), dim3(bt::NT), 0, stream, a, gx, gy, ntiles, nch, flag_region * SK_GROUPS);
   return hipGetLastError();

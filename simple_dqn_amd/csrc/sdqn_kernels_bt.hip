@@ -51,7 +51,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         BT_CASE(4, Conv2FwdWT, 64, 64, 2, 2, 1); BT_CASE(5, Conv2FwdWT, 128, 64, 2, 2, 3);
 #ifdef SDQN_EXPERIMENTS
         PP_CASE(10, Conv2FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Conv2FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Conv2FwdWT, 128, 64, 2, 2, 2);
-        case 9: return launch_sk<SkCfg<Conv2FwdWT, 2>>(a, s, 0);
+        case 9: return launch_sk<SkCfg<Conv2FwdWT, CRS2 / 32, 2>>(a, s, 0);
 #endif
 #ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
         case 6: return launch_bt<BT2(Conv2FwdWT, 64, 64, 2, 2, 2)>(a, s);
@@ -67,7 +67,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         BT_CASE(4, Conv3FwdWT, 64, 64, 2, 2, 1); BT_CASE(5, Conv3FwdWT, 128, 64, 2, 2, 3);
 #ifdef SDQN_EXPERIMENTS
         PP_CASE(10, Conv3FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Conv3FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Conv3FwdWT, 128, 64, 2, 2, 2);
-        case 9: return launch_sk<SkCfg<Conv3FwdWT, 2>>(a, s, 1);
+        case 9: return launch_sk<SkCfg<Conv3FwdWT, CRS3 / 32, 2>>(a, s, 1);
 #endif
 #ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
         case 6: return launch_bt<BT2(Conv3FwdWT, 64, 64, 2, 2, 2)>(a, s);
