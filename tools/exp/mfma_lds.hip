@@ -5,8 +5,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-template <int MODE>     // 0: MFMA only, 1: + fragment reads, 2: + LDS writes + barrier per chunk
-__global__ void __launch_bounds__(256) k(float* out, int chunks) {
+template <int MODE>     // 0: MFMA only, 1: + fragment reads, 2: + LDS writes + barrier per chunk, 3 / 4: + the chunk's 16 KB fetched from global memory
+                        // through a two-deep register ring (3: a 64 KB region per workgroup, L2-resident; 4: a fresh 16 KB per chunk, streamed)
+__global__ void __launch_bounds__(256) k(float* out, int chunks, const float4* __restrict__ src) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (64 + 64) * 36];
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   for (int e = tid; e < 2 * 128 * 36; e += 256) smem[e] = 1e-3f * (e & 63);
@@ -14,6 +15,14 @@ __global__ void __launch_bounds__(256) k(float* out, int chunks) {
   f32x16 acc;
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
   float4 w = make_float4(tid * 1e-4f, 1.f, 2.f, 3.f);
+  float4 r0[4], r1[4];
+  const size_t wg_base = MODE == 3 ? (size_t)blockIdx.x * 4096 : (size_t)blockIdx.x * 1024 * 1024;      // float4 units: 64 KB / 16 MB per workgroup
+  auto gl = [&](int c, float4* r) {
+    const size_t o = wg_base + (MODE == 3 ? (size_t)(c & 3) * 1024 : ((size_t)c * 1024) % (1024 * 1024));
+#pragma unroll
+    for (int p = 0; p < 4; ++p) r[p] = src[o + p * 256 + tid];
+  };
+  if (MODE >= 3) { gl(0, r0); gl(1, r1); }
   for (int c = 0; c < chunks; ++c) {
     const float* As = smem + (c & 1) * (128 * 36);
     const float* Bs = As + 64 * 36;
@@ -34,10 +43,13 @@ __global__ void __launch_bounds__(256) k(float* out, int chunks) {
     for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
     if (MODE >= 2) {
       float* Ws = smem + ((c + 1) & 1) * (128 * 36);
-      *reinterpret_cast<float4*>(Ws + (tid >> 3) * 36 + (tid & 7) * 4) = w;
-      *reinterpret_cast<float4*>(Ws + (32 + (tid >> 3)) * 36 + (tid & 7) * 4) = w;
-      *reinterpret_cast<float4*>(Ws + (64 + (tid >> 3)) * 36 + (tid & 7) * 4) = w;
-      *reinterpret_cast<float4*>(Ws + (96 + (tid >> 3)) * 36 + (tid & 7) * 4) = w;
+      float4 s0 = w, s1 = w, s2 = w, s3 = w;
+      if (MODE >= 3) { float4* r = (c & 1) ? r1 : r0; s0 = r[0]; s1 = r[1]; s2 = r[2]; s3 = r[3]; }
+      *reinterpret_cast<float4*>(Ws + (tid >> 3) * 36 + (tid & 7) * 4) = s0;
+      *reinterpret_cast<float4*>(Ws + (32 + (tid >> 3)) * 36 + (tid & 7) * 4) = s1;
+      *reinterpret_cast<float4*>(Ws + (64 + (tid >> 3)) * 36 + (tid & 7) * 4) = s2;
+      *reinterpret_cast<float4*>(Ws + (96 + (tid >> 3)) * 36 + (tid & 7) * 4) = s3;
+      if (MODE >= 3) { if (c & 1) gl(c + 2, r1); else gl(c + 2, r0); }
       __syncthreads();
     }
   }
@@ -47,11 +59,12 @@ __global__ void __launch_bounds__(256) k(float* out, int chunks) {
 }
 template <int MODE> void run(const char* nm, int blocks) {
   float* out; hipMalloc(&out, 4 * 256 * 4096);
+  static float4* src = nullptr; if (!src) { hipMalloc(&src, (size_t)768 * 16 * 1024 * 1024 + (1 << 20)); hipMemset(src, 0, (size_t)768 * 16 * 1024 * 1024); }
   const int chunks = 4000;
-  hipLaunchKernelGGL((k<MODE>), dim3(blocks), dim3(256), 0, 0, out, 200);
+  hipLaunchKernelGGL((k<MODE>), dim3(blocks), dim3(256), 0, 0, out, 200, src);
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipEventRecord(e0); hipLaunchKernelGGL((k<MODE>), dim3(blocks), dim3(256), 0, 0, out, chunks); hipEventRecord(e1); hipEventSynchronize(e1);
+  hipEventRecord(e0); hipLaunchKernelGGL((k<MODE>), dim3(blocks), dim3(256), 0, 0, out, chunks, src); hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   // blocks <= 256: one workgroup per CU; 512 / 768: two / three per CU (waves per SIMD)
   const double per_chunk_ns = ms * 1e6 / chunks / ((blocks + 255) / 256);
@@ -65,5 +78,11 @@ int main() {
   run<2>("the same, two workgroups per CU", 512);
   run<2>("the same, three workgroups per CU", 768);
   run<1>("fragment reads only, two workgroups per CU", 512);
+  run<3>("+ the chunk's 16 KB from an L2-resident region, 1 wg / CU", 256);
+  run<3>("the same, two workgroups per CU", 512);
+  run<3>("the same, three workgroups per CU", 768);
+  run<4>("+ the chunk's 16 KB streamed from HBM, 1 wg / CU", 256);
+  run<4>("the same, two workgroups per CU", 512);
+  run<4>("the same, three workgroups per CU", 768);
   return 0;
 }
