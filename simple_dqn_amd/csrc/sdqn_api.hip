@@ -1960,7 +1960,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   }
   else if (!strncmp(name, "bt:", 3)) {                     // block-tile engine: menu entry of kernel id (0 built-in, -1 latency engine)
     int id = atoi(name + 3);
-    if (id < 0 || id >= K_COUNT || value < -1 || value > (EXPERIMENTS ? 12 : 8)) { set_error("bad bt override"); return SDQN_ERR_ARG; }
+    if (id < 0 || id >= K_COUNT || value < -1 || value > (EXPERIMENTS ? 13 : 8)) { set_error("bad bt override"); return SDQN_ERR_ARG; }
     h->bt[id] = value;
   }
   else if (!strcmp(name, "bwd_order")) { if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name); h->bwd_order = value; }

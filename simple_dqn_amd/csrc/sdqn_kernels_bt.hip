@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include "gemm_engine_bt.h"
 #ifdef SDQN_EXPERIMENTS
+#include "gemm_engine_glds.h"    // operand panels straight into LDS (global_load_lds_dwordx4): written at the end of round 4, not yet run on a GPU
 #include "gemm_engine_sk.h"      // chunk-granular work assignment (stream-K) for the forward convs: built in the last hours of round 4, see its header
 #include "gemm_engine_pp.h"      // ping-pong form (8 waves, two per SIMD): built, correct, measured SLOWER than bt_tile everywhere — tools/exp/README.md
 #endif
@@ -28,6 +29,8 @@ namespace sdqn {
 #ifdef SDQN_EXPERIMENTS
 #define PP(P, BM, BN, WM, WN, D) PpCfg<P, BM, BN, WM, WN, D>                // ping-pong routine (gemm_engine_pp.h): 8 waves, two per SIMD
 #define PP_CASE(N, P, BM, BN, WM, WN, D) case N: return launch_pp<PP(P, BM, BN, WM, WN, D)>(a, s)
+#define GL(P, BM, BN, WM, WN) GlCfg<P, BM, BN, WM, WN>
+#define GL_CASE(N, P, BM, BN, WM, WN) case N: return launch_gl<GL(P, BM, BN, WM, WN)>(a, s)
 #endif
 
 // built-in block shapes (menu entry 0 maps onto these)
@@ -52,6 +55,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
 #ifdef SDQN_EXPERIMENTS
         PP_CASE(10, Conv2FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Conv2FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Conv2FwdWT, 128, 64, 2, 2, 2);
         case 9: return launch_sk<SkCfg<Conv2FwdWT, CRS2 / 32, 2>>(a, s, 0);
+        GL_CASE(13, Conv2FwdWT, 64, 64, 2, 2);
 #endif
 #ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
         case 6: return launch_bt<BT2(Conv2FwdWT, 64, 64, 2, 2, 2)>(a, s);
@@ -68,6 +72,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
 #ifdef SDQN_EXPERIMENTS
         PP_CASE(10, Conv3FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Conv3FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Conv3FwdWT, 128, 64, 2, 2, 2);
         case 9: return launch_sk<SkCfg<Conv3FwdWT, CRS3 / 32, 2>>(a, s, 1);
+        GL_CASE(13, Conv3FwdWT, 64, 64, 2, 2);
 #endif
 #ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
         case 6: return launch_bt<BT2(Conv3FwdWT, 64, 64, 2, 2, 2)>(a, s);
@@ -84,6 +89,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 8: return launch_bt<BTU(Fc4FwdWT, 64, 64, 2, 2, 2)>(a, s);        // unconditional ring loads (run-time K split): 21.0 us at S4 = 7, the latency engine 18.1
 #ifdef SDQN_EXPERIMENTS
         PP_CASE(10, Fc4FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Fc4FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Fc4FwdWT, 128, 64, 2, 2, 2);
+        GL_CASE(13, Fc4FwdWT, 64, 64, 2, 2);
 #endif
 #ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
         case 6: return launch_bt<BT2(Fc4FwdWT, 64, 64, 2, 2, 2)>(a, s);
@@ -99,6 +105,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         BT_CASE(4, Fc4DgradWT, 128, 64, 2, 2, 2); BT_CASE(5, Fc4DgradWT, 32, 128, 1, 4, 3);
 #ifdef SDQN_EXPERIMENTS
         PP_CASE(10, Fc4DgradWT, 64, 64, 2, 2, 2); PP_CASE(11, Fc4DgradWT, 64, 64, 2, 2, 3); PP_CASE(12, Fc4DgradWT, 32, 128, 1, 4, 2);
+        GL_CASE(13, Fc4DgradWT, 64, 64, 2, 2);
         case 6: return launch_bt<BT2(Fc4DgradWT, 64, 64, 2, 2, 2)>(a, s);
         case 7: return launch_bt<BT2(Fc4DgradWT, 32, 128, 1, 4, 2)>(a, s);
 #endif
@@ -160,6 +167,7 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
 #ifdef SDQN_EXPERIMENTS
       case 10: return launch_pp_multi<PP(Conv3DgradWT, 64, 64, 2, 2, 2), PP(Conv3WgradWT, 64, 64, 2, 2, 2), PP(Fc4WgradBT, 64, 64, 2, 2, 2)>(a, true, true, f4, s);
       case 11: return launch_pp_multi<PP(Conv3DgradWT, 64, 64, 2, 2, 3), PP(Conv3WgradWT, 64, 64, 2, 2, 3), PP(Fc4WgradBT, 64, 64, 2, 2, 3)>(a, true, true, f4, s);
+      case 13: return launch_gl_multi<GL(Conv3DgradWT, 64, 64, 2, 2), GL(Conv3WgradWT, 64, 64, 2, 2), GL(Fc4WgradBT, 64, 64, 2, 2)>(a, true, true, f4, s);
       case 5: return launch_bt_multi<BT2(Conv3DgradWT, 64, 64, 2, 2, 2), BT2(Conv3WgradWT, 64, 64, 2, 2, 2), BT2(Fc4WgradBT, 64, 64, 2, 2, 2)>(a, true, true, f4, s);
       case 6: return launch_bt_multi<BT2(Conv3DgradWT, 64, 64, 2, 2, 1), BT2(Conv3WgradWT, 64, 64, 2, 2, 1), BT2(Fc4WgradBT, 64, 64, 2, 2, 1)>(a, true, true, f4, s);
 #endif
@@ -176,6 +184,7 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
 #ifdef SDQN_EXPERIMENTS
       case 10: return launch_pp_multi<PP(NoProblem, 64, 64, 2, 2, 2), PP(Conv2WgradWT, 64, 64, 2, 2, 2), PP(Conv2DgradWT, 128, 32, 4, 1, 2)>(a, false, true, true, s);
       case 11: return launch_pp_multi<PP(NoProblem, 64, 64, 2, 2, 2), PP(Conv2WgradWT, 64, 64, 2, 2, 3), PP(Conv2DgradWT, 128, 32, 4, 1, 3)>(a, false, true, true, s);
+      case 13: return launch_gl_multi<GL(NoProblem, 64, 64, 2, 2), GL(Conv2WgradWT, 64, 64, 2, 2), GL(Conv2DgradWT, 128, 32, 4, 1)>(a, false, true, true, s);
       case 5: return launch_bt_multi<NOP, BT2(Conv2WgradWT, 64, 64, 2, 2, 2), BT2(Conv2DgradWT, 128, 32, 4, 1, 2)>(a, false, true, true, s);
       case 6: return launch_bt_multi<NOP, BT2(Conv2WgradWT, 64, 64, 2, 2, 1), BT2(Conv2DgradWT, 128, 32, 4, 1, 1)>(a, false, true, true, s);
 #endif

@@ -250,3 +250,25 @@ def test_stream_k_forward_launches_match_the_block_tile_routine(sd, A, B):
             # (first GPU run: every check above green at both shapes; this one 2.4e-3 on conv1's gradient at B = 160 — the size of a few
             #  flipped conv2 gates there — and < 1e-3 everywhere else: bound left at 5e-3 until round 5 looks at it element by element)
             assert np.linalg.norm(g - r) / max(1e-12, np.linalg.norm(r)) < 5e-3, (spec, i)
+
+
+@pytest.mark.experiments
+@pytest.mark.parametrize("A,B", [(3, 256), (6, 160)])
+def test_direct_to_lds_panels_match_the_block_tile_routine(sd, A, B):
+    """gemm_engine_glds.h (experiments build, menu entry 13): the operand panels fetched straight into LDS (global_load_lds_dwordx4, lane-linear
+    images with the bank swizzle on the source addresses, three stages, counted waits).  Same fragments, same MFMA order, same epilogues as
+    bt_tile: every stage and every gradient BIT-IDENTICAL to the block-tile routine, launch by launch and all together, ragged grids included.
+    (Written at the end of round 4 without a GPU at hand: the maps are validated by tests/test_emul.py variants 3 / 4, the instruction order by
+    tools/isa_census.py; this test is its first run.)"""
+    mb = random_minibatch(B, A, 110 + B, reward_range=(-2, 3))
+    base = [("keep_gradients", 1), ("bt:3", 1), ("bt:5", 1), ("s4", 7)]
+    ref = _net(sd, A, B, 17, base)
+    ref.train(mb)
+    for ids in ((1,), (2,), (3,), (5,), (16,), (17,), (1, 2, 3, 5, 16, 17)):
+        net = _net(sd, A, B, 17, base + [("bt:%d" % k, 13) for k in ids])
+        net.train(mb)
+        for name, n in dict(a2=2 * B * 81 * 64, a3=2 * B * 49 * 64, a4=2 * B * 512, d3p=B * 121 * 64, d2p=B * 121 * 64, d1=B * 400 * 32).items():
+            assert np.array_equal(net.debug_read(name, n), ref.debug_read(name, n)), (ids, name)
+        for i in range(5):
+            assert np.array_equal(net.get_layer(i, 3), ref.get_layer(i, 3)), (ids, i)
+
