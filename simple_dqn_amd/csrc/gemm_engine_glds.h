@@ -20,16 +20,21 @@
 // 14.2 us (bt_tile 12.8), conv3_fwd 23.3 (22.6), conv2_fwd 30.6 (28.7), bwd2 40.8 (37.6), bwd3 64 (40.5: 54 KB of LDS per workgroup), fc4_fwd
 // with 7 K slabs 18.7 (bt_tile 21.0, latency engine 18.1) — the loop is rolled (run-time chunk counts for every problem here): the address
 // arithmetic of the panel loads is redone every chunk and only two chunks are in flight, where the micro-kernel that promised 62-74 % had
-// neither cost.  Round 5: chunk counts as template arguments for the forward / dgrad problems, a fourth stage, the per-chunk address increments
-// hoisted into SGPR adds.
+// neither cost.  Since then (no GPU left in the round: census only): the forward convs and the dgrads take their chunk count as a template
+// argument (GlCfg<..., NITC>) — fully unrolled, 22 VALU instructions and one vmcnt(4) per chunk, 34 VGPRs — NOT yet measured.  Round 5: measure
+// that, then a fourth stage and SGPR address increments for the run-time-count problems (weight gradients, fc4 forward).
 #pragma once
 #include "gemm_engine_bt.h"
 
 namespace sdqn {
 
-template <class P_, int BM_, int BN_, int WM_, int WN_>
+// NITC_: the problem's chunk count when it is a compile-time fact (K / 32 of the forward convs and the dgrads; 0 = run-time: K slabs / splits).
+// With it the chunk loop is fully unrolled — the stage rotation, the k offsets and most of the loads' address arithmetic fold into immediates
+// (the rolled loop redoes them every chunk: the first GPU run's handicap against bt_tile's unrolled loops).
+template <class P_, int BM_, int BN_, int WM_, int WN_, int NITC_ = 0>
 struct GlCfg {
   typedef P_ P;
+  static constexpr int NITC = NITC_;
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
   static constexpr int KIND = 5;
   static constexpr int SM = BM / (32 * WM), SN = BN / (32 * WN);
@@ -185,6 +190,23 @@ __device__ __forceinline__ void gl_tile(const StepArgs& a, int bx, int by, int b
       for (int sn = 0; sn < SN; ++sn) P::epi_begin(a, m0 + (wm * SM + sm) * 32, n0 + (wn * SN + sn) * 32, lane, epi[sm][sn]);
   };
 
+  if constexpr (C::NITC > 0) {
+    constexpr int nit = C::NITC;                                   // (launch_gl checks that the problem's K range is exactly NITC chunks)
+    issue(kbeg, 0);
+    issue(kbeg + (nit > 1 ? 1 : 0) * bt::BK, 1);
+    gl_wait<C::LPC>();
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < nit; ++t) {
+      issue(kbeg + (t + 2 < nit ? t + 2 : nit - 1) * bt::BK, (t + 2) % 3);
+      if (t + 1 == nit) epi_prefetch();
+      const float* cur = smem + (t % 3) * C::STAGE;
+      compute(cur, cur + C::AF);
+      gl_wait<C::LPC>();
+      __syncthreads();
+    }
+    gl_wait<0>();
+  } else {
   const int nit = (kend - kbeg) / bt::BK;                          // whole chunks (launch_gl)
   if (nit > 0) {
     issue(kbeg, 0);
@@ -204,6 +226,7 @@ __device__ __forceinline__ void gl_tile(const StepArgs& a, int bx, int by, int b
     }
     gl_wait<0>();                                                  // nothing of this workgroup may land in LDS after it has gone
   } else epi_prefetch();
+  }
 
 #pragma unroll
   for (int sm = 0; sm < SM; ++sm)
@@ -246,7 +269,11 @@ __global__ void __launch_bounds__(bt::NT) gl_kernel(const StepArgs a, const int 
 template <class C>
 inline bool gl_whole_chunks(const StepArgs& a) {
   typedef typename C::P P;
-  for (int bz = 0; bz < P::nbz(a); ++bz) { int z, ks, kb, ke; P::ksplit(a, bz, z, ks, kb, ke); if ((ke - kb) % bt::BK != 0) return false; }
+  for (int bz = 0; bz < P::nbz(a); ++bz) {
+    int z, ks, kb, ke; P::ksplit(a, bz, z, ks, kb, ke);
+    if ((ke - kb) % bt::BK != 0) return false;
+    if (C::NITC > 0 && (ke - kb) != C::NITC * bt::BK) return false;
+  }
   return true;
 }
 template <class C>

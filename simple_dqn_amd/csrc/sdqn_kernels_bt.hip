@@ -30,7 +30,9 @@ namespace sdqn {
 #define PP(P, BM, BN, WM, WN, D) PpCfg<P, BM, BN, WM, WN, D>                // ping-pong routine (gemm_engine_pp.h): 8 waves, two per SIMD
 #define PP_CASE(N, P, BM, BN, WM, WN, D) case N: return launch_pp<PP(P, BM, BN, WM, WN, D)>(a, s)
 #define GL(P, BM, BN, WM, WN) GlCfg<P, BM, BN, WM, WN>
+#define GLN(P, BM, BN, WM, WN, NIT) GlCfg<P, BM, BN, WM, WN, NIT>      // compile-time chunk count: unrolled chunk loop
 #define GL_CASE(N, P, BM, BN, WM, WN) case N: return launch_gl<GL(P, BM, BN, WM, WN)>(a, s)
+#define GLN_CASE(N, P, BM, BN, WM, WN, NIT) case N: return launch_gl<GLN(P, BM, BN, WM, WN, NIT)>(a, s)
 #endif
 
 // built-in block shapes (menu entry 0 maps onto these)
@@ -55,7 +57,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
 #ifdef SDQN_EXPERIMENTS
         PP_CASE(10, Conv2FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Conv2FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Conv2FwdWT, 128, 64, 2, 2, 2);
         case 9: return launch_sk<SkCfg<Conv2FwdWT, CRS2 / 32, 2>>(a, s, 0);
-        GL_CASE(13, Conv2FwdWT, 64, 64, 2, 2);
+        GLN_CASE(13, Conv2FwdWT, 64, 64, 2, 2, CRS2 / 32);
 #endif
 #ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
         case 6: return launch_bt<BT2(Conv2FwdWT, 64, 64, 2, 2, 2)>(a, s);
@@ -72,7 +74,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
 #ifdef SDQN_EXPERIMENTS
         PP_CASE(10, Conv3FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Conv3FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Conv3FwdWT, 128, 64, 2, 2, 2);
         case 9: return launch_sk<SkCfg<Conv3FwdWT, CRS3 / 32, 2>>(a, s, 1);
-        GL_CASE(13, Conv3FwdWT, 64, 64, 2, 2);
+        GLN_CASE(13, Conv3FwdWT, 64, 64, 2, 2, CRS3 / 32);
 #endif
 #ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
         case 6: return launch_bt<BT2(Conv3FwdWT, 64, 64, 2, 2, 2)>(a, s);
@@ -105,7 +107,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         BT_CASE(4, Fc4DgradWT, 128, 64, 2, 2, 2); BT_CASE(5, Fc4DgradWT, 32, 128, 1, 4, 3);
 #ifdef SDQN_EXPERIMENTS
         PP_CASE(10, Fc4DgradWT, 64, 64, 2, 2, 2); PP_CASE(11, Fc4DgradWT, 64, 64, 2, 2, 3); PP_CASE(12, Fc4DgradWT, 32, 128, 1, 4, 2);
-        GL_CASE(13, Fc4DgradWT, 64, 64, 2, 2);
+        GLN_CASE(13, Fc4DgradWT, 64, 64, 2, 2, NFC / 32);
         case 6: return launch_bt<BT2(Fc4DgradWT, 64, 64, 2, 2, 2)>(a, s);
         case 7: return launch_bt<BT2(Fc4DgradWT, 32, 128, 1, 4, 2)>(a, s);
 #endif
@@ -167,7 +169,7 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
 #ifdef SDQN_EXPERIMENTS
       case 10: return launch_pp_multi<PP(Conv3DgradWT, 64, 64, 2, 2, 2), PP(Conv3WgradWT, 64, 64, 2, 2, 2), PP(Fc4WgradBT, 64, 64, 2, 2, 2)>(a, true, true, f4, s);
       case 11: return launch_pp_multi<PP(Conv3DgradWT, 64, 64, 2, 2, 3), PP(Conv3WgradWT, 64, 64, 2, 2, 3), PP(Fc4WgradBT, 64, 64, 2, 2, 3)>(a, true, true, f4, s);
-      case 13: return launch_gl_multi<GL(Conv3DgradWT, 64, 64, 2, 2), GL(Conv3WgradWT, 64, 64, 2, 2), GL(Fc4WgradBT, 64, 64, 2, 2)>(a, true, true, f4, s);
+      case 13: return launch_gl_multi<GLN(Conv3DgradWT, 64, 64, 2, 2, CRS3 / 32), GL(Conv3WgradWT, 64, 64, 2, 2), GL(Fc4WgradBT, 64, 64, 2, 2)>(a, true, true, f4, s);
       case 5: return launch_bt_multi<BT2(Conv3DgradWT, 64, 64, 2, 2, 2), BT2(Conv3WgradWT, 64, 64, 2, 2, 2), BT2(Fc4WgradBT, 64, 64, 2, 2, 2)>(a, true, true, f4, s);
       case 6: return launch_bt_multi<BT2(Conv3DgradWT, 64, 64, 2, 2, 1), BT2(Conv3WgradWT, 64, 64, 2, 2, 1), BT2(Fc4WgradBT, 64, 64, 2, 2, 1)>(a, true, true, f4, s);
 #endif
@@ -184,7 +186,7 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
 #ifdef SDQN_EXPERIMENTS
       case 10: return launch_pp_multi<PP(NoProblem, 64, 64, 2, 2, 2), PP(Conv2WgradWT, 64, 64, 2, 2, 2), PP(Conv2DgradWT, 128, 32, 4, 1, 2)>(a, false, true, true, s);
       case 11: return launch_pp_multi<PP(NoProblem, 64, 64, 2, 2, 2), PP(Conv2WgradWT, 64, 64, 2, 2, 3), PP(Conv2DgradWT, 128, 32, 4, 1, 3)>(a, false, true, true, s);
-      case 13: return launch_gl_multi<GL(NoProblem, 64, 64, 2, 2), GL(Conv2WgradWT, 64, 64, 2, 2), GL(Conv2DgradWT, 128, 32, 4, 1)>(a, false, true, true, s);
+      case 13: return launch_gl_multi<GL(NoProblem, 64, 64, 2, 2), GL(Conv2WgradWT, 64, 64, 2, 2), GLN(Conv2DgradWT, 128, 32, 4, 1, 8)>(a, false, true, true, s);
       case 5: return launch_bt_multi<NOP, BT2(Conv2WgradWT, 64, 64, 2, 2, 2), BT2(Conv2DgradWT, 128, 32, 4, 1, 2)>(a, false, true, true, s);
       case 6: return launch_bt_multi<NOP, BT2(Conv2WgradWT, 64, 64, 2, 2, 1), BT2(Conv2DgradWT, 128, 32, 4, 1, 1)>(a, false, true, true, s);
 #endif
