@@ -21,8 +21,11 @@
 // with 7 K slabs 18.7 (bt_tile 21.0, latency engine 18.1) — the loop is rolled (run-time chunk counts for every problem here): the address
 // arithmetic of the panel loads is redone every chunk and only two chunks are in flight, where the micro-kernel that promised 62-74 % had
 // neither cost.  Since then (no GPU left in the round: census only): the forward convs and the dgrads take their chunk count as a template
-// argument (GlCfg<..., NITC>) — fully unrolled, 22 VALU instructions and one vmcnt(4) per chunk, 34 VGPRs — NOT yet measured.  Round 5: measure
-// that, then a fourth stage and SGPR address increments for the run-time-count problems (weight gradients, fc4 forward).
+// argument (GlCfg<..., NITC>) — fully unrolled, 22 VALU instructions and one vmcnt(4) per chunk, 34 VGPRs — and the round's very last GPU
+// call measured them: conv3_fwd 22.57 us (bt_tile 22.55), fc4_dgrad 12.77 (12.78), conv2_fwd 31.7 (28.8: three workgroups per CU instead of
+// four), bit-identical again.  So on the real operands the direct-to-LDS path EQUALS the register ring instead of beating it as it does in the
+// micro-kernel (whose 16 KB per chunk are one contiguous block): what these launches wait for is not how the bytes get from L2 into LDS but how
+// fast this access pattern (64 + 64 row pieces of 128 B per chunk and workgroup) is served at all.  Round 5: TCP / TCC counters on exactly that.
 #pragma once
 #include "gemm_engine_bt.h"
 
