@@ -1289,6 +1289,7 @@ extern "C" int sdqn_net_predict_one(sdqn_net_t h, const uint8_t* state, float* q
 // of the `hist` slots ending there.  When the ring is full the last hist-1 frames are copied back to the start
 // (one 21 KB D2D every SB_SLOTS-hist+1 adds), so an add is ONE 7 KB H2D from a pinned staging slot.
 static constexpr int SB_SLOTS = 64;
+static uint64_t next_statebuf_gen() { static uint64_t n = 0; return (++n << 40) | 1; }
 struct sdqn_statebuf_s {
   uint8_t* d = nullptr;          // [SB_SLOTS][FRAME]
   uint8_t* host = nullptr;       // [hist][FRAME] mirror in state_buffer.py order (oldest first)
@@ -1296,7 +1297,8 @@ struct sdqn_statebuf_s {
   int hist = 0;
   int64_t frame = 0;             // bytes per screen
   int pos = 0;                   // slot of the newest frame; window = slots [pos-hist+1, pos]
-  uint64_t gen = 1;              // bumped by every add / reset: identifies the state a speculative forward was enqueued for
+  uint64_t gen = next_statebuf_gen();   // bumped by every add / reset: identifies the state a speculative forward was enqueued for
+                                 // (own 2^40 range per buffer: a buffer allocated where a destroyed one lay never matches its generations)
 };
 extern "C" int sdqn_statebuf_create(sdqn_statebuf_t* out, int H, int W, int hist) {
   ARGCHK(out, "NULL argument");
@@ -1450,7 +1452,7 @@ extern "C" int sdqn_net_act_greedy(sdqn_net_t h, sdqn_statebuf_t sb, int* action
   int rc = sdqn_net_predict_state(h, sb, q); if (rc) return rc;
   const int A = h->A;
   int best = 0;
-  for (int k = 1; k < A; ++k) if (q[k] > q[best]) best = k;         // (np.argmax: NaN handling aside, the first maximum)
+  for (int k = 1; k < A; ++k) if (q[k] > q[best] || (q[k] != q[k] && q[best] == q[best])) best = k;   // np.argmax: the first maximum, a NaN counts as one
   *action = best;
   if (q_out) memcpy(q_out, q, (size_t)A * 4);
   return SDQN_OK;
@@ -1463,6 +1465,8 @@ extern "C" int sdqn_net_act_greedy(sdqn_net_t h, sdqn_statebuf_t sb, int* action
 extern "C" int sdqn_net_act_step(sdqn_net_t h, sdqn_statebuf_t sb, sdqn_replay_t r, const uint8_t* screen, int action, int64_t reward,
                                  int terminal, int speculate) {
   ARGCHK(h && sb && screen, "NULL argument");
+  ARGCHK(!r || r->frame == (int64_t)sb->frame, "the replay memory's screens (%lld bytes) and the state buffer's (%lld) differ: one screen pointer feeds both",
+         (long long)(r ? r->frame : 0), (long long)sb->frame);             // (replay_memory.py:28's assert: sdqn_replay_add copies r->frame bytes)
   int rc = sdqn_statebuf_add(sb, screen); if (rc) return rc;
   if (r) { rc = sdqn_replay_add(r, action, reward, screen, terminal); if (rc) return rc; }
   if (speculate && !h->gen && (size_t)sb->hist * sb->frame == (size_t)STATE) return predict_state_enqueue(h, sb);
@@ -1961,6 +1965,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   else if (!strncmp(name, "bt:", 3)) {                     // block-tile engine: menu entry of kernel id (0 built-in, -1 latency engine)
     int id = atoi(name + 3);
     if (id < 0 || id >= K_COUNT || value < -1 || value > (EXPERIMENTS ? 13 : 8)) { set_error("bad bt override"); return SDQN_ERR_ARG; }
+    if (!EXPERIMENTS && id == K_WGRADS && value >= 6) EXP_OPTION_REFUSED(name);      // (one of the three weight gradients only: timing experiments)
     h->bt[id] = value;
   }
   else if (!strcmp(name, "bwd_order")) { if (!EXPERIMENTS && value) EXP_OPTION_REFUSED(name); h->bwd_order = value; }
@@ -2056,6 +2061,7 @@ extern "C" int sdqn_dp_init(sdqn_net_t h, const char* rccl_path, const char id[1
       if (h->theta_t != h->theta) HIPCHK(launch_refresh_planes(h->theta_t, nullptr, h->wpt[1], g_stream));
     }
     HIPCHK(hipStreamSynchronize(g_stream));
+    h->spec_pending = false;               // rank 0's parameters replaced ours: a forward enqueued before the sync is not "predict now"
   }
   return SDQN_OK;
 }

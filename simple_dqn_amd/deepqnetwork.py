@@ -220,6 +220,7 @@ class DeepQNetwork:
         `mem.add(action, reward, screen, terminal)` (agent.py:62 / replay_memory.py:26-34); `speculate` also enqueues the acting forward of
         the new state, so that the next predict_state(state_buffer) only collects Q-values that are already on their way."""
         assert screen.shape == state_buffer.dims
+        assert mem is None or screen.shape == mem.dims              # (replay_memory.py:28: mem.add's own assert)
         scr = np.ascontiguousarray(screen, dtype=np.uint8)
         rh = mem._h if mem is not None else None
         _lib.check(self._lib.sdqn_net_act_step(self._h, state_buffer._h, rh, _lib.ptr(scr, C.c_uint8), int(action), int(reward),
@@ -357,6 +358,8 @@ class DeepQNetwork:
     def set_option(self, name, value):
         """'keep_gradients' (materialise the fc4 gradient; disables the fused fc4 RMSProp), 'two_streams'."""
         _lib.check(self._lib.sdqn_net_set_option(self._h, name.encode(), int(value)))
+        if name == "dp_overlap":
+            self._dp_overlap_opt = int(value)
 
     def sync(self):
         _lib.check(self._lib.sdqn_net_sync(self._h))
@@ -398,15 +401,31 @@ class DeepQNetwork:
         all of them activate it, or all of them tear the second communicator down and run the serial form (one all-reduce on the
         library stream).  Without a `vote` the ranks cannot agree, so the serial form runs.  dp_form() says which one it is."""
         path = (rccl or _lib.rccl_path()).encode()
-        _lib.check(self._lib.sdqn_dp_init(self._h, path, unique_id, rank, nranks))
-        form = self.dp_form()
-        if form["form"] == "serial" and form["second_communicator"] and not form["overlap_forced"]:
+        # Every rank must issue the SAME control-plane collectives whatever happens locally: the ranks whose start-up went fine will sit
+        # in the vote, so a rank whose init / probe raised casts vote(False) before it re-raises (ADVICE r4) — and whether a vote happens
+        # at all is decided from facts every rank shares (nranks, the dp_overlap option), not from this rank's communicator state.
+        req = self._dp_overlap_req()                                  # (-2: auto also for a 1-rank communicator, tests)
+        will_vote = vote is not None and ((nranks >= 2 and req == -1) or req == -2)
+        try:
+            _lib.check(self._lib.sdqn_dp_init(self._h, path, unique_id, rank, nranks))
+            form = self.dp_form()
+            probing = form["form"] == "serial" and form["second_communicator"] and not form["overlap_forced"]
             ok = C.c_int(0)
-            _lib.check(self._lib.sdqn_dp_probe(self._h, int(probe_timeout_ms), int(bool(inject_probe_timeout)), C.byref(ok)))
-            agreed = bool(vote(bool(ok.value))) if vote is not None else False
-            _lib.check(self._lib.sdqn_dp_set_overlap(self._h, int(agreed)))
-            self._dp_vote = dict(local_probe_ok=bool(ok.value), agreed=agreed, voted=vote is not None)
+            if probing:
+                _lib.check(self._lib.sdqn_dp_probe(self._h, int(probe_timeout_ms), int(bool(inject_probe_timeout)), C.byref(ok)))
+        except Exception:
+            if will_vote:
+                vote(False)
+            raise
+        if probing or will_vote:
+            agreed = bool(vote(bool(ok.value) and probing)) if will_vote else False
+            if probing:
+                _lib.check(self._lib.sdqn_dp_set_overlap(self._h, int(agreed)))
+            self._dp_vote = dict(local_probe_ok=bool(ok.value), agreed=agreed, voted=will_vote)
         return self.dp_form()
+
+    def _dp_overlap_req(self):
+        return getattr(self, "_dp_overlap_opt", -1)
 
     def dp_form(self):
         """Which data-parallel form runs: 'none' / 'serial' / 'overlapped', the start-up probe's local result and the vote."""

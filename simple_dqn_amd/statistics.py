@@ -132,6 +132,7 @@ class Statistics:
         return np.mean(best)
 
     def write(self, epoch, phase):
+        self._resolve_pending()                                         # a deferred cost still outstanding belongs in this row's meancost
         t = self._tally
         now = time.process_time()
         total_time, epoch_time = now - self.start_time, max(now - t.began, 1e-9)

@@ -69,3 +69,23 @@ def test_deferred_cost_protocol_keeps_the_running_mean_bit_identical(tmp_path):
     b.on_train_deferred(lambda: 7.0, 51); a.net.train_iterations = 51; a.on_train(7.0)
     b.reset(); a.reset()                                # a phase end collects before the tally is replaced
     assert b.average_cost == a.average_cost == 0 and not b._pending
+
+
+def test_write_collects_a_deferred_cost_that_is_still_outstanding(tmp_path):
+    """the last train step's cost of a phase is still pending when main.py calls write(); the CSV's meancost column must hold
+    the same running mean the immediate on_train form gives (4.0, 8.0 -> 6.0), not the mean without the last cost."""
+    rows = {}
+    for form in ("immediate", "deferred"):
+        p = str(tmp_path / (form + ".csv"))
+        net = _Net()
+        st = Statistics(_Agent(), net, _Mem(), None, make_args(csv_file=p))
+        for i, c in enumerate([4.0, 8.0]):
+            net.train_iterations = i + 1
+            if form == "immediate":
+                st.on_train(c)
+            else:
+                st.on_train_deferred(lambda c=c: c, i + 1)
+        st.write(1, "train")
+        st.close()
+        rows[form] = list(csv.reader(open(p)))[1]
+    assert float(rows["deferred"][11]) == float(rows["immediate"][11]) == 6.0
