@@ -386,7 +386,7 @@ def q_mae_on_timed_ring(net, mem, B, A, mt, steps=10):
     hold_rng = MT19937(); hold_rng.setstate(tuple(mt[:]))
     for _ in range(steps + 1):                                       # the batch after the comparison steps, as before
         hold = omem.getMinibatch(hold_rng)[0].copy()
-    tf_mae, tf_max, fr_max, fr_mae, o64_max, h64_max = [], [], [], [], [], []
+    tf_mae, tf_max, fr_max, fr_mae, o64_max, h64_max, h64_mae = [], [], [], [], [], [], []
     for _ in range(steps):
         mb = [x.copy() for x in omem.getMinibatch(rng)]
         load(forced)
@@ -398,7 +398,7 @@ def q_mae_on_timed_ring(net, mem, B, A, mt, steps=10):
         e = np.abs(q - forced.predict(hold)); tf_mae.append(float(e.mean())); tf_max.append(float(e.max()))
         qf = free.predict(hold)
         ef = np.abs(q - qf); fr_max.append(float(ef.max())); fr_mae.append(float(ef.mean()))
-        o64_max.append(float(np.abs(qf - q64).max())); h64_max.append(float(np.abs(q - q64).max()))
+        o64_max.append(float(np.abs(qf - q64).max())); h64_max.append(float(np.abs(q - q64).max())); h64_mae.append(float(np.abs(q - q64).mean()))
     first = next((i + 1 for i, v in enumerate(fr_max) if v > 1e-5), None)
     within_drift = h64_max[-1] <= max(1.5 * o64_max[-1], tol)
     # the free-running pair is identical to ~1e-8 until the first gate flip, and the teacher-forced pair takes that very step from
@@ -418,7 +418,10 @@ def q_mae_on_timed_ring(net, mem, B, A, mt, steps=10):
     ok = (checks["free_running_mae_lt_tol"] or within_drift) and checks["teacher_forced_mean_mae_lt_tol"] and \
         checks["teacher_forced_median_step_max_abs_lt_1e-5"] and checks["teacher_forced_worst_element_lt_2e-3"]
     g = lambda v: float("%.3g" % v)
-    return {"mae": g(fr_mae[-1]), "max_abs": g(fr_max[-1]), "after_steps": steps, "tolerance": tol,
+    return {"mae": g(fr_mae[-1]), "max_abs": g(fr_max[-1]),
+            #  the same two figures against the CPU reference that does not flip gates: the fp64 oracle's trajectory
+            "mae_vs_fp64_oracle": g(h64_mae[-1]), "max_abs_vs_fp64_oracle": g(h64_max[-1]), "oracle_fp32_max_abs_vs_fp64_oracle": g(o64_max[-1]),
+            "after_steps": steps, "tolerance": tol,
             "tolerance_on": "free-running mae after %d steps (fp32 oracle loaded once), OR the fp64 yardstick below" % steps,
             "mode": "free-running", "pass": bool(ok), "checks": checks,
             "free_running": {"mae": g(fr_mae[-1]), "max_abs": g(fr_max[-1]), "per_step_max_abs": [g(v) for v in fr_max],
@@ -430,6 +433,47 @@ def q_mae_on_timed_ring(net, mem, B, A, mt, steps=10):
                                "steps_with_gate_flip": len(flip_steps), "gate_flip_steps": flip_steps,
                                "note": "oracle re-loaded with the library's (theta, theta-, s) before each step: one-step errors"},
             "ring_frames": int(mem.size), "note": "same ring, same sampler state as the timed network"}
+
+
+def oracle_yardstick_block(net, mem, B, A, mt, half=False, steps=(1, 3)):
+    """Non-self-referential error figures for one leg of the line: max(steps) more train steps of the library on
+    its own ring and sampler stream next to (a) the numpy oracle of the SAME semantics (fp32, or half activations for the float16
+    legs) and (b) the fp64 oracle — the CPU reference with no half / fp32 rounding anywhere — all three started from the library's
+    (theta, theta-, RMSProp s) and fed the same minibatches.  After each step in `steps`: the largest |Q| difference on a held-out
+    batch of the ring, library vs fp64 and same-semantics oracle vs fp64 (the yardstick: the library should not be further from fp64
+    than the restatement of its own arithmetic is), and library vs that oracle (max and mean).  Reported, never part of `pass`."""
+    import numpy as np
+    from oracle.dqn_numpy import OracleDQN
+    from oracle.replay_numpy import MT19937
+    net.sync()
+
+    def load(o, dt):
+        o.W = [w.astype(dt) for w in net.get_weights(0)]
+        o.Wt = [w.astype(dt) for w in net.get_weights(1)]
+        o.S = [w.astype(dt) for w in net.get_weights(2)]
+
+    same = OracleDQN(A, batch_size=B, weights=net.get_weights(0), half_activations=bool(half)); load(same, np.float32)
+    o64 = OracleDQN(A, batch_size=B, weights=net.get_weights(0), dtype=np.float64); load(o64, np.float64)
+    omem = oracle_view(mem, B)
+    rng = MT19937(); rng.setstate(tuple(mt[:]))
+    hold_rng = MT19937(); hold_rng.setstate(tuple(mt[:]))
+    for _ in range(max(steps) + 1):
+        hold = omem.getMinibatch(hold_rng)[0].copy()
+    tag = "half" if half else "fp32"
+    g = lambda v: float("%.3g" % v)
+    rows = {}
+    for s in range(1, max(steps) + 1):
+        mb = [x.copy() for x in omem.getMinibatch(rng)]
+        net.train_from_memory(mem, 1, mt_state=mt, want_cost=False)
+        same.train(mb); o64.train(mb)
+        assert tuple(mt[:]) == rng.getstate(), "native sampler and oracle sampler diverged"
+        if s in steps:
+            q, qs, q64 = net.predict(hold).astype(np.float64), same.predict(hold).astype(np.float64), o64.predict(hold)
+            rows[str(s)] = {"hip_%s_vs_fp64_max_abs" % tag: g(np.abs(q - q64).max()), "oracle_%s_vs_fp64_max_abs" % tag: g(np.abs(qs - q64).max()),
+                            "hip_vs_oracle_%s_max_abs" % tag: g(np.abs(q - qs).max()), "hip_vs_oracle_%s_mae" % tag: g(np.abs(q - qs).mean()),
+                            "q_fp64_max_abs": g(np.abs(q64).max())}
+    return {"after_steps": rows, "oracle": "oracle/dqn_numpy.py OracleDQN(%s) and OracleDQN(dtype=float64), loaded with the library's state; "
+                                           "same ring and sampler stream as the leg's timed region" % ("half_activations=True" if half else "float32")}
 
 
 def cpu_standin_torch(B, A, seed, budget_s):
@@ -611,6 +655,7 @@ def b256_leg(sd, make_args, seed, steps=300, warmup=100, ring=200000):
     net.sync()
     el = time.perf_counter() - t0
     w = kernel_work(B, A)
+    yard = oracle_yardstick_block(net, mem, B, A, mt, half=False)
     flops = sum(w[i]["flops"] for i in (0, 1, 2, 3, 4, 5, 16, 17, 18))
     k_us = {p["name"]: round(p["total_ms"] / p["launches"] * 1e3, 2) for p in prof}
     conv1_us = k_us.get("conv1_fwd(gather+norm+conv+relu)")
@@ -629,7 +674,7 @@ def b256_leg(sd, make_args, seed, steps=300, warmup=100, ring=200000):
             "frac_fp32_peak_whole_step": round(flops / (el / steps) / F32_PEAK, 4), "flops_per_step": flops,
             "roofline_step": step_roofline(B, A, el / steps * 1e3),
             "roofline": dict(_roofline_entry(dom["id"], dom["name"], dom["total_ms"] / dom["launches"], B, A), measured_in="warm-up pass, every launch bracketed"),
-            "kernels_us": k_us,
+            "kernels_us": k_us, "q_vs_cpu_ref": yard,
             "north_star_target": {"path": "replay gather + conv1 (B=256)", "target_frac_hbm": 0.40, "standalone_gather": gather,
                                   "fused_gather_conv1": fused, "frac_hbm": round(best, 4), "met": bool(best >= 0.40)}}
 
@@ -659,8 +704,10 @@ def fp16_b256_leg(sd, make_args, seed, steps=300, warmup=140, ring=200000):
     net.sync()
     el = time.perf_counter() - t0
     w = kernel_work(B, A)
+    yard = oracle_yardstick_block(net, mem, B, A, mt, half=True)
     flops = sum(w[i]["flops"] for i in (0, 1, 2, 3, 4, 5, 16, 17, 18))
-    return {"workload": "batch_size=256, num_actions=3, --datatype float16, replay_size=%d (NOT the headline; same process, after the headline's "
+    return {"q_vs_cpu_ref": yard,
+            "workload": "batch_size=256, num_actions=3, --datatype float16, replay_size=%d (NOT the headline; same process, after the headline's "
                         "timed region)" % ring,
             "value": round(steps / el, 2), "unit": "train_steps/sec", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "warmup": warmup,
             "frac_fp16_peak_whole_step": round(flops / (el / steps) / BF16_PEAK, 4), "flops_per_step": flops,
@@ -698,7 +745,9 @@ def fp16_leg(sd, make_args, seed, steps=1500, warmup=300, ring=200000):
     net.train_from_memory(mem, steps, mt_state=mt, want_cost=False)
     net.sync()
     el = time.perf_counter() - t0
-    return {"workload": "BASELINE.json configs[4] on one GPU: Space Invaders shapes, batch_size=32, num_actions=6, --datatype float16 "
+    yard = oracle_yardstick_block(net, mem, B, A, mt, half=True)
+    return {"q_vs_cpu_ref": yard,
+            "workload": "BASELINE.json configs[4] on one GPU: Space Invaders shapes, batch_size=32, num_actions=6, --datatype float16 "
                         "(half activations / deltas / MFMA operands, fp32 accumulation + master weights + RMSProp), replay_size=%d "
                         "(NOT the headline; same process, after the headline's timed region)" % ring,
             "value": round(steps / el, 2), "unit": "train_steps/sec", "ms_per_step": round(el / steps * 1e3, 5), "steps": steps, "warmup": warmup,

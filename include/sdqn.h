@@ -97,6 +97,15 @@ int sdqn_replay_minibatch_to_host(sdqn_replay_t h);
  * (C callers that write into the buffers, arrays from elsewhere) the states are uploaded as before.  simple_dqn_amd's
  * ReplayMemory exposes the two buffers as write-tracking numpy views and declares this only while they are untouched. */
 int sdqn_replay_declare_minibatch_clean(sdqn_replay_t h);
+/* replay_memory.py:79 without the wait (round 5): the reference's getMinibatch() returns arrays; most callers hand them straight back
+ * to DeepQNetwork.train (agent.py:112-114) and never read the 1.8 MB of states on the host.  sdqn_replay_minibatch_gen reports the
+ * generation of the device minibatch (bumped by every gather launch) and of the host copy (set by sdqn_replay_minibatch_to_host), so a
+ * host binding can hand out LAZY state arrays and fetch them only when somebody looks.  sdqn_replay_declare_minibatch_on_device is the
+ * one-shot declaration for that case: "the two state arguments of the next sdqn_net_train_host stand for device minibatch `gen` — the
+ * host buffers may not hold it yet, and I have not written into them".  Honoured only while `gen` still IS the device minibatch's
+ * generation; otherwise the call uploads the host buffers as always.  (rewards / actions / terminals always come from the arguments.) */
+int sdqn_replay_minibatch_gen(sdqn_replay_t h, uint64_t* device_gen, uint64_t* host_gen);
+int sdqn_replay_declare_minibatch_on_device(sdqn_replay_t h, uint64_t gen);
 /* device-side timing of the last n gather launches, for bench.py (HIP events on the library stream) */
 int sdqn_replay_bench_gather(sdqn_replay_t h, const int64_t* idx_host, int iters, float* ms_per_launch);
 /* the same with a different index set per launch (idx_host = nsets x batch_size, cycled): a repeated set is served from L2 / MALL

@@ -62,6 +62,8 @@ SIGNATURES = {
     "sdqn_replay_gather": (C.c_int, [_vp, _i64p]),
     "sdqn_replay_minibatch_to_host": (C.c_int, [_vp]),
     "sdqn_replay_declare_minibatch_clean": (C.c_int, [_vp]),
+    "sdqn_replay_minibatch_gen": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "sdqn_replay_declare_minibatch_on_device": (C.c_int, [_vp, C.c_uint64]),
     "sdqn_replay_bench_gather": (C.c_int, [_vp, _i64p, C.c_int, _f32p]),
     "sdqn_replay_bench_gather_sets": (C.c_int, [_vp, _i64p, C.c_int, C.c_int, _f32p]),
     "sdqn_net_create": (C.c_int, [C.POINTER(_vp), C.POINTER(NetCfg)]),

@@ -137,7 +137,7 @@ struct sdqn_replay_s {
   // train(tuple) call on the very same pinned arrays may read it in place instead of uploading 2 x B x state bytes again — when the
   // host copy is as new as the device copy (generations) AND the caller has declared that it did not write into the host arrays
   // (sdqn_replay_declare_minibatch_clean: one-shot, consumed by the next sdqn_net_train_host)
-  uint64_t mb_dev_gen = 1, mb_host_gen = 0; bool mb_clean_declared = false;
+  uint64_t mb_dev_gen = 1, mb_host_gen = 0; bool mb_clean_declared = false, mb_clean_on_device = false;
   hipEvent_t mb_upload_ev = nullptr;      // tuple API: the H2D of h_pre | h_post issued by sdqn_net_train_host (waited for before that call returns)
 };
 
@@ -345,7 +345,18 @@ extern "C" int sdqn_replay_minibatch_to_host(sdqn_replay_t r) {
   return SDQN_OK;
 }
 extern "C" int sdqn_replay_declare_minibatch_clean(sdqn_replay_t r) {
-  ARGCHK(r, "NULL handle"); r->mb_clean_declared = true; return SDQN_OK;
+  ARGCHK(r, "NULL handle"); r->mb_clean_declared = true; r->mb_clean_on_device = false; return SDQN_OK;
+}
+extern "C" int sdqn_replay_minibatch_gen(sdqn_replay_t r, uint64_t* device_gen, uint64_t* host_gen) {
+  ARGCHK(r, "NULL handle");
+  if (device_gen) *device_gen = r->mb_dev_gen;
+  if (host_gen) *host_gen = r->mb_host_gen;
+  return SDQN_OK;
+}
+extern "C" int sdqn_replay_declare_minibatch_on_device(sdqn_replay_t r, uint64_t gen) {
+  ARGCHK(r, "NULL handle");
+  r->mb_clean_declared = true; r->mb_clean_on_device = gen == r->mb_dev_gen;       // (a stale generation: the host buffers are uploaded as always)
+  return SDQN_OK;
 }
 extern "C" int sdqn_replay_bench_gather(sdqn_replay_t r, const int64_t* idx_host, int iters, float* ms_per_launch) {
   ARGCHK(r && idx_host && iters > 0 && ms_per_launch, "bad arguments");
@@ -1546,8 +1557,8 @@ extern "C" int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8
   sdqn_replay_s* owner = nullptr;                               // (handles are created / destroyed / used from ONE host thread: sdqn.h)
   bool reuse = false;                                           // train on the device copy the last gather left (no state upload)
   for (sdqn_replay_s* r : g_replays) {
-    if (h && pre && post && pre == r->h_pre && post == r->h_post && r->B == h->B) { owner = r; reuse = r->mb_clean_declared && r->mb_host_gen == r->mb_dev_gen; }
-    r->mb_clean_declared = false;                               // one-shot, whoever it was meant for
+    if (h && pre && post && pre == r->h_pre && post == r->h_post && r->B == h->B) { owner = r; reuse = r->mb_clean_declared && (r->mb_host_gen == r->mb_dev_gen || r->mb_clean_on_device); }
+    r->mb_clean_declared = false; r->mb_clean_on_device = false;          // one-shot, whoever it was meant for
   }
   ARGCHK(h && pre && actions && rewards && post && terminals, "NULL argument");
   for (int i = 0; i < h->B; ++i) ARGCHK(actions[i] < h->A, "action %d out of range at %d", (int)actions[i], i);

@@ -12,6 +12,7 @@ import logging
 import numpy as np
 
 from . import _lib
+from ._lazy import LazyMinibatchArray
 
 logger = logging.getLogger(__name__)
 
@@ -160,8 +161,6 @@ class DeepQNetwork:
         assert prestates.shape == poststates.shape
         assert prestates.shape[0] == actions.shape[0] == rewards.shape[0] == poststates.shape[0] == terminals.shape[0]
         assert prestates.shape == (self.batch_size, self.history_length) + self.screen_dim
-        pre = np.ascontiguousarray(prestates, dtype=np.uint8)
-        post = np.ascontiguousarray(poststates, dtype=np.uint8)
         act = np.ascontiguousarray(actions, dtype=np.uint8)
         rew = np.ascontiguousarray(rewards, dtype=np.int64)
         term = np.ascontiguousarray(terminals).astype(np.uint8)
@@ -169,13 +168,29 @@ class DeepQNetwork:
         want = self.callback is not None
         if self.optimizer == "adam":
             _lib.check(self._lib.sdqn_net_set_epoch(self._h, int(epoch)))        # optimizer.optimize(.., epoch), :165
-        # the reference's loop body net.train(mem.getMinibatch()): the states are still on the device from the gather; if the two
-        # arrays ARE that memory's buffers and nothing has written into them since, say so and the library skips their upload
-        owner = getattr(prestates, "_owner", None)
-        mem = owner() if owner is not None else None
-        if (mem is not None and prestates is getattr(mem, "prestates", None) and poststates is getattr(mem, "poststates", None)
-                and not getattr(mem, "_mb_dirty", True)):
-            _lib.check(self._lib.sdqn_replay_declare_minibatch_clean(mem._h))
+        # The reference's loop body net.train(mem.getMinibatch()): the gathered states are still on the device.
+        #  * untouched lazy views of one ReplayMemory (nobody has looked at or written the host buffers since the gather, and no other
+        #    gather has replaced the device minibatch): the step reads the device copy, the 1.8 MB never cross PCIe in either direction;
+        #  * the memory's own buffers, fetched but not written since: same, declared the round-3 way;
+        #  * anything else (written buffers, foreign arrays): uploaded.
+        mem = None
+        if (isinstance(prestates, LazyMinibatchArray) and isinstance(poststates, LazyMinibatchArray) and prestates._mem is poststates._mem
+                and prestates._which == "pre" and poststates._which == "post"):
+            mem = prestates._mem
+            if mem._mb_pending and mem._mb_gen == mem._device_minibatch_gen():
+                _lib.check(self._lib.sdqn_replay_declare_minibatch_on_device(mem._h, mem._mb_gen))
+                pre, post = mem._raw_mb["mb_pre"], mem._raw_mb["mb_post"]       # (addresses only: they name the handle's buffers)
+            else:
+                prestates, poststates = mem._states("pre"), mem._states("post")   # fetch; then the ordinary path below
+                mem = None
+        if mem is None:
+            pre = np.ascontiguousarray(prestates, dtype=np.uint8)
+            post = np.ascontiguousarray(poststates, dtype=np.uint8)
+            owner = getattr(prestates, "_owner", None)
+            m2 = owner() if owner is not None else None
+            if (m2 is not None and prestates is getattr(m2, "_prestates", None) and poststates is getattr(m2, "_poststates", None)
+                    and not getattr(m2, "_mb_pending", True) and not getattr(m2, "_mb_dirty", True)):
+                _lib.check(self._lib.sdqn_replay_declare_minibatch_clean(m2._h))
         _lib.check(self._lib.sdqn_net_train_host(self._h, _lib.ptr(pre, C.c_uint8), _lib.ptr(act, C.c_uint8),
                                                  _lib.ptr(rew, C.c_int64), _lib.ptr(post, C.c_uint8),
                                                  _lib.ptr(term, C.c_uint8), C.byref(cost) if want else None))

@@ -5,6 +5,7 @@ copy lives in pinned host DRAM (the numpy attributes are views of it) with a mir
 getMinibatch() gathers (s, a, r, s', terminal) with a HIP kernel (sdqn_replay_gather).  Index
 sampling consumes Python's global `random` stream exactly like the reference (:59), natively.
 """
+import array
 import ctypes as C
 import logging
 import random
@@ -12,6 +13,7 @@ import random
 import numpy as np
 
 from . import _lib
+from ._lazy import LazyMinibatchArray
 from ._tracked import DirtySlots, TrackedArray
 
 logger = logging.getLogger(__name__)
@@ -54,10 +56,14 @@ class ReplayMemory:
         # getMinibatch(), DeepQNetwork.train(minibatch) lets the step read the device copy of the gathered states in place instead of
         # uploading them again (sdqn_replay_declare_minibatch_clean)
         self._mb_dirty = True
+        self._mb_pending = False                # a gather has run whose states have not been copied into the host buffers yet (_lazy.py)
         raw_mb = {"mb_pre": np.ctypeslib.as_array(mp, shape=shp), "mb_post": np.ctypeslib.as_array(mq, shape=shp)}
         self._raw_bytes.update({k: v.reshape(-1).view(np.uint8) for k, v in raw_mb.items()})
-        self.prestates = TrackedArray(raw_mb["mb_pre"], self, "mb_pre")
-        self.poststates = TrackedArray(raw_mb["mb_post"], self, "mb_post")
+        self._raw_mb = raw_mb
+        self._prestates = TrackedArray(raw_mb["mb_pre"], self, "mb_pre")
+        self._poststates = TrackedArray(raw_mb["mb_post"], self, "mb_post")
+        self._lazy_pre, self._lazy_post = LazyMinibatchArray(self, "pre"), LazyMinibatchArray(self, "post")
+        self._mb_gen = 0                        # generation of the device minibatch the last gather() of THIS object produced
         self._mb_actions = np.ctypeslib.as_array(ma, shape=(self.batch_size,))
         self._mb_rewards = np.ctypeslib.as_array(mr, shape=(self.batch_size,))
         self._mb_terminals = np.ctypeslib.as_array(mt, shape=(self.batch_size,)).view(np.bool_)
@@ -70,6 +76,33 @@ class ReplayMemory:
         h, self._h = getattr(self, "_h", None), None
         if h is not None and self._lib is not None:
             self._lib.sdqn_replay_destroy(h)
+
+    # replay_memory.py:21-22: the preallocated minibatch buffers as attributes.  Reading them fetches the last gather's states first
+    # (getMinibatch() itself no longer waits for that copy: _lazy.py); the same arrays every time, aliased like the reference's
+    # (the attributes ARE what getMinibatch() returns, like the reference's `return self.prestates, ..., self.poststates, ...`:
+    #  `pre is mem.prestates` holds; np.asarray(mem.prestates) is the pinned buffer itself)
+    @property
+    def prestates(self):
+        return self._lazy_pre
+
+    @property
+    def poststates(self):
+        return self._lazy_post
+
+    def _states(self, which):
+        self._materialize()
+        return self._prestates if which == "pre" else self._poststates
+
+    def _materialize(self):
+        if self._mb_pending:
+            _lib.check(self._lib.sdqn_replay_minibatch_to_host(self._h))     # D2H of [pre | post] (+ the three small arrays) and the wait
+            self._mb_pending = False
+            self._mb_dirty = False              # host and device copies of the minibatch are identical from here on
+
+    def _device_minibatch_gen(self):
+        g = C.c_uint64()
+        _lib.check(self._lib.sdqn_replay_minibatch_gen(self._h, C.byref(g), None))
+        return g.value
 
     # count / current live in the native handle (add() updates them there)
     def _state(self):
@@ -164,24 +197,37 @@ class ReplayMemory:
             self._dirty_frames.take(); self._dirty_meta.take()
 
     def sample_indexes(self):
-        """replay_memory.py:54-68 on Python's GLOBAL random stream (shared with agent.py:32,50-51)."""
+        """replay_memory.py:54-68 on Python's GLOBAL random stream (shared with agent.py:32,50-51): the generator's state goes in as a
+        copy, the library's sampler draws from it, and Python's own generator is advanced by exactly the 32-bit words that were drawn
+        (one getrandbits call: Modules/_randommodule.c — rebuilding a 625-tuple for random.setstate cost 40 us per call)."""
         st = random.getstate()
-        self._mt[:] = st[1]
-        _lib.check(self._lib.sdqn_replay_sample(self._h, self._mt, _lib.ptr(self._idx, C.c_int64), None))
-        random.setstate((st[0], tuple(self._mt[:]), st[2]))
+        arr = array.array("I", st[1])
+        mt = (C.c_uint32 * _lib.MT_WORDS).from_buffer(arr)
+        w0, w1 = C.c_uint64(), C.c_uint64()
+        self._lib.sdqn_mt_words(C.byref(w0))
+        try:
+            _lib.check(self._lib.sdqn_replay_sample(self._h, mt, _lib.ptr(self._idx, C.c_int64), None))
+        finally:
+            self._lib.sdqn_mt_words(C.byref(w1))
+            if w1.value != w0.value:
+                random.getrandbits(32 * (w1.value - w0.value))
         return self._idx
 
     def gather(self, indexes):
+        """replay_memory.py:71-79 by index: the HIP gather is ENQUEUED (states into the device minibatch) and the call returns at once.
+        prestates / poststates come back as lazy views of the aliased buffers (their host copy is fetched on first access, _lazy.py;
+        DeepQNetwork.train consumes the device copy directly while nobody has looked); actions / rewards / terminals are
+        `ring[indexes]` of the host master copy — fresh arrays, exactly the reference's fancy-index copies (:76-78)."""
         idx = np.ascontiguousarray(indexes, dtype=np.int64)
         assert idx.shape == (self.batch_size,)
         self._check_mirror()
         _lib.check(self._lib.sdqn_replay_gather(self._h, _lib.ptr(idx, C.c_int64)))
-        _lib.check(self._lib.sdqn_replay_minibatch_to_host(self._h))
-        self._mb_dirty = False                          # host and device copies of the minibatch are identical from here on
+        self._mb_pending = True
+        self._mb_dirty = False
+        self._mb_gen = self._device_minibatch_gen()
         self.last_indexes = idx.copy()
-        # replay_memory.py:76-79: prestates/poststates are the preallocated (aliased) buffers, the three small arrays are
-        # fresh fancy-index copies in the reference — a caller may keep them across calls
-        return self.prestates, self._mb_actions.copy(), self._mb_rewards.copy(), self.poststates, self._mb_terminals.copy()
+        raw = self._raw
+        return self._lazy_pre, raw["actions"][idx], raw["rewards"][idx], self._lazy_post, raw["terminals"][idx]
 
     def getMinibatch(self):                                        # :50-79
         assert self.count > self.history_length

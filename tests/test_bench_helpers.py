@@ -122,3 +122,58 @@ def test_no_roofline_fraction_exceeds_one():
         r = bench.step_roofline(B, A, r["t_min_us"] * 1e-3)                  # a step at its own roofline: exactly 1, never above
         assert r["frac"] <= 1 + 1e-3 and r["t_min_us"] >= r["t_hbm_us"] and r["t_matrix_us"] < r["t_matrix_us_all_fp32"]
     assert list(_walk_fracs({"a": {"frac_hbm": 0.3, "x": [{"frac": 1.2}]}, "b": 5})) == [("/a/frac_hbm", 0.3), ("/a/x[0]/frac", 1.2)]
+
+
+class _OracleBackedNet:
+    """Stand-in for simple_dqn_amd.DeepQNetwork on a box without a GPU: the fp32 numpy oracle behind the few methods the bench's
+    error-figure helpers call (get_weights / train_from_memory with the library's MT19937 stream / predict / sync)."""
+
+    def __init__(self, A, B, seed, half=False):
+        from oracle.dqn_numpy import OracleDQN, xavier_weights
+        self.o = OracleDQN(A, batch_size=B, weights=xavier_weights(A, seed), half_activations=half)
+        self.B = B
+
+    def sync(self):
+        pass
+
+    def get_weights(self, which):
+        return [w.copy() for w in (self.o.W, self.o.Wt, self.o.S)[which]]
+
+    def predict(self, states):
+        return self.o.predict(states)
+
+    def train_from_memory(self, mem, n, mt_state=None, want_cost=True):
+        from oracle.replay_numpy import MT19937
+        rng = MT19937(); rng.setstate(tuple(mt_state[:]))
+        for _ in range(n):
+            self.o.train([x.copy() for x in bench.oracle_view(mem, self.B).getMinibatch(rng)])
+        for i, v in enumerate(rng.getstate()):
+            mt_state[i] = v
+
+
+def test_oracle_yardstick_block_and_fp64_fields_of_the_metric():
+    """every leg of the line carries a non-self-referential error figure (library vs the fp64 oracle next to the
+    same-semantics oracle vs fp64, after 1 and 3 steps) and the metric's top level names the fp64 pair.  Exercised here with the fp32
+    oracle standing in for the library: it then IS its own same-semantics oracle (difference exactly 0) and sits at fp32 round-off
+    from fp64."""
+    import ctypes as C
+    from oracle.replay_numpy import MT19937, ReplayOracle, synthetic_fill
+    A, B = 3, 8
+    mem = ReplayOracle(600, batch_size=B)
+    synthetic_fill(mem, 5, num_actions=A)
+    seed_rng = MT19937(); seed_rng.seed(11)
+    for half in (False, True):
+        mt = (C.c_uint32 * 625)(*seed_rng.getstate())
+        net = _OracleBackedNet(A, B, 3, half=half)
+        blk = bench.oracle_yardstick_block(net, mem, B, A, mt, half=half)
+        tag = "half" if half else "fp32"
+        assert sorted(blk["after_steps"]) == ["1", "3"]
+        for row in blk["after_steps"].values():
+            assert row["hip_vs_oracle_%s_max_abs" % tag] == 0.0
+            assert row["hip_%s_vs_fp64_max_abs" % tag] == row["oracle_%s_vs_fp64_max_abs" % tag] < (5e-2 if half else 1e-4)
+            assert row["q_fp64_max_abs"] > 0
+    mt = (C.c_uint32 * 625)(*seed_rng.getstate())
+    m = bench.q_mae_on_timed_ring(_OracleBackedNet(A, B, 4), mem, B, A, mt, steps=2)
+    for key in ("mae", "max_abs", "mae_vs_fp64_oracle", "max_abs_vs_fp64_oracle", "oracle_fp32_max_abs_vs_fp64_oracle", "pass"):
+        assert key in m
+    assert m["mae"] == 0.0 and 0 < m["max_abs_vs_fp64_oracle"] == m["oracle_fp32_max_abs_vs_fp64_oracle"] < 1e-4 and m["pass"]

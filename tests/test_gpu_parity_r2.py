@@ -603,6 +603,77 @@ def test_tuple_api_is_asynchronous_and_safe(sd):
         assert np.array_equal(n3.get_layer(i, 0), n2.get_layer(i, 0)), i
 
 
+def test_tuple_api_lazy_states_read_write_alias_and_stale_generation(sd):
+    """Round 5: getMinibatch() enqueues the gather and returns at once; prestates / poststates of the tuple are lazy
+    views of the aliased buffers (replay_memory.py:21-22,76-79) whose host copy is fetched on first access, the three small arrays are
+    ring[indexes].  Cases: read-after-return (bytes = the reference's gather), untouched tuple -> train reads the device copy,
+    read-then-train, write-then-train (the written host data is what trains), Statistics-style aliasing (statistics.py:85-86), and a
+    tuple whose device minibatch has been replaced by a later gather (trains on the aliased buffers' CURRENT content like the reference)."""
+    from oracle.replay_numpy import ReplayOracle
+    from simple_dqn_amd._lazy import LazyMinibatchArray
+    A, B, size = 4, 32, 1500
+    args = make_args(batch_size=B)
+    mem, omem = sd.ReplayMemory(size, args), ReplayOracle(size, batch_size=B)
+    synthetic_fill(mem, 813, num_actions=A); synthetic_fill(omem, 813, num_actions=A)
+    mem.sync_mirror()
+    # read after return
+    random.seed(21); st = random.getstate()
+    mb = mem.getMinibatch()
+    assert isinstance(mb[0], LazyMinibatchArray) and isinstance(mb[3], LazyMinibatchArray) and mem._mb_pending
+    assert mb[0].shape == (B, 4, 84, 84) and mb[1].shape == mb[2].shape == mb[4].shape == (B,) and mem._mb_pending      # no fetch for metadata
+    random.setstate(st); omb = omem.getMinibatch()
+    for a, b in zip(mb, omb):
+        assert np.array_equal(np.asarray(a), b)
+    assert not mem._mb_pending and np.shares_memory(np.asarray(mb[0]), np.asarray(mem.prestates)) and mb[0] is mem.prestates and mb[1].flags.writeable and mb[1].base is None
+    after_one = random.getstate()
+    random.setstate(st); omem.getMinibatch(); assert random.getstate() == after_one                                  # same stream position
+
+    def fresh():
+        return _net(sd, A, B, 814)[0]
+
+    def same(n1, n2):
+        for i in range(5):
+            assert np.array_equal(n1.get_layer(i, 0), n2.get_layer(i, 0)), i
+
+    # untouched tuple == explicit arrays == read-then-train
+    n_dev, n_host, n_read = fresh(), fresh(), fresh()
+    random.seed(22)
+    for s in range(3):
+        st = random.getstate()
+        mb = mem.getMinibatch(); n_dev.train(mb)
+        assert mem._mb_pending                                                  # nobody looked: the states never came to the host
+        random.setstate(st); mb = mem.getMinibatch(); n_host.train(tuple(np.array(x) for x in mb))
+        random.setstate(st); mb = mem.getMinibatch(); assert int(np.asarray(mb[0]).sum()) > 0; n_read.train(mb)
+    same(n_dev, n_host); same(n_dev, n_read)
+    # write-then-train: what the caller wrote is what trains
+    n_w, n_ref = fresh(), fresh()
+    mb = mem.getMinibatch()
+    mb[0][:, 0] = 7; mb[3][5] = 0                                                # through the lazy views (fetch, then tracked writes)
+    expect = tuple(np.array(x) for x in mb)
+    assert (expect[0][:, 0] == 7).all() and (expect[3][5] == 0).all()
+    n_w.train(mb); n_ref.train(expect)
+    same(n_w, n_ref)
+    # the small arrays are the caller's own copies: edits are honoured, the ring is untouched
+    n_w, n_ref = fresh(), fresh()
+    mb = mem.getMinibatch()
+    mb[2][:] = 1; mb[4][:] = False
+    n_w.train(mb)
+    n_ref.train((np.array(mem.prestates), mb[1], np.ones(B, np.int64), np.array(mem.poststates), np.zeros(B, bool)))
+    same(n_w, n_ref)
+    # Statistics-style aliasing: the array kept from one call shows the next call's states (the reference's aliased buffers)
+    keep = mem.getMinibatch()[0]
+    first = np.array(keep)
+    mb2 = mem.getMinibatch()
+    assert np.array_equal(np.asarray(keep), np.asarray(mb2[0])) and keep is mem.prestates and not np.array_equal(first, np.asarray(keep))
+    # stale generation: the device minibatch was replaced by a later gather before train() -> the buffers' current content trains
+    n_s, n_ref = fresh(), fresh()
+    mb1 = mem.getMinibatch()
+    mb2 = mem.getMinibatch()
+    n_s.train(mb1)
+    n_ref.train((np.array(mb2[0]), mb1[1], mb1[2], np.array(mb2[3]), mb1[4]))
+    same(n_s, n_ref)
+
+
 # ---- multi-GPU readiness that a 1-GPU box can check --------------------------------------------------------------------
 def test_bench_dry_run_dp_two_ranks(sd):
     """bench.py under torch.distributed.run with 2 ranks sharing the one GPU (control plane only: gloo id exchange,
