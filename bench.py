@@ -679,6 +679,82 @@ def b256_leg(sd, make_args, seed, steps=300, warmup=100, ring=200000):
                                   "fused_gather_conv1": fused, "frac_hbm": round(best, 4), "met": bool(best >= 0.40)}}
 
 
+def dp_b256_leg(sd, make_args, dist, torch, rank, world, dev, seed, dry_run, steps=150, warmup=60, ring=100000):
+    """world > 1 only: BASELINE.json configs[2]'s shape (batch_size 256 per learner, A = 3) under the same N-rank
+    data-parallel step as the headline, so that an N-GPU record carries both regimes — at B = 32 the gradient all-reduce is of the size
+    of the step, at B = 256 the step is 3x longer for the same 6.7 MB payload (cost model: 0.92 vs 0.73 scaling efficiency at N = 8).
+    Own communicator (fresh unique id from rank 0), own ring and sampler stream per rank, the timed region bracketed like the
+    headline's (barrier + sync both sides, MAX over ranks).  Every rank issues the same control-plane collectives whatever happens
+    locally; a failure anywhere is reported in the record and never takes the headline line down."""
+    import ctypes as C
+    from simple_dqn_amd import _lib
+    from simple_dqn_amd.deepqnetwork import dp_unique_id
+    B, A = 256, 3
+    err, net, el, form = None, None, 0.0, None
+    ids = [dp_unique_id() if (rank == 0 and not dry_run) else None]
+    dist.broadcast_object_list(ids, src=0)
+
+    def vote(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t[0]))
+    try:
+        args = make_args(batch_size=B, random_seed=seed + 1, device_id=dev)
+        mem = sd.ReplayMemory(ring, args)
+        fill_ring(mem, seed + 500 + 1000 * rank, A)
+        net = sd.DeepQNetwork(A, args)
+        net.update_target_network()
+        mt = (C.c_uint32 * 625)()
+        _lib.check(sd.load().sdqn_mt_seed(mt, seed + 9 + 1000 * rank))
+    except Exception as e:
+        err = "setup: " + repr(e)[:200]
+    if not dry_run:
+        try:
+            if err is None:
+                net.dp_init(ids[0], rank, world, vote=vote)
+            else:
+                vote(False)                                            # (the collective the healthy ranks are sitting in)
+        except Exception as e:
+            err = err or ("dp_init: " + repr(e)[:200])
+        flush_c_stdio()
+    oks = [None] * world
+    dist.all_gather_object(oks, err)
+    if any(oks):
+        if net is not None and not dry_run:
+            try: net.dp_shutdown()
+            except Exception: pass
+        return {"error": "setup failed on ranks %s" % [i for i, e in enumerate(oks) if e], "per_rank_errors": oks}
+    try:
+        form = net.dp_form()["form"]
+        net.train_from_memory(mem, warmup, mt_state=mt, want_cost=False)
+    except Exception as e:
+        err = "warmup: " + repr(e)[:200]
+    dist.barrier(); net.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    try:
+        if err is None:
+            net.train_from_memory(mem, steps, mt_state=mt, want_cost=False)
+    except Exception as e:
+        err = "timed: " + repr(e)[:200]
+    dist.barrier(); net.sync(); torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_gather_object(oks, err)
+    if not dry_run:
+        try: net.dp_shutdown()
+        except Exception: pass
+        flush_c_stdio()
+    if any(oks):
+        return {"error": "step failed on ranks %s" % [i for i, e in enumerate(oks) if e], "per_rank_errors": oks}
+    el = float(t[0])
+    return {"workload": "BASELINE.json configs[2] shapes per learner: batch_size=256, num_actions=3, replay_size=%d per rank, %d-rank data parallel "
+                        "(NOT the headline; same job, after the headline's timed region)" % (ring, world),
+            "value": round(steps * world / el, 2), "unit": "train_steps/sec", "n_gpus": world, "global_batch": B * world, "ms_per_step": round(el / steps * 1e3, 4),
+            "steps": steps, "warmup": warmup, "scaling": "weak", "dp_form": form, "dry_run": bool(dry_run),
+            "expected_steps_per_s_model": expected_dp_rates(B, A, "float32")["per_n"].get(str(world))}
+
+
 def fp16_b256_leg(sd, make_args, seed, steps=300, warmup=140, ring=200000):
     """The throughput regime in float16 (batch_size 256, A = 3: configs[2]'s shape in configs[4]'s precision), in the same process as the
     headline so that the driver's JSON line carries it (VERDICT r3 item 1 names this number): half block-tile routines, weight gradients
@@ -934,6 +1010,12 @@ def main():
         t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t[0])
+    dp_b256 = None
+    if world > 1 and B == 32 and a.datatype == "float32" and not a.batch_norm and not a.no_b256 and not a.profile_run:
+        try:
+            dp_b256 = dp_b256_leg(sd, make_args, dist, torch, rank, world, dev, a.seed, a.dry_run_dp)
+        except Exception as e:                                         # (a rank that raises here has already left the others' collectives: report)
+            dp_b256 = {"error": repr(e)[:300]}
     live = [p for p in net.profile_read() if p["id"] == dom["id"]][0]
     live_src = "timed region, every %d%s launch carries start/stop events (kernel-packet timestamps)" % (every, "th" if every > 3 else ("nd" if every == 2 else "rd"))
     if live["launches"] == 0:                                        # (K = 0)
@@ -971,6 +1053,8 @@ def main():
                          "allreduce_model": allreduce_model(world, payload),
                          "allreduce_model_all_n": {str(n): allreduce_model(n, payload)["expected_us"] for n in (2, 4, 8)},
                          "devices": [r["bound_device"] for r in dp_rows], "dry_run": bool(a.dry_run_dp), "per_rank": dp_rows}
+        if dp_b256 is not None:
+            out["config_b256"] = dp_b256
         out["roofline"] = roofline_entry(dom["id"], dom["name"], live["total_ms"] / max(live["launches"], 1), B, A)
         out["roofline"]["measured_in"] = live_src
         out["roofline"]["launches_bracketed"] = int(live["launches"])

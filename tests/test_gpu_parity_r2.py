@@ -690,6 +690,10 @@ def test_bench_dry_run_dp_two_ranks(sd):
     out = json.loads(lines[-1])
     assert out["n_gpus"] == 2 and out["steps"] == 30 and out["value"] > 0
     assert out["dp"]["ranks"] == 2 and len(out["dp"]["per_rank"]) == 2
+    # (round 5) an N-rank record carries the throughput regime too: configs[2]'s shape per learner, timed like the headline
+    b = out["config_b256"]
+    assert "error" not in b, b
+    assert b["n_gpus"] == 2 and b["global_batch"] == 512 and b["value"] > 0 and b["dry_run"] is True and b["scaling"] == "weak"
 
 
 def _run_bench(extra, timeout=900):
