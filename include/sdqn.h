@@ -185,9 +185,6 @@ int sdqn_net_act_step(sdqn_net_t h, sdqn_statebuf_t sb, sdqn_replay_t r, const u
  * forward of the buffered state with per-workgroup phase stamps.  q_out float[A], stamps_out uint64[256][80] ({kind, clock} pairs; the last
  * word of a workgroup's row = its XCC id); either may be NULL. */
 int sdqn_net_debug_act(sdqn_net_t h, sdqn_statebuf_t sb, float* q_out, unsigned long long* stamps_out);
-/* Experiments build only (returns SDQN_ERR_ARG otherwise): timing probe of the training forward conv chain as one XCC-local launch, ns (state, net)
- * pairs per XCC (tools/exp/chain_probe.py).  stamps_out uint64[grid][80] nullable. */
-int sdqn_exp_chain_probe(sdqn_net_t h, int ns, int grid, int reps, float* us_per_launch, unsigned long long* stamps_out);
 /* DeepQNetwork.train, deepqnetwork.py:107-172, minibatch given as host arrays.
  * cost_out nullable: NULL -> the step itself is not waited for.  Buffer contract: when the call returns, all five arrays
  * are free to be overwritten — pageable arrays were copied into a pinned double buffer; pre / post that ARE a
@@ -241,6 +238,12 @@ int sdqn_net_overflow_steps(sdqn_net_t h, int64_t* n);
 /* the `epoch` argument of DeepQNetwork.train (deepqnetwork.py:107,165): Neon's Adam bias-corrects with t = epoch + 1 */
 int sdqn_net_set_epoch(sdqn_net_t h, int epoch);
 
+/* Which launches a train step of this handle is made of, and how its optimizer pass runs — a function of (batch regime, datatype,
+ * batch_norm, data-parallel form, option fused_launches) only (tests/test_step_structure.py enumerates the combinations):
+ *   structure: 0 fused (fc4_dgrad | bwd3 | bwd2 | bwd1)   1 float16 block-tile (fc4_dgrad | conv3_dgrad | conv2_dgrad | wgrads | bwd1)
+ *              2 fused with fc4's all-reduce + update overlapped on the second communicator   3 one launch per problem   4 generic path
+ *   update:    0 one update launch   1 serial data parallel (local sums, all-reduce, apply)   2 overlapped data parallel   3 grad_only */
+int sdqn_net_step_structure(sdqn_net_t h, int* structure, int* update);
 /* options: "grad_only" (see sdqn_net_apply_update), "keep_gradients" (1: the fc4 gradient is materialised and readable with which=3; 0 (default): on one
  * GPU RMSProp of fc4 is fused into the wgrad epilogue), "two_streams" (0 default; 1: wgrad kernels overlap the dgrad chain on a side stream), "fused_launches" (1 default:
  * independent backward stages share one grid), "xcd_map" (0 default = only where it wins time: conv1/conv2/fc4 forward; 1: the

@@ -17,10 +17,6 @@ class SdqnError(RuntimeError):
 
 
 def lib_path():
-    # SDQN_LIB_VARIANT=experiments: the build with the measured-slower step structures compiled in (`make -C simple_dqn_amd/csrc
-    # experiments`; tests marked `experiments`, tools/exp).  Never the default: the product library has ONE step structure per regime.
-    if os.environ.get("SDQN_LIB_VARIANT") == "experiments":
-        return os.path.join(_HERE, "libsdqn_hip_exp.so")
     return os.path.join(_HERE, "libsdqn_hip.so")
 
 
@@ -62,6 +58,7 @@ SIGNATURES = {
     "sdqn_replay_gather": (C.c_int, [_vp, _i64p]),
     "sdqn_replay_minibatch_to_host": (C.c_int, [_vp]),
     "sdqn_replay_declare_minibatch_clean": (C.c_int, [_vp]),
+    "sdqn_net_step_structure": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sdqn_replay_minibatch_gen": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sdqn_replay_declare_minibatch_on_device": (C.c_int, [_vp, C.c_uint64]),
     "sdqn_replay_bench_gather": (C.c_int, [_vp, _i64p, C.c_int, _f32p]),
@@ -85,7 +82,6 @@ SIGNATURES = {
     "sdqn_net_predict_state": (C.c_int, [_vp, _vp, _f32p]),
     "sdqn_net_act_step": (C.c_int, [_vp, _vp, _vp, _u8p, C.c_int, C.c_int64, C.c_int, C.c_int]),
     "sdqn_net_act_greedy": (C.c_int, [_vp, _vp, C.POINTER(C.c_int), _f32p]),
-    "sdqn_exp_chain_probe": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _f32p, C.POINTER(C.c_uint64)]),
     "sdqn_net_debug_act": (C.c_int, [_vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]),
     "sdqn_net_train_host": (C.c_int, [_vp, _u8p, _u8p, _i64p, _u8p, _u8p, _f32p]),
     "sdqn_net_train_replay": (C.c_int, [_vp, _vp, _i64p, _f32p]),

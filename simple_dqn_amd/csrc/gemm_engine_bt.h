@@ -71,16 +71,6 @@ __device__ __forceinline__ float4 f4_to_float4(const f4& v) { return make_float4
 
 typedef __bf16 bt_bf16x8 __attribute__((ext_vector_type(8)));
 // eight fp32 values -> three bf16 fragments with hi + mid + lo == x exactly (round-to-nearest splits, exact residuals)
-#ifdef SDQN_EXPERIMENTS
-// timing experiment only (X = 19 / 16): the three "planes" are bit casts — WRONG numbers, the MFMA / LDS schedule of a kernel whose
-// operands arrive pre-split (what producer-written bf16 planes would cost in the consumer)
-__device__ __forceinline__ void fake8_bf16x3(const float* x, bt_bf16x8& hi, bt_bf16x8& mid, bt_bf16x8& lo) {
-  union { float f[4]; bt_bf16x8 v; } a, b;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { a.f[e] = x[e]; b.f[e] = x[4 + e]; }
-  hi = a.v; mid = b.v; lo = a.v;
-}
-#endif
 __device__ __forceinline__ void split8_bf16x3(const float* x, bt_bf16x8& hi, bt_bf16x8& mid, bt_bf16x8& lo) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -210,9 +200,6 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = As[bt::mk_off(BM, 16 * st + e, x) + h * (8 * BM)];
         }
-#ifdef SDQN_EXPERIMENTS
-        if constexpr (X > 9) fake8_bf16x3(v, a1[sm], a2[sm], a3[sm]); else
-#endif
         split8_bf16x3(v, a1[sm], a2[sm], a3[sm]);
       }
 #pragma unroll
@@ -229,9 +216,6 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = Bs[bt::mk_off(BN, 16 * st + e, x) + h * (8 * BN)];
         }
-#ifdef SDQN_EXPERIMENTS
-        if constexpr (X > 9) fake8_bf16x3(v, b1[sn], b2[sn], b3[sn]); else
-#endif
         split8_bf16x3(v, b1[sn], b2[sn], b3[sn]);
       }
 #pragma unroll
@@ -398,204 +382,6 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
     }
 }
 
-#ifdef SDQN_EXPERIMENTS   // (measured slower than fp32 MFMA at B = 256: tools/exp/README.md)
-// ---- plane mode: fp32 GEMM stages on packed-bf16 MFMA with the VALU work of the exact split kept off the critical resource -------------
-// X = 9 / 6 above splits BOTH operands per wave at fragment-read time and is VALU-bound (conv2_fwd 37.7 us against 30.4 on fp32 MFMA).
-// With the splits out of the consumer the same launches take 22.8 us (9 products) / 18.9 us (6): tools/exp/bt_x3_ceiling.py.  Here:
-//   * the WEIGHT operand (B of every forward / dgrad stage) is read as three bf16 planes that whoever writes the weights keeps in global
-//     memory next to them (StepArgs::wpt / wpm: k-contiguous for the stage, like the fp16 mode's half copies) — no arithmetic at all,
-//     16-byte loads straight into the LDS panel;
-//   * the ACTIVATION / DELTA operand (A) is split ONCE PER WORKGROUP while it is staged into LDS (the loader thread that fetched a
-//     float4 writes its three 8-byte plane pieces): a quarter of the per-wave split work at a 2 x 2 wave grid, and no change to any
-//     producer;
-//   * panels [x][3 planes][32 k] bf16, row pitch 208 bytes (conflict-free ds_read_b128 fragments); per 32-deep chunk and sub-tile 18 (NP =
-//     9) or 12 (NP = 6) v_mfma_f32_32x32x16_bf16 = 576 / 384 matrix-pipe cycles instead of 1024; the hi x hi products accumulate in
-//     their own accumulator, the small cross terms in a second one (added once in the epilogue).
-// NP = 9: every partial product of the two exact three-way splits — the result is the fp32 sum of exact products (not narrower than an
-// fmaf chain); NP = 6 drops lo x mid, mid x lo, lo x lo (each below 2^-24 of the product).
-template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 2, int NP_ = 9>
-struct BtCfgXP {
-  typedef P_ P;
-  static constexpr int KIND = 1;                        // bt_run_tile: plane mode (bt_tile_xp)
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, D = D_, NP = NP_;
-  static constexpr int SM = BM / (32 * WM), SN = BN / (32 * WN);
-  static_assert(WM * WN * 64 == bt::NT && SM >= 1 && SN >= 1 && SM * 32 * WM == BM && SN * 32 * WN == BN, "block = 4 waves x sub-tiles of 32 x 32");
-  static_assert(P::A_K, "the activation / delta operand is k-contiguous fp32 (split at staging)");
-  static_assert(NP == 9 || NP == 6, "9 or 6 partial products");
-  static constexpr int PITCH = 3 * 32 + 8;              // ushorts per panel row: [3 planes][32 k] + pad (208 bytes)
-  static constexpr int AU = BM * PITCH, BU = BN * PITCH, STAGE = AU + BU;     // ushorts
-  static constexpr int LDS = (2 * STAGE + 1) / 2;       // floats: double-buffered
-  static constexpr int BITEMS = (BN * 12 + bt::NT - 1) / bt::NT;              // 16-byte plane pieces per thread and chunk: BN rows x 3 planes x 4
-};
-
-// four fp32 values -> their three bf16 planes, each packed as one 8-byte piece (scalar code: small uint16 arrays end up in scratch)
-__device__ __forceinline__ void split4_pack(const float4& v, uint2& p0, uint2& p1, uint2& p2) {
-  uint16_t a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
-  split_bf16x3(v.x, a0, a1, a2); split_bf16x3(v.y, b0, b1, b2); split_bf16x3(v.z, c0, c1, c2); split_bf16x3(v.w, d0, d1, d2);
-  p0 = make_uint2((uint32_t)a0 | ((uint32_t)b0 << 16), (uint32_t)c0 | ((uint32_t)d0 << 16));
-  p1 = make_uint2((uint32_t)a1 | ((uint32_t)b1 << 16), (uint32_t)c1 | ((uint32_t)d1 << 16));
-  p2 = make_uint2((uint32_t)a2 | ((uint32_t)b2 << 16), (uint32_t)c2 | ((uint32_t)d2 << 16));
-}
-
-template <class C>
-__device__ __forceinline__ void bt_tile_xp(const StepArgs& a, int bx, int by, int bz, float* smem_f) {
-  typedef typename C::P P;
-  typedef typename P::aoff_t aoff_t;
-  constexpr int BM = C::BM, BN = C::BN, SM = C::SM, SN = C::SN, WN = C::WN, D = C::D, NP = C::NP, PITCH = C::PITCH, BI = C::BITEMS;
-  constexpr int PA = bt::passes(BM);
-  unsigned short* smem = reinterpret_cast<unsigned short*>(smem_f);
-  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave - wm * WN;
-  const int m0 = bx * BM, n0 = by * BN;
-  int z, ks, kbeg, kend;
-  P::ksplit(a, bz, z, ks, kbeg, kend);
-  const int M = P::M(a), N = P::N(a);
-  aoff_t ag[PA];
-#pragma unroll
-  for (int p = 0; p < PA; ++p) { const int m = m0 + bt::km_item_row(tid, p); ag[p] = P::a_row(a, z, m < M ? m : M - 1); }
-  // B items of this thread: (row n, plane q, 8-k piece) — fixed for the whole block
-  const unsigned short* bpl = P::bp(a, z);
-  int boff[BI], blds[BI];
-#pragma unroll
-  for (int j = 0; j < BI; ++j) {
-    int it = tid + bt::NT * j; if (it >= BN * 12) it = BN * 12 - 1;
-    const int nl = it / 12, rem = it - nl * 12, q = rem >> 2, k8 = (rem & 3) * 8;
-    const int n = n0 + nl;
-    boff[j] = q * XP_PLANE + P::bp_col(a, z, n < N ? n : N - 1) + k8;       // + bp_row(kc) per chunk (k8 < 32: inside one contiguous run)
-    blds[j] = nl * PITCH + q * 32 + k8;
-  }
-  // two register sets with NAMED members (register arrays reached through pointers ended up in scratch in this routine: 112 bytes per
-  // lane and a 2x slower kernel): up to 4 A float4 (BM <= 128) and 3 B pieces (BN <= 64) per set
-  static_assert(PA <= 4 && BI <= 3, "staging set: 4 + 3 pieces");
-  typedef float xp_v4 __attribute__((ext_vector_type(4)));      // (a native vector: copies of HIP's float4 struct became memcpy through scratch)
-  struct Set { float4 a0, a1, a2, a3; xp_v4 b0, b1, b2; };
-  Set s0, s1;
-  auto gload = [&](int kc, Set& g) {
-    const int k = kc + bt::km_item_k(tid);
-    const aoff_t ca = P::a_col(a, z, k);
-    g.a0 = f4_to_float4(P::a_load4(a, z, ag[0] + ca));
-    if constexpr (PA > 1) g.a1 = f4_to_float4(P::a_load4(a, z, ag[1] + ca));
-    if constexpr (PA > 2) g.a2 = f4_to_float4(P::a_load4(a, z, ag[2] + ca));
-    if constexpr (PA > 3) g.a3 = f4_to_float4(P::a_load4(a, z, ag[3] + ca));
-    const int rk = P::bp_row(a, z, kc);
-    g.b0 = *reinterpret_cast<const xp_v4*>(bpl + boff[0] + rk);
-    if constexpr (BI > 1) g.b1 = *reinterpret_cast<const xp_v4*>(bpl + boff[1] + rk);
-    if constexpr (BI > 2) g.b2 = *reinterpret_cast<const xp_v4*>(bpl + boff[2] + rk);
-  };
-  auto st_a = [&](unsigned short* As, int p, const float4& v) {
-    uint2 p0, p1, p2;
-    split4_pack(v, p0, p1, p2);
-    unsigned short* row = As + bt::km_item_row(tid, p) * PITCH + bt::km_item_k(tid);
-    *reinterpret_cast<uint2*>(row) = p0; *reinterpret_cast<uint2*>(row + 32) = p1; *reinterpret_cast<uint2*>(row + 64) = p2;
-  };
-  auto st_b = [&](unsigned short* Bs, int j, const xp_v4 v) {
-    if (BN * 12 % bt::NT == 0 || tid + bt::NT * j < BN * 12) *reinterpret_cast<xp_v4*>(Bs + blds[j]) = v;
-  };
-  auto lds_store = [&](const Set& g, unsigned short* As, unsigned short* Bs) {
-    st_a(As, 0, g.a0);
-    if constexpr (PA > 1) st_a(As, 1, g.a1);
-    if constexpr (PA > 2) st_a(As, 2, g.a2);
-    if constexpr (PA > 3) st_a(As, 3, g.a3);
-    st_b(Bs, 0, g.b0);
-    if constexpr (BI > 1) st_b(Bs, 1, g.b1);
-    if constexpr (BI > 2) st_b(Bs, 2, g.b2);
-  };
-  f32x16 acc[SM][SN], accs[SM][SN];
-#pragma unroll
-  for (int sm = 0; sm < SM; ++sm)
-#pragma unroll
-    for (int sn = 0; sn < SN; ++sn)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) { acc[sm][sn][q] = 0.0f; accs[sm][sn][q] = 0.0f; }
-  auto compute = [&](const unsigned short* As, const unsigned short* Bs) {
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      bt_bf16x8 fa[SM][3], fb[SN][3];
-#pragma unroll
-      for (int sm = 0; sm < SM; ++sm)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) fa[sm][q] = *reinterpret_cast<const bt_bf16x8*>(As + ((wm * SM + sm) * 32 + i) * PITCH + 32 * q + 16 * st + 8 * h);
-#pragma unroll
-      for (int sn = 0; sn < SN; ++sn)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) fb[sn][q] = *reinterpret_cast<const bt_bf16x8*>(Bs + ((wn * SN + sn) * 32 + i) * PITCH + 32 * q + 16 * st + 8 * h);
-#pragma unroll
-      for (int sm = 0; sm < SM; ++sm)
-#pragma unroll
-        for (int sn = 0; sn < SN; ++sn) {
-          f32x16 m = acc[sm][sn], s = accs[sm][sn];
-          if constexpr (NP == 9) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sm][2], fb[sn][2], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sm][1], fb[sn][2], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sm][2], fb[sn][1], s, 0, 0, 0);
-          }
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sm][0], fb[sn][2], s, 0, 0, 0);
-          m = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sm][0], fb[sn][0], m, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sm][2], fb[sn][0], s, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sm][1], fb[sn][1], s, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sm][0], fb[sn][1], s, 0, 0, 0);
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sm][1], fb[sn][0], s, 0, 0, 0);
-          acc[sm][sn] = m; accs[sm][sn] = s;
-        }
-    }
-  };
-  const int nch = (kend - kbeg) / bt::BK;             // (forward / dgrad K ranges are whole chunks)
-  static_assert(D == 2, "plane mode: two chunks in flight");
-  // one chunk: set (fa_, fb_) is free to receive chunk c + 2, set (na, nb) holds chunk c + 1 (fetched one iteration ago)
-  // (the two halves of the loop body are written out with the set index a compile-time constant: handing the sets to one lambda as
-  //  references let the compiler fold both calls into one body with swapped pointers — and keep a set in scratch memory)
-#define SDQN_XP_STEP(C_, FR_, NX_)                                                     \
-  {                                                                                    \
-    const int c_ = (C_);                                                               \
-    unsigned short* cur = smem + (c_ & 1) * C::STAGE;                                  \
-    unsigned short* nxt = smem + ((c_ + 1) & 1) * C::STAGE;                            \
-    if (c_ + 2 < nch) gload(kbeg + (c_ + 2) * bt::BK, FR_);                            \
-    compute(cur, cur + C::AU);                                                         \
-    if (c_ + 1 < nch) { lds_store(NX_, nxt, nxt + C::AU); __syncthreads(); }           \
-  }
-  if (nch > 0) {
-    gload(kbeg, s0);
-    if (nch > 1) gload(kbeg + bt::BK, s1);
-    lds_store(s0, smem, smem + C::AU);
-    __syncthreads();
-    for (int c = 0; c < nch; c += 2) {
-      SDQN_XP_STEP(c, s0, s1)
-      if (c + 1 < nch) SDQN_XP_STEP(c + 1, s1, s0)
-    }
-  }
-#undef SDQN_XP_STEP
-#pragma unroll
-  for (int sm = 0; sm < SM; ++sm)
-#pragma unroll
-    for (int sn = 0; sn < SN; ++sn) {
-      const int ms = m0 + (wm * SM + sm) * 32, ns = n0 + (wn * SN + sn) * 32;
-      if (ms >= M || ns >= N) continue;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int m = ms + bt::acc_row(q, h), n = ns + i;
-        if (m < M && n < N) P::store(a, z, ks, m, n, accs[sm][sn][q] + acc[sm][sn][q]);
-      }
-    }
-}
-
-template <class C>
-__global__ void __launch_bounds__(bt::NT) bt_kernel_xp(const StepArgs a, const int gx, const int gy) {
-  __shared__ __attribute__((aligned(16))) float smem[C::LDS];
-  const int t = blockIdx.x;
-  const int per_z = gx * gy, bz = t / per_z, r = t - bz * per_z;
-  bt_tile_xp<C>(a, r % gx, r / gx, bz, smem);
-}
-template <class C>
-inline hipError_t launch_bt_xp(const StepArgs& a, hipStream_t stream) {
-  typedef typename C::P P;
-  const int gx = (P::M(a) + C::BM - 1) / C::BM, gy = (P::N(a) + C::BN - 1) / C::BN, gz = P::nbz(a);
-  if (gx * gy * gz == 0) return hipSuccess;
-  SDQN_LAUNCH((bt_kernel_xp<C>), dim3(gx * gy * gz), dim3(bt::NT), 0, stream, a, gx, gy);
-  return hipGetLastError();
-}
-
-#endif  // SDQN_EXPERIMENTS (plane mode)
 
 // ---- the float16 mode's forward / dgrad stages (packed-fp16 MFMA, both operands k-contiguous halves: problems_h16.h) --------------------
 // Same structure with half panels: chunks of 64 k (a 128-byte row chunk = 8 lanes x 16 bytes, like the fp32 chunk), LDS rows of 72 halves
@@ -956,9 +742,6 @@ inline hipError_t launch_bt(const StepArgs& a, hipStream_t stream) {
 // block-id ranges dispatch to different configurations; the LDS footprint is the largest one's
 template <class C>
 __device__ __forceinline__ void bt_run_tile(const StepArgs& a, int bx, int by, int bz, float* smem) {
-#ifdef SDQN_EXPERIMENTS
-  if constexpr (C::KIND == 1) bt_tile_xp<C>(a, bx, by, bz, smem); else
-#endif
   if constexpr (C::KIND == 3) bt_tile_hw<C>(a, bx, by, bz, smem); else
   bt_tile<C>(a, bx, by, bz, smem);
 }

@@ -143,15 +143,10 @@ __device__ inline float opt_apply(float w, float& s1, float& s2, float gsum, con
 // host-side launch choices that never reach a kernel (kept out of StepArgs: kernel-argument bytes are not free)
 struct LaunchTune {
   int nw_override[12];      // tuning hook: waves per tile for kernel id i (0 = built-in choice)
-  int rb[12];               // B >= 128: register-blocked routine of kernel id i, menu entry (sdqn_kernels_rb.hip); 0 = unblocked routine
-  int hoist;                // bit 0: K_BWD2 / K_BWD1 carry the NEXT step's target conv1 / conv2; bit 1: K_CONV1_FWD / K_CONV2_FWD carry
-                            // this step's target conv3 / fc4 and compute the online net only (StepArgs::nz = 1)
-  int order;                // experiment (option "bwd_order"): order of the problems inside the fused backward launches
   const int64_t* host_idx;  // ring paths, B <= 32: this step's sampled indexes in HOST memory (they ride in the kernel arguments of conv1_bf16_kernel)
   int r3_xcd;               // round-3 kernels' XCD-contiguous tile maps: bit 0 conv1_fwd (bf16), bit 1 conv1_wgrad (bf16)
   int wt;                   // write-through (sc1) epilogue stores per launch: 1 conv2_fwd, 2 conv3_fwd, 4 fc4_fwd, 8 fc4_dgrad, 16 bwd3, 32 bwd2, 64 conv1_wgrad, 128 conv1_fwd
   int bt[K_COUNT];          // B >= 128, float32: block-tile engine (sdqn_kernels_bt.hip) per kernel id; 0 = built-in block shape, n > 0 = menu entry, < 0 = latency engine
-  int btx[K_COUNT];         // block-tile engine, arithmetic per kernel id: 0 = fp32 MFMA, 9 / 6 = exact bf16x3 splits of both operands on packed-bf16 MFMA (9 / 6 partial products)
   int r3;                   // round-3 launch variants (sdqn_kernels_r3.hip); bit 0: this K_FC4_DGRAD launch also carries the fc4_wgrad tiles; bit 1: conv3_fwd on 36-deep K-chunks; bit 2: conv1_fwd on packed-bf16 MFMA
 };
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s);     // the GEMM-shaped stages (single or multi-problem launches)
@@ -164,12 +159,6 @@ hipError_t launch_bn_update(const UpdateArgs& u, hipStream_t s);   // optimizer 
 hipError_t launch_prep(const PrepArgs& p, hipStream_t s, double* zero8 = nullptr);   // zero8: an 8-byte accumulator the launch also clears
 hipError_t launch_grad_to_half(const float* g, half_t* gh, int64_t n, int* state, hipStream_t s);       // fp16 DP payload; state = {flag, log2 scale, good steps}
 hipError_t launch_grad_from_half(const half_t* gh, float* g, int64_t n, int* state, hipStream_t s);
-#ifdef SDQN_EXPERIMENTS
-// round 3: update(i) + conv1_fwd(i + 1) as one launch (sdqn_kernels_r3.hip); u.skip_fc4 must be 1, u.w1_ctr == ctr
-hipError_t launch_upd_conv1(const UpdateArgs& u, const StepArgs& a, const int64_t* host_idx, unsigned* ctr, unsigned target, unsigned* timeout, int xcd, hipStream_t s);
-// round 3: head + fc4_dgrad as one launch (sdqn_kernels_r3.hip; B <= 32, A <= 8, fp32, no batch-norm); ctr counts head-block arrivals (monotonic)
-hipError_t launch_head_f4d(const StepArgs& a, const HeadArgs& h, unsigned* ctr, unsigned target, unsigned* timeout, hipStream_t s);
-#endif
 // ---- the acting forward as ONE launch (sdqn_act.hip): float32, standard geometry, no batch-norm ---------------------------------------
 constexpr int ACT_GRID = 256;                     // workgroups of 256 threads (one per CU when the chip is idle; any placement is correct)
 constexpr int ACT_XCC_FLOATS = 21248 + 8 * 32 * 64;  // one XCC's scratch: a1 [400][32] | a2 [81][64] | a3 [49][64] (+ pad) | fc4 partials [8 stripes][32 chunks][64]
@@ -188,9 +177,6 @@ struct ActArgs {
   unsigned seq;               // launch number (selects the control block / partial slot)
 };
 hipError_t launch_act(const ActArgs& a, bool q_system_scope, hipStream_t s);
-#ifdef SDQN_EXPERIMENTS
-hipError_t launch_chain_probe(const ActArgs& a, int ns, int grid, hipEvent_t e0, hipEvent_t e1, hipStream_t s);     // tools/exp/chain_probe.py
-#endif
 hipError_t launch_w1_planes(const float* theta, unsigned short* w1p, hipStream_t s);   // conv1's three bf16 weight planes of one net (problems.h: split_bf16x3)
 hipError_t launch_refresh16(const float* theta, half_t* wh, half_t* wht, hipStream_t s);   // fp16 mode: rebuild both half copies
 hipError_t launch_refresh_planes(const float* theta, unsigned short* wpm, unsigned short* wpt, hipStream_t s);   // plane mode: rebuild the bf16 planes of conv2 / conv3 (both layouts) and fc4 (master; wpm may be nullptr: target net)

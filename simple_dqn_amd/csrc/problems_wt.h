@@ -165,17 +165,6 @@ struct Fc4WgradBT : Fc4WgradWT {
       rms_step2(w[2], w[3], st[2], st[3], v[4 * g + 2], v[4 * g + 3], a.bsz, a.rho, a.one_minus_rho, a.lr, a.eps);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { stw(a.theta_w, base + epi_row(4 * g + e), w[e]); stw(a.state, base + epi_row(4 * g + e), st[e]); }
-#ifdef SDQN_EXPERIMENTS
-      if (a.wpm) {                                // plane mode: W4's master-layout bf16 planes follow (lanes along n: 64-byte rows per plane)
-        unsigned short* wp = const_cast<unsigned short*>(a.wpm);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          uint16_t hi, mid, lo; split_bf16x3(w[e], hi, mid, lo);
-          const uint32_t el = (base + epi_row(4 * g + e)) >> 2;
-          wp[el] = hi; wp[XP_PLANE + el] = mid; wp[2 * XP_PLANE + el] = lo;
-        }
-      }
-#endif
       __builtin_amdgcn_sched_barrier(0);      // keep the groups apart: hoisting all 32 loads is exactly the register bill this form avoids
     }
   }

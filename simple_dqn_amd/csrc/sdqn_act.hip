@@ -379,67 +379,6 @@ __global__ void __launch_bounds__(NT) act_kernel(const ActArgs a) {
   }
 }
 
-#ifdef SDQN_EXPERIMENTS
-// ---- experiment: the TRAINING forward conv chain as one XCC-local launch, in this file's arithmetic ---------------------
-// ns (state, net) pairs per XCC — 8 at B = 32 with both nets — instead of one state: conv1 -> conv2 -> conv3 of every pair stay inside the
-// XCC that owns it; items are claimed from the XCC's ticket counter in topological order (all conv1 items, pair by pair, then conv2, then
-// conv3), and an item waits for ITS pair's producer phase only (one counter per XCC, pair and phase), so conv2 of the first pairs starts
-// while conv1 of the last ones is still running.  No fc4 / head: the probe measures what the three forward launches conv1_fwd + conv2_fwd +
-// conv3_fwd (21.4 us in profiles/r03_final_kernel_stats.csv) would cost as one XCC-local launch.  Phase stamps as in act_kernel.
-constexpr int P_DONE = 8 * 16;                       // ctl words: ticket of XCC x at 16 x; done counter of (x, pair j, phase p) at P_DONE + 16 ((8 x + j) 3 + p)
-template <bool ST>
-__global__ void __launch_bounds__(NT) chain_probe_kernel(const ActArgs a, const int ns) {
-  __shared__ float red[4 * 2 * 256];
-  __shared__ unsigned bcast[4];
-  Wg g;
-  g.tid = threadIdx.x; g.lane = g.tid & 63; g.w = g.tid >> 6; g.r = g.lane & 15; g.kq = g.lane >> 4;
-  g.ctl = a.ctl; g.red = red; g.bcast = bcast;
-  g.stamps = ST ? a.stamps + (size_t)blockIdx.x * 2 * ACT_STAMPS : nullptr; g.nst = 0;
-  stamp<ST>(g, 0);
-  const unsigned x = xcc_id();
-  if constexpr (ST) { if (g.tid == 0) a.stamps[(size_t)blockIdx.x * 2 * ACT_STAMPS + 2 * ACT_STAMPS - 1] = x; }
-  const int T1 = I1 * ns, T2 = I2 * ns, T3 = I3 * ns;
-  unsigned* tick = g.ctl + 16 * x;
-  // a.A != 0 (probe only): STATIC tickets — workgroup b takes items b / 8, b / 8 + grid / 8, ... of XCC b % 8's list, which is only correct
-  // under the round-robin placement the probe verifies (a mismatch aborts the launch) — to separate the cost of the ticket atomics (one
-  // address per XCC, ~4 700 claims per launch at ns = 8) from the cost of the hand-offs
-  const bool stat = a.A != 0;
-  const int stride = (int)gridDim.x / 8;
-  if (stat && x != (blockIdx.x & 7u)) { if (g.tid == 0) __hip_atomic_store(g.ctl + P_DONE - 16, 1u, RLX_AGENT); return; }
-  if (g.tid == 0) bcast[0] = stat ? blockIdx.x / 8 : __hip_atomic_fetch_add(tick, 1u, RLX_AGENT);
-  __syncthreads();
-  int t = (int)bcast[0];
-  while (t < T1 + T2 + T3) {
-    unsigned tn = 0;
-    if (g.tid == 0) tn = stat ? (unsigned)(t + stride) : __hip_atomic_fetch_add(tick, 1u, RLX_AGENT);
-    const int ph = t < T1 ? 0 : (t < T1 + T2 ? 1 : 2);
-    const int l = ph == 0 ? t : (ph == 1 ? t - T1 : t - T1 - T2), per = ph == 0 ? I1 : (ph == 1 ? I2 : I3);
-    const int j = l / per, it = l - j * per;
-    ActArgs aj = a; aj.state = a.state + (size_t)(x * ns + j) * STATE;
-    float* sx = a.scratch + (size_t)(x * ns + j) * ACT_XCC_FLOATS;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sx, 0, ACT_XCC_FLOATS * 4, 0x00020000);
-    const int dw = P_DONE + 16 * ((8 * x + j) * 3);
-    if (ph == 0) {
-      stamp<ST>(g, (1u << 16) | l);
-      conv1_item<ST>(aj, g, sx, it);
-      signal_nr(g, dw + 0);
-      stamp<ST>(g, (2u << 16) | l);
-    } else if (ph == 1) {
-      if (!conv2_item<ST>(aj, g, sx, rs, it, [&]() { return wait_ge(g, dw + 0, I1); })) return;
-      signal_nr(g, dw + 16);
-      stamp<ST>(g, (4u << 16) | l);
-    } else {
-      if (!conv3_item<ST>(aj, g, sx, rs, it, [&]() { return wait_ge(g, dw + 16, I2); })) return;
-      signal_nr(g, dw + 32);
-      stamp<ST>(g, (6u << 16) | l);
-    }
-    __syncthreads();
-    if (g.tid == 0) bcast[0] = tn;
-    __syncthreads();
-    t = (int)bcast[0];
-  }
-}
-#endif  // SDQN_EXPERIMENTS
 
 }  // namespace act
 
@@ -455,13 +394,5 @@ hipError_t launch_act(const ActArgs& a, bool q_system_scope, hipStream_t s) {
   return hipGetLastError();
 }
 
-#ifdef SDQN_EXPERIMENTS
-// e0 / e1 receive the dispatch packet's own begin / end timestamps (hipExtLaunchKernel: what rocprofv3's kernel trace reports)
-hipError_t launch_chain_probe(const ActArgs& a, int ns, int grid, hipEvent_t e0, hipEvent_t e1, hipStream_t s) {
-  if (a.stamps) hipExtLaunchKernelGGL((act::chain_probe_kernel<true>), dim3(grid), dim3(act::NT), 0, s, e0, e1, 0, a, ns);
-  else hipExtLaunchKernelGGL((act::chain_probe_kernel<false>), dim3(grid), dim3(act::NT), 0, s, e0, e1, 0, a, ns);
-  return hipGetLastError();
-}
-#endif
 
 }  // namespace sdqn

@@ -52,7 +52,7 @@ hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStre
     const hipError_t e = launch_kernel_r3(id, a, t, s, &handled);
     if (handled) return e;
   }
-  if (a.h16 || t.hoist || t.order || (a.B >= 128 && id >= 0 && id < 12 && t.rb[id] > 0)) {
+  if (a.h16) {
     bool handled = false;
     const hipError_t e = launch_kernel_ext(id, a, t, s, &handled);
     if (handled) return e;
@@ -281,14 +281,6 @@ hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s, bool
     else SDQN_LAUNCH((head_kernel<MAX_ACTIONS, false, false, true>), dim3(a.B), dim3(512), 0, s, a, h);
     return hipGetLastError();
   }
-#ifdef SDQN_EXPERIMENTS
-  if (h.next_B > 0 && !a.bn) {                       // option "hoist": + one workgroup fetching the next step's indexes
-    if (a.A <= 4) SDQN_LAUNCH((head_kernel<4, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
-    else if (a.A <= 8) SDQN_LAUNCH((head_kernel<8, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
-    else SDQN_LAUNCH((head_kernel<MAX_ACTIONS, false, true>), dim3(a.B + 1), dim3(512), 0, s, a, h);
-    return hipGetLastError();
-  }
-#endif
   if (a.bn) SDQN_LAUNCH((head_kernel<MAX_ACTIONS, true>), dim3(a.B), dim3(512), 0, s, a, h);     // --batch_norm (not tuned per bucket)
   else if (a.A <= 4) SDQN_LAUNCH((head_kernel<4, false>), dim3(a.B), dim3(512), 0, s, a, h);
   else if (a.A <= 8) SDQN_LAUNCH((head_kernel<8, false>), dim3(a.B), dim3(512), 0, s, a, h);

@@ -10,11 +10,6 @@
 // LaunchTune::bt[id]: 0 = the built-in block shape, n > 0 = menu entry n (tools/sweep_bt.py), < 0 = this launch on the latency engine.
 #include <stdlib.h>
 #include "gemm_engine_bt.h"
-#ifdef SDQN_EXPERIMENTS
-#include "gemm_engine_glds.h"    // operand panels straight into LDS (global_load_lds_dwordx4): written at the end of round 4, not yet run on a GPU
-#include "gemm_engine_sk.h"      // chunk-granular work assignment (stream-K) for the forward convs: built in the last hours of round 4, see its header
-#include "gemm_engine_pp.h"      // ping-pong form (8 waves, two per SIMD): built, correct, measured SLOWER than bt_tile everywhere — tools/exp/README.md
-#endif
 #include "problems_wt.h"
 #include "problems_h16.h"
 #include "kernels.h"
@@ -26,14 +21,6 @@ namespace sdqn {
 #define BTX(P, BM, BN, WM, WN, D, X) BtCfg<P, BM, BN, WM, WN, D, X>
 #define BT2(P, BM, BN, WM, WN, D) BtCfg<P, BM, BN, WM, WN, D, 0, 2>       // two chunks per barrier interval
 #define BT_CASE(N, P, BM, BN, WM, WN, D) case N: return launch_bt<BT(P, BM, BN, WM, WN, D)>(a, s)
-#ifdef SDQN_EXPERIMENTS
-#define PP(P, BM, BN, WM, WN, D) PpCfg<P, BM, BN, WM, WN, D>                // ping-pong routine (gemm_engine_pp.h): 8 waves, two per SIMD
-#define PP_CASE(N, P, BM, BN, WM, WN, D) case N: return launch_pp<PP(P, BM, BN, WM, WN, D)>(a, s)
-#define GL(P, BM, BN, WM, WN) GlCfg<P, BM, BN, WM, WN>
-#define GLN(P, BM, BN, WM, WN, NIT) GlCfg<P, BM, BN, WM, WN, NIT>      // compile-time chunk count: unrolled chunk loop
-#define GL_CASE(N, P, BM, BN, WM, WN) case N: return launch_gl<GL(P, BM, BN, WM, WN)>(a, s)
-#define GLN_CASE(N, P, BM, BN, WM, WN, NIT) case N: return launch_gl<GLN(P, BM, BN, WM, WN, NIT)>(a, s)
-#endif
 
 // built-in block shapes (menu entry 0 maps onto these)
 typedef BT(Conv2FwdWT, 64, 64, 2, 2, 2) C2F;
@@ -54,15 +41,6 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 0: return launch_bt<C2F>(a, s);
         BT_CASE(1, Conv2FwdWT, 64, 64, 2, 2, 3); BT_CASE(2, Conv2FwdWT, 128, 64, 2, 2, 2); BT_CASE(3, Conv2FwdWT, 128, 64, 4, 1, 2);
         BT_CASE(4, Conv2FwdWT, 64, 64, 2, 2, 1); BT_CASE(5, Conv2FwdWT, 128, 64, 2, 2, 3);
-#ifdef SDQN_EXPERIMENTS
-        PP_CASE(10, Conv2FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Conv2FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Conv2FwdWT, 128, 64, 2, 2, 2);
-        case 9: return launch_sk<SkCfg<Conv2FwdWT, CRS2 / 32, 2>>(a, s, 0);
-        GLN_CASE(13, Conv2FwdWT, 64, 64, 2, 2, CRS2 / 32);
-#endif
-#ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
-        case 6: return launch_bt<BT2(Conv2FwdWT, 64, 64, 2, 2, 2)>(a, s);
-        case 7: return launch_bt<BT2(Conv2FwdWT, 64, 64, 2, 2, 1)>(a, s);
-#endif
         default: break;
       }
       break;
@@ -71,15 +49,6 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 0: return launch_bt<C3F>(a, s);
         BT_CASE(1, Conv3FwdWT, 64, 64, 2, 2, 3); BT_CASE(2, Conv3FwdWT, 128, 64, 2, 2, 2); BT_CASE(3, Conv3FwdWT, 128, 64, 4, 1, 2);
         BT_CASE(4, Conv3FwdWT, 64, 64, 2, 2, 1); BT_CASE(5, Conv3FwdWT, 128, 64, 2, 2, 3);
-#ifdef SDQN_EXPERIMENTS
-        PP_CASE(10, Conv3FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Conv3FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Conv3FwdWT, 128, 64, 2, 2, 2);
-        case 9: return launch_sk<SkCfg<Conv3FwdWT, CRS3 / 32, 2>>(a, s, 1);
-        GLN_CASE(13, Conv3FwdWT, 64, 64, 2, 2, CRS3 / 32);
-#endif
-#ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
-        case 6: return launch_bt<BT2(Conv3FwdWT, 64, 64, 2, 2, 2)>(a, s);
-        case 7: return launch_bt<BT2(Conv3FwdWT, 64, 64, 2, 2, 1)>(a, s);
-#endif
         default: break;
       }
       break;
@@ -89,14 +58,6 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         BT_CASE(1, Fc4FwdWT, 64, 64, 2, 2, 3); BT_CASE(2, Fc4FwdWT, 128, 64, 2, 2, 2); BT_CASE(3, Fc4FwdWT, 128, 128, 2, 2, 2);
         BT_CASE(4, Fc4FwdWT, 64, 128, 2, 2, 2); BT_CASE(5, Fc4FwdWT, 128, 128, 2, 2, 3);
         case 8: return launch_bt<BTU(Fc4FwdWT, 64, 64, 2, 2, 2)>(a, s);        // unconditional ring loads (run-time K split): 21.0 us at S4 = 7, the latency engine 18.1
-#ifdef SDQN_EXPERIMENTS
-        PP_CASE(10, Fc4FwdWT, 64, 64, 2, 2, 2); PP_CASE(11, Fc4FwdWT, 64, 64, 2, 2, 3); PP_CASE(12, Fc4FwdWT, 128, 64, 2, 2, 2);
-        GL_CASE(13, Fc4FwdWT, 64, 64, 2, 2);
-#endif
-#ifdef SDQN_EXPERIMENTS      // two chunks per barrier interval: measured slower (LDS doubles, fewer co-resident workgroups)
-        case 6: return launch_bt<BT2(Fc4FwdWT, 64, 64, 2, 2, 2)>(a, s);
-        case 7: return launch_bt<BT2(Fc4FwdWT, 64, 64, 2, 2, 1)>(a, s);
-#endif
         default: break;
       }
       break;
@@ -105,12 +66,6 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 0: return launch_bt<F4D>(a, s);
         BT_CASE(1, Fc4DgradWT, 64, 64, 2, 2, 3); BT_CASE(2, Fc4DgradWT, 64, 128, 2, 2, 2); BT_CASE(3, Fc4DgradWT, 32, 128, 1, 4, 2);
         BT_CASE(4, Fc4DgradWT, 128, 64, 2, 2, 2); BT_CASE(5, Fc4DgradWT, 32, 128, 1, 4, 3);
-#ifdef SDQN_EXPERIMENTS
-        PP_CASE(10, Fc4DgradWT, 64, 64, 2, 2, 2); PP_CASE(11, Fc4DgradWT, 64, 64, 2, 2, 3); PP_CASE(12, Fc4DgradWT, 32, 128, 1, 4, 2);
-        GLN_CASE(13, Fc4DgradWT, 64, 64, 2, 2, NFC / 32);
-        case 6: return launch_bt<BT2(Fc4DgradWT, 64, 64, 2, 2, 2)>(a, s);
-        case 7: return launch_bt<BT2(Fc4DgradWT, 32, 128, 1, 4, 2)>(a, s);
-#endif
         default: break;
       }
       break;
@@ -124,36 +79,6 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
   return hipErrorInvalidValue;
 }
 
-#ifdef SDQN_EXPERIMENTS
-// the built-in block shapes on packed-bf16 MFMA through exact three-way splits of both operands (gemm_engine_bt.h: X = 9 / 6 partial products):
-// fp32-class results, measured SLOWER than fp32 MFMA while the split runs per wave at fragment-read time (VALU-bound) — tools/exp/README.md
-template <int X>
-static hipError_t launch_single_x(int id, const StepArgs& a, hipStream_t s) {
-  switch (id) {
-    case K_CONV2_FWD: return launch_bt<BTX(Conv2FwdWT, 64, 64, 2, 2, 2, X)>(a, s);
-    case K_CONV3_FWD: return launch_bt<BTX(Conv3FwdWT, 64, 64, 2, 2, 2, X)>(a, s);
-    case K_FC4_FWD: return launch_bt<BTX(Fc4FwdWT, 64, 64, 2, 2, 2, X)>(a, s);
-    case K_FC4_DGRAD: return launch_bt<BTX(Fc4DgradWT, 64, 64, 2, 2, 2, X)>(a, s);
-    case K_FC4_WGRAD: return launch_bt<BTX(Fc4WgradBT, 64, 64, 2, 2, 2, X)>(a, s);
-    case K_CONV3_DGRAD: return launch_bt<BTX(Conv3DgradWT, 64, 64, 2, 2, 2, X)>(a, s);
-    case K_CONV3_WGRAD: return launch_bt<BTX(Conv3WgradWT, 64, 64, 2, 2, 2, X)>(a, s);
-    case K_CONV2_DGRAD: return launch_bt<BTX(Conv2DgradWT, 128, 32, 4, 1, 2, X)>(a, s);
-    case K_CONV2_WGRAD: return launch_bt<BTX(Conv2WgradWT, 64, 64, 2, 2, 2, X)>(a, s);
-    default: break;
-  }
-  return hipErrorInvalidValue;
-}
-template <int X>
-static hipError_t launch_fused_x(int id, const StepArgs& a, hipStream_t s) {
-  const bool f4 = a.f4w_count > 0;
-  if (id == K_BWD3)
-    return launch_bt_multi<BTX(Conv3DgradWT, 64, 64, 2, 2, 2, X), BTX(Conv3WgradWT, 64, 64, 2, 2, 2, X), BTX(Fc4WgradBT, 64, 64, 2, 2, 2, X)>(a, true, true, f4, s);
-  if (id == K_BWD2 && !f4)
-    return launch_bt_multi<NOP, BTX(Conv2WgradWT, 64, 64, 2, 2, 2, X), BTX(Conv2DgradWT, 128, 32, 4, 1, 2, X)>(a, false, true, true, s);
-  return hipErrorInvalidValue;
-}
-
-#endif  // SDQN_EXPERIMENTS
 
 static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t s) {
   const bool f4 = a.f4w_count > 0;         // (B > 32: all of fc4_wgrad rides in bwd3 or none of it, sdqn_api.hip)
@@ -166,13 +91,6 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
       case 3: return launch_bt_multi<F4W, C3D, C3W>(a, f4, true, true, s);
       case 4: return launch_bt_multi<BT(Conv3DgradWT, 128, 64, 2, 2, 2), BT(Conv3WgradWT, 128, 64, 2, 2, 2), BT(Fc4WgradBT, 64, 128, 2, 2, 2)>(a, true, true, f4, s);
       case 7: return launch_bt_multi<C3D, BT(Conv3WgradWT, 64, 64, 2, 2, 2), BT(Fc4WgradBT, 64, 64, 2, 2, 2)>(a, true, true, f4, s);     // guarded ring loads (until round 4's second session: 39.2 vs 38.1 us)
-#ifdef SDQN_EXPERIMENTS
-      case 10: return launch_pp_multi<PP(Conv3DgradWT, 64, 64, 2, 2, 2), PP(Conv3WgradWT, 64, 64, 2, 2, 2), PP(Fc4WgradBT, 64, 64, 2, 2, 2)>(a, true, true, f4, s);
-      case 11: return launch_pp_multi<PP(Conv3DgradWT, 64, 64, 2, 2, 3), PP(Conv3WgradWT, 64, 64, 2, 2, 3), PP(Fc4WgradBT, 64, 64, 2, 2, 3)>(a, true, true, f4, s);
-      case 13: return launch_gl_multi<GLN(Conv3DgradWT, 64, 64, 2, 2, CRS3 / 32), GL(Conv3WgradWT, 64, 64, 2, 2), GL(Fc4WgradBT, 64, 64, 2, 2)>(a, true, true, f4, s);
-      case 5: return launch_bt_multi<BT2(Conv3DgradWT, 64, 64, 2, 2, 2), BT2(Conv3WgradWT, 64, 64, 2, 2, 2), BT2(Fc4WgradBT, 64, 64, 2, 2, 2)>(a, true, true, f4, s);
-      case 6: return launch_bt_multi<BT2(Conv3DgradWT, 64, 64, 2, 2, 1), BT2(Conv3WgradWT, 64, 64, 2, 2, 1), BT2(Fc4WgradBT, 64, 64, 2, 2, 1)>(a, true, true, f4, s);
-#endif
       default: break;
     }
   } else if (id == K_BWD2 && !f4) {
@@ -183,13 +101,6 @@ static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t 
       case 3: return launch_bt_multi<NOP, C2D, C2W>(a, false, true, true, s);
       case 4: return launch_bt_multi<NOP, BT(Conv2DgradWT, 128, 32, 4, 1, 2), BT(Conv2WgradWT, 128, 64, 2, 2, 2)>(a, false, true, true, s);
       case 7: return launch_bt_multi<NOP, BT(Conv2WgradWT, 64, 64, 2, 2, 2), C2D>(a, false, true, true, s);      // guarded ring loads
-#ifdef SDQN_EXPERIMENTS
-      case 10: return launch_pp_multi<PP(NoProblem, 64, 64, 2, 2, 2), PP(Conv2WgradWT, 64, 64, 2, 2, 2), PP(Conv2DgradWT, 128, 32, 4, 1, 2)>(a, false, true, true, s);
-      case 11: return launch_pp_multi<PP(NoProblem, 64, 64, 2, 2, 2), PP(Conv2WgradWT, 64, 64, 2, 2, 3), PP(Conv2DgradWT, 128, 32, 4, 1, 3)>(a, false, true, true, s);
-      case 13: return launch_gl_multi<GL(NoProblem, 64, 64, 2, 2), GL(Conv2WgradWT, 64, 64, 2, 2), GLN(Conv2DgradWT, 128, 32, 4, 1, 8)>(a, false, true, true, s);
-      case 5: return launch_bt_multi<NOP, BT2(Conv2WgradWT, 64, 64, 2, 2, 2), BT2(Conv2DgradWT, 128, 32, 4, 1, 2)>(a, false, true, true, s);
-      case 6: return launch_bt_multi<NOP, BT2(Conv2WgradWT, 64, 64, 2, 2, 1), BT2(Conv2DgradWT, 128, 32, 4, 1, 1)>(a, false, true, true, s);
-#endif
       default: break;
     }
   }
@@ -627,47 +538,7 @@ static hipError_t launch_c1w_bt2(const StepArgs& a, hipStream_t s) {
 // ---- plane mode (StepArgs::xp = 9 / 6): conv2 / conv3 forward, the three dgrads on packed-bf16 MFMA with weight planes ------------------
 // EXPERIMENTS BUILD ONLY.  Exact (9 partial products) it ran the B = 256 step in 262.7 us against 224.5 on fp32 MFMA, with 6 products in
 // 244.9 (one box, alternating runs; tools/exp/README.md): the launches are latency- not MFMA-bound there and the split costs VALU time.
-#ifdef SDQN_EXPERIMENTS
-template <int NP>
-static hipError_t launch_xp(int id, const StepArgs& a, hipStream_t s) {
-  typedef BtCfgXP<XPF<Conv2FwdWT, OFF2, CRS2>, 64, 64, 2, 2, 2, NP> XC2F;
-  typedef BtCfgXP<XPF<Conv3FwdWT, OFF3, CRS3>, 64, 64, 2, 2, 2, NP> XC3F;
-  typedef BtCfgXP<XPD<Fc4DgradWT, OFF4>, 64, 64, 2, 2, 2, NP> XF4D;
-  typedef BtCfgXP<XPD<Conv3DgradWT, OFF3>, 64, 64, 2, 2, 2, NP> XC3D;
-  typedef BtCfgXP<XPD<Conv2DgradWT, OFF2>, 128, 32, 4, 1, 2, NP> XC2D;
-  const bool f4 = a.f4w_count > 0;
-  switch (id) {
-    case K_CONV2_FWD: return launch_bt_xp<XC2F>(a, s);
-    case K_CONV3_FWD: return launch_bt_xp<XC3F>(a, s);
-    case K_FC4_DGRAD: return launch_bt_xp<XF4D>(a, s);
-    case K_CONV3_DGRAD: return launch_bt_xp<XC3D>(a, s);
-    case K_CONV2_DGRAD: return launch_bt_xp<XC2D>(a, s);
-    case K_BWD3: return launch_bt_multi<XC3D, C3W, F4W>(a, true, true, f4, s);          // the weight gradients stay on fp32 MFMA (both operands x-contiguous)
-    case K_BWD2: if (!f4) return launch_bt_multi<NOP, C2W, XC2D>(a, false, true, true, s); break;
-    default: break;
-  }
-  return hipErrorInvalidValue;
-}
-
-__global__ void __launch_bounds__(256) refresh_planes_kernel(const float* theta, unsigned short* wpm, unsigned short* wpt) {
-  for (int64_t e = OFF2 + (int64_t)blockIdx.x * 256 + threadIdx.x; e < OFF5; e += (int64_t)gridDim.x * 256) {
-    uint16_t hi, mid, lo; split_bf16x3(theta[e], hi, mid, lo);
-    if (wpm) { wpm[e] = hi; wpm[XP_PLANE + e] = mid; wpm[2 * XP_PLANE + e] = lo; }
-    if (e < OFF4) {
-      const int L = e < OFF3 ? 1 : 2, off = L == 1 ? OFF2 : OFF3, K = L == 1 ? CRS2 : CRS3;
-      const int64_t r = e - off; const int k = (int)(r / 64), n = (int)(r - (int64_t)k * 64);
-      const int64_t t = off + (int64_t)n * K + k;
-      wpt[t] = hi; wpt[XP_PLANE + t] = mid; wpt[2 * XP_PLANE + t] = lo;
-    }
-  }
-}
-hipError_t launch_refresh_planes(const float* theta, unsigned short* wpm, unsigned short* wpt, hipStream_t s) {
-  hipLaunchKernelGGL(refresh_planes_kernel, dim3(1024), dim3(256), 0, s, theta, wpm, wpt);
-  return hipGetLastError();
-}
-#else
 hipError_t launch_refresh_planes(const float*, unsigned short*, unsigned short*, hipStream_t) { return hipErrorInvalidValue; }   // (never called: no planes)
-#endif  // SDQN_EXPERIMENTS
 
 // ---- float16 mode, B >= 128: forward / dgrad launches on the half block-tile routine (menu per kernel id like the fp32 one) ---------------
 #define BTH(P, BM, BN, WM, WN, D) BtCfgH<P, BM, BN, WM, WN, D>
@@ -692,7 +563,7 @@ static hipError_t launch_single_h(int id, int menu, const StepArgs& a, hipStream
 // (the loaders mask any k >= kend), so the routine takes every B >= 128; what it does not take: fp16 mode, batch-norm (raw outputs)
 hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = false;
-  if (a.B < 128 || a.bn || t.hoist || t.order) return hipSuccess;
+  if (a.B < 128 || a.bn) return hipSuccess;
   if (id < 0 || id >= K_COUNT || t.bt[id] < 0) return hipSuccess;
   if (a.h16) {                             // float16 mode: forward launches, dgrads, and the weight gradients behind them
     if (id == K_WGRADS && a.h16 == 2) {    // fc4_wgrad (+ fused RMSProp) || conv3_wgrad || conv2_wgrad: k-major half panels, transpose reads
@@ -703,10 +574,9 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
       *handled = true;
       if (t.bt[id] == 1) return launch_bt_multi<BtCfgHW<Fc4WgradH, 64, 64, 2, 2, 4>, BtCfgHW<Conv3WgradH, 64, 64, 2, 2, 4>, BtCfgHW<Conv2WgradH, 64, 64, 2, 2, 4>>(a, true, true, true, s);
       if (t.bt[id] == 2) return launch_bt_multi<BtCfgHW<Fc4WgradH, 64, 64, 2, 2, 3>, BtCfgHW<Conv3WgradH, 64, 64, 2, 2, 3>, BtCfgHW<Conv2WgradH, 64, 64, 2, 2, 3>>(a, true, true, true, s);
-      const int m = t.bt[id];             // (menu 6 / 7 / 8: ONE of the three problems only — timing experiments, incomplete gradients)
-      return launch_bt_multi<HF4W, HC3W, HC2W>(a, m == 0 || m == 6, m == 0 || m == 7, m == 0 || m == 8, s);
+      return launch_bt_multi<HF4W, HC3W, HC2W>(a, true, true, true, s);
     }
-    if (id == K_CONV1_FWD && t.bt[id] == 0 && t.nw_override[id] == 0 && t.rb[id] == 0 && a.idx_t == nullptr) {   // one workgroup per (net, sample)
+    if (id == K_CONV1_FWD && t.bt[id] == 0 && t.nw_override[id] == 0 && a.idx_t == nullptr) {   // one workgroup per (net, sample)
       *handled = true;
       return launch_conv1_h(a, s);
     }
@@ -718,7 +588,7 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
       *handled = true;
       return e1;
     }
-    if (id >= 12 || t.nw_override[id] > 0 || t.rb[id] > 0) return hipSuccess;
+    if (id >= 12 || t.nw_override[id] > 0) return hipSuccess;
     const hipError_t eh = launch_single_h(id, t.bt[id], a, s);
     if (eh == hipErrorInvalidValue) return hipSuccess;
     *handled = true;
@@ -728,28 +598,14 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
   // slabs and unconditional ring loads): block-tile only on request (menu entry > 0).  fc4_dgrad (196 blocks) moved here in round 4's second
   // session: 12.4 us against 14.4 once its gating activations are fetched before the K loop (17.0 with the dependent loads in the epilogue)
   if (id == K_FC4_FWD && t.bt[id] == 0) return hipSuccess;
-  if (id < 12 && (t.nw_override[id] > 0 || t.rb[id] > 0)) return hipSuccess;      // explicit latency-engine tuning hooks win
+  if (id < 12 && t.nw_override[id] > 0) return hipSuccess;      // explicit latency-engine tuning hooks win
   hipError_t e = hipErrorInvalidValue;
-#ifdef SDQN_EXPERIMENTS
-  if (a.xp && a.wpm && a.wpt[0] && t.bt[id] == 0) {        // plane mode: the stages whose B operand is a weight matrix
-    e = a.xp == 6 ? launch_xp<6>(id, a, s) : launch_xp<9>(id, a, s);
-    if (e != hipErrorInvalidValue) { *handled = true; return e; }
-  }
-#endif
   if ((id == K_BWD1 && a.f4w_count == 0) || id == K_CONV1_WGRAD) {             // conv1's weight gradient: bytes x three bf16 planes of delta1
     e = t.bt[id] == 1 ? launch_c1w_bt(a, s) : launch_c1w_bt2(a, s);      // (menu 1: the first form, fragments from single-byte / two-byte LDS reads)
     if (e == hipErrorInvalidValue) return hipSuccess;
     *handled = true;
     return e;
   }
-#ifdef SDQN_EXPERIMENTS
-  const int x = t.btx[id];
-  if (x == 9 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<9>(id, a, s) : launch_single_x<9>(id, a, s);
-  else if (x == 6 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<6>(id, a, s) : launch_single_x<6>(id, a, s);
-  else if (x == 19 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<19>(id, a, s) : launch_single_x<19>(id, a, s);
-  else if (x == 16 && t.bt[id] == 0) e = (id == K_BWD3 || id == K_BWD2) ? launch_fused_x<16>(id, a, s) : launch_single_x<16>(id, a, s);
-  else
-#endif
   if (id == K_BWD3 || id == K_BWD2) e = launch_fused(id, t.bt[id], a, s);
   else if (id == K_CONV2_FWD || id == K_CONV3_FWD || id == K_FC4_FWD || id == K_FC4_DGRAD || id == K_FC4_WGRAD || id == K_CONV3_DGRAD ||
            id == K_CONV3_WGRAD || id == K_CONV2_DGRAD || id == K_CONV2_WGRAD) e = launch_single(id, t.bt[id], a, s);

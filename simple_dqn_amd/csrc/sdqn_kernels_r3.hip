@@ -528,28 +528,6 @@ __global__ void __launch_bounds__(640) conv1_bf16_rows_kernel(const Conv1Args c)
   if (nitems > 0) flush(nitems - 1);
 }
 
-#ifdef SDQN_EXPERIMENTS      // (measured slower than the update as a launch of its own: not in the product build)
-// ---- update(i) + conv1_fwd(i + 1) in ONE launch (train_many, steps after the first of a call; B <= 32 ring path) ------------
-// The optimizer pass is the last launch of a step and conv1 the first of the next: nothing between them but a kernel boundary.
-// Block order: [update blocks (W1 first) | target-net conv1 | online conv1].  Only the online conv1 workgroups depend on the update,
-// and only on W1 (8 192 of the 1.7 M parameters); the target-net half runs beside the update.  One launch, one boundary less, and
-// the 5 us latency chain of the update overlaps the target half of conv1.
-__global__ void __launch_bounds__(256) upd_conv1_kernel(const UpdateArgs u, const Conv1Args c, const IdxIn ix, const FusedW1 fw, const int n_upd) {
-  __shared__ __attribute__((aligned(16))) unsigned short sw[3 * K1 * W1P_PITCH];
-  static_assert(sizeof(UpdateArgs) % 8 == 0 && sizeof(Conv1Args) % 8 == 0, "argument blocks are 8-byte aligned: the index block's offset is their sum");
-  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
-  const int64_t my_idx = *reinterpret_cast<const int64_t*>(ka + sizeof(UpdateArgs) + sizeof(Conv1Args) + 8 * (threadIdx.x & 31));
-  (void)ix;
-  if ((int)blockIdx.x < n_upd) {
-    float4 (*part)[32] = reinterpret_cast<float4 (*)[32]>(sw);                               // 4 KB
-    float* cost_sh = reinterpret_cast<float*>(sw) + 1024;                                    // 16 KB behind it
-    update_body<false, true>(u, (int)blockIdx.x, n_upd, part, cost_sh);
-    return;
-  }
-  conv1_bf16_body<true, true>(c, my_idx, (int)blockIdx.x - n_upd, sw, fw);
-}
-
-#endif  // SDQN_EXPERIMENTS
 
 // ---- conv1 weight gradient on packed-bf16 MFMA ---------------------------------------------------------------------------
 // gW1[(c,r,s)][map] = sum over (sample, y, x) of byte(c, 4y + r, 4x + s) / 255 * delta1(sample, y, x, map): the bytes are exact in
@@ -675,19 +653,6 @@ __global__ void __launch_bounds__(1024) conv1_wgrad_bf16_kernel(const C1wArgs c,
   }
 }
 
-#ifdef SDQN_EXPERIMENTS
-hipError_t launch_upd_conv1(const UpdateArgs& u, const StepArgs& a, const int64_t* host_idx, unsigned* ctr, unsigned target, unsigned* timeout, int xcd, hipStream_t s) {
-  const int tiles = (a.B * PIX1 + 31) / 32, wgs = (tiles + 3) / 4;
-  Conv1Args c; c.src = a.src; c.a1 = a.a1; c.w1p[0] = a.w1p[0]; c.w1p[1] = a.w1p[1]; c.idx = a.idx;
-  c.B = a.B; c.nz = 2; c.from_ring = 1; c.tiles_per_net = tiles; c.wgs_per_net = wgs; c.tpw = 1; c.xcd = xcd; c.pad_ = 0;
-  IdxIn ix; memset(ix.v, 0, sizeof ix.v); memcpy(ix.v, host_idx, (size_t)a.B * sizeof(int64_t));
-  FusedW1 fw; fw.theta = a.theta[0]; fw.ctr = ctr; fw.target = target; fw.timeout = timeout;
-  const int n_upd = CONV_BLOCKS + u.A * FC5_BLOCKS_PER_ACTION + 2;                          // launch_update's grid with the fc4 part fused into bwd3
-  SDQN_LAUNCH(upd_conv1_kernel, dim3(n_upd + 2 * wgs), dim3(256), 0, s, u, c, ix, fw, n_upd);
-  return hipGetLastError();
-}
-
-#endif  // SDQN_EXPERIMENTS
 
 // the three planes of one net's W1 from its fp32 weights (after set_weights / replica broadcast; the update kernel writes them itself)
 __global__ void __launch_bounds__(256) w1_planes_kernel(const float* theta, unsigned short* w1p) {
@@ -702,183 +667,6 @@ hipError_t launch_w1_planes(const float* theta, unsigned short* w1p, hipStream_t
   return hipGetLastError();
 }
 
-#ifdef SDQN_EXPERIMENTS      // (measured slower than head and fc4_dgrad as two launches: not in the product build)
-// ---- head + fc4_dgrad in ONE launch (B <= 32, A <= 8, fp32) -------------------------------------------------------------------
-// fc4_dgrad is 98 tiles that each stream a 64 KB panel of W4 — which depends on nothing the head computes — before they need
-// delta4.  As two launches the panel fetch starts only after the head has finished AND a kernel boundary has passed.  Here the
-// B head workgroups and the 98 dgrad workgroups start together (130 <= 256 CUs: every workgroup has its own CU, so the launch's
-// 135 KB LDS / 1024-thread footprint costs nobody residency — the reason the two earlier in-launch hand-offs lost):
-//   dgrad wave : issues its W4 loads (one 32-deep chunk per wave), then the workgroup waits for the head counter,
-//                then loads its delta4 rows with sc1 loads, stages both panels, 16 MFMAs, fixed-order combine, epilogue
-//   head block : the head kernel's arithmetic unchanged; delta4 leaves with write-through stores, then one arrival per block
-// Same k-slot map, same chunk per wave and same combine order as gemm_tile<Staged<Fc4Dgrad>, 16>: bit-identical values.
-struct HeadHandoff { unsigned* ctr; unsigned target; unsigned* timeout; };
-
-template <int AMAX>
-__global__ void __launch_bounds__(1024) head_f4d_kernel(const StepArgs a, const HeadArgs h, const HeadHandoff w) {
-  constexpr int WAVE_LDS = 2 * PANEL;
-  __shared__ float smem[16 * WAVE_LDS];                    // 135 KB: the dgrad tile's panels; the head blocks use the first 2 A x 512 floats
-  __shared__ float sh_q[2][AMAX];
-  __shared__ float sh_dc;
-  __shared__ int sh_act;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if ((int)blockIdx.x >= a.B) {
-    // ---------------- fc4_dgrad tile by = blockIdx.x - B: rows 0..B-1 of delta3, columns [32 by, 32 by + 32) of (pix, f)
-    const int n0 = ((int)blockIdx.x - a.B) * 32, M = a.B, N = NIN4;
-    const int hb = lane >> 5;
-    const int kc = wave * 32;                                // NFC = 512 = 16 waves x one 32-deep chunk
-    int srow[4], scol[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = (lane >> 3) + 8 * j; srow[j] = (m < M ? m : M - 1) * NFC;
-      const int n = n0 + (lane >> 3) + 8 * j; scol[j] = (n < N ? n : N - 1) * NFC;
-    }
-    const int kq = kc + 4 * (lane & 7);
-    f4 prb[4], pra[4];
-    const float* __restrict__ w4 = a.theta[0] + OFF4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) prb[j] = ld4(w4 + kq + scol[j]);      // the W4 panel: independent of the head
-    if (tid == 0) {
-      int spins = 0;
-      while ((int)(__hip_atomic_load(w.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - w.target) < 0) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > 2000000) { __hip_atomic_store(w.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {                            // delta4 was written by other workgroups of THIS launch: sc1 loads (past this XCD's L2)
-      const float* p = a.d4 + srow[j] + kq;
-      pra[j].x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      pra[j].y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      pra[j].z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      pra[j].w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    float* pan_a = smem + wave * WAVE_LDS;
-    float* pan_b = pan_a + PANEL;
-    { float* d = pan_a + (4 * (lane & 7)) * 33 + (lane >> 3);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { d[8 * j] = pra[j].x; d[33 + 8 * j] = pra[j].y; d[66 + 8 * j] = pra[j].z; d[99 + 8 * j] = pra[j].w; } }
-    { float* d = pan_b + (4 * (lane & 7)) * 33 + (lane >> 3);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { d[8 * j] = prb[j].x; d[33 + 8 * j] = prb[j].y; d[66 + 8 * j] = prb[j].z; d[99 + 8 * j] = prb[j].w; } }
-    wave_lds_sync();
-    float fa[16], fb[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) { fa[t] = pan_a[kslot(t, 0) * 33 + hb * (4 * 33) + (lane & 31)]; fb[t] = pan_b[kslot(t, 0) * 33 + hb * (4 * 33) + (lane & 31)]; }
-    wave_lds_sync();
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
-    { float* cw = smem + wave * WAVE_LDS;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) cw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[r]; }
-    __syncthreads();
-    { const int ml = tid >> 5, nl = tid & 31;
-      float v = smem[ml * 33 + nl];
-#pragma unroll
-      for (int wv = 1; wv < 16; ++wv) v += smem[wv * WAVE_LDS + ml * 33 + nl];
-      if (ml < M && n0 + nl < N) Fc4DgradWT::store(a, 0, 0, ml, n0 + nl, v); }
-    return;
-  }
-  // ---------------- head of sample n = blockIdx.x: threads 0..511 own one hidden unit each, 512..1023 only keep the barriers company
-  const int n = blockIdx.x, j = tid & 511;
-  const bool on = tid < 512;
-  float (*prod)[NFC] = reinterpret_cast<float (*)[NFC]>(smem);            // [2 A][512]
-  const int A = a.A;
-  const float* __restrict__ th0 = a.theta[0];
-  const float* __restrict__ th1 = a.theta[1];
-  const float* __restrict__ slab = a.slab4;
-  const int64_t sstride = (int64_t)2 * a.B * NFC;
-  float t[2][7];
-  float a4v[2] = {0.0f, 0.0f};
-  float w5[2][AMAX];
-  int m_act = 0, m_term = 0; int64_t m_rew = 0;
-  if (on) {
-#pragma unroll
-    for (int z = 0; z < 2; ++z)
-#pragma unroll
-      for (int s = 0; s < 7; ++s) t[z][s] = slab[s * sstride + ((int64_t)z * a.B + n) * NFC + j];
-#pragma unroll
-    for (int act = 0; act < AMAX; ++act) {
-      const int ac = act < A ? act : A - 1;
-      w5[0][act] = th0[OFF5 + ac * NFC + j];
-      w5[1][act] = th1[OFF5 + ac * NFC + j];
-    }
-    if (j == 0) { m_act = h.st_actions[n]; m_rew = h.st_rewards[n]; m_term = h.st_terminals[n]; }
-    m_act = m_act < A ? m_act : A - 1;
-#pragma unroll
-    for (int z = 0; z < 2; ++z) { float v = 0.0f;
-#pragma unroll
-      for (int s = 0; s < 7; ++s) v += t[z][s];                                                   // fixed order
-      a4v[z] = v; }
-#pragma unroll
-    for (int z = 0; z < 2; ++z) {
-      const float v = fmaxf(a4v[z], 0.0f);
-      a4v[z] = v;
-      a.a4[((int64_t)z * a.B + n) * NFC + j] = v;
-#pragma unroll
-      for (int act = 0; act < AMAX; ++act)
-        if (act < A) prod[z * A + act][j] = w5[z][act] * v;
-    }
-  }
-  __syncthreads();
-  if (on) {
-    for (int row = wave; row < 2 * A; row += 8) {
-      float p = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) p += prod[row][lane + 64 * k];                                  // fixed order
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
-      if (lane == 0) {
-        const int z = row / A, act = row - z * A;
-        sh_q[z][act] = p;
-        h.q[((int64_t)z * a.B + n) * A + act] = p;
-      }
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const int act = m_act, term = m_term; const int64_t rew = m_rew;
-    float m = sh_q[1][0];
-    for (int k = 1; k < A; ++k) m = fmaxf(m, sh_q[1][k]);
-    double rr = (double)rew;
-    rr = rr < h.min_reward ? h.min_reward : (rr > h.max_reward ? h.max_reward : rr);
-    const double y = term ? rr : rr + h.discount * (double)m;
-    const float d = sh_q[0][act] - (float)y;
-    h.cost_terms[n] = 0.5f * (d * d);
-    float dc = d;
-    if (h.clip_error != 0.0f) dc = fminf(fmaxf(d, -h.clip_error), h.clip_error);
-    h.maxq[n] = m;
-    sh_dc = dc; sh_act = act;
-  }
-  __syncthreads();
-  if (on) {
-    const float dc = sh_dc; const int act = sh_act;
-    float wa = 0.0f;
-#pragma unroll
-    for (int k = 0; k < AMAX; ++k) wa = (k == act) ? w5[0][k] : wa;
-    const float d4v = a4v[0] > 0.0f ? wa * dc : 0.0f;
-    wt_store(&a.d4[(int64_t)n * NFC + j], d4v);                                                   // write-through: read by the dgrad tiles of this launch
-    if (j < A) h.dq[(int64_t)n * A + j] = (j == act) ? dc : 0.0f;
-  }
-  __builtin_amdgcn_s_waitcnt(0);                                                                  // this wave's delta4 stores are out (vmcnt 0)
-  __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(w.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // one arrival per head block
-}
-
-hipError_t launch_head_f4d(const StepArgs& a, const HeadArgs& h, unsigned* ctr, unsigned target, unsigned* timeout, hipStream_t s) {
-  HeadHandoff w; w.ctr = ctr; w.target = target; w.timeout = timeout;
-  const dim3 grid(a.B + NIN4 / 32);
-  if (a.A <= 4) SDQN_LAUNCH(head_f4d_kernel<4>, grid, dim3(1024), 0, s, a, h, w);
-  else SDQN_LAUNCH(head_f4d_kernel<8>, grid, dim3(1024), 0, s, a, h, w);
-  return hipGetLastError();
-}
-
-#endif  // SDQN_EXPERIMENTS
 
 // ---- float16 mode: the same write-through epilogues (half outputs leave with 2-byte sc1 stores), every launch but bwd3 -----------------------------------
 __device__ __forceinline__ void wt_store_h(half_t* p, half_t v) {
@@ -948,10 +736,6 @@ struct Conv1WgradHWWT : Conv1WgradHW {
 };
 hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = true;
-#ifdef SDQN_EXPERIMENTS
-  if (id == K_FC4_DGRAD && (t.r3 & 1) && a.B <= 32 && !a.h16 && a.f4w_count > 0 && a.f4d_flags)
-    return launch_multi<1024, Staged<Fc4DgradSig>, 16, Fc4WgradWait, 1, NoProblem, 2>(a, true, false, s);
-#endif
   if (id == K_CONV1_FWD && (t.r3 & 4) && !a.h16 && !a.bn && a.w1p[0] && a.w1p[a.nz > 1 ? 1 : 0]) {
     const int tiles = (a.B * PIX1 + 31) / 32, tpw = a.B >= 128 ? 4 : 1, wgs = (tiles + 4 * tpw - 1) / (4 * tpw);
     Conv1Args c; c.src = a.src; c.a1 = a.a1; c.w1p[0] = a.w1p[0]; c.w1p[1] = a.w1p[1]; c.idx = a.idx;
@@ -994,7 +778,7 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
   // conv2 / conv3 forward with ONE workgroup per 32 x 64 output block (N = 64 = two 32-wide tiles): the register-blocked routine with
   // 1 x 2 accumulators per wave loads the gathered A rows once for both tiles (the gather is the expensive operand: 64 cache lines per
   // load instruction).  Same k order per accumulator as the unblocked tile: bit-identical.
-  if (a.B <= 32 && a.h16 == 2 && !a.bn && t.wt && !t.order && !(id >= 0 && id < 12 && t.nw_override[id] > 0)) {      // float16 mode, default launch forms
+  if (a.B <= 32 && a.h16 == 2 && !a.bn && t.wt && !(id >= 0 && id < 12 && t.nw_override[id] > 0)) {      // float16 mode, default launch forms
     if (id == K_CONV1_FWD && (t.wt & 128)) return launch_gemm<Conv1FwdHWT, 8>(a, s);
     if (id == K_CONV2_FWD && (t.wt & 1)) return launch_gemm<Conv2FwdHWT, 16>(a, s);
     if (id == K_CONV3_FWD && (t.wt & 2)) return launch_gemm<Conv3FwdHWT, 16>(a, s);
@@ -1004,14 +788,14 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     if (id == K_BWD2 && (t.wt & 32)) return launch_multi<512, NoProblem, 2, Conv2DgradHWT, 8, Conv2WgradHWWT, 8>(a, true, true, s);
     if (id == K_BWD1 && (t.wt & 64)) return launch_multi<1024, NoProblem, 2, Conv1WgradHWWT, 16, NoProblem, 2>(a, true, false, s);
   }
-  if (a.B <= 32 && !a.h16 && !a.bn && t.wt && !t.hoist && !t.order && !(id >= 0 && id < 12 && t.nw_override[id] > 0)) {       // write-through epilogues: the default launch forms with the *WT problems
+  if (a.B <= 32 && !a.h16 && !a.bn && t.wt && !(id >= 0 && id < 12 && t.nw_override[id] > 0)) {       // write-through epilogues: the default launch forms with the *WT problems
     if (id == K_CONV2_FWD && (t.wt & 1) && !(t.r3 & 16)) return launch_gemm<Conv2FwdWT, 16>(a, s);
     if (id == K_FC4_FWD && (t.wt & 4)) return launch_gemm<Staged<Fc4FwdWT>, 14>(a, s);
     if (id == K_FC4_DGRAD && (t.wt & 8) && !(t.r3 & 1)) return launch_gemm<Staged<Fc4DgradWT>, 16>(a, s);
     if (id == K_BWD3 && (t.wt & 16) && a.f4w_count > 0) return launch_multi<512, Staged<Conv3DgradWT>, 8, Conv3WgradWT, 8, Fc4WgradWT, 1>(a, true, true, s);
     if (id == K_BWD2 && (t.wt & 32) && a.f4w_count == 0) return launch_multi<512, NoProblem, 2, Conv2DgradWT, 8, Conv2WgradWT, 8>(a, true, true, s);
   }
-  if (a.B >= 128 && !a.h16 && !a.bn && t.wt && !t.hoist && !t.order && !(id >= 0 && id < 12 && (t.nw_override[id] > 0 || t.rb[id] > 0))) {
+  if (a.B >= 128 && !a.h16 && !a.bn && t.wt && !(id >= 0 && id < 12 && t.nw_override[id] > 0)) {
     // throughput regime: the same launch forms as sdqn_kernels.hip, write-through epilogues
     if (id == K_CONV2_FWD && (t.wt & 1)) return launch_gemm<Staged<Conv2FwdWT>, 8>(a, s);
     if (id == K_CONV3_FWD && (t.wt & 2)) return launch_gemm<Staged<Conv3FwdWT>, 8>(a, s);
@@ -1021,10 +805,6 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     if (id == K_BWD2 && (t.wt & 32) && a.f4w_count == 0) return launch_multi<512, NoProblem, 2, Staged<Conv2DgradWT>, 8, Conv2WgradWT, 8>(a, true, true, s);
     if (id == K_BWD1 && (t.wt & 64) && a.f4w_count == 0 && !(t.r3 & 8)) return launch_multi<1024, NoProblem, 2, Conv1WgradWT, 16, NoProblem, 2>(a, true, false, s);
   }
-#ifdef SDQN_EXPERIMENTS
-  if (id == K_CONV2_FWD && (t.r3 & 16) && a.B < 128 && !a.h16 && !a.bn) return launch_gemm<RB<Conv2Fwd, 1, 2>, 16>(a, s);
-  if (id == K_CONV3_FWD && (t.r3 & 32) && a.B < 128 && !a.h16 && !a.bn) return launch_gemm<RB<Conv3Fwd, 1, 2>, 16>(a, s);
-#endif
   if (id == K_CONV3_FWD && (t.r3 & 2) && a.B < 128 && !a.h16 && !a.bn) {
     static_assert(CRS3 == 16 * 36, "conv3's K is 16 chunks of 36");
     const dim3 grid((Conv3Fwd::M(a) + 31) / 32, (Conv3Fwd::N(a) + 31) / 32, Conv3Fwd::nbz(a));

@@ -42,25 +42,6 @@ __device__ inline void opt_apply4(float* __restrict__ theta, float* __restrict__
       u.w1p[(n + i) * CRS1 + k] = hi; u.w1p[W1P_PLANE + (n + i) * CRS1 + k] = mid; u.w1p[2 * W1P_PLANE + (n + i) * CRS1 + k] = lo;
     }
   }
-#ifdef SDQN_EXPERIMENTS
-  if (u.wpm && e >= OFF2 && e < OFF5) {           // plane mode (B >= 128): the bf16 planes of conv2 / conv3 / fc4 follow these 4 weights
-    uint16_t pl[3][4];
-    split_bf16x3(w.x, pl[0][0], pl[1][0], pl[2][0]); split_bf16x3(w.y, pl[0][1], pl[1][1], pl[2][1]);
-    split_bf16x3(w.z, pl[0][2], pl[1][2], pl[2][2]); split_bf16x3(w.w, pl[0][3], pl[1][3], pl[2][3]);
-#pragma unroll
-    for (int q = 0; q < 3; ++q)                   // master layout: 4 consecutive elements = one 8-byte store per plane
-      *reinterpret_cast<uint2*>(u.wpm + (int64_t)q * XP_PLANE + e) = make_uint2((uint32_t)pl[q][0] | ((uint32_t)pl[q][1] << 16), (uint32_t)pl[q][2] | ((uint32_t)pl[q][3] << 16));
-    if (e < OFF4) {                               // conv2 / conv3 also transposed: [n][K]
-      const int L = e < OFF3 ? 1 : 2;
-      const int off = L == 1 ? OFF2 : OFF3, K = L == 1 ? CRS2 : CRS3, N = 64;
-      const int64_t r = e - off; const int k = (int)(r / N), n = (int)(r - (int64_t)k * N);
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) u.wpt[(int64_t)q * XP_PLANE + off + (int64_t)(n + i) * K + k] = pl[q][i];
-    }
-  }
-#endif
   if (u.wh && e < OFF5) {                         // fp16 mode: refresh both half copies of these 4 weights
     const int L = e < OFF2 ? 0 : (e < OFF3 ? 1 : (e < OFF4 ? 2 : 3));
     const int off = L == 0 ? OFF1 : (L == 1 ? OFF2 : (L == 2 ? OFF3 : OFF4));

@@ -442,6 +442,15 @@ class DeepQNetwork:
     def _dp_overlap_req(self):
         return getattr(self, "_dp_overlap_opt", -1)
 
+    STEP_STRUCTURES = ("fused", "h16_block_tile", "dp_overlap", "unfused", "generic")
+    UPDATE_FORMS = ("single", "dp_serial", "dp_overlap", "grad_only")
+
+    def step_structure(self):
+        """(launch structure of a train step, form of its optimizer pass) — DESIGN.md 12's table, as the library itself sees this handle."""
+        a, b = C.c_int(), C.c_int()
+        _lib.check(self._lib.sdqn_net_step_structure(self._h, C.byref(a), C.byref(b)))
+        return self.STEP_STRUCTURES[a.value], self.UPDATE_FORMS[b.value]
+
     def dp_form(self):
         """Which data-parallel form runs: 'none' / 'serial' / 'overlapped', the start-up probe's local result and the vote."""
         f, p, c2 = C.c_int(0), C.c_int(-1), C.c_int(0)

@@ -10,8 +10,6 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "experiments: exercises a step structure that only the experiments build contains "
-                                       "(make -C simple_dqn_amd/csrc experiments; run with SDQN_LIB_VARIANT=experiments)")
 
 
 def _device_count():
@@ -33,11 +31,6 @@ def _device_count():
 def pytest_collection_modifyitems(config, items):
     """`-m gpu` tests need a ROCm device: on a box without one they are skipped (with the reason), not failed.  On a GPU
     box nothing is skipped and an unloadable libsdqn_hip.so aborts the collection loudly (_device_count)."""
-    if os.environ.get("SDQN_LIB_VARIANT") != "experiments":
-        skip_exp = pytest.mark.skip(reason="experiments build only (SDQN_LIB_VARIANT=experiments): the product library does not contain this step structure")
-        for it in items:
-            if "experiments" in it.keywords:
-                it.add_marker(skip_exp)
     gpu_items = [it for it in items if "gpu" in it.keywords]
     if not gpu_items or _device_count() > 0:
         return

@@ -138,19 +138,6 @@ def test_deferred_cost_gives_the_same_statistics_and_random_stream(sd):
         assert np.array_equal(x, y)
 
 
-def test_chain_probe_exists_only_in_the_experiments_build(sd):
-    """sdqn_exp_chain_probe (tools/exp/chain_probe.py) is exported by both libraries (one header), but only the experiments build contains
-    the kernel: the product library refuses by name."""
-    import os
-    net = _net(sd, 4, 621)
-    t = C.c_float()
-    rc = sd.load().sdqn_exp_chain_probe(net._h, 1, 256, 2, C.byref(t), None)
-    if os.environ.get("SDQN_LIB_VARIANT") == "experiments":
-        assert rc == 0 and 2.0 < t.value < 200.0
-    else:
-        assert rc != 0 and b"experiments build" in sd.load().sdqn_last_error()
-
-
 def test_a_launch_that_delivers_nothing_falls_back_to_the_five_launch_forward(sd, capfd):
     """Every poll inside the one-launch forward is bounded, and the host's wait for the Q partials is too (2 ms, then a stream
     synchronisation): a launch that delivers nothing (injected: its work appears claimed already) makes the library fall back to the

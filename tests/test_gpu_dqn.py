@@ -7,7 +7,7 @@ import pytest
 
 from oracle.dqn_numpy import OracleDQN, xavier_weights
 from oracle.replay_numpy import ReplayOracle, synthetic_fill
-from util import experiments_build, make_args, random_minibatch
+from util import make_args, random_minibatch
 
 pytestmark = pytest.mark.gpu
 Q_TOL = 1e-4          # north_star: "within 1e-4 fp32 on Q-values"
@@ -258,24 +258,22 @@ def test_train_replay_equals_train_host(sd):
         assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
 
 
-def test_fused_and_streamed_paths_bit_identical(sd):
-    """fc4 RMSProp fused into the wgrad epilogue and the two-stream backward must give bit-identical weights
-    to the plain single-stream, materialised-gradient path."""
+def test_fused_and_unfused_paths_bit_identical(sd):
+    """fc4 RMSProp fused into the wgrad epilogue, the multi-problem backward launches and the XCD-contiguous placement must give
+    bit-identical weights to the plain one-launch-per-problem, materialised-gradient path; the step structures retired in round 5
+    are refused by name (tools/exp/experiments_r04.patch holds them)."""
     A, B = 4, 32
     nets = []
-    # last column (round 3): fc4_wgrad (+ fused RMSProp) riding in the fc4_dgrad launch behind write-after-read flags (default 1)
-    # vs inside bwd3 (round-2 launch structure)
-    for keep, two, fl, xm, f4e in ((0, 1, 0, 0, 1), (1, 1, 0, 0, 1), (0, 0, 1, 0, 1), (1, 0, 1, 1, 1), (0, 0, 1, 1, 1), (0, 0, 1, 0, 0),
-                                   (1, 0, 1, 0, 0), (0, 0, 1, 1, 0), (1, 0, 0, 0, 0), (0, 0, 0, 0, 1), (1, 0, 0, 0, 1), (0, 0, 0, 0, 0)):
-        if (two or f4e) and not experiments_build():        # two_streams / f4w_early exist in the experiments build only (round 4)
-            continue
+    for keep, fl, xm in ((0, 1, 0), (1, 1, 1), (0, 1, 1), (1, 1, 0), (1, 0, 0), (0, 0, 1), (0, 0, 0)):
         n, _ = _pair(sd, A, B, 81)
         n.set_option("keep_gradients", keep)
-        n.set_option("two_streams", two)
         n.set_option("fused_launches", fl)
         n.set_option("xcd_map", xm)              # placement may only change speed, never results
-        n.set_option("f4w_early", f4e)
         nets.append(n)
+    for name in ("two_streams", "f4w_early", "hoist", "fuse_upd", "head_f4d", "bwd_order", "bt_x", "bt_planes", "rb:1", "btx:2"):
+        nets[0].set_option(name, 0)              # (switching a retired experiment OFF is a no-op, not an error)
+        with pytest.raises(Exception, match="removed from the library"):
+            nets[0].set_option(name, 1)
     for s in range(4):
         mb = random_minibatch(B, A, 82 + s)
         for n in nets:
@@ -286,36 +284,6 @@ def test_fused_and_streamed_paths_bit_identical(sd):
             assert np.array_equal(a, b)
         for a, b in zip(n.get_weights(2), nets[-1].get_weights(2)):
             assert np.array_equal(a, b)
-
-
-@pytest.mark.experiments
-@pytest.mark.parametrize("A,B", [(4, 32), (6, 7)])
-def test_fc4_wgrad_in_dgrad_launch_bit_identical_in_the_fused_loop(sd, A, B):
-    """Round 3: K_F4D_F4W (fc4_dgrad + fc4_wgrad + RMSProp of W4 in one launch, in-place update ordered behind the dgrad's
-    reads of the same W4 rows by per-row-block flags) against the round-2 launch structure, through train_from_memory over
-    several calls (epochs continue across calls, a target sync in between), full and ragged batch: weights, RMSProp state
-    and mean cost bit-identical; the hand-off never times out (sync() would raise)."""
-    size = 3000
-    args = make_args(batch_size=B)
-    mem = sd.ReplayMemory(size, args)
-    synthetic_fill(mem, 91, num_actions=A)
-    mem.sync_mirror()
-    outs = []
-    for f4e in (1, 0):
-        n, _ = _pair(sd, A, B, 92)
-        n.set_option("f4w_early", f4e)
-        random.seed(93)
-        costs = [n.train_from_memory(mem, 5, want_cost=True)]
-        n.update_target_network()
-        costs.append(n.train_from_memory(mem, 1, want_cost=True))
-        costs.append(n.train_from_memory(mem, 17, want_cost=True))
-        n.sync()
-        outs.append((n.get_weights(0), n.get_weights(2), costs))
-    for a, b in zip(outs[0][0], outs[1][0]):
-        assert np.array_equal(a, b)
-    for a, b in zip(outs[0][1], outs[1][1]):
-        assert np.array_equal(a, b)
-    assert outs[0][2] == outs[1][2]
 
 
 @pytest.mark.parametrize("A,B", [(4, 32), (6, 7), (3, 160)])
@@ -412,37 +380,6 @@ def test_conv3_36_deep_chunks_against_the_32_deep_routine(sd):
         assert np.abs(a31 - a30).max() <= 2e-6 * np.abs(a30).max() and not np.array_equal(a31, a30)
         assert np.abs(q1 - q0).max() < 1e-5 and np.abs(q1 - o.predict(mb[0])).max() < Q_TOL
         assert np.array_equal(p1, q1[0])                                # predict_one == row 0 of the padded batch, same routine
-
-
-@pytest.mark.experiments
-@pytest.mark.parametrize("A,B", [(4, 32), (6, 7)])
-def test_update_fused_with_next_conv1_is_bit_identical(sd, A, B):
-    """Round 3: inside train_many the optimizer pass of step i and conv1 of step i + 1 are ONE launch (upd_conv1_kernel: the online
-    conv1 workgroups wait for the 64 W1 blocks of the same launch, read W1 with sc1 loads and split it into bf16 planes themselves).
-    Against the two-launch form (option fuse_upd = 0) through calls of 5, 1 and 17 steps with a target sync in between, full and
-    ragged batch: weights, optimizer state, mean costs and the next predict bit-identical; the hand-off never times out (sync raises)."""
-    size = 3000
-    args = make_args(batch_size=B)
-    mem = sd.ReplayMemory(size, args)
-    synthetic_fill(mem, 95, num_actions=A)
-    hold = random_minibatch(B, A, 96)[0]
-    outs = []
-    for fuse in (1, 0):
-        n, _ = _pair(sd, A, B, 97)
-        n.set_option("fuse_upd", fuse)
-        random.seed(98)
-        costs = [n.train_from_memory(mem, 5, want_cost=True)]
-        n.update_target_network()
-        costs.append(n.train_from_memory(mem, 1, want_cost=True))
-        costs.append(n.train_from_memory(mem, 17, want_cost=True))
-        n.sync()
-        outs.append((n.get_weights(0), n.get_weights(2), costs, n.predict(hold)))
-    for a, b in zip(outs[0][0], outs[1][0]):
-        assert np.array_equal(a, b)
-    for a, b in zip(outs[0][1], outs[1][1]):
-        assert np.array_equal(a, b)
-    assert outs[0][2] == outs[1][2] and np.array_equal(outs[0][3], outs[1][3])
-    assert not np.array_equal(outs[0][0][0], xavier_weights(A, 97)[0])                 # (W1 did move)
 
 
 def test_target_network_semantics(sd):
@@ -864,40 +801,3 @@ def test_fp16_fused_replay_path(sd):
     for i in range(5):
         assert np.array_equal(n1.get_layer(i), n2.get_layer(i)), i
 
-
-@pytest.mark.gpu
-@pytest.mark.experiments
-@pytest.mark.parametrize("A", [4, 6])
-def test_head_and_fc4_dgrad_in_one_launch_is_bit_identical(A):
-    """Option head_f4d: the B head workgroups and the 98 fc4_dgrad tiles share one launch; the tiles fetch their W4 panels while the
-    head runs and pick up delta4 through an in-launch hand-off (write-through stores, arrival counter, sc1 loads).  Same arithmetic and
-    summation order as the two launches: weights, RMSProp state, cost and Q-values bit-identical, from the ring and through the tuple API."""
-    import ctypes as C
-    import simple_dqn_amd as sd
-    from oracle.replay_numpy import synthetic_fill
-    B, size = 32, 3000
-    args = make_args(batch_size=B)
-    mem = sd.ReplayMemory(size, args)
-    synthetic_fill(mem, 4242, num_actions=A)
-    mem.sync_mirror()
-    nets, costs = [], []
-    for on in (1, 0):
-        net = sd.DeepQNetwork(A, args)
-        net.set_weights(xavier_weights(A, 4243), 0)
-        net.update_target_network()
-        net.set_option("head_f4d", on)
-        mt = (C.c_uint32 * 625)(); sd.load().sdqn_mt_seed(mt, 23)
-        c = [net.train_from_memory(mem, 1, mt_state=mt, want_cost=True) for _ in range(3)]
-        c.append(net.train_from_memory(mem, 9, mt_state=mt, want_cost=True))
-        mb = random_minibatch(B, A, 77)
-        net.train(mb)
-        net.sync()
-        nets.append(net); costs.append(c)
-    assert costs[0] == costs[1]
-    for l in range(5):
-        assert np.array_equal(nets[0].get_layer(l, 0), nets[1].get_layer(l, 0)), l
-        assert np.array_equal(nets[0].get_layer(l, 2), nets[1].get_layer(l, 2)), l
-    held = random_minibatch(B, A, 78)[0]
-    assert np.array_equal(nets[0].predict(held), nets[1].predict(held))
-    pre0, mq0 = nets[0].last_q(); pre1, mq1 = nets[1].last_q()
-    assert np.array_equal(pre0, pre1) and np.array_equal(mq0, mq1)

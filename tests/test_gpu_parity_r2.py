@@ -343,43 +343,6 @@ def test_fp16_dp_half_payload_and_overflow_skip(sd):
     #     tests/test_gpu_dp_multiproc.py::test_fp16_dynamic_payload_scale_state_machine
 
 
-@pytest.mark.experiments
-def test_hoisted_target_forward_is_bit_identical(sd):
-    """Option "hoist" (off by default: measured slower, tools/exp/README.md): train_many runs the target-net forward of step
-    i+1 inside launches of step i (it depends on theta- and the sampled
-    poststates only: deepqnetwork.py:119-125).  Same tiles, same K split -> every weight, optimizer state and cost must be
-    bit-identical to the un-hoisted order, across calls of different lengths, a target sync between calls, and with the
-    materialised-gradient update."""
-    A, B, size = 4, 32, 4000
-    args = make_args(batch_size=B)
-    mem = sd.ReplayMemory(size, args)
-    synthetic_fill(mem, 701, num_actions=A)
-    mem.sync_mirror()
-    lib = sd.load()
-    for keep in (0, 1):
-        nets, costs = [], []
-        for hoist in (0, 1):
-            n, _, _ = _net(sd, A, B, 702)
-            n.set_option("hoist", hoist)
-            n.set_option("conv3_c36", 0)                     # the riding target conv3 is the 32-deep routine: same routine on both sides
-            n.set_option("conv1_bf16", 0)                    # ... and the hoisted target conv1 the fp32-MFMA engine's
-            n.set_option("conv1w_bf16", 0)                   # (bwd1 carries the hoisted target conv2 only in its multi-problem engine form)
-            n.set_option("keep_gradients", keep)
-            mt = (C.c_uint32 * 625)(); lib.sdqn_mt_seed(mt, 703)
-            c = []
-            for steps in (1, 2, 7, 3):
-                c.append(n.train_from_memory(mem, steps, mt_state=mt, want_cost=True))
-                if steps == 7:
-                    n.update_target_network()
-            nets.append(n); costs.append(c)
-        assert costs[0] == costs[1], (keep, costs)
-        for which in (0, 1, 2):
-            for i in range(5):
-                assert np.array_equal(nets[0].get_layer(i, which), nets[1].get_layer(i, which)), (keep, which, i)
-        st = random_minibatch(B, A, 704)[0]
-        assert np.array_equal(nets[0].predict(st), nets[1].predict(st))
-
-
 # ---- boundary: --device_id, ring-action validation, error text ------------------------------------------------------
 def test_device_id_is_honoured_or_refused(sd):
     """src/deepqnetwork.py:29-34 passes args.device_id to the backend.  Here: the drop-in classes bind it; the bound
@@ -747,13 +710,6 @@ def test_dispatch_order_and_slab_options_keep_the_numbers(sd, datatype):
         cost = [n.train_from_memory(mem, s, mt_state=mt, want_cost=True) for s in (1, 2)]
         return n, cost
     base, cb = run([])
-    from util import experiments_build
-    for order in ((1, 2) if datatype == "float32" else (1,)) if experiments_build() else ():       # (bwd_order: experiments build only, round 4)
-        n, c = run([("bwd_order", order)])
-        assert c == cb, order
-        for which in (0, 2):
-            for i in range(5):
-                assert np.array_equal(base.get_layer(i, which), n.get_layer(i, which)), (order, which, i)
     tol = 2e-6 if datatype == "float32" else 2e-3
     for opts in ([("tps:2", 14)], [("tps:1", 10), ("tps:3", 7)], [("s4", 4)]):
         n, c = run(opts)

@@ -5,13 +5,6 @@ import zlib
 import numpy as np
 
 
-def experiments_build():
-    """True when the tests run against libsdqn_hip_exp.so (SDQN_LIB_VARIANT=experiments): the build that still contains the step
-    structures measured slower than the default (hoist, f4w_early, fuse_upd, head_f4d, two_streams, fwd_rb, bwd_order, rb:<id>)."""
-    import os
-    return os.environ.get("SDQN_LIB_VARIANT") == "experiments"
-
-
 def make_args(**kw):
     """The argparse namespace of /root/reference/src/main.py:16-84 with its defaults."""
     d = dict(screen_width=84, screen_height=84, history_length=4, replay_size=1000000,
