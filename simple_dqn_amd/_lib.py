@@ -17,7 +17,8 @@ class SdqnError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libsdqn_hip.so")
+    # SDQN_LIB_PATH: another build of the same library (same-box A/B of two builds in tools/exp); never set by the package or the tests
+    return os.environ.get("SDQN_LIB_PATH") or os.path.join(_HERE, "libsdqn_hip.so")
 
 
 class NetCfg(C.Structure):
