@@ -103,7 +103,8 @@ int sdqn_replay_declare_minibatch_clean(sdqn_replay_t h);
  * host binding can hand out LAZY state arrays and fetch them only when somebody looks.  sdqn_replay_declare_minibatch_on_device is the
  * one-shot declaration for that case: "the two state arguments of the next sdqn_net_train_host stand for device minibatch `gen` — the
  * host buffers may not hold it yet, and I have not written into them".  Honoured only while `gen` still IS the device minibatch's
- * generation; otherwise the call uploads the host buffers as always.  (rewards / actions / terminals always come from the arguments.) */
+ * generation (gen = 0: whatever it holds now — the reference's aliased buffers always show the latest gather); otherwise the call uploads
+ * the host buffers as always.  (rewards / actions / terminals always come from the arguments.) */
 int sdqn_replay_minibatch_gen(sdqn_replay_t h, uint64_t* device_gen, uint64_t* host_gen);
 int sdqn_replay_declare_minibatch_on_device(sdqn_replay_t h, uint64_t gen);
 /* device-side timing of the last n gather launches, for bench.py (HIP events on the library stream) */

@@ -189,7 +189,19 @@ def check(rc):
     raise SdqnError("libsdqn_hip status %d: %s" % (rc, msg))
 
 
+_ARRAY_TYPES = {}
+
+
 def ptr(arr, ctype):
+    """A ctypes view of a numpy array's memory for a POINTER(ctype) parameter.  Writable arrays go through the buffer protocol
+    ((ctype * n).from_buffer: 0.7 us, and the object keeps the array alive for the call); read-only ones through numpy's
+    ctypes.data_as (2.3 us) — the reference-style loop passes seven arrays per step."""
+    if arr.flags.writeable and arr.flags.c_contiguous and arr.size:
+        key = (ctype, arr.nbytes // C.sizeof(ctype))
+        t = _ARRAY_TYPES.get(key)
+        if t is None:
+            t = _ARRAY_TYPES[key] = ctype * key[1]
+        return t.from_buffer(arr)
     return arr.ctypes.data_as(C.POINTER(ctype))
 
 

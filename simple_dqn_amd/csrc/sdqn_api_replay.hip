@@ -217,7 +217,7 @@ extern "C" int sdqn_replay_minibatch_gen(sdqn_replay_t r, uint64_t* device_gen, 
 }
 extern "C" int sdqn_replay_declare_minibatch_on_device(sdqn_replay_t r, uint64_t gen) {
   ARGCHK(r, "NULL handle");
-  r->mb_clean_declared = true; r->mb_clean_on_device = gen == r->mb_dev_gen;       // (a stale generation: the host buffers are uploaded as always)
+  r->mb_clean_declared = true; r->mb_clean_on_device = gen == 0 || gen == r->mb_dev_gen;    // (a stale generation: the host buffers are uploaded as always)
   return SDQN_OK;
 }
 extern "C" int sdqn_replay_bench_gather(sdqn_replay_t r, const int64_t* idx_host, int iters, float* ms_per_launch) {

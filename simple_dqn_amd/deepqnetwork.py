@@ -169,16 +169,18 @@ class DeepQNetwork:
         if self.optimizer == "adam":
             _lib.check(self._lib.sdqn_net_set_epoch(self._h, int(epoch)))        # optimizer.optimize(.., epoch), :165
         # The reference's loop body net.train(mem.getMinibatch()): the gathered states are still on the device.
-        #  * untouched lazy views of one ReplayMemory (nobody has looked at or written the host buffers since the gather, and no other
-        #    gather has replaced the device minibatch): the step reads the device copy, the 1.8 MB never cross PCIe in either direction;
+        #  * untouched lazy views of one ReplayMemory (nobody has looked at or written the host buffers since the last gather): the step
+        #    reads the device copy, the 1.8 MB never cross PCIe in either direction;
         #  * the memory's own buffers, fetched but not written since: same, declared the round-3 way;
         #  * anything else (written buffers, foreign arrays): uploaded.
         mem = None
         if (isinstance(prestates, LazyMinibatchArray) and isinstance(poststates, LazyMinibatchArray) and prestates._mem is poststates._mem
                 and prestates._which == "pre" and poststates._which == "post"):
             mem = prestates._mem
-            if mem._mb_pending and mem._mb_gen == mem._device_minibatch_gen():
-                _lib.check(self._lib.sdqn_replay_declare_minibatch_on_device(mem._h, mem._mb_gen))
+            if mem._mb_pending:
+                # (generation 0 = "whatever the device minibatch holds now": the aliased buffers of the reference always show the LATEST
+                #  gather, replay_memory.py:21-22,76-77 — and while the host copy has not been fetched the device copy is that content)
+                _lib.check(self._lib.sdqn_replay_declare_minibatch_on_device(mem._h, 0))
                 pre, post = mem._raw_mb["mb_pre"], mem._raw_mb["mb_post"]       # (addresses only: they name the handle's buffers)
             else:
                 prestates, poststates = mem._states("pre"), mem._states("post")   # fetch; then the ordinary path below

@@ -63,7 +63,6 @@ class ReplayMemory:
         self._prestates = TrackedArray(raw_mb["mb_pre"], self, "mb_pre")
         self._poststates = TrackedArray(raw_mb["mb_post"], self, "mb_post")
         self._lazy_pre, self._lazy_post = LazyMinibatchArray(self, "pre"), LazyMinibatchArray(self, "post")
-        self._mb_gen = 0                        # generation of the device minibatch the last gather() of THIS object produced
         self._mb_actions = np.ctypeslib.as_array(ma, shape=(self.batch_size,))
         self._mb_rewards = np.ctypeslib.as_array(mr, shape=(self.batch_size,))
         self._mb_terminals = np.ctypeslib.as_array(mt, shape=(self.batch_size,)).view(np.bool_)
@@ -161,6 +160,8 @@ class ReplayMemory:
     def _check_mirror(self):
         """Before every device use of the ring: slots written through the numpy views since the last upload go to the HBM
         mirror now (frames and packed metadata separately — a rewards-only edit does not re-send 7 KB per slot)."""
+        if not self._dirty_frames.iv and not self._dirty_meta.iv:         # (the common case: nothing was written through the views)
+            return
         frames = self._dirty_frames.take()
         for lo, hi in frames:
             _lib.check(self._lib.sdqn_replay_upload(self._h, lo, hi - lo))           # (also re-packs + sends the range's metadata)
@@ -224,7 +225,6 @@ class ReplayMemory:
         _lib.check(self._lib.sdqn_replay_gather(self._h, _lib.ptr(idx, C.c_int64)))
         self._mb_pending = True
         self._mb_dirty = False
-        self._mb_gen = self._device_minibatch_gen()
         self.last_indexes = idx.copy()
         raw = self._raw
         return self._lazy_pre, raw["actions"][idx], raw["rewards"][idx], self._lazy_post, raw["terminals"][idx]
