@@ -162,6 +162,7 @@ struct sdqn_net_s {
   int dp_overlap_req = -1;
   bool dp_overlap = false;        // the overlapped form is active
   int dp_probe_result = -1;       // -1 not probed, 0 timed out / failed, 1 ok (sdqn_dp_probe)
+  int wt_kid = -1; unsigned long long* wt_words = nullptr;     // timing build: per-wave stamps around launches of this id (pinned: {buffer, null, blocks})
   std::vector<void*> allocs;
 };
 #define GENCHK(x) do { hipError_t ge_ = (x); if (ge_ != hipSuccess) { set_error("%s -> %s", #x, hipGetErrorString(ge_)); return ge_ == hipErrorInvalidValue ? SDQN_ERR_ARG : SDQN_ERR_HIP; } } while (0)
@@ -226,13 +227,24 @@ int train_replay_slot(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* pinned_idx
 int gen_train_replay(sdqn_net_s* h, sdqn_replay_s* r, const int64_t* idx_host);
 
 inline bool prof_single_kernel(int kid) { return kid != K_ALLREDUCE && kid != K_BN; }
+#ifdef SDQN_TIMING
+namespace sdqn { hipError_t set_wave_timing_buffer(unsigned long long* const* p, const unsigned* nb, hipStream_t s); }
+// timing build: sdqn_debug_time_step_waves arms per-wave stamps around ONE launch id of a real train step (h->wt_kid), stream-ordered
+#define SDQN_WAVE_TIMING_ARM(STRM, KID) do { if (h->wt_kid == (KID) && h->wt_words) HIPCHK(sdqn::set_wave_timing_buffer((unsigned long long* const*)h->wt_words, (const unsigned*)(h->wt_words + 2), (STRM))); } while (0)
+#define SDQN_WAVE_TIMING_DISARM(STRM, KID) do { if (h->wt_kid == (KID) && h->wt_words) HIPCHK(sdqn::set_wave_timing_buffer((unsigned long long* const*)(h->wt_words + 1), (const unsigned*)(h->wt_words + 2), (STRM))); } while (0)
+#else
+#define SDQN_WAVE_TIMING_ARM(STRM, KID) do {} while (0)
+#define SDQN_WAVE_TIMING_DISARM(STRM, KID) do {} while (0)
+#endif
 #define LAUNCH_ON(STRM, KID, expr) do { \
   const bool pf_ = h->prof_on && (h->prof_filter < 0 || h->prof_filter == (KID)) && (h->prof_seen[KID]++ % h->prof_every) == 0; ProfPair pp_; \
   const bool px_ = pf_ && h->prof_mode == 1 && prof_single_kernel(KID); \
   if (pf_) { pp_.id = (KID); int r1_ = prof_event(h, &pp_.a); if (r1_) return r1_; r1_ = prof_event(h, &pp_.b); if (r1_) return r1_; \
              if (px_) { sdqn::LaunchEvents& le = sdqn::launch_events(); le.start = pp_.a; le.stop = pp_.b; le.used = false; } \
              else HIPCHK(hipEventRecord(pp_.a, (STRM))); } \
+  SDQN_WAVE_TIMING_ARM(STRM, KID); \
   hipError_t le_ = (expr); \
+  SDQN_WAVE_TIMING_DISARM(STRM, KID); \
   bool pu_ = true; \
   if (px_) { sdqn::LaunchEvents& le = sdqn::launch_events(); pu_ = le.used; le.start = le.stop = nullptr; le.used = false; } \
   if (le_ != hipSuccess) { \

@@ -91,8 +91,25 @@ __device__ __forceinline__ int64_t pick_half(int64_t v, int s, bool hi) {
 // phase stamps (s_memtime) of wave 0 of every workgroup: dbg[(block*8 + phase)]; NOT in the product build
 __device__ unsigned long long* g_sdqn_dbg = nullptr;
 #define SDQN_STAMP(ph) do { if (g_sdqn_dbg && threadIdx.x == 0) g_sdqn_dbg[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8) + (ph)] = clock64(); } while (0)
+// per-WAVE stamps of the latency engine's tile routine (round 5: which operand lands when, tools/landing_hist.py):
+// wdbg[((block * 16 + wave) * 4 + phase)], phase 0 = before the first operand load, 1 = all loads issued, 2 = A landed, 3 = B landed;
+// + the XCC the workgroup ran on in wdbg[blocks * 64 + block]
+__device__ unsigned long long* g_sdqn_wdbg = nullptr;
+__device__ unsigned g_sdqn_wdbg_blocks = 0;
+// (the stamps are TAKEN into registers where they belong and WRITTEN at the end of the tile: a store, or the load of the buffer pointer,
+//  next to the operand loads would sit in the same in-order vmcnt queue and turn every stamp into "everything before me has landed")
+#define SDQN_WSTAMP_DECL unsigned long long wst_[4] = {0, 0, 0, 0}
+#define SDQN_WSTAMP(ph) do { if (wst_[ph] == 0) wst_[ph] = clock64(); } while (0)
+#define SDQN_WSTAMP_FLUSH do { unsigned long long* wd_ = g_sdqn_wdbg; if (wd_ && (threadIdx.x & 63) == 0) { \
+  const size_t b_ = (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); const unsigned nb_ = g_sdqn_wdbg_blocks; \
+  if (b_ < nb_ && (threadIdx.x >> 6) < 16) { \
+    for (int q_ = 0; q_ < 4; ++q_) wd_[(b_ * 16 + (threadIdx.x >> 6)) * 4 + q_] = wst_[q_]; \
+    if (threadIdx.x == 0) { unsigned x_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x_)); wd_[(size_t)nb_ * 64 + b_] = x_; } } } } while (0)
 #else
 #define SDQN_STAMP(ph) do {} while (0)
+#define SDQN_WSTAMP_DECL do {} while (0)
+#define SDQN_WSTAMP(ph) do {} while (0)
+#define SDQN_WSTAMP_FLUSH do {} while (0)
 #endif
 
 // LDS floats one workgroup of NW waves needs (only the fixed-order combine of the NW partial tiles uses LDS)
@@ -122,6 +139,7 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
   typedef typename P::aoff_t aoff_t;
 
   SDQN_STAMP(0);
+  SDQN_WSTAMP_DECL;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // provably wave-uniform -> SGPR index math
   const int m0 = bx * 32, n0 = by * 32;
@@ -277,9 +295,10 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
     }
   };
   (void)pra; (void)prb;
-  if constexpr (STG_A || STG_B) { if (kc < kend) stage_load(kc); }
+  if constexpr (STG_A || STG_B) { SDQN_WSTAMP(0); if (kc < kend) stage_load(kc); SDQN_WSTAMP(1); }
   while (kc < kend) {
     float fa[16], fb[16];
+    SDQN_WSTAMP(0);
     if constexpr (!STG_A) load_a(kc, fa);
     if constexpr (!STG_B) load_b(kc, fb);
     if constexpr (STG_A || STG_B) {
@@ -306,7 +325,11 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
       wave_lds_sync();                                     // panel reads issued before the next chunk's stores
     }
 #ifdef SDQN_TIMING
+    SDQN_WSTAMP(1);
+    asm volatile("" :: "v"(fa[0]), "v"(fa[3]), "v"(fa[4]), "v"(fa[8]), "v"(fa[12]), "v"(fa[15]));      // A landed (its loads were issued first: in-order return)
+    SDQN_WSTAMP(2);
     asm volatile("" :: "v"(fa[0]), "v"(fb[0]), "v"(fa[15]), "v"(fb[15]));      // operands landed
+    SDQN_WSTAMP(3);
     SDQN_STAMP(3);
 #endif
 #pragma unroll
@@ -345,6 +368,7 @@ __device__ __forceinline__ void gemm_tile(const StepArgs& a, int bx, int by, int
     P::store16(a, z, ks, m0, n0, lane, M, N, v, epi);     // lane holds rows (r&3)+8(r>>2)+4(l>>5), column l&31
   }
   SDQN_STAMP(6);
+  SDQN_WSTAMP_FLUSH;
 }
 
 // ---- fp16-mode tile body: packed-fp16 MFMA -------------------------------------------------------------------

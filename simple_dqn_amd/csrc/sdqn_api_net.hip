@@ -584,4 +584,29 @@ extern "C" int sdqn_debug_time_kernel(sdqn_net_t h, sdqn_replay_t r, const int64
   hipFree(d);
   return replay_release_idx(r, slot);
 }
+// round 5: ONE real train step (ring path) with per-wave stamps around the launches of kernel id `kernel` (latency engine's tile routine):
+// out_waves [max_blocks][16 waves][4 phases] cycles + out_xcc [max_blocks] (gemm_engine.h: SDQN_WSTAMP).  `steps_before` ordinary steps run
+// first, so the stamped launch sits in a warmed-up dependent chain.
+extern "C" int sdqn_debug_time_step_waves(sdqn_net_t h, sdqn_replay_t r, uint32_t* mt, int kernel, int steps_before, unsigned long long* out_waves,
+                                          unsigned long long* out_xcc, int max_blocks) {
+  ARGCHK(h && r && mt && out_waves && out_xcc && max_blocks > 0, "bad arguments");
+  const size_t n = (size_t)max_blocks * 64 + max_blocks;
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, n * 8));
+  HIPCHK(hipMemset(d, 0, n * 8));
+  if (!h->wt_words) HIPCHK(hipHostMalloc((void**)&h->wt_words, 32, hipHostMallocDefault));
+  h->wt_words[0] = (unsigned long long)(uintptr_t)d; h->wt_words[1] = 0; h->wt_words[2] = (unsigned long long)(unsigned)max_blocks;
+  int rc = sdqn_net_train_many(h, r, mt, steps_before, nullptr); if (rc) { hipFree(d); return rc; }
+  h->wt_kid = kernel;
+  rc = sdqn_net_train_many(h, r, mt, 1, nullptr);
+  h->wt_kid = -1;
+  if (rc) { hipFree(d); return rc; }
+  HIPCHK(hipStreamSynchronize(g_stream));
+  std::vector<unsigned long long> tmp(n);
+  HIPCHK(hipMemcpy(tmp.data(), d, n * 8, hipMemcpyDeviceToHost));
+  memcpy(out_waves, tmp.data(), (size_t)max_blocks * 64 * 8);
+  memcpy(out_xcc, tmp.data() + (size_t)max_blocks * 64, (size_t)max_blocks * 8);
+  hipFree(d);
+  return SDQN_OK;
+}
 #endif

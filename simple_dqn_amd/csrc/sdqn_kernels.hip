@@ -272,6 +272,18 @@ hipError_t set_timing_buffer(unsigned long long* p) {
   if (e == hipSuccess) e = set_timing_buffer_bt(p);
   return e != hipSuccess ? e : hipMemcpyToSymbol(HIP_SYMBOL(g_sdqn_dbg), &p, sizeof p);
 }
+hipError_t set_wave_timing_buffer_rb(unsigned long long* const* p, const unsigned* nb, hipStream_t s);
+hipError_t set_wave_timing_buffer_r3(unsigned long long* const* p, const unsigned* nb, hipStream_t s);
+hipError_t set_wave_timing_buffer_bt(unsigned long long* const* p, const unsigned* nb, hipStream_t s);
+// stream-ordered (the pointer and block count are read from PINNED host words the caller keeps alive): armed right in front of ONE launch of
+// a real train step and disarmed behind it, so the stamped launch sees the caches exactly as its predecessors in the step left them
+hipError_t set_wave_timing_buffer(unsigned long long* const* p, const unsigned* nb, hipStream_t s) {
+  hipError_t e = set_wave_timing_buffer_rb(p, nb, s);
+  if (e == hipSuccess) e = set_wave_timing_buffer_r3(p, nb, s);
+  if (e == hipSuccess) e = set_wave_timing_buffer_bt(p, nb, s);
+  if (e == hipSuccess) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sdqn_wdbg_blocks), nb, sizeof *nb, 0, hipMemcpyHostToDevice, s);
+  return e != hipSuccess ? e : hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sdqn_wdbg), p, sizeof *p, 0, hipMemcpyHostToDevice, s);
+}
 #endif
 
 hipError_t launch_head(const StepArgs& a, const HeadArgs& h, hipStream_t s, bool q_system_scope) {

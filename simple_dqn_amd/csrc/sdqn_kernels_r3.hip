@@ -818,6 +818,10 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
 
 #ifdef SDQN_TIMING
 hipError_t set_timing_buffer_r3(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sdqn_dbg), &p, sizeof p); }
+hipError_t set_wave_timing_buffer_r3(unsigned long long* const* p, const unsigned* nb, hipStream_t s) {
+  hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sdqn_wdbg_blocks), nb, sizeof *nb, 0, hipMemcpyHostToDevice, s);
+  return e != hipSuccess ? e : hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sdqn_wdbg), p, sizeof *p, 0, hipMemcpyHostToDevice, s);
+}
 #endif
 
 }  // namespace sdqn
