@@ -734,6 +734,147 @@ struct Conv1WgradHWWT : Conv1WgradHW {
 
   __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab1[(int64_t)ks * NW1 + m * K1 + n], v * a.inv_loss_scale); }
 };
+// ---- the same pipeline with SPECIALISED waves: 10 matrix waves + 2 staging waves (12 = three per SIMD) -----------------------------------
+// In conv1_bf16_rows_kernel every wave does both halves of a trip — staging (last item's output out, next item's bytes converted into
+// LDS, the load five items ahead) and matrix work — so its MFMAs start behind a vmcnt wait and the ten waves reach their MFMAs together
+// (1.1 us per item where the matrix pipe needs 0.5).  Here waves 10 and 11 do ALL the global traffic (4 loads + 5 stores per thread and
+// item) and the conversion; waves 0..9 only read fragments from LDS, run their 24 MFMAs and write the output image: no matrix wave ever
+// waits on vmcnt.  One barrier per item, the same double buffers, the same arithmetic in the same order: bit-identical to the 10-wave kernel.
+// 15.3 -> 14.2 us at B = 256 (same box).  (Staging TWO items ahead into three image buffers, so that a matrix wave reads the next item's
+// fragments under this item's MFMAs: 15.1 us — slower; all eight fragments ahead do not fit 168 registers beside the planes.)
+constexpr int C1S_LOADERS = 128;                                   // threads of the two staging waves
+constexpr int C1S_LPT = (C1R_CHUNKS + C1S_LOADERS - 1) / C1S_LOADERS;   // 16-byte input pieces per staging thread and item: 4 (420 pieces)
+__global__ void __launch_bounds__(768) conv1_bf16_rows2_kernel(const Conv1Args c) {
+  __shared__ __attribute__((aligned(16))) unsigned short img[2 * C1R_ITEM];                   // 26 880 B
+  __shared__ __attribute__((aligned(16))) unsigned short sw[3 * K1 * W1P_PITCH];              // 50 688 B (used once, before the loop)
+  __shared__ __attribute__((aligned(16))) float outl[2 * C1R_OUT];                           // 23 040 B: an item's output, double-buffered
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Gz = c.wgs_per_net;
+  const int z = (int)blockIdx.x / Gz, g = (int)blockIdx.x - z * Gz;
+  const int nsamp = (c.B - g + Gz - 1) / Gz, nitems = C1R_NCH * nsamp;
+  int64_t my_idx = 0;
+  if (c.from_ring) { const int nn = g + Gz * lane; my_idx = c.idx[nn < c.B ? nn : c.B - 1]; }
+  // W1's planes: one coalesced copy per workgroup into LDS (all 768 threads, 4 pieces each)
+  {
+    const c1p_u32x4* wp = reinterpret_cast<const c1p_u32x4*>(c.w1p[z]);
+    c1p_u32x4 wv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wv[j] = wp[tid + 768 * j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int cc = tid + 768 * j, row = cc >> 5, col = cc & 31; *reinterpret_cast<c1p_u32x4*>(sw + row * W1P_PITCH + col * 8) = wv[j]; }
+  }
+  static_assert(3 * K1 * CRS1 / 8 == 4 * 768, "the planes are exactly four 16-byte pieces per thread");
+  if (wave >= 10) {
+    // ================= staging waves =================
+    const int lid = tid - 640;
+    auto org_of = [&](int si) -> int64_t {
+      if (!c.from_ring) return ((int64_t)z * c.B + g + (int64_t)si * Gz) * (int64_t)STATE;
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_idx, si), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_idx >> 32), si);
+      return ((int64_t)(((uint64_t)hi << 32) | lo) - C0 + z) * (int64_t)FRAME;
+    };
+    int poff[C1S_LPT], pdst[C1S_LPT];                         // piece j of this thread: byte offset inside a sample's item window / LDS element
+#pragma unroll
+    for (int j = 0; j < C1S_LPT; ++j) {
+      const int pc = lid + C1S_LOADERS * j, pcc = pc < C1R_CHUNKS ? pc : C1R_CHUNKS - 1;
+      const int fc = pcc / (C1R_SEG / 16), pw = pcc - fc * (C1R_SEG / 16);
+      poff[j] = fc * FRAME + 16 * pw; pdst[j] = pc < C1R_CHUNKS ? fc * C1R_SEG + 16 * pw : -1;
+    }
+    auto gload = [&](int item, c1p_u32x4 (&fv)[C1S_LPT]) {    // (clamped, unconditional: a guarded load costs a vmcnt(0))
+      const int ic = item < nitems ? item : nitems - 1;
+      const int si = ic / C1R_NCH, ch = ic - si * C1R_NCH;
+      const uint8_t* base = c.src + org_of(si) + ch * (4 * ST1 * W0);
+#pragma unroll
+      for (int j = 0; j < C1S_LPT; ++j) fv[j] = *reinterpret_cast<const c1p_u32x4*>(base + poff[j]);
+    };
+    auto lstore = [&](const c1p_u32x4 (&fv)[C1S_LPT], unsigned short* dst) {      // 16 bytes -> 16 bf16 (the upper half of the float of an 8-bit integer)
+#pragma unroll
+      for (int j = 0; j < C1S_LPT; ++j) {
+        if (pdst[j] < 0) continue;
+        c1p_u32x4 o[2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t w = fv[j][e];
+          const uint32_t f0 = __float_as_uint((float)(w & 255u)), f1 = __float_as_uint((float)((w >> 8) & 255u));
+          const uint32_t f2 = __float_as_uint((float)((w >> 16) & 255u)), f3 = __float_as_uint((float)(w >> 24));
+          o[e >> 1][2 * (e & 1)] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);
+          o[e >> 1][2 * (e & 1) + 1] = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
+        }
+        c1p_u32x4* d = reinterpret_cast<c1p_u32x4*>(dst + pdst[j]);
+        d[0] = o[0]; d[1] = o[1];
+      }
+    };
+    auto flush = [&](int item) {                              // 640 sixteen-byte pieces of the item's output: 5 per staging thread, whole lines in order
+      const int si = item / C1R_NCH, ch = item - si * C1R_NCH;
+      float* outs = c.a1 + (((int64_t)z * c.B + g + (int64_t)si * Gz) * PIX1 + ch * (4 * Q1)) * K1;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)outs, 0, 4 * Q1 * K1 * 4, 0x00020000);
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int pc = lid + C1S_LOADERS * u;
+        const c1p_f32x4 v = *reinterpret_cast<const c1p_f32x4*>(outl + (item & 1) * C1R_OUT + (pc >> 3) * C1R_OPITCH + 4 * (pc & 7));
+        c1p_u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(v[e]);
+        if (c.pad_) __builtin_amdgcn_raw_buffer_store_b128(w, rs, 16 * pc, 0, 16); else __builtin_amdgcn_raw_buffer_store_b128(w, rs, 16 * pc, 0, 0);
+      }
+    };
+    c1p_u32x4 fv[C1R_D][C1S_LPT];
+#pragma unroll
+    for (int u = 0; u < C1R_D; ++u) gload(u, fv[u]);
+    lstore(fv[0], img);
+    gload(C1R_D, fv[0]);
+    __syncthreads();                                          // planes + item 0 in LDS
+    for (int i0 = 0; i0 < nitems; i0 += C1R_D) {
+#pragma unroll
+      for (int u = 0; u < C1R_D; ++u) {
+        const int item = i0 + u;
+        if (item > 0) flush(item - 1);
+        lstore(fv[(u + 1) % C1R_D], img + ((item + 1) & 1) * C1R_ITEM);
+        gload(item + 1 + C1R_D, fv[(u + 1) % C1R_D]);
+        __syncthreads();
+      }
+    }
+    if (nitems > 0) flush(nitems - 1);
+    return;
+  }
+  // ================= matrix waves =================
+  const int tj = wave >> 1, nh = wave & 1;
+  __syncthreads();                                            // planes + item 0 in LDS
+  bf16x8_t Bf[3][8];
+  {
+    const unsigned short* bw = sw + (nh * 16 + m) * W1P_PITCH + 8 * kg;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) Bf[p][t] = *reinterpret_cast<const bf16x8_t*>(bw + p * K1 * W1P_PITCH + 32 * t);
+  }
+  const int pos = 16 * tj + m, pl = pos / Q1, q = pos - pl * Q1;
+  const int a_off = (ST1 * pl + kg) * W0 + ST1 * q;
+  for (int item = 0; item < nitems; ++item) {
+    const unsigned short* cur = img + (item & 1) * C1R_ITEM + a_off;
+    bf16x8_t A[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const unsigned short* ap = cur + (t >> 1) * C1R_SEG + 4 * (t & 1) * W0;
+      union { c1p_u32x2 u[2]; bf16x8_t v; } X;
+      X.u[0] = *reinterpret_cast<const c1p_u32x2*>(ap); X.u[1] = *reinterpret_cast<const c1p_u32x2*>(ap + 4);
+      A[t] = X.v;
+    }
+    c1p_f32x4 acc[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) acc[p] = c1p_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[p][t], A[t], acc[p], 0, 0, 0);
+    c1p_f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(div255((acc[0][e] + acc[1][e]) + acc[2][e]), 0.0f);
+    *reinterpret_cast<c1p_f32x4*>(outl + (item & 1) * C1R_OUT + pos * C1R_OPITCH + nh * 16 + 4 * kg) = v;
+    __syncthreads();
+  }
+}
+
 hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = true;
   if (id == K_CONV1_FWD && (t.r3 & 4) && !a.h16 && !a.bn && a.w1p[0] && a.w1p[a.nz > 1 ? 1 : 0]) {
@@ -750,7 +891,8 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
       // number of samples where that is possible: Gz = ceil(B / ceil(B / (256 / nz)))
       const int cap = 256 / (a.nz > 1 ? 2 : 1), per = (a.B + cap - 1) / cap;
       c.wgs_per_net = (a.B + per - 1) / per;
-      SDQN_LAUNCH(conv1_bf16_rows_kernel, dim3(a.nz * c.wgs_per_net), dim3(640), 0, s, c);
+      if (t.bt[K_CONV1_FWD] == 2) SDQN_LAUNCH(conv1_bf16_rows_kernel, dim3(a.nz * c.wgs_per_net), dim3(640), 0, s, c);      // (one role per wave set: the 10-wave form)
+      else SDQN_LAUNCH(conv1_bf16_rows2_kernel, dim3(a.nz * c.wgs_per_net), dim3(768), 0, s, c);
       return hipGetLastError();
     }
     IdxIn ix;
