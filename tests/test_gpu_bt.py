@@ -144,3 +144,30 @@ def test_xcd_contiguous_block_maps_are_placement_only(sd, A, B):
         assert np.array_equal(on.get_layer(i, 3), off.get_layer(i, 3)), i
     assert np.array_equal(on.last_q()[0], off.last_q()[0])
 
+
+
+@pytest.mark.parametrize("A,B", [(3, 256), (4, 160), (6, 136)])
+def test_conv1_forward_forms_at_large_batch(sd, A, B):
+    """Round 5: conv1 forward at B >= 128 is a persistent row-chunk pipeline (default: 10 matrix waves + 2 staging waves; bt:0 = 2: every
+    wave does both roles) on v_mfma_f32_16x16x32_bf16 — the two forms do the same arithmetic in the same order: BIT-identical a1 for both
+    nets, from the staged minibatch and from the ring (fused gather), ragged workgroup loads included (B = 136: 68 workgroups per net take
+    two samples each, B = 160: 80).  Round 4's staged kernel (bt:0 = 1, 32 x 32 x 16 tiles) adds the same exact products in another order:
+    1e-6 of max|a1|."""
+    import ctypes as C
+    from bench import fill_ring
+    mb = random_minibatch(B, A, 911)
+    args = make_args(batch_size=B)
+    mem = sd.ReplayMemory(3000, args)
+    fill_ring(mem, 912, A)
+    outs = {}
+    for form in (0, 2, 1):
+        net = _net(sd, A, B, 910, opts=(("bt:0", form),))
+        net.set_option("grad_only", 1)
+        net.train(mb)                                                     # staged host minibatch: both nets' conv1 (z = 0 online, 1 target)
+        host = net.debug_read("a1", 2 * B * 400 * 32).copy()
+        mt = (C.c_uint32 * 625)(); sd.load().sdqn_mt_seed(mt, 913)
+        net.train_from_memory(mem, 1, mt_state=mt, want_cost=False)       # ring path: the gather fused into the kernel's loads
+        outs[form] = (host, net.debug_read("a1", 2 * B * 400 * 32).copy())
+    for k in (0, 1):
+        assert np.array_equal(outs[0][k], outs[2][k]) and np.abs(outs[0][k]).max() > 0
+        assert np.abs(outs[0][k] - outs[1][k]).max() <= 1e-6 * np.abs(outs[1][k]).max()
