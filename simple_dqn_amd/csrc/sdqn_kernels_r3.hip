@@ -734,17 +734,19 @@ struct Conv1WgradHWWT : Conv1WgradHW {
 
   __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab1[(int64_t)ks * NW1 + m * K1 + n], v * a.inv_loss_scale); }
 };
-// ---- the same pipeline with SPECIALISED waves: 10 matrix waves + 2 staging waves (12 = three per SIMD) -----------------------------------
+// ---- the same pipeline with SPECIALISED waves: 10 matrix waves + NLW = 4 staging waves (one per SIMD) ------------------------------------
 // In conv1_bf16_rows_kernel every wave does both halves of a trip — staging (last item's output out, next item's bytes converted into
 // LDS, the load five items ahead) and matrix work — so its MFMAs start behind a vmcnt wait and the ten waves reach their MFMAs together
-// (1.1 us per item where the matrix pipe needs 0.5).  Here waves 10 and 11 do ALL the global traffic (4 loads + 5 stores per thread and
-// item) and the conversion; waves 0..9 only read fragments from LDS, run their 24 MFMAs and write the output image: no matrix wave ever
+// (1.1 us per item where the matrix pipe needs 0.5).  Here the staging waves (10 and up) do ALL the global traffic (2 loads + 3 stores per
+// thread and item with four of them) and the conversion; waves 0..9 only read fragments from LDS, run their 24 MFMAs and write the output image: no matrix wave ever
 // waits on vmcnt.  One barrier per item, the same double buffers, the same arithmetic in the same order: bit-identical to the 10-wave kernel.
-// 15.3 -> 14.2 us at B = 256 (same box).  (Staging TWO items ahead into three image buffers, so that a matrix wave reads the next item's
+// 15.3 -> 13.5 us at B = 256 (same box; two staging waves: 14.2-14.8 — the conversion on 128 threads is then the critical path).  (Staging TWO items ahead into three image buffers, so that a matrix wave reads the next item's
 // fragments under this item's MFMAs: 15.1 us — slower; all eight fragments ahead do not fit 168 registers beside the planes.)
-constexpr int C1S_LOADERS = 128;                                   // threads of the two staging waves
-constexpr int C1S_LPT = (C1R_CHUNKS + C1S_LOADERS - 1) / C1S_LOADERS;   // 16-byte input pieces per staging thread and item: 4 (420 pieces)
-__global__ void __launch_bounds__(768) conv1_bf16_rows2_kernel(const Conv1Args c) {
+template <int NLW>                                                 // staging waves (2 or 4)
+__global__ void __launch_bounds__(640 + 64 * NLW) conv1_bf16_rows2_kernel(const Conv1Args c) {
+  constexpr int C1S_LOADERS = 64 * NLW, NT = 640 + 64 * NLW;
+  constexpr int C1S_LPT = (C1R_CHUNKS + C1S_LOADERS - 1) / C1S_LOADERS;   // 16-byte input pieces per staging thread and item (420 pieces)
+  constexpr int C1S_FPT = (640 + C1S_LOADERS - 1) / C1S_LOADERS;          // 16-byte output pieces per staging thread and item (640 pieces)
   __shared__ __attribute__((aligned(16))) unsigned short img[2 * C1R_ITEM];                   // 26 880 B
   __shared__ __attribute__((aligned(16))) unsigned short sw[3 * K1 * W1P_PITCH];              // 50 688 B (used once, before the loop)
   __shared__ __attribute__((aligned(16))) float outl[2 * C1R_OUT];                           // 23 040 B: an item's output, double-buffered
@@ -758,13 +760,13 @@ __global__ void __launch_bounds__(768) conv1_bf16_rows2_kernel(const Conv1Args c
   // W1's planes: one coalesced copy per workgroup into LDS (all 768 threads, 4 pieces each)
   {
     const c1p_u32x4* wp = reinterpret_cast<const c1p_u32x4*>(c.w1p[z]);
-    c1p_u32x4 wv[4];
+    constexpr int NPC = 3 * K1 * CRS1 / 8, PPT = (NPC + NT - 1) / NT;
+    c1p_u32x4 wv[PPT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wv[j] = wp[tid + 768 * j];
+    for (int j = 0; j < PPT; ++j) { const int cc = tid + NT * j; wv[j] = wp[cc < NPC ? cc : NPC - 1]; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int cc = tid + 768 * j, row = cc >> 5, col = cc & 31; *reinterpret_cast<c1p_u32x4*>(sw + row * W1P_PITCH + col * 8) = wv[j]; }
+    for (int j = 0; j < PPT; ++j) { const int cc = tid + NT * j, row = cc >> 5, col = cc & 31; if (cc < NPC) *reinterpret_cast<c1p_u32x4*>(sw + row * W1P_PITCH + col * 8) = wv[j]; }
   }
-  static_assert(3 * K1 * CRS1 / 8 == 4 * 768, "the planes are exactly four 16-byte pieces per thread");
   if (wave >= 10) {
     // ================= staging waves =================
     const int lid = tid - 640;
@@ -809,8 +811,9 @@ __global__ void __launch_bounds__(768) conv1_bf16_rows2_kernel(const Conv1Args c
       float* outs = c.a1 + (((int64_t)z * c.B + g + (int64_t)si * Gz) * PIX1 + ch * (4 * Q1)) * K1;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)outs, 0, 4 * Q1 * K1 * 4, 0x00020000);
 #pragma unroll
-      for (int u = 0; u < 5; ++u) {
+      for (int u = 0; u < C1S_FPT; ++u) {
         const int pc = lid + C1S_LOADERS * u;
+        if (pc >= 640) continue;
         const c1p_f32x4 v = *reinterpret_cast<const c1p_f32x4*>(outl + (item & 1) * C1R_OUT + (pc >> 3) * C1R_OPITCH + 4 * (pc & 7));
         c1p_u32x4 w;
 #pragma unroll
@@ -892,7 +895,7 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
       const int cap = 256 / (a.nz > 1 ? 2 : 1), per = (a.B + cap - 1) / cap;
       c.wgs_per_net = (a.B + per - 1) / per;
       if (t.bt[K_CONV1_FWD] == 2) SDQN_LAUNCH(conv1_bf16_rows_kernel, dim3(a.nz * c.wgs_per_net), dim3(640), 0, s, c);      // (one role per wave set: the 10-wave form)
-      else SDQN_LAUNCH(conv1_bf16_rows2_kernel, dim3(a.nz * c.wgs_per_net), dim3(768), 0, s, c);
+      else SDQN_LAUNCH(conv1_bf16_rows2_kernel<4>, dim3(a.nz * c.wgs_per_net), dim3(896), 0, s, c);      // (staging waves 2 / 4 / 6: 14.8 / 13.5 / 13.4 us)
       return hipGetLastError();
     }
     IdxIn ix;
