@@ -22,11 +22,12 @@ import numpy as np
 
 
 class LazyMinibatchArray:
-    __slots__ = ("_memref", "_which", "__weakref__")
+    __slots__ = ("_memref", "_which", "_shape", "__weakref__")
     __array_priority__ = 0.0
 
     def __init__(self, mem, which):
         self._memref, self._which = weakref.ref(mem), which       # (one per ReplayMemory and role, owned by it: no reference cycle)
+        self._shape = (mem.batch_size, mem.history_length) + tuple(mem.dims)
 
     @property
     def _mem(self):
@@ -38,22 +39,21 @@ class LazyMinibatchArray:
     # ---- known without the data ----------------------------------------------------------------------------------------
     @property
     def shape(self):
-        m = self._mem
-        return (m.batch_size, m.history_length) + tuple(m.dims)
+        return self._shape
 
     dtype = np.dtype(np.uint8)
     ndim = 4
 
     @property
     def size(self):
-        return int(np.prod(self.shape))
+        return int(np.prod(self._shape))
 
     @property
     def nbytes(self):
         return self.size
 
     def __len__(self):
-        return self._mem.batch_size
+        return self._shape[0]
 
     # ---- everything else looks at the data ---------------------------------------------------------------------------------
     def _arr(self):

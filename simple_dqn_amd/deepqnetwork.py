@@ -35,6 +35,7 @@ class DeepQNetwork:
         self.discount_rate = args.discount_rate
         self.history_length = args.history_length
         self.screen_dim = (args.screen_height, args.screen_width)
+        self._state_shape = (self.batch_size, self.history_length) + self.screen_dim      # what train() / predict() take
         self.clip_error = args.clip_error
         self.min_reward = args.min_reward
         self.max_reward = args.max_reward
@@ -153,14 +154,15 @@ class DeepQNetwork:
 
     def train(self, minibatch, epoch=0):                           # :107-172
         prestates, actions, rewards, poststates, terminals = minibatch
-        assert len(prestates.shape) == 4
-        assert len(poststates.shape) == 4
-        assert len(actions.shape) == 1
-        assert len(rewards.shape) == 1
-        assert len(terminals.shape) == 1
-        assert prestates.shape == poststates.shape
-        assert prestates.shape[0] == actions.shape[0] == rewards.shape[0] == poststates.shape[0] == terminals.shape[0]
-        assert prestates.shape == (self.batch_size, self.history_length) + self.screen_dim
+        ps, qs, as_, rs, ts = prestates.shape, poststates.shape, actions.shape, rewards.shape, terminals.shape     # (the reference's asserts, :108-115)
+        assert len(ps) == 4
+        assert len(qs) == 4
+        assert len(as_) == 1
+        assert len(rs) == 1
+        assert len(ts) == 1
+        assert ps == qs
+        assert ps[0] == as_[0] == rs[0] == qs[0] == ts[0]
+        assert ps == self._state_shape
         act = np.ascontiguousarray(actions, dtype=np.uint8)
         rew = np.ascontiguousarray(rewards, dtype=np.int64)
         term = np.ascontiguousarray(terminals).astype(np.uint8)
@@ -181,20 +183,20 @@ class DeepQNetwork:
                 # (generation 0 = "whatever the device minibatch holds now": the aliased buffers of the reference always show the LATEST
                 #  gather, replay_memory.py:21-22,76-77 — and while the host copy has not been fetched the device copy is that content)
                 _lib.check(self._lib.sdqn_replay_declare_minibatch_on_device(mem._h, 0))
-                pre, post = mem._raw_mb["mb_pre"], mem._raw_mb["mb_post"]       # (addresses only: they name the handle's buffers)
+                pre_p, post_p = mem._mb_ptrs                                   # (addresses only: they name the handle's buffers)
             else:
                 prestates, poststates = mem._states("pre"), mem._states("post")   # fetch; then the ordinary path below
                 mem = None
         if mem is None:
             pre = np.ascontiguousarray(prestates, dtype=np.uint8)
             post = np.ascontiguousarray(poststates, dtype=np.uint8)
+            pre_p, post_p = _lib.ptr(pre, C.c_uint8), _lib.ptr(post, C.c_uint8)
             owner = getattr(prestates, "_owner", None)
             m2 = owner() if owner is not None else None
             if (m2 is not None and prestates is getattr(m2, "_prestates", None) and poststates is getattr(m2, "_poststates", None)
                     and not getattr(m2, "_mb_pending", True) and not getattr(m2, "_mb_dirty", True)):
                 _lib.check(self._lib.sdqn_replay_declare_minibatch_clean(m2._h))
-        _lib.check(self._lib.sdqn_net_train_host(self._h, _lib.ptr(pre, C.c_uint8), _lib.ptr(act, C.c_uint8),
-                                                 _lib.ptr(rew, C.c_int64), _lib.ptr(post, C.c_uint8),
+        _lib.check(self._lib.sdqn_net_train_host(self._h, pre_p, _lib.ptr(act, C.c_uint8), _lib.ptr(rew, C.c_int64), post_p,
                                                  _lib.ptr(term, C.c_uint8), C.byref(cost) if want else None))
         self.train_iterations += 1                                 # :168
         if self.callback:

@@ -60,6 +60,7 @@ class ReplayMemory:
         raw_mb = {"mb_pre": np.ctypeslib.as_array(mp, shape=shp), "mb_post": np.ctypeslib.as_array(mq, shape=shp)}
         self._raw_bytes.update({k: v.reshape(-1).view(np.uint8) for k, v in raw_mb.items()})
         self._raw_mb = raw_mb
+        self._mb_ptrs = (_lib.ptr(raw_mb["mb_pre"], C.c_uint8), _lib.ptr(raw_mb["mb_post"], C.c_uint8))    # (constant: the handle's pinned buffers)
         self._prestates = TrackedArray(raw_mb["mb_pre"], self, "mb_pre")
         self._poststates = TrackedArray(raw_mb["mb_post"], self, "mb_post")
         self._lazy_pre, self._lazy_post = LazyMinibatchArray(self, "pre"), LazyMinibatchArray(self, "post")
