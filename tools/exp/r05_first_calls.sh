@@ -1,3 +1,5 @@
+# (SUPERSEDED by tools/exp/r05_call1.sh, which is what round 5 ran: the counter passes below without the experiments-build A/B — that build left the
+#  tree in round 5, tools/exp/experiments_r04.patch.)
 # Round 5, first gpurun call (prepared at the end of round 4, when the GPU minutes had run out): what the block-tile launches at B = 256 wait for.
 # a block-chunk takes ~1 550 cycles of a CU for 1 024 of matrix time; measured away so far — dependent MFMA chains, the
 # prefetch depth, a second wave per SIMD, exposed LDS round trips, the work balance (stream-K), the staging path (direct-to-LDS = register ring).
