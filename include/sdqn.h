@@ -104,7 +104,9 @@ int sdqn_replay_declare_minibatch_clean(sdqn_replay_t h);
  * one-shot declaration for that case: "the two state arguments of the next sdqn_net_train_host stand for device minibatch `gen` — the
  * host buffers may not hold it yet, and I have not written into them".  Honoured only while `gen` still IS the device minibatch's
  * generation (gen = 0: whatever it holds now — the reference's aliased buffers always show the latest gather); otherwise the call uploads
- * the host buffers as always.  (rewards / actions / terminals always come from the arguments.) */
+ * the host buffers as always.  rewards / actions / terminals always come from the arguments — compared by value with what that gather
+ * left on the device (ring[idx] of the three arrays, snapshotted by sdqn_replay_gather): when they are equal the step reads the device
+ * copy and the call uploads nothing; any edit (a clipped reward, another action) is uploaded and used, as before. */
 int sdqn_replay_minibatch_gen(sdqn_replay_t h, uint64_t* device_gen, uint64_t* host_gen);
 int sdqn_replay_declare_minibatch_on_device(sdqn_replay_t h, uint64_t gen);
 /* device-side timing of the last n gather launches, for bench.py (HIP events on the library stream) */
@@ -194,6 +196,9 @@ int sdqn_net_debug_act(sdqn_net_t h, sdqn_statebuf_t sb, float* q_out, unsigned 
  * Threading: handles are created, used and destroyed from ONE host thread (no internal locking). */
 int sdqn_net_train_host(sdqn_net_t h, const uint8_t* pre, const uint8_t* actions, const int64_t* rewards,
                         const uint8_t* post, const uint8_t* terminals, float* cost_out);
+/* How sdqn_net_train_host has been served on this handle: calls / calls that read the states from the device minibatch in place (no
+ * 2 x batch x state H2D) / calls that uploaded nothing at all (small arrays equal to what the gather left on the device).  Any NULL. */
+int sdqn_net_tuple_counters(sdqn_net_t h, int64_t* calls, int64_t* states_in_place, int64_t* nothing_uploaded);
 /* same step with the minibatch gathered on the device straight from the replay ring:
  * fuses replay_memory.py:71-78 with deepqnetwork.py:94-100 (no u8 minibatch is materialised) */
 int sdqn_net_train_replay(sdqn_net_t h, sdqn_replay_t r, const int64_t* idx_host, float* cost_out);

@@ -60,6 +60,7 @@ SIGNATURES = {
     "sdqn_replay_minibatch_to_host": (C.c_int, [_vp]),
     "sdqn_replay_declare_minibatch_clean": (C.c_int, [_vp]),
     "sdqn_net_step_structure": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sdqn_net_tuple_counters": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sdqn_replay_minibatch_gen": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sdqn_replay_declare_minibatch_on_device": (C.c_int, [_vp, C.c_uint64]),
     "sdqn_replay_bench_gather": (C.c_int, [_vp, _i64p, C.c_int, _f32p]),

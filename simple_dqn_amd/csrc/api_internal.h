@@ -58,6 +58,10 @@ struct sdqn_replay_s {
   // (sdqn_replay_declare_minibatch_clean: one-shot, consumed by the next sdqn_net_train_host)
   uint64_t mb_dev_gen = 1, mb_host_gen = 0; bool mb_clean_declared = false, mb_clean_on_device = false;
   hipEvent_t mb_upload_ev = nullptr;      // tuple API: the H2D of h_pre | h_post issued by sdqn_net_train_host (waited for before that call returns)
+  // what the last sdqn_replay_gather left in d_rew | d_act | d_term, as [rewards 8 B x B | actions B | terminals B] taken from the host
+  // master at enqueue time (== the device metadata in stream order), and the device generation it belongs to: a tuple whose small
+  // arrays equal it trains on the device copy (sdqn_net_train_host)
+  uint8_t* mb_snap = nullptr; uint64_t mb_snap_gen = 0;
 };
 extern std::vector<sdqn_replay_s*> g_replays;      // live handles: sdqn_net_train_host recognises their pinned minibatch buffers
 
@@ -110,7 +114,9 @@ struct sdqn_net_s {
   bool head_q_system = false;              // (run_forward: this forward's head writes system-scope)
   // the acting forward as ONE launch (sdqn_act.hip; float32, no batch-norm): per-XCC scratch copies, fc4 partial slots, control blocks
   float *act_scratch = nullptr, *act_q = nullptr; unsigned* act_ctl = nullptr; unsigned act_seq = 0;
-  bool act_on = false, act_last = false, act_inject = false; int act_fallbacks = 0;     // act_inject (tests): the next one-launch forward finds its work already claimed and delivers nothing     // act_last: the forward being collected came from that launch
+  bool act_on = false, act_last = false, act_inject = false; int act_fallbacks = 0;
+  int64_t tuple_calls = 0, tuple_states_skipped = 0, tuple_small_skipped = 0;   // sdqn_net_train_host: calls / calls without the state upload / without any upload
+      // act_inject (tests): the next one-launch forward finds its work already claimed and delivers nothing     // act_last: the forward being collected came from that launch
   // deferred cost read-back (sdqn_net_train_many_deferred): pinned ring of cost sums the stream copies into
   double* cost_ring = nullptr; int cost_steps[64] = {0}; int64_t cost_ticket = 0;
   bool spec_pending = false; const void* spec_sb = nullptr; uint64_t spec_gen = 0;

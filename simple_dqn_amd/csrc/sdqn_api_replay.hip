@@ -14,6 +14,7 @@ int replay_free(sdqn_replay_s* r) {
   hipHostFree(r->h_meta); hipHostFree(r->h_pre); hipHostFree(r->h_rew); hipHostFree(r->h_idx);
   for (int i = 0; i < NSLOT; ++i) if (r->slot_ev[i]) hipEventDestroy(r->slot_ev[i]);
   if (r->mb_upload_ev) hipEventDestroy(r->mb_upload_ev);
+  free(r->mb_snap);
   delete r;
   return SDQN_OK;
 }
@@ -59,6 +60,8 @@ extern "C" int sdqn_replay_create(sdqn_replay_t* out, int64_t size, int H, int W
   for (int i = 0; i < NSLOT; ++i) RCHK(hipEventCreateWithFlags(&r->slot_ev[i], hipEventDisableTiming));
   RCHK(hipEventCreateWithFlags(&r->mb_upload_ev, hipEventDisableTiming));
 #undef RCHK
+  r->mb_snap = (uint8_t*)malloc((size_t)batch * 10);
+  if (!r->mb_snap) { set_error("out of host memory (minibatch metadata snapshot)"); replay_free(r); return SDQN_ERR_HIP; }
   g_replays.push_back(r);
   *out = r;
   return SDQN_OK;
@@ -180,21 +183,32 @@ int replay_gather_generic(sdqn_replay_s* r, const int64_t* didx) {      // any g
   HIPCHK(launch_gather_generic(g, g_stream));
   return SDQN_OK;
 }
+// what the gather being enqueued will leave in d_rew | d_act | d_term: the packed metadata the device mirror was uploaded FROM
+// (h_meta == d_meta in stream order; sdqn_net_train_host compares a tuple's small arrays with this)
+static void snapshot_small(sdqn_replay_s* r, const int64_t* idx) {
+  const size_t B = (size_t)r->B;
+  int64_t* rew = reinterpret_cast<int64_t*>(r->mb_snap); uint8_t* act = r->mb_snap + B * 8; uint8_t* term = act + B;
+  for (size_t i = 0; i < B; ++i) { const MetaRec& m = r->h_meta[idx[i]]; rew[i] = m.reward; act[i] = m.action; term[i] = m.terminal; }
+  r->mb_snap_gen = r->mb_dev_gen;
+}
 extern "C" int sdqn_replay_gather(sdqn_replay_t r, const int64_t* idx_host) {
   ARGCHK(r && idx_host, "NULL argument");
+  for (int i = 0; i < r->B; ++i)
+    ARGCHK(idx_host[i] >= r->hist && idx_host[i] < r->count, "index %lld out of range (count %lld)", (long long)idx_host[i], (long long)r->count);
   if (!r->tuned_geom) {
     int slot; const int64_t* didx; int rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
     rc = replay_gather_generic(r, didx); if (rc) return rc;
+    snapshot_small(r, idx_host);
     return replay_release_idx(r, slot);
   }
   if (r->B <= 256) {               // the indexes ride in the kernel arguments: no pinned slot, no release event (sdqn_kernels.hip)
-    for (int i = 0; i < r->B; ++i)
-      ARGCHK(idx_host[i] >= r->hist && idx_host[i] < r->count, "index %lld out of range (count %lld)", (long long)idx_host[i], (long long)r->count);
     HIPCHK(launch_gather(gather_args(r, nullptr), g_stream, idx_host));
+    snapshot_small(r, idx_host);
     return SDQN_OK;
   }
   int slot; const int64_t* didx; int rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
   HIPCHK(launch_gather(gather_args(r, didx), g_stream));
+  snapshot_small(r, idx_host);
   return replay_release_idx(r, slot);
 }
 extern "C" int sdqn_replay_minibatch_to_host(sdqn_replay_t r) {

@@ -455,6 +455,12 @@ class DeepQNetwork:
         _lib.check(self._lib.sdqn_net_step_structure(self._h, C.byref(a), C.byref(b)))
         return self.STEP_STRUCTURES[a.value], self.UPDATE_FORMS[b.value]
 
+    def tuple_counters(self):
+        """How train(minibatch) calls have been served: (calls, states read from the device minibatch in place, nothing uploaded at all)."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(self._lib.sdqn_net_tuple_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def dp_form(self):
         """Which data-parallel form runs: 'none' / 'serial' / 'overlapped', the start-up probe's local result and the vote."""
         f, p, c2 = C.c_int(0), C.c_int(-1), C.c_int(0)

@@ -608,6 +608,9 @@ def test_tuple_api_lazy_states_read_write_alias_and_stale_generation(sd):
         random.setstate(st); mb = mem.getMinibatch(); n_host.train(tuple(np.array(x) for x in mb))
         random.setstate(st); mb = mem.getMinibatch(); assert int(np.asarray(mb[0]).sum()) > 0; n_read.train(mb)
     same(n_dev, n_host); same(n_dev, n_read)
+    # ... and how the library served them: the untouched tuple uploaded NOTHING (states in place, small arrays equal to what the gather
+    # left on the device); arrays from elsewhere are uploaded whole; a host read of the states changes nothing about that
+    assert n_dev.tuple_counters() == (3, 3, 3) and n_host.tuple_counters() == (3, 0, 0) and n_read.tuple_counters() == (3, 3, 3)
     # write-then-train: what the caller wrote is what trains
     n_w, n_ref = fresh(), fresh()
     mb = mem.getMinibatch()
@@ -623,6 +626,27 @@ def test_tuple_api_lazy_states_read_write_alias_and_stale_generation(sd):
     n_w.train(mb)
     n_ref.train((np.array(mem.prestates), mb[1], np.ones(B, np.int64), np.array(mem.poststates), np.zeros(B, bool)))
     same(n_w, n_ref)
+    assert n_w.tuple_counters() == (1, 1, 0)                                     # states in place, the edited small arrays uploaded
+    # one edited element is enough (the comparison is by value over all 10 x B bytes); a ring slot rewritten between the gather and the
+    # step changes nothing: the tuple's arrays and the device copy both hold the gather-time values
+    for which, val in ((1, None), (2, 5), (4, None)):
+        n_w, n_ref = fresh(), fresh()
+        mb = mem.getMinibatch()
+        if which == 1: mb[1][B - 1] = (int(mb[1][B - 1]) + 1) % A
+        elif which == 2: mb[2][0] += val
+        else: mb[4][3] = not mb[4][3]
+        n_w.train(mb)
+        n_ref.train(tuple(np.array(x) for x in mb))
+        same(n_w, n_ref); assert n_w.tuple_counters() == (1, 1, 0), which
+    n_w, n_ref = fresh(), fresh()
+    mb = mem.getMinibatch()
+    expect = tuple(np.array(x) for x in mb)
+    slot = int(mem.last_indexes[0])
+    keep = (int(mem.actions[slot]), int(mem.rewards[slot]), bool(mem.terminals[slot]))
+    mem.actions[slot] = (keep[0] + 1) % A; mem.rewards[slot] = keep[1] + 3; mem.terminals[slot] = not keep[2]    # the ring moves on ...
+    n_w.train(mb); n_ref.train(expect)                                          # ... the tuple and the device minibatch do not
+    same(n_w, n_ref); assert n_w.tuple_counters() == (1, 1, 1)
+    mem.actions[slot], mem.rewards[slot], mem.terminals[slot] = keep            # put the ring back for the cases below
     # Statistics-style aliasing: the array kept from one call shows the next call's states (the reference's aliased buffers)
     keep = mem.getMinibatch()[0]
     first = np.array(keep)
