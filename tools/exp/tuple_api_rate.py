@@ -18,6 +18,8 @@ for _ in range(50): net.train(mem.getMinibatch())
 net.sync(); t = time.perf_counter(); N = 2000
 for _ in range(N): net.train(mem.getMinibatch())
 net.sync(); print("getMinibatch + train(tuple): %.0f steps/s" % (N / (time.perf_counter() - t)))
+print("served as (calls, states in place, nothing uploaded):", net.tuple_counters())
+if os.environ.get("ONLY_TUPLE"): sys.exit(0)
 mb = random_minibatch(B, A, 3)
 for _ in range(50): net.train(mb)
 net.sync(); t = time.perf_counter()
