@@ -590,6 +590,21 @@ def gather_large(sd, args_factory, mem_small_fill, A, Bbig=4096):
     return e
 
 
+def box_check(gather_large_entry, capture="profiles/r05_final_bench.json"):
+    """How THIS box compares with the one the committed captures were taken on, by the one HBM-bound probe the line already carries
+    (the standalone gather at B = 4096: 376 MB per launch).  Boxes of the pool differ: with the same build one that reads 0.90 here
+    ran the B = 256 legs 15 % and the float16 B = 256 leg 22 % slower, the B = 32 headline 4 % (profiles/r05_side_rates.txt)."""
+    try:
+        ref = json.load(open(os.path.join(ROOT, capture)))["replay_gather_large"]["achieved"]
+        x = gather_large_entry["achieved"]
+        return {"probe": "replay_gather_u8, B=4096 (replay_gather_large)", "GBps": x, "capture_box_GBps": ref, "ratio": round(x / ref, 3),
+                "capture": capture,
+                "note": "ratio < 0.95: a slower box than the committed captures' — the throughput-regime legs (config_b256, config_fp16_b256) follow "
+                        "this ratio or worse, the B=32 headline by about a third of it"}
+    except Exception as e:                                         # (no capture in the tree, probe failed: say so, never fail the line)
+        return {"error": repr(e)[:200]}
+
+
 def allreduce_model(n, payload_bytes):
     """What the ONE collective of a data-parallel step should cost on an 8 x MI355X node, from the link arithmetic (SURVEY.md §5;
     a MODEL to judge an N-GPU record against, not a measurement — no N > 1 communicator has run on the builder's 1-GPU boxes).
@@ -967,6 +982,7 @@ def main():
                 pre["replay_gather_large"] = gather_large(sd, make_args, fill_ring, A)
             except Exception as e:
                 pre["replay_gather_large"] = {"error": repr(e)[:200]}
+            pre["box"] = box_check(pre["replay_gather_large"])
 
     # ---- warmup (untimed): includes a pass with every kernel bracketed to find the dominant one
     n_prof = min(60, max(a.warmup // 2, 1)) if a.warmup else 20      # W = 0 still needs a pass to find the dominant kernel
