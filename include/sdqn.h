@@ -270,8 +270,9 @@ int sdqn_net_step_structure(sdqn_net_t h, int* structure, int* update);
  * batch_norm, 84x84x4: the acting forward of sdqn_net_predict_state / _predict_one is ONE launch, sdqn_act.hip; 0: the five batched
  * forward kernels at batch 1; test hook "act_inject_failure": the next such launch delivers nothing, which exercises the host's fall-back to the
  * five launches).  The step structures that were built, tested and measured SLOWER — "hoist", "f4w_early", "fuse_upd",
- * "head_f4d", "two_streams", "fwd_rb", "bwd_order", "rb:<id>", "bt_x", "btx:<id>", "bt_planes" — exist only in the experiments build
- * (make -C simple_dqn_amd/csrc experiments -> libsdqn_hip_exp.so); this library refuses a non-zero value for them with SDQN_ERR_ARG. */
+ * "head_f4d", "two_streams", "fwd_rb", "bwd_order", "rb:<id>", "bt_x", "btx:<id>", "bt_planes" — left the library in round 5
+ * (tools/exp/experiments_r04.patch re-creates the last tree that contained them, results in tools/exp/README.md); a non-zero value for one of
+ * these names is refused with SDQN_ERR_ARG, zero is accepted and does nothing. */
 int sdqn_net_set_option(sdqn_net_t h, const char* name, int value);
 
 /* test hook: raw read-back of an internal device buffer ("a1","a2","a3","a4","d4","d3p","d2p","d1","q",

@@ -40,37 +40,6 @@ SDQN_HD constexpr int mk_floats(int BX) { return BK * BX; }
 
 SDQN_HD constexpr int panel_floats(bool kcontig, int BX) { return kcontig ? km_floats(BX) : mk_floats(BX); }
 
-// ---- ping-pong routine (gemm_engine_pp.h): 512 threads = two groups of 4 waves, ALL of them loaders.  A panel is BX x 8 float4 items;
-// item -> (row, k4) for KM panels, (k, x4) for MK panels; a 32-wide panel has 256 items: threads t and t + 256 carry the same one
-constexpr int NT2 = 512;
-SDQN_HD constexpr int pp_items(int BX) { return BX * 8; }
-SDQN_HD constexpr int pp_passes(int BX) { return (pp_items(BX) + NT2 - 1) / NT2; }
-SDQN_HD constexpr int pp_item(int BX, int tid, int p) { return (tid + NT2 * p) % pp_items(BX); }
-SDQN_HD constexpr int pp_km_row(int it) { return it >> 3; }
-SDQN_HD constexpr int pp_km_k(int it) { return (it & 7) * 4; }
-SDQN_HD constexpr int pp_mk_k(int BX, int it) { return it / (BX / 4); }
-SDQN_HD constexpr int pp_mk_x(int BX, int it) { return (it % (BX / 4)) * 4; }
-
-// ---- direct-to-LDS panels (gemm_engine_glds.h: global_load_lds_dwordx4) ------------------------------------------------------------------
-// A wave's load instruction lands LANE-LINEAR in LDS: lane l's 16 bytes at base + 16 l, whatever address it fetched.  So the panel image is
-// a plain array of float4 slots, slot p = 64 (instruction) + lane, and the layout is chosen by WHICH item the lane of slot p fetches:
-//   KM panel [x][8 float4] with NO padding (pitch 32 floats) and the bank swizzle in the slot index: item (x, q) lives in slot
-//     8 x + (q ^ ((x >> 1) & 7)) — the 16 lanes of a ds_read_b128 group (rows x0 .. x0 + 15, one q) then hit 16 distinct 16-byte bank groups
-//     ((x & 1) * 8 + (q ^ ((x >> 1) & 7)) is a bijection of (x & 15) for every q);
-//   MK panel [k][BX / 4 float4]: slot (BX / 4) k + x4 / 4 — the layout bt_tile already uses (mk_off), lane-linear as it is.
-SDQN_HD constexpr int g_km_slot(int x, int q) { return 8 * x + (q ^ ((x >> 1) & 7)); }
-SDQN_HD constexpr int g_km_slot_x(int p) { return p >> 3; }
-SDQN_HD constexpr int g_km_slot_q(int p) { return (p & 7) ^ ((p >> 4) & 7); }         // (x >> 1) & 7 with x = p >> 3
-SDQN_HD constexpr int g_km_off(int x, int k) { return 4 * g_km_slot(x, k >> 2) + (k & 3); }      // float offset of element (x, k)
-SDQN_HD constexpr int g_km_floats(int BX) { return BX * 32; }
-SDQN_HD constexpr int g_mk_slot_k(int BX, int p) { return p / (BX / 4); }
-SDQN_HD constexpr int g_mk_slot_x(int BX, int p) { return (p % (BX / 4)) * 4; }
-SDQN_HD constexpr int g_panel_floats(bool kcontig, int BX) { return kcontig ? g_km_floats(BX) : mk_floats(BX); }
-SDQN_HD constexpr int g_passes(int BX) { return BX * 8 / NT; }                       // float4 slots per thread and panel (BX >= 32)
-SDQN_HD constexpr int g_frag_off(bool kcontig, int BX, int x, int t, int h) {
-  return kcontig ? g_km_off(x, kslot(t, h)) : mk_off(BX, kslot(t, h), x);
-}
-
 // ---- fragment of lane (i = l & 31, h = l >> 5) for sub-tile row/column x0 + i, MFMA step t ------------------------------
 SDQN_HD constexpr int frag_off(bool kcontig, int BX, int x, int t, int h) {
   return kcontig ? km_off(x, kslot(t, h)) : mk_off(BX, kslot(t, h), x);

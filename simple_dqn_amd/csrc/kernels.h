@@ -1,4 +1,4 @@
-// kernels.h — launch interface between the host orchestration (sdqn_api.hip) and the device
+// kernels.h — launch interface between the host orchestration (sdqn_api_*.hip) and the device
 // code (sdqn_kernels.hip).  Kernel ids double as the profiler's slots.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -9,7 +9,7 @@
 
 namespace sdqn {
 struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; bool used = false; };
-LaunchEvents& launch_events();             // thread-local (sdqn_kernels.hip); armed by sdqn_api.hip's LAUNCH_ON for ONE launch
+LaunchEvents& launch_events();             // thread-local (sdqn_kernels.hip); armed by api_internal.h's LAUNCH_ON for ONE launch
 }
 
 #define SDQN_LAUNCH(kernel, grid, block, shmem, stream, ...) do { \

@@ -139,7 +139,7 @@ hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStre
 // HOIST (option "hoist" only; compiled out of the default kernel — even this one branch was measurable): one extra workgroup
 // fetches the next step's indexes from their pinned host slot into HBM.
 // QSYS (acting path, round 4): h.q is HOST memory (mapped, pinned) and every Q-value leaves with a system-scope store the moment it is
-// summed, so the host can poll for it instead of paying a D2H copy packet + a stream synchronisation (sdqn_api.hip: predict_state).
+// summed, so the host can poll for it instead of paying a D2H copy packet + a stream synchronisation (sdqn_api_act.hip: predict_state).
 template <int AMAX, bool BN, bool HOIST = false, bool QSYS = false>
 __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadArgs h) {
   SDQN_STAMP(0);

@@ -81,7 +81,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
 
 
 static hipError_t launch_fused(int id, int menu, const StepArgs& a, hipStream_t s) {
-  const bool f4 = a.f4w_count > 0;         // (B > 32: all of fc4_wgrad rides in bwd3 or none of it, sdqn_api.hip)
+  const bool f4 = a.f4w_count > 0;         // (B > 32: all of fc4_wgrad rides in bwd3 or none of it, sdqn_api_step.hip)
   if (id == K_BWD3) {
     // dispatch order = block-id order: the long conv3 problems first, the short fc4_wgrad tiles (8 chunks + the RMSProp stream) fill in
     switch (menu) {

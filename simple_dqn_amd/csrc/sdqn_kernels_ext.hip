@@ -55,7 +55,7 @@ static hipError_t launch_kernel_h16(int id, const StepArgs& a, const LaunchTune&
         return launch_multi<512, Conv3DgradH, 8, Conv3WgradHW, 8, Fc4WgradHW, 8>(a, true, true, s);
       case K_BWD2: return launch_multi<512, NoProblem, 2, Conv2DgradH, 8, Conv2WgradHW, 8>(a, true, true, s);
       case K_BWD1: return launch_multi<1024, NoProblem, 2, Conv1WgradHW, 16, NoProblem, 2>(a, true, false, s);
-      // round 4, B >= 128: every weight gradient that does not need delta1 in ONE launch, behind the block-tile dgrad chain (sdqn_api.hip)
+      // round 4, B >= 128: every weight gradient that does not need delta1 in ONE launch, behind the block-tile dgrad chain (sdqn_api_step.hip)
       case K_WGRADS: return launch_multi<512, Fc4WgradHW, 8, Conv3WgradHW, 8, Conv2WgradHW, 8>(a, true, true, s);
       default: break;
     }

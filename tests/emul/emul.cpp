@@ -130,100 +130,12 @@ static void run_bt(const StepArgs& a) {
   }
 }
 
-// ---- the direct-to-LDS panels (bt_map.h: g_* maps; gemm_engine_glds.h) executed on the host ------------------------------------------------
-// 256 "threads" x passes fetch the item of their slot (p = 256 pass + tid lands lane-linear: float4 slot p of the panel image), the four waves
-// read their fragments through g_frag_off: a wrong slot <-> item map, a hole in the coverage or a swizzle that the reads do not undo shows up
-// as a wrong gradient against the oracle.
-template <class P, int BM, int BN, int WM, int WN>
-static void run_gl(const StepArgs& a) {
-  using namespace sdqn::bt;
-  constexpr bool AK = P::A_K, BKC = P::B_K;
-  constexpr int SM = BM / (32 * WM), SN = BN / (32 * WN), PA = g_passes(BM), PB = g_passes(BN);
-  const int M = P::M(a), N = P::N(a);
-  const int gx = (M + BM - 1) / BM, gy = (N + BN - 1) / BN;
-  std::vector<float> As(g_panel_floats(AK, BM)), Bs(g_panel_floats(BKC, BN));
-  for (int bz = 0; bz < P::nbz(a); ++bz) {
-    int z, ks, kbeg, kend; P::ksplit(a, bz, z, ks, kbeg, kend);
-    const int nch = (kend - kbeg + BK - 1) / BK;
-    for (int by = 0; by < gy; ++by) for (int bx = 0; bx < gx; ++bx) {
-      const int m0 = bx * BM, n0 = by * BN;
-      std::vector<float> acc((size_t)4 * SM * SN * 64 * 16, 0.f);
-      for (int c = 0; c < nch; ++c) {
-        const int kc = kbeg + c * BK;
-        std::fill(As.begin(), As.end(), -1e30f); std::fill(Bs.begin(), Bs.end(), -1e30f);
-        for (int tid = 0; tid < NT; ++tid) {
-          for (int ps = 0; ps < PA; ++ps) {
-            const int p = tid + 256 * ps; f4 v;
-            if (AK) {
-              const int m = m0 + g_km_slot_x(p), k = kc + 4 * g_km_slot_q(p);
-              v = P::a_load4(a, z, P::a_row(a, z, m < M ? m : M - 1) + P::a_col(a, z, k < kend ? k : kbeg));
-              if (k >= kend) v.x = v.y = v.z = v.w = 0.f;       // (the device routine only runs whole chunks; the emulator keeps the tail exact)
-            } else {
-              const int m = m0 + g_mk_slot_x(BM, p), k = kc + g_mk_slot_k(BM, p);
-              v = P::a_load4(a, z, P::a_row(a, z, m + 4 <= M ? m : M - 4) + P::a_col(a, z, k < kend ? k : kbeg));
-              if (k >= kend) v.x = v.y = v.z = v.w = 0.f;
-            }
-            As[4 * p] = v.x; As[4 * p + 1] = v.y; As[4 * p + 2] = v.z; As[4 * p + 3] = v.w;
-          }
-          for (int ps = 0; ps < PB; ++ps) {
-            const int p = tid + 256 * ps; f4 v;
-            if (BKC) {
-              const int n = n0 + g_km_slot_x(p), k = kc + 4 * g_km_slot_q(p);
-              v = P::b_load4(a, z, P::b_col(a, z, n < N ? n : N - 1) + P::b_row(a, z, k < kend ? k : kbeg));
-              if (k >= kend) v.x = v.y = v.z = v.w = 0.f;
-            } else {
-              const int n = n0 + g_mk_slot_x(BN, p), k = kc + g_mk_slot_k(BN, p);
-              v = P::b_load4(a, z, P::b_col(a, z, n + 4 <= N ? n : N - 4) + P::b_row(a, z, k < kend ? k : kbeg));
-              if (k >= kend) v.x = v.y = v.z = v.w = 0.f;
-            }
-            Bs[4 * p] = v.x; Bs[4 * p + 1] = v.y; Bs[4 * p + 2] = v.z; Bs[4 * p + 3] = v.w;
-          }
-        }
-        for (int wave = 0; wave < 4; ++wave) {
-          const int wm = wave / WN, wn = wave % WN;
-          for (int sm = 0; sm < SM; ++sm) for (int sn = 0; sn < SN; ++sn) {
-            float* ac = &acc[((((size_t)wave * SM + sm) * SN + sn) * 64) * 16];
-            for (int t = 0; t < 16; ++t) {
-              float fa[64], fb[64];
-              for (int l = 0; l < 64; ++l) {
-                const int i = l & 31, h = l >> 5;
-                fa[l] = As[g_frag_off(AK, BM, (wm * SM + sm) * 32 + i, t, h)];
-                fb[l] = Bs[g_frag_off(BKC, BN, (wn * SN + sn) * 32 + i, t, h)];
-              }
-              for (int l = 0; l < 64; ++l) for (int r = 0; r < 16; ++r) {
-                const int row = acc_row(r, l >> 5), col = l & 31;
-                float d = ac[l * 16 + r];
-                d += fa[row] * fb[col];
-                d += fa[row + 32] * fb[col + 32];
-                ac[l * 16 + r] = d;
-              }
-            }
-          }
-        }
-      }
-      for (int wave = 0; wave < 4; ++wave) {
-        const int wm = wave / WN, wn = wave % WN;
-        for (int sm = 0; sm < SM; ++sm) for (int sn = 0; sn < SN; ++sn) {
-          const int ms = m0 + (wm * SM + sm) * 32, ns = n0 + (wn * SN + sn) * 32;
-          const float* ac = &acc[((((size_t)wave * SM + sm) * SN + sn) * 64) * 16];
-          for (int l = 0; l < 64; ++l) for (int r = 0; r < 16; ++r) {
-            const int m = ms + acc_row(r, l >> 5), n = ns + (l & 31);
-            if (m < M && n < N) P::store(a, z, ks, m, n, ac[l * 16 + r]);
-          }
-        }
-      }
-    }
-  }
-}
-
-static int g_bt_variant = 0;       // 0: naive loops; 1 / 2: the block-tile maps at the built-in / the alternative block shapes; 3 / 4: the direct-to-LDS panel maps
+static int g_bt_variant = 0;       // 0: naive loops; 1 / 2: the block-tile maps at the built-in / the alternative block shapes
 extern "C" void emul_set_bt(int v) { g_bt_variant = v; }
 template <class P, int BM1, int BN1, int WM1, int WN1, int BM2, int BN2, int WM2, int WN2>
 static void run_any(const StepArgs& a) {
   if (g_bt_variant == 1) run_bt<P, BM1, BN1, WM1, WN1>(a);
   else if (g_bt_variant == 2) run_bt<P, BM2, BN2, WM2, WN2>(a);
-  else if (g_bt_variant == 3) run_gl<P, BM1, BN1, WM1, WN1>(a);
-  else if (g_bt_variant == 4) run_gl<P, BM2, BN2, WM2, WN2>(a);
   else run<P>(a);
 }
 

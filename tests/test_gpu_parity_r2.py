@@ -404,7 +404,7 @@ def test_untracked_writes_cannot_go_stale_silently(sd):
 
 
 def test_ring_action_out_of_range_is_rejected(sd):
-    """the ring paths took actions unchecked (the tuple API checks them, sdqn_api.hip train_host)."""
+    """the ring paths took actions unchecked (the tuple API checks them, sdqn_api_step.hip: sdqn_net_train_host)."""
     A, B, size = 4, 8, 300
     args = make_args(batch_size=B)
     mem = sd.ReplayMemory(size, args)

@@ -1,6 +1,8 @@
 """Experiment: the training forward conv chain conv1 -> conv2 -> conv3 as ONE XCC-local launch (sdqn_act.hip:
 chain_probe_kernel, experiments build), ns (state, net) pairs per XCC — 8 = batch 32 with both nets — against the three forward launches
-of the product step.   SDQN_LIB_VARIANT=experiments python tools/exp/chain_probe.py"""
+of the product step.   SDQN_LIB_VARIANT=experiments python tools/exp/chain_probe.py
+Historical (round 4): the probe and the experiments build left the library in round 5 — runs on the tree that
+tools/exp/experiments_r04.patch re-creates (on commit 4b59432); the result is in tools/exp/README.md."""
 import os, sys, ctypes as C
 os.environ.setdefault("SDQN_LIB_VARIANT", "experiments")
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
