@@ -429,7 +429,7 @@ __device__ __forceinline__ void gemm_tile_h(const StepArgs& a, int bx, int by, i
 }
 
 }  // namespace sdqn
-#include "gemm_engine_rb.h"      // register-blocked routine of the throughput regime (B >= 128)
+#include "gemm_engine_rb.h"      // register-blocked routine of the float16 mode (B >= 128)
 namespace sdqn {
 
 
@@ -567,7 +567,7 @@ __device__ __forceinline__ void gemm_tile_hw(const StepArgs& a, int bx, int by, 
 template <class P, int NW, int NT>
 __device__ __forceinline__ void run_tile(const StepArgs& a, int bx, int by, int bz, float* smem) {
   if constexpr (is_rb<P>::value && uses_f16_mfma<P>::value) gemm_tile_hb<P, NW, NT>(a, bx, by, bz, smem);
-  else if constexpr (is_rb<P>::value) gemm_tile_rb<P, NW, NT>(a, bx, by, bz, smem);
+  else if constexpr (is_rb<P>::value) static_assert(!is_rb<P>::value, "register blocking exists for the packed-fp16 problems only (gemm_engine_rb.h)");
   else if constexpr (uses_f16_wgrad<P>::value) gemm_tile_hw<P, NW, NT>(a, bx, by, bz, smem);
   else if constexpr (uses_f16_mfma<P>::value) gemm_tile_h<P, NW, NT>(a, bx, by, bz, smem);
   else gemm_tile<P, NW, NT>(a, bx, by, bz, smem);

@@ -82,8 +82,6 @@ extern "C" int sdqn_net_create(sdqn_net_t* out, const sdqn_net_cfg* c) {
     if (c->datatype == 1 && !h->bn) h->tps1 = 10;
     if (h->tps1 > T1) h->tps1 = T1; if (h->tps2 > T2) h->tps2 = T2; if (h->tps3 > T3) h->tps3 = T3;
   }
-  // (the register-blocked routine, gemm_engine_rb.h, is available per kernel id through set_option "rb:<id>" / "tps:<l>":
-  //  measured slower than these choices at B = 256 in every fused launch — tools/exp/README.md — so it is off by default)
   h->ns1 = ceil_div(T1, h->tps1); h->ns2 = ceil_div(T2, h->tps2); h->ns3 = ceil_div(T3, h->tps3);
   // fc4 forward K-splits: parallelism at B = 32; at B >= 128 the M x N tiles fill the chip in fp32 (3 620 -> 3 650 steps/s at B = 256),
   // not in float16 where a wave owns a 64 x 64 block (S4 = 1: 4 850 steps/s, 7: 5 770)

@@ -81,7 +81,7 @@ hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStre
       default: break;
     }
   }
-  if (a.B >= 128) {            // throughput regime (thousands of tiles per launch): tools/sweep_nw.py / tools/sweep_rb.py at B = 256
+  if (a.B >= 128) {            // throughput regime (thousands of tiles per launch): tools/sweep_nw.py at B = 256
     switch (id) {
       case K_CONV1_FWD: return launch_gemm<Conv1Fwd, 8>(a, s);
       case K_CONV2_FWD: return launch_gemm<Staged<Conv2Fwd>, 8>(a, s);

@@ -1,7 +1,8 @@
-"""Bring-up helper (not product): run one configuration of the B=256 step N times (for rocprofv3 --pmc / --kernel-trace).
+"""[historical, rounds 2-4: the float32 register-blocked routine and its option "rb:<id>" left the library in round 5 — runs on the
+tree of tools/exp/experiments_r04.patch]  Bring-up helper (not product): run one configuration of the B=256 step N times (for rocprofv3 --pmc / --kernel-trace).
    python tools/rb_probe.py "rb:1=2,rb:2=4" [steps]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import simple_dqn_amd as sd
 from util import make_args, random_minibatch
 B, A = 256, 3

@@ -1,7 +1,8 @@
-"""Bring-up helper (not product): s_memtime phase stamps + placement (HW_ID / XCC_ID) of the register-blocked routine at
+"""[historical, rounds 2-4: the float32 register-blocked routine and its option "rb:<id>" left the library in round 5 — runs on the
+tree of tools/exp/experiments_r04.patch]  Bring-up helper (not product): s_memtime phase stamps + placement (HW_ID / XCC_ID) of the register-blocked routine at
 B = 256, from the -DSDQN_TIMING build.   python tools/rb_stamps.py "<kernel id>:<menu>" ..."""
 import ctypes as C, os, sys, collections
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import simple_dqn_amd._lib as L
 L.lib_path = lambda: os.path.join(os.path.dirname(os.path.abspath(L.__file__)), "libsdqn_hip_timing.so")

@@ -1,10 +1,11 @@
-"""Tuning + bring-up helper (not product): the register-blocked tile routine (gemm_engine_rb.h) at B = 256.
+"""[historical, rounds 2-4: the float32 register-blocked routine and its option "rb:<id>" left the library in round 5 — runs on the
+tree of tools/exp/experiments_r04.patch]  Tuning + bring-up helper (not product): the register-blocked tile routine (gemm_engine_rb.h) at B = 256.
 For every kernel id and menu entry of sdqn_kernels_rb.hip: (1) one train step from identical weights on an identical
 minibatch vs the unblocked routine — gradients of all layers and Q must agree to fp32 round-off (the two routines differ
 only in how K is split over waves, i.e. in summation grouping); (2) HIP-event time per launch over STEPS steps.
    python tools/sweep_rb.py [B] [A]          (GPU box)"""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import simple_dqn_amd as sd
 from util import make_args, random_minibatch
