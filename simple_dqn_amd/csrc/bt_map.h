@@ -47,14 +47,5 @@ SDQN_HD constexpr int frag_off(bool kcontig, int BX, int x, int t, int h) {
 // accumulator register r of lane l is C[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31] of its 32 x 32 sub-tile
 SDQN_HD constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// ---- packed-fp16 form (v_mfma_f32_32x32x16_f16): 64-deep chunks, lane (i, h) feeds halves k = 16 s + 8 h .. + 7 of step s ----
-constexpr int BKH = 64;           // halves per chunk row (128 bytes, like the fp32 chunk)
-constexpr int KMH_PITCH = 72;     // halves per row of a half KM panel (= 36 dwords: the same bank picture as the fp32 panel)
-SDQN_HD constexpr int kmh_item_row(int tid, int p) { return (tid >> 3) + 32 * p; }
-SDQN_HD constexpr int kmh_item_k(int tid) { return (tid & 7) * 8; }
-SDQN_HD constexpr int kmh_off(int x, int k) { return x * KMH_PITCH + k; }
-SDQN_HD constexpr int kmh_halves(int BX) { return BX * KMH_PITCH; }
-SDQN_HD constexpr int fragh_off(int x, int s, int h) { return kmh_off(x, 16 * s + 8 * h); }
-
 }  // namespace bt
 }  // namespace sdqn

@@ -274,10 +274,6 @@ SDQN_HD int row3(const StepArgs& a, int z, int m) {          // conv3 patch orig
   return (((z * a.B + n) * P2 + p) * Q2 + q) * K2;
 }
 SDQN_HD int col3(int k) { int rs = k >> 6, c = k & 63, r = rs / 3, s = rs - r * 3; return (r * Q2 + s) * K2 + c; }
-SDQN_HD int prow3(int m) {                                   // (n,p,q) of conv3 output -> d3p (pad 2)
-  int n = m / PIX3, pix = m - n * PIX3, p = pix / Q3, q = pix - p * Q3;
-  return ((n * PD3 + p + 2) * PD3 + q + 2) * K3;
-}
 SDQN_HD int prow2(int m) {                                   // (n,p,q) of conv2 output -> d2p (pad 1)
   int n = m / PIX2, pix = m - n * PIX2, p = pix / Q2, q = pix - p * Q2;
   return ((n * PD2 + p + 1) * PD2 + q + 1) * K2;

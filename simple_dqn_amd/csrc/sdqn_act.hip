@@ -58,7 +58,6 @@ __device__ __forceinline__ f32x4 ld4_sc1(__amdgpu_buffer_rsrc_t rs, int float_of
   f32x4 f; f.x = __uint_as_float(v.x); f.y = __uint_as_float(v.y); f.z = __uint_as_float(v.z); f.w = __uint_as_float(v.w); return f;
 }
 __device__ __forceinline__ float ld_sc1(const float* p) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), RLX_AGENT)); }
-__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), RLX_AGENT); }
 
 struct Wg {
   int tid, lane, w, r, kq;
