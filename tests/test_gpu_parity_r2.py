@@ -661,6 +661,62 @@ def test_tuple_api_lazy_states_read_write_alias_and_stale_generation(sd):
     same(n_s, n_ref)
 
 
+def test_minibatch_generations_at_the_c_abi(sd):
+    """sdqn_replay_minibatch_gen / sdqn_replay_declare_minibatch_on_device with an EXPLICIT generation (what a host binding that keeps
+    several tuples alive would pass; DeepQNetwork.train passes 0 = 'whatever the aliased buffers show now'): every gather launch bumps the
+    device generation, a fetch brings the host generation level, the current generation is honoured (nothing uploaded), a stale one is
+    not — the host buffers' content trains, as for any caller that never declared anything."""
+    import ctypes as C
+    from simple_dqn_amd import _lib
+    A, B, size = 4, 32, 1200
+    mem = sd.ReplayMemory(size, make_args(batch_size=B))
+    synthetic_fill(mem, 913, num_actions=A); mem.sync_mirror()
+    lib, h = mem._lib, mem._h
+
+    def gens():
+        d, g = C.c_uint64(), C.c_uint64()
+        _lib.check(lib.sdqn_replay_minibatch_gen(h, C.byref(d), C.byref(g)))
+        assert d.value == mem._device_minibatch_gen()
+        return d.value, g.value
+
+    def train_raw(net, small):
+        act, rew, term = (np.ascontiguousarray(x) for x in small)
+        pre_p, post_p = mem._mb_ptrs
+        _lib.check(net._lib.sdqn_net_train_host(net._h, pre_p, _lib.ptr(act, C.c_uint8), _lib.ptr(rew, C.c_int64), post_p,
+                                                _lib.ptr(term.view(np.uint8), C.c_uint8), None))
+
+    random.seed(31)
+    d0, _ = gens()
+    mb1 = mem.getMinibatch()
+    d1, g1 = gens()
+    assert d1 == d0 + 1 and g1 != d1                             # gathered, not fetched
+    small1 = (mb1[1], mb1[2], mb1[4])
+    n_cur, n_ref = _net(sd, A, B, 914)[0], _net(sd, A, B, 914)[0]
+    _lib.check(lib.sdqn_replay_declare_minibatch_on_device(h, d1))
+    train_raw(n_cur, small1)
+    assert n_cur.tuple_counters() == (1, 1, 1)                   # the current generation, named explicitly: the device copy trains
+    host1 = (np.array(mb1[0]), np.array(mb1[3]))                 # (the fetch)
+    assert gens() == (d1, d1)
+    n_ref.train((host1[0], small1[0], small1[1], host1[1], small1[2]))
+    for i in range(5):
+        assert np.array_equal(n_cur.get_layer(i, 0), n_ref.get_layer(i, 0)), i
+    # a later gather replaces the device minibatch; the host buffers still hold generation d1 (nobody has looked at the new one)
+    mb2 = mem.getMinibatch()
+    d2, g2 = gens()
+    assert d2 == d1 + 1 and g2 == d1 and mem._mb_pending
+    n_stale, n_ref = _net(sd, A, B, 915)[0], _net(sd, A, B, 915)[0]
+    _lib.check(lib.sdqn_replay_declare_minibatch_on_device(h, d1))          # stale: not honoured
+    train_raw(n_stale, small1)
+    assert n_stale.tuple_counters() == (1, 0, 0)                 # uploaded from the host buffers = generation d1's states
+    n_ref.train((host1[0], small1[0], small1[1], host1[1], small1[2]))
+    for i in range(5):
+        assert np.array_equal(n_stale.get_layer(i, 0), n_ref.get_layer(i, 0)), i
+    # the declaration is one-shot: the next call without one uploads again even though nothing changed
+    train_raw(n_stale, small1)
+    assert n_stale.tuple_counters() == (2, 0, 0)
+    assert np.array_equal(np.asarray(mb2[0]), np.asarray(mem.prestates)) and gens() == (d2, d2)
+
+
 # ---- multi-GPU readiness that a 1-GPU box can check --------------------------------------------------------------------
 def test_bench_dry_run_dp_two_ranks(sd):
     """bench.py under torch.distributed.run with 2 ranks sharing the one GPU (control plane only: gloo id exchange,
