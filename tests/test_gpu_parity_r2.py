@@ -661,6 +661,38 @@ def test_tuple_api_lazy_states_read_write_alias_and_stale_generation(sd):
     same(n_s, n_ref)
 
 
+def test_train_iterations_and_device_sync_at_the_c_abi(sd):
+    """deepqnetwork.py:168 for a C caller: sdqn_net_train_iterations counts every step whichever entry point ran it (tuple, ring,
+    n-step loop); sdqn_device_sync returns once the library stream has drained (the cost of the last step is then final)."""
+    import ctypes as C
+    from simple_dqn_amd import _lib
+    A, B = 4, 32
+    mem = sd.ReplayMemory(900, make_args(batch_size=B))
+    synthetic_fill(mem, 921, num_actions=A); mem.sync_mirror()
+    net = _net(sd, A, B, 922)[0]
+    n = C.c_int64(-1)
+
+    def iters():
+        _lib.check(net._lib.sdqn_net_train_iterations(net._h, C.byref(n)))
+        return n.value
+
+    assert iters() == 0
+    random.seed(5)
+    net.train(mem.getMinibatch())                                   # sdqn_net_train_host
+    net.train(random_minibatch(B, A, 923))
+    assert iters() == 2
+    net.train_from_memory(mem, 5)                                   # sdqn_net_train_many
+    assert iters() == 7 == net.train_iterations
+    idx = mem.sample_indexes()
+    _lib.check(net._lib.sdqn_net_train_replay(net._h, mem._h, _lib.ptr(idx, C.c_int64), None))      # not waited for ...
+    assert iters() == 8
+    assert net._lib.sdqn_device_sync() == 0                         # ... until here
+    w = [net.get_layer(i) for i in range(5)]
+    assert net._lib.sdqn_device_sync() == 0 and all(np.array_equal(a, net.get_layer(i)) for i, a in enumerate(w))
+    with pytest.raises(Exception):
+        _lib.check(net._lib.sdqn_net_train_iterations(net._h, None))
+
+
 def test_minibatch_generations_at_the_c_abi(sd):
     """sdqn_replay_minibatch_gen / sdqn_replay_declare_minibatch_on_device with an EXPLICIT generation (what a host binding that keeps
     several tuples alive would pass; DeepQNetwork.train passes 0 = 'whatever the aliased buffers show now'): every gather launch bumps the
