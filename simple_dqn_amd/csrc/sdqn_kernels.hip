@@ -40,11 +40,14 @@ hipError_t launch_kernel_ext(int id, const StepArgs& a, const LaunchTune& t, hip
 
 hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled);
 hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled);
+hipError_t launch_kernel_ss(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled);
 
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s) {
-  if (a.B >= 128) {            // throughput regime: the block-tile engine (round 4; sdqn_kernels_bt.hip) takes what it implements
-    bool handled = false;
-    const hipError_t e = launch_kernel_bt(id, a, t, s, &handled);
+  if (a.B >= 128) {            // throughput regime: the sample-stationary forward convolutions (round 6; sdqn_kernels_ss.hip), then the
+    bool handled = false;      // block-tile engine (round 4; sdqn_kernels_bt.hip) take what they implement
+    hipError_t e = launch_kernel_ss(id, a, t, s, &handled);
+    if (handled) return e;
+    e = launch_kernel_bt(id, a, t, s, &handled);
     if (handled) return e;
   }
   if (t.r3 || t.wt) {          // round-3 launch variants live in their own translation unit (same reason as sdqn_kernels_ext.hip)
@@ -266,10 +269,12 @@ __global__ void __launch_bounds__(512) head_kernel(const StepArgs a, const HeadA
 hipError_t set_timing_buffer_rb(unsigned long long* p);
 hipError_t set_timing_buffer_r3(unsigned long long* p);
 hipError_t set_timing_buffer_bt(unsigned long long* p);
+hipError_t set_timing_buffer_ss(unsigned long long* p);
 hipError_t set_timing_buffer(unsigned long long* p) {
   hipError_t e = set_timing_buffer_rb(p);
   if (e == hipSuccess) e = set_timing_buffer_r3(p);
   if (e == hipSuccess) e = set_timing_buffer_bt(p);
+  if (e == hipSuccess) e = set_timing_buffer_ss(p);
   return e != hipSuccess ? e : hipMemcpyToSymbol(HIP_SYMBOL(g_sdqn_dbg), &p, sizeof p);
 }
 hipError_t set_wave_timing_buffer_rb(unsigned long long* const* p, const unsigned* nb, hipStream_t s);

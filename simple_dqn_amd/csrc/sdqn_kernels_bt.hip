@@ -41,6 +41,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 0: return launch_bt<C2F>(a, s);
         BT_CASE(1, Conv2FwdWT, 64, 64, 2, 2, 3); BT_CASE(2, Conv2FwdWT, 128, 64, 2, 2, 2); BT_CASE(3, Conv2FwdWT, 128, 64, 4, 1, 2);
         BT_CASE(4, Conv2FwdWT, 64, 64, 2, 2, 1); BT_CASE(5, Conv2FwdWT, 128, 64, 2, 2, 3);
+        case 6: return launch_bt<C2F>(a, s);      // (entry 0 is the sample-stationary routine since round 6: sdqn_kernels_ss.hip)
         default: break;
       }
       break;
@@ -49,6 +50,7 @@ static hipError_t launch_single(int id, int menu, const StepArgs& a, hipStream_t
         case 0: return launch_bt<C3F>(a, s);
         BT_CASE(1, Conv3FwdWT, 64, 64, 2, 2, 3); BT_CASE(2, Conv3FwdWT, 128, 64, 2, 2, 2); BT_CASE(3, Conv3FwdWT, 128, 64, 4, 1, 2);
         BT_CASE(4, Conv3FwdWT, 64, 64, 2, 2, 1); BT_CASE(5, Conv3FwdWT, 128, 64, 2, 2, 3);
+        case 6: return launch_bt<C3F>(a, s);
         default: break;
       }
       break;

@@ -1,0 +1,43 @@
+// sdqn_kernels_ss.hip — the throughput regime's forward convolutions on the SAMPLE-STATIONARY routine (conv_ss.h): own translation
+// unit, like every other family of launch variants.
+//   conv2_fwd  a1 [2][B][20][20][32] -> a2 [2][B][81][64]     4 x 4 stride 2     (deepqnetwork.py:85)
+//   conv3_fwd  a2 [2][B][9][9][64]   -> a3 [2][B][49][64]     3 x 3 stride 1     (deepqnetwork.py:87)
+// float32, no batch-norm (the raw-output problems stay on the latency engine), B >= 128.  LaunchTune::bt[id] == 0 selects this routine;
+// menu entries > 0 are the block-tile engine's block shapes (sdqn_kernels_bt.hip; entry 6 = its former built-in 64 x 64 shape).
+#include <stdlib.h>
+#include "conv_ss.h"
+#include "kernels.h"
+
+namespace sdqn {
+
+// two samples per workgroup when one per workgroup would not fit the chip in one round (nz B > 256 workgroups), else one
+typedef ss::Cfg<P1, Q1, K1, 4, 4, ST2, P2, Q2, 2> C2S2;
+typedef ss::Cfg<P1, Q1, K1, 4, 4, ST2, P2, Q2, 1> C2S1;
+typedef ss::Cfg<P2, Q2, K2, 3, 3, 1, P3, Q3, 2> C3S2;
+typedef ss::Cfg<P2, Q2, K2, 3, 3, 1, P3, Q3, 1> C3S1;
+
+hipError_t launch_kernel_ss(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
+  *handled = false;
+  if (a.B < 128 || a.bn || a.h16) return hipSuccess;
+  if (id != K_CONV2_FWD && id != K_CONV3_FWD) return hipSuccess;
+  if (t.bt[id] != 0 || t.nw_override[id] > 0) return hipSuccess;
+  const int ns = a.nz * a.B > 256 ? 2 : 1;
+  ss::Args c;
+  c.B = a.B; c.G = (a.B + ns - 1) / ns; c.dbg = 0;
+#ifdef SDQN_TIMING
+  if (const char* e = getenv("SDQN_SS_DBG")) c.dbg = atoi(e);
+#endif
+  *handled = true;
+  if (id == K_CONV2_FWD) {
+    c.in = a.a1; c.out = a.a2; c.w[0] = a.theta[0] + OFF2; c.w[1] = a.theta[a.nz > 1 ? 1 : 0] + OFF2; c.wt = t.wt & 1;
+    return ns == 2 ? ss::launch<C2S2>(c, a.nz, s) : ss::launch<C2S1>(c, a.nz, s);
+  }
+  c.in = a.a2; c.out = a.a3; c.w[0] = a.theta[0] + OFF3; c.w[1] = a.theta[a.nz > 1 ? 1 : 0] + OFF3; c.wt = (t.wt >> 1) & 1;
+  return ns == 2 ? ss::launch<C3S2>(c, a.nz, s) : ss::launch<C3S1>(c, a.nz, s);
+}
+
+#ifdef SDQN_TIMING
+hipError_t set_timing_buffer_ss(unsigned long long* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sdqn_dbg), &p, sizeof p); }
+#endif
+
+}  // namespace sdqn

@@ -54,11 +54,13 @@ def test_block_tile_fused_unfused_and_menu_entries_agree(sd, A, B):
     mb = random_minibatch(B, A, 50 + B, reward_range=(-2, 3))
     # (fc4 forward / dgrad run on the latency engine by default — too few blocks for this routine to pay there — so the reference of
     #  this comparison selects their block-tile form explicitly: menu entry 1)
+    # (conv2 / conv3 forward run on the sample-stationary routine by default since round 6 — another order of the same sums,
+    #  test_sample_stationary_forward_convolutions — so the reference selects their former built-in block shape: menu entry 6)
     base = [("keep_gradients", 1), ("bt:3", 1), ("bt:5", 1)]
-    ref = _net(sd, A, B, 9, base)
+    ref = _net(sd, A, B, 9, base + [("bt:1", 6), ("bt:2", 6)])
     ref.train(mb)
     g0 = [ref.get_layer(i, 3) for i in range(5)]
-    variants = [[("fused_launches", 0)]]
+    variants = [[("fused_launches", 0), ("bt:1", 6), ("bt:2", 6)]]
     variants += [[("bt:1", m), ("bt:2", m), ("bt:3", m), ("bt:5", m), ("bt:16", min(m, 4)), ("bt:17", min(m, 4))] for m in (1, 2, 3, 4, 5)]
     for opts in variants:
         net = _net(sd, A, B, 9, base + opts)
@@ -171,3 +173,30 @@ def test_conv1_forward_forms_at_large_batch(sd, A, B):
     for k in (0, 1):
         assert np.array_equal(outs[0][k], outs[2][k]) and np.abs(outs[0][k]).max() > 0
         assert np.abs(outs[0][k] - outs[1][k]).max() <= 1e-6 * np.abs(outs[1][k]).max()
+
+
+@pytest.mark.parametrize("A,B", [(3, 256), (6, 160), (4, 136), (4, 128), (3, 129)])
+def test_sample_stationary_forward_convolutions(sd, A, B):
+    """Round 6: conv2 / conv3 forward at B >= 128 on the sample-stationary routine (csrc/conv_ss.h: whole samples staged once in LDS,
+    im2col at ds_read time, weights streamed through an LDS ring, exact-fp32 16 x 16 x 4 MFMA, specialised staging waves).  Same
+    products, one accumulator per output, another k order than the block-tile routine (menu entry 6, the former default): every
+    activation agrees to fp32 round-off — two samples per workgroup (2 B > 256), one (B = 128), an odd batch whose last workgroup
+    holds one sample (B = 129) — and the result is bit-stable from run to run and from net to net."""
+    mb = random_minibatch(B, A, 300 + B, reward_range=(-2, 3))
+    new = _net(sd, A, B, 31, [("keep_gradients", 1)])
+    again = _net(sd, A, B, 31, [("keep_gradients", 1)])
+    old = _net(sd, A, B, 31, [("keep_gradients", 1), ("bt:1", 6), ("bt:2", 6)])
+    for n in (new, again, old):
+        n.train(mb)
+    for name, cnt in dict(a2=2 * B * 81 * 64, a3=2 * B * 49 * 64, a4=2 * B * 512).items():
+        x, y = new.debug_read(name, cnt), old.debug_read(name, cnt)
+        assert _rel(x, y) < 2e-6, (name, _rel(x, y))
+        assert np.array_equal(x, again.debug_read(name, cnt)), name
+    assert np.abs(new.last_q()[0] - old.last_q()[0]).max() < 2e-6
+    for i in range(5):
+        assert np.array_equal(new.get_layer(i, 3), again.get_layer(i, 3)), i
+    new.train(mb); again.train(mb); old.train(mb)      # a second step from the updated weights: still the same bits
+    assert np.array_equal(new.debug_read("a3", 2 * B * 49 * 64), again.debug_read("a3", 2 * B * 49 * 64))
+    # predict() (one net) takes the same routine
+    q1, q2 = new.predict(mb[0]), old.predict(mb[0])
+    assert np.abs(q1 - q2).max() < 1e-4
