@@ -44,38 +44,64 @@ constexpr int NR = 4;             // weight-chunk ring
 constexpr int FC = 3;             // chunks of the tile-by-tile final phase
 constexpr int NSTG = 256;         // staging threads (waves 4..7)
 
-template <int HI_, int WI_, int CI_, int R_, int S_, int ST_, int PO_, int QO_, int NS_>
+template <int HI_, int WI_, int CI_, int R_, int S_, int ST_, int PO_, int QO_, int NS_, int PPAD_, int RPAD_, int SPAD_>
 struct Cfg {
   static constexpr int HI = HI_, WI = WI_, CI = CI_, R = R_, S = S_, ST = ST_, PO = PO_, QO = QO_, NS = NS_;
-  static constexpr int PITCH = CI + 4;                  // floats per pixel of the LDS image
-  static constexpr int IMG = HI * WI * PITCH;           // floats per sample image
+  // LDS image of a sample: pixel pitch CI + PPAD floats, row pitch WI PITCH + RPAD, sample pitch HI RPITCH + SPAD.  The paddings are
+  // searched (tools/exp/ss_bank_search.py) so that the 16 lanes of every ds_read_b128 group — tile rows {0-3, 12-15} at k-slot kq and
+  // rows {4-11} at kq + 1 — hit 16 different 16-byte bank groups in EVERY tile, output-row wraps and the sample seam included: with the
+  // plain CI + 4 pitch a third of the reads were 2- or 3-way conflicts and a conv2 chunk took 3 340 cycles instead of 3 070
+  static constexpr int PITCH = CI + PPAD_;              // floats per pixel of the LDS image
+  static constexpr int RPITCH = WI * PITCH + RPAD_;     // floats per image row
+  static constexpr int IMG = HI * RPITCH + SPAD_;       // floats per sample image
+  static_assert(PPAD_ % 4 == 0 && RPAD_ % 4 == 0 && SPAD_ % 4 == 0, "16-byte aligned pieces");
   static constexpr int NPOS = PO * QO;
-  static constexpr int NT = (NS * NPOS + 15) / 16;      // tiles of 16 output positions per workgroup
+  // tiles of 16 output positions per workgroup.  81 = 5 x 16 + 1 and 49 = 3 x 16 + 1: a padded tile for the 1-2 positions left over
+  // would be a tenth (conv2) / a seventh (conv3) of the matrix work.  They are computed by the STAGING waves instead, on the vector
+  // ALU, under the matrix waves' MFMAs: LV positions x 64 maps, every staging wave a quarter of each chunk's channels
+  static constexpr int LV = (NS * NPOS) % 16 <= 4 ? (NS * NPOS) % 16 : 0;
+  static constexpr int NT = LV ? (NS * NPOS) / 16 : (NS * NPOS + 15) / 16;
   static constexpr int NCH = R * S, KO = NCH - FC;      // weight chunks = kernel taps (r, s); the first KO with K as the outer loop
   static constexpr int GR = CI / 16;                    // 16-channel groups per chunk (4 MFMA steps each)
   static constexpr int WCH = CI * WPITCH;               // floats per staged weight chunk
   static constexpr int OUTT = 16 * WPITCH;              // floats per collected output tile
   static constexpr int LDS = NS * IMG + NR * WCH + 2 * OUTT;
   static_assert(LDS * 4 <= 160 * 1024, "LDS budget");
-  static_assert(CI % 16 == 0 && (CI / 16) % 2 == 0 && KO >= S && S >= 3 && NCH > NR, "chunk schedule");
+  static_assert(4 * LV * NO <= WCH && 2 * OUTT <= WCH, "the left-over positions' partial sums (and nothing else) live in the ring slot the final phase leaves free");
+  static_assert(FC * (CI / 16) >= 4, "a pair's collection rides in the next pair's first four steps");
+  static_assert(CI % 16 == 0 && (CI / 16) % 2 == 0 && KO >= S && S >= 3 && NCH > NR && (KO % S == 0 || KO % S + FC == S), "chunk schedule (the final phase stays inside ONE kernel row or starts one)");
   // staging geometry: 16-byte pieces
   static constexpr int PPX = CI / 4;                    // pieces per pixel
   static constexpr int ROWP = WI * PPX;                 // pieces per image row
   static constexpr int WP = CI * NO / 4 / NSTG;         // pieces of a weight chunk per staging thread
   static_assert(WP * NSTG * 4 == CI * NO, "whole weight pieces per thread");
-  // image rows: kernel row r = 0 needs rows ST p (p < PO) — loaded before the first MFMA; the other rows ("rest") arrive under the
-  // first S - 2 chunks (they are first needed by chunk S = kernel row 1)
-  static constexpr bool row_is_first(int h) { return h % ST == 0 && h / ST < PO; }
-  static constexpr int n_rest() { int n = 0; for (int h = 0; h < HI; ++h) if (!row_is_first(h)) ++n; return n; }
-  static constexpr int rest_row(int i) { int n = 0; for (int h = 0; h < HI; ++h) if (!row_is_first(h)) { if (n == i) return h; ++n; } return HI - 1; }
+  // ORDER of the kernel rows in the K loop: the rows congruent to 0 modulo the stride first (conv2, stride 2: r = 0, 2, 1, 3).  Kernel
+  // row r needs image rows ST p + r: r = 0 and r = 2 share all but one of theirs, so the other parity — half of the input — is first
+  // needed by chunk 8 of 16 instead of chunk 4, and its loads spread over five intervals instead of two (every CU asks for its rows at
+  // the same time: 14 MB in two intervals were HBM-bandwidth-bound and the staging waves reached the barriers late).  The weight chunks
+  // stream in the same order (logical chunk i = physical tap (rord(i / S), i % S)); the sum order is the logical one
+  static constexpr int rord(int ri) { int n = 0; for (int res = 0; res < ST; ++res) for (int r = res; r < R; r += ST) { if (n == ri) return r; ++n; } return R - 1; }
+  static constexpr int need_ri(int h) { for (int ri = 0; ri < R; ++ri) { const int d = h - rord(ri); if (d >= 0 && d % ST == 0 && d / ST < PO) return ri; } return R; }
+  // image rows: the first kernel row's (need_ri == 0) are loaded before the first MFMA; the others ("rest", in the order they are
+  // needed) PR (sample, row) entries per interval, committed LAG intervals after their loads were issued
+  static constexpr int n_rest() { int n = 0; for (int h = 0; h < HI; ++h) if (need_ri(h) >= 1 && need_ri(h) < R) ++n; return n; }
+  static constexpr int rest_row(int i) { int n = 0; for (int ri = 1; ri < R; ++ri) for (int h = 0; h < HI; ++h) if (need_ri(h) == ri) { if (n == i) return h; ++n; } return HI - 1; }
+  static constexpr int first_row(int i) { int n = 0; for (int h = 0; h < HI; ++h) if (need_ri(h) == 0) { if (n == i) return h; ++n; } return HI - 1; }
   static constexpr int NREST = n_rest();
+  static constexpr int NQ = NS * NREST;                 // rest entries: entry q = (row rest_row(q / NS), sample q % NS)
+  // entry q, issued in interval q / pr and committed lag intervals later, is visible at barrier #(q / pr + lag + 1); the matrix waves
+  // read the first fragments of chunk need_ri S one barrier early, i.e. behind barrier #(need_ri S - 1)
+  static constexpr bool sched_ok(int pr, int lag) { for (int q = 0; q < NQ; ++q) if (q / pr + lag + 1 > need_ri(rest_row(q / NS)) * S - 1) return false; return true; }
+  static constexpr int pick_pr(int lag) { for (int pr = 1; pr <= NQ; ++pr) if (sched_ok(pr, lag)) return pr; return 0; }
+  static constexpr int LAG = NQ == 0 ? 1 : (pick_pr(2) ? 2 : 1);
+  static constexpr int PR = NQ == 0 ? 0 : pick_pr(LAG);                                           // rest entries per interval
+  static constexpr int NI = PR ? (NQ + PR - 1) / PR : 0;                                          // intervals that issue rest rows
+  static_assert(NQ == 0 || (PR > 0 && NI - 1 + LAG < KO), "the rest rows arrive in time");
   // a staging pass moves ONE image row: lane lid < ROWP its piece lid (uniform row base + a per-lane constant: no address arithmetic
   // per piece — the piece-linear map p = lid + 256 j cost ~50 VALU instructions per piece in divisions, or a serial walk, in front of
   // the first load)
   static_assert(ROWP <= NSTG, "one row per pass");
   static constexpr int P0 = NS * PO;                                                              // first-row passes
-  static constexpr int RPARTS = S - 2;                                                            // intervals that carry rest rows (visible at barrier #(S - 1): the matrix waves read chunk S's first fragments one barrier early)
-  static constexpr int PR = NREST > 0 ? (NS * NREST + RPARTS - 1) / RPARTS : 0;                  // rest-row passes per interval
 };
 
 struct Args {
@@ -111,10 +137,11 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
     const float* const isrc = c.in + ((int64_t)z * c.B + n0) * (C::HI * C::WI * C::CI);
     f32x4 wv[NR][C::WP];                                                 // weight chunks in flight (prologue: four; later one)
     f32x4 r0[C::P0];                                                     // first rows
-    f32x4 rr[C::PR > 0 ? C::PR : 1];                                     // one interval's share of the rest rows
+    f32x4 rr[C::LAG][C::PR > 0 ? C::PR : 1];                             // the rest rows in flight: LAG intervals' worth
     auto w_issue = [&](int ch, f32x4* q) {
+      const int pc = C::rord(ch / C::S) * C::S + ch % C::S;              // logical chunk ch = physical tap (rord(ch / S), ch % S)
 #pragma unroll
-      for (int j = 0; j < C::WP; ++j) q[j] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)ch * (C::CI * NO) + 4 * (lid + NSTG * j));
+      for (int j = 0; j < C::WP; ++j) q[j] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)pc * (C::CI * NO) + 4 * (lid + NSTG * j));
     };
     auto w_commit = [&](int ch, const f32x4* q) {
       float* dst = wr + (ch % NR) * C::WCH;
@@ -130,18 +157,46 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
       const int se = s_ < nvalid ? s_ : nvalid - 1;                      // (an odd batch's missing sample: a duplicate nobody stores)
       return *reinterpret_cast<const f32x4*>(rsrc + (se * C::HI + row) * (C::WI * C::CI));
     };
-    auto row_commit = [&](int s_, int row, const f32x4& v) { if (rlane) *reinterpret_cast<f32x4*>(rdst + s_ * C::IMG + row * (C::WI * C::PITCH)) = v; };
+    auto row_commit = [&](int s_, int row, const f32x4& v) { if (rlane) *reinterpret_cast<f32x4*>(rdst + s_ * C::IMG + row * C::RPITCH) = v; };
+    // the left-over positions (Cfg::LV): lane = output map lid & 63, wave lid >> 6 = channel quarter; chunk ch = tap (r, s): CI / 4
+    // products per position, operands from LDS (the patch value is the same address in every lane: a broadcast read), fmaf chain =
+    // what the MFMA does per k-slot; the four waves' partial sums are added in wave order at the end
+    // (not free: fp32 MFMA runs on the vector ALU's multipliers, and every vector instruction of this wave costs the matrix wave it shares
+    //  the SIMD with ~10 cycles — 160 per conv2 chunk against 256+ for the padded tile; v_pk_fma_f32 pairs of positions: 250, worse)
+    float lacc[C::LV > 0 ? C::LV : 1];
+#pragma unroll
+    for (int l = 0; l < C::LV; ++l) lacc[l] = 0.0f;
+    auto left_chunk = [&](int ch) {
+      if constexpr (C::LV > 0) {
+        constexpr int CQ = C::CI / 4;
+        const int r = C::rord(ch / C::S), s_ = ch % C::S, wq = lid >> 6;
+        const float* const wsl = wr + (ch % NR) * C::WCH + (wq * CQ) * WPITCH + (lid & 63);
+#pragma unroll
+        for (int l = 0; l < C::LV; ++l) {
+          const int P = 16 * C::NT + l, sp = P / C::NPOS, pos = P - sp * C::NPOS, pp = pos / C::QO, qq = pos - pp * C::QO;
+          const float* const asl = img + sp * C::IMG + (C::ST * pp + r) * C::RPITCH + (C::ST * qq + s_) * C::PITCH + wq * CQ;
+#pragma unroll
+          for (int c4 = 0; c4 < CQ; c4 += 4) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(asl + c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lacc[l] = __builtin_fmaf(a4[e], wsl[(c4 + e) * WPITCH], lacc[l]);
+          }
+        }
+      }
+    };
     // ---- prologue: chunk 0 and the first rows are what the first MFMA waits for; chunks 1..3 fly behind them ----
     w_issue(0, wv[0]);
 #pragma unroll
-    for (int j = 0; j < C::P0; ++j) r0[j] = row_issue(j / C::PO, C::ST * (j % C::PO));
+    for (int j = 0; j < C::P0; ++j) r0[j] = row_issue(j / C::PO, C::first_row(j % C::PO));
 #pragma unroll
     for (int d = 1; d < NR; ++d) w_issue(d, wv[d]);
     w_commit(0, wv[0]);
 #pragma unroll
-    for (int j = 0; j < C::P0; ++j) row_commit(j / C::PO, C::ST * (j % C::PO), r0[j]);
+    for (int j = 0; j < C::P0; ++j) row_commit(j / C::PO, C::first_row(j % C::PO), r0[j]);
     w_commit(1, wv[1]);                                                  // (the matrix waves prefetch chunk 1's first fragments before barrier #1)
+#if !defined(SS_ABL) || SS_ABL != 9
     SS_STAMP_T(256, 6);
+#endif
     stg_barrier();                                                     // barrier #0
     // ---- K-outer intervals: commit what the previous interval issued, issue chunk i + 4 and a share of the rest rows ----
 #pragma unroll
@@ -152,13 +207,11 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
       if (i == 0) {
 #pragma unroll
         for (int d = 2; d < NR; ++d) w_commit(d, wv[d]);
-      } else {
-        w_commit(i + 3, wv[0]);
-        if constexpr (C::PR > 0) {
-          if (i - 1 < C::RPARTS) {
+      } else w_commit(i + 3, wv[0]);
+      if constexpr (C::PR > 0) {
+        if (i >= C::LAG && i - C::LAG < C::NI) {
 #pragma unroll
-            for (int j = 0; j < C::PR; ++j) { const int q = (i - 1) * C::PR + j; if (q < C::NS * C::NREST) row_commit(q / C::NREST, C::rest_row(q % C::NREST), rr[j]); }
-          }
+          for (int j = 0; j < C::PR; ++j) { const int q = (i - C::LAG) * C::PR + j; if (q < C::NQ) row_commit(q % C::NS, C::rest_row(q / C::NS), rr[i % C::LAG][j]); }
         }
       }
 #ifdef SDQN_TIMING
@@ -166,11 +219,15 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
 #endif
       if (i + 4 < C::NCH) w_issue(i + 4, wv[0]);
       if constexpr (C::PR > 0) {
-        if (i < C::RPARTS) {
+        if (i < C::NI) {
 #pragma unroll
-          for (int j = 0; j < C::PR; ++j) { const int q = i * C::PR + j; if (q < C::NS * C::NREST) rr[j] = row_issue(q / C::NREST, C::rest_row(q % C::NREST)); }
+          for (int j = 0; j < C::PR; ++j) { const int q = i * C::PR + j; if (q < C::NQ) rr[i % C::LAG][j] = row_issue(q % C::NS, C::rest_row(q / C::NS)); }
         }
       }
+#ifdef SDQN_TIMING
+      if (!(c.dbg & 8))
+#endif
+      left_chunk(i);                                                   // (chunk i sits in its ring slot until interval i + 1 refills it)
       stg_barrier();                                                   // barrier #(i + 1)
     }
     // ---- final phase: finished tiles, two per round, leave as whole 256-byte rows ----
@@ -178,6 +235,13 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
     const int nrows = nvalid * C::NPOS;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, nrows * NO * 4, 0x00020000);
     const int orow = lid >> 4, ocol = 4 * (lid & 15);
+    float* const lpart = wr + ((C::KO + FC) % NR) * C::WCH;              // the ring slot of chunk KO - 1: free from barrier #KO on
+    if constexpr (C::LV > 0) {
+#pragma unroll
+      for (int f = 0; f < FC; ++f) left_chunk(C::KO + f);
+#pragma unroll
+      for (int l = 0; l < C::LV; ++l) lpart[((lid >> 6) * C::LV + l) * NO + (lid & 63)] = lacc[l];      // (visible behind the first round's barriers)
+    }
 #pragma unroll 1
     for (int t0 = 0; t0 < C::NT; t0 += 2) {
       stg_barrier();                                                   // B: the matrix waves may overwrite the collection buffers
@@ -188,74 +252,101 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(outl + u * C::OUTT + orow * WPITCH + ocol);
         u32x4 w;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(v[e]);
-        const int off = (P < nrows ? P * NO + ocol : nrows * NO) * 4;     // (past the end: dropped by the buffer's range check)
+        for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(fmaxf(v[e], 0.0f));      // Rectlin (deepqnetwork.py:85-87)
+        const int off = (P < nrows && t0 + u < C::NT ? P * NO + ocol : nrows * NO) * 4;     // (past the end: dropped by the buffer's range check)
+#ifdef SDQN_TIMING
+        if (c.dbg & 4) continue;
+#endif
         if (c.wt) __builtin_amdgcn_raw_buffer_store_b128(w, rs, off, 0, 16); else __builtin_amdgcn_raw_buffer_store_b128(w, rs, off, 0, 0);
       }
     }
+    if constexpr (C::LV > 0) {                                           // the left-over positions: four partial sums in wave order, Rectlin, one 256-byte row each
+      if (lid < C::LV * NO) {
+        const int l = lid >> 6, n = lid & 63, P = 16 * C::NT + l;
+        const float* const q = lpart + l * NO + n;
+        const float v = ((q[0] + q[C::LV * NO]) + q[2 * C::LV * NO]) + q[3 * C::LV * NO];
+        if (P < nrows) {
+          float* const dst = obase + (size_t)P * NO + n;
+          if (c.wt) __hip_atomic_store(dst, fmaxf(v, 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = fmaxf(v, 0.0f);
+        }
+      }
+    }
+#if !defined(SS_ABL) || SS_ABL != 9
     SS_STAMP_T(256, 7);
+#endif
     return;
   }
 
   // ================= matrix waves: wave w owns output maps 16 w .. 16 w + 15 of every position =================
+  // MFMA operand roles: the WEIGHTS are the row operand (lane (m, kq): W[k-slot kq][map 16 w + m]), the patches the column operand (lane
+  // (m, kq): position m of the tile, k-slot kq), so D[map][position]: a lane ends up with maps 16 w + 4 kq .. + 3 of position m — one
+  // 16-byte LDS store per finished tile
   const int m = lane & 15, kq = lane >> 4;
-  int abase[C::NT];                                                      // float index of this lane's patch origin per tile (+ its 4 channels)
+  int ap[C::NT];                                                         // float index in img of this lane's patch origin per tile (+ its 4 channels), at the CURRENT kernel row
 #pragma unroll
   for (int t = 0; t < C::NT; ++t) {
     int P = 16 * t + m; if (P > C::NS * C::NPOS - 1) P = C::NS * C::NPOS - 1;
     const int s = P / C::NPOS, pos = P - s * C::NPOS, p = pos / C::QO, q = pos - p * C::QO;
-    abase[t] = s * C::IMG + ((C::ST * p) * C::WI + C::ST * q) * C::PITCH + 4 * kq;
+    ap[t] = s * C::IMG + (C::ST * p) * C::RPITCH + (C::ST * q) * C::PITCH + 4 * kq;
+    // (one register per tile, unrelated as far as hipcc knows: it otherwise derives the origins of the second sample's tiles from the
+    //  first's with a v_add of a 32-bit literal in front of every read whose offset no longer fits the 16-bit field — between the MFMAs)
+    asm volatile("" : "+v"(ap[t]));
   }
-  const int wlane = (4 * kq) * WPITCH + 16 * wave + m;                   // B fragment: k-row 4 kq (+ 16 g + j), map 16 w + m
+  const float* const wl = wr + (4 * kq) * WPITCH + 16 * wave + m;        // B fragment: k-row 4 kq (+ 16 g + j), map 16 w + m
   f32x4 acc[C::NT];
 #pragma unroll
   for (int t = 0; t < C::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   SS_STAMP_T(0, 0);
+  __builtin_amdgcn_s_setprio(3);                                         // (the staging wave on this SIMD issues its vector work in the MFMAs' shadow, never in front of one)
   __syncthreads();                                                       // barrier #0
   SS_STAMP_T(0, 1);
-  // K-outer phase, software-pipelined by hand: the fragments of group (i, gq + 1) — or of (i + 1, 0) — are read from LDS while the MFMAs
-  // of group (i, gq) run (left alone hipcc reads a whole chunk's fragments at the top of the iteration and waits for them).  Reading
-  // chunk i + 1's first group BEFORE barrier #(i + 1) is safe: weight chunk i + 1 and the image rows it needs are visible since
-  // barrier #i at the latest (the staging waves' schedule above)
+  // K-outer phase, software-pipelined by hand: the fragments of the NEXT group — (i, gq + 1), or (i + 1, 0) — are read from LDS while the
+  // MFMAs of group (i, gq) run (left alone hipcc reads a whole chunk's fragments at the top of the iteration and waits for them).
+  // Reading chunk i + 1's first group BEFORE barrier #(i + 1) is safe: weight chunk i + 1 and the image rows it needs are visible since
+  // barrier #i at the latest (the staging waves' schedule above).  The loop runs over kernel ROWS with the S taps of a row unrolled:
+  // every fragment address is then ap[t] + a compile-time offset (tap s, channel group, next row) — with a run-time chunk index the 11-22
+  // v_add_u32 per chunk sat between the MFMAs and cost ~270 cycles per chunk (an issue slot between two MFMAs is not free)
+  constexpr int RK = C::KO / C::S, TAIL = C::KO - RK * C::S;             // whole kernel rows of the K-outer phase + taps of a partial one
   f32x4 av[2][C::NT];
   float bv[2][4];
-  auto load_group = [&](f32x4* a_, float* b_, int i, int gq) {
+  // group (dr, s_, gq): kernel row (current + dr), tap s_, channels 16 gq ..; ring slot of its chunk: compile-time when S == NR
+  auto load_group = [&](f32x4* a_, float* b_, int dr, int s_, int gq, int slot) {
 #if defined(SS_ABL) && SS_ABL == 2
     return;
 #endif
-#if defined(SS_ABL) && (SS_ABL == 3 || SS_ABL == 1)
-    i = 0;
-#endif
-    const int r = i / C::S, s = i - r * C::S;
-    const float* const ai = img + (r * C::WI + s) * C::PITCH + 16 * gq;
-    const float* const wi = wr + (i % NR) * C::WCH + wlane + (16 * gq) * WPITCH;
+    const float* const wi = wl + slot * C::WCH + (16 * gq) * WPITCH;
 #pragma unroll
     for (int j = 0; j < 4; ++j) b_[j] = wi[j * WPITCH];
 #pragma unroll
-    for (int t = 0; t < C::NT; ++t) a_[t] = *reinterpret_cast<const f32x4*>(ai + abase[t]);
-#if defined(SS_ABL) && SS_ABL == 1
-#pragma unroll
-    for (int t = 0; t < C::NT; ++t) a_[t] = *reinterpret_cast<const f32x4*>(img + (16 * t + m) * 36 + 4 * kq + 16 * gq);
-#endif
+    for (int t = 0; t < C::NT; ++t) a_[t] = *reinterpret_cast<const f32x4*>(img + ap[t] + dr * C::RPITCH + s_ * C::PITCH + 16 * gq);
   };
-  load_group(av[0], bv[0], 0, 0);
-#pragma unroll 1
-  for (int i = 0; i < C::KO; ++i) {
+  auto mfma_group = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < C::NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[buf][j], av[buf][t][j], acc[t], 0, 0, 0);
+    // the next group's reads, ONE between every three MFMAs: issued as a burst at the top of the group (all four matrix waves at once,
+    // right behind the barrier) they fill the LDS queue and the in-order wave cannot issue its next MFMA for 300-400 cycles per group
+#pragma unroll
+    for (int q = 0; q < C::NT + 2; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * C::NT - 3 * (C::NT + 2), 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // one chunk = tap s_ of the current kernel row; `i` = its logical chunk index (ring slot i % NR); `bump` != 0: the row's last tap — the
+  // tile origins move to the next kernel row of the order (by bump floats) before its first group is read; `last`: nothing to read behind it
+  auto chunk = [&](int i, int s_, int bump, bool row_end, bool last) {
 #pragma unroll
     for (int gq = 0; gq < C::GR; ++gq) {
-      if (gq + 1 < C::GR) load_group(av[(gq + 1) & 1], bv[(gq + 1) & 1], i, gq + 1);
-      else load_group(av[(gq + 1) & 1], bv[(gq + 1) & 1], i + 1 < C::KO ? i + 1 : i, 0);
+      const int nb = (gq + 1) & 1;
+      if (gq + 1 < C::GR) load_group(av[nb], bv[nb], 0, s_, gq + 1, i % NR);
+      else if (!last) {
+        if (row_end) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int t = 0; t < C::NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[gq & 1][t][j], bv[gq & 1][j], acc[t], 0, 0, 0);
-      // the next group's reads, ONE between every three MFMAs: issued as a burst at the top of the group (all four matrix waves at once,
-      // right behind the barrier) they fill the LDS queue and the in-order wave cannot issue its next MFMA for 300-400 cycles per group
-      // (tools/exp/ss_stamps.py: 3 750-4 500 cycles per conv2 chunk against 2 816 of matrix time)
-#pragma unroll
-      for (int q = 0; q < C::NT + 2; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * C::NT - 3 * (C::NT + 2), 0);
-      __builtin_amdgcn_sched_barrier(0);
+          for (int t = 0; t < C::NT; ++t) ap[t] += bump;                 // (this group's fragments are in registers already)
+          load_group(av[nb], bv[nb], 0, 0, 0, (i + 1) % NR);
+        } else load_group(av[nb], bv[nb], 0, s_ + 1, 0, (i + 1) % NR);
+      }
+      mfma_group(gq & 1);
     }
     // barrier #(i + 1), WITHOUT __syncthreads()'s fence: that would drain lgkmcnt and expose the reads just issued for chunk i + 1.  This
     // wave wrote nothing; the operand makes the wait for chunk i's last B fragments (and, LDS reads returning in order, for every read of
@@ -264,47 +355,84 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
     if (!(c.dbg & 2))
 #endif
     asm volatile("s_barrier" :: "v"(bv[(C::GR - 1) & 1][3]) : "memory");
+  };
+#pragma unroll
+  for (int t = 0; t < C::NT; ++t) ap[t] += C::rord(0) * C::RPITCH;
+  load_group(av[0], bv[0], 0, 0, 0, 0);
+#pragma unroll 1
+  for (int ri = 0; ri < RK; ++ri) {
+    int bump = 0;
+#pragma unroll
+    for (int q = 0; q < RK; ++q) if (ri == q) bump = (C::rord(q + 1) - C::rord(q)) * C::RPITCH;
+#pragma unroll
+    for (int s_ = 0; s_ < C::S; ++s_) {
+      chunk(C::S == NR ? s_ : ri * C::S + s_, s_, bump, s_ + 1 == C::S, false);     // (the last row's final read: the tail's / the final phase's first group — harmless)
 #ifdef SDQN_TIMING
-    if (i == 0) SS_STAMP_T(0, 2);
-    if (i == 4) SS_STAMP_T(0, 3);
+#if !defined(SS_ABL) || SS_ABL != 9
+      if (ri == 0 && s_ == 0) SS_STAMP_T(0, 2);
+      if (ri == 1 && s_ == 0) SS_STAMP_T(0, 3);
 #endif
+#endif
+    }
   }
+#pragma unroll
+  for (int s_ = 0; s_ < TAIL; ++s_) chunk(RK * C::S + s_, s_, 0, false, s_ + 1 == TAIL);
   SS_STAMP_T(0, 4);
-  // ---- final phase: the last FC chunks tile by tile, B fragments in registers ----
+  // ---- final phase: the last FC chunks (taps TAIL .. of kernel row RK, and on), two tiles at a time, B fragments in registers; a step =
+  // one 16-channel group of one tap for both tiles of the pair (8 MFMAs), its two A fragments read two steps ahead through a ring of
+  // three, across pair boundaries too — the collection of a finished pair (barrier B, Rectlin, LDS stores, barrier A) exposes no read ----
   float bf[FC][C::GR][4];
 #pragma unroll
   for (int f = 0; f < FC; ++f)
 #pragma unroll
     for (int gq = 0; gq < C::GR; ++gq)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[f][gq][j] = wr[((C::KO + f) % NR) * C::WCH + wlane + (16 * gq + j) * WPITCH];
+      for (int j = 0; j < 4; ++j) bf[f][gq][j] = wl[((C::KO + f) % NR) * C::WCH + (16 * gq + j) * WPITCH];
+  constexpr int NP = (C::NT + 1) / 2, SPP = FC * C::GR, NSTEP = NP * SPP;     // pairs, steps per pair, steps
+  f32x4 fa[3][2];
+  auto fin_load_a = [&](int u, int w) {                                  // A fragment w (tile of the pair) of step u (compile-time u)
+    const int pi = u / SPP, f = (u % SPP) / C::GR, gq = u % C::GR;
+    const int t0 = 2 * pi, t1 = t0 + 1 < C::NT ? t0 + 1 : t0;
+    const int ci = C::KO + f, dr = 0, s_ = ci % C::S;                    // (the final chunks are taps of kernel row rord(RK): Cfg's chunk-schedule assert)
+    fa[u % 3][w] = *reinterpret_cast<const f32x4*>(img + ap[w ? t1 : t0] + dr * C::RPITCH + s_ * C::PITCH + 16 * gq);
+  };
+  auto fin_load = [&](int u) { fin_load_a(u, 0); fin_load_a(u, 1); };
+  fin_load(0); fin_load(1);
+  // the collection of a finished pair (barrier B: the staging waves have read the previous one; Rectlin + LDS stores; barrier A) rides in
+  // the NEXT pair's steps 1..3 — its accumulators are final and stay where they are, so nothing waits: done at the pair's end it idled the
+  // matrix pipe ~500 cycles per pair (result latency + stores + lgkmcnt(0) + two barriers)
+  auto collect = [&](int pi) {                                           // (raw sums: the staging waves apply the Rectlin on their way out)
+    const int t0 = 2 * pi; const bool two = t0 + 1 < C::NT;
+    *reinterpret_cast<f32x4*>(outl + m * WPITCH + 16 * wave + 4 * kq) = acc[t0];
+    if (two) *reinterpret_cast<f32x4*>(outl + C::OUTT + m * WPITCH + 16 * wave + 4 * kq) = acc[two ? t0 + 1 : t0];
+  };
 #pragma unroll
-  for (int t0 = 0; t0 < C::NT; t0 += 2) {
-    constexpr int NT = C::NT;
-    const bool two = t0 + 1 < NT;
+  for (int u = 0; u < NSTEP; ++u) {
+    const int pi = u / SPP, k = u % SPP, f = k / C::GR, gq = k % C::GR;
+    const int t0 = 2 * pi;
+    const bool two = t0 + 1 < C::NT;
+#if defined(SS_ABL) && SS_ABL == 9
+    if (u == 0) SS_STAMP_T(0, 2);
+    if (u == SPP) SS_STAMP_T(0, 3);
+    if (u == 2 * SPP) SS_STAMP_T(0, 6);
+    if (u == 3 * SPP) SS_STAMP_T(0, 7);
+#endif
+    if (pi > 0 && k == 1) { asm volatile("s_barrier" ::: "memory"); collect(pi - 1); }                          // B (bare: reads in flight)
+    if (pi > 0 && k == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                        // A (the stores and every read issued so far are two steps old)
+    // the order below IS the issue order (a sched_barrier behind every pair of MFMAs): left to itself the scheduler puts the two MFMAs
+    // of ONE accumulator back to back — 40 cycles each instead of 32 (the 16 x 16 x 4 shape's dependent latency)
+    if (u + 2 < NSTEP) fin_load_a(u + 2, 0);
 #pragma unroll
-    for (int f = 0; f < FC; ++f) {
-      const int r = (C::KO + f) / C::S, s = (C::KO + f) - r * C::S;
-      const float* const ai = img + (r * C::WI + s) * C::PITCH;
-#pragma unroll
-      for (int gq = 0; gq < C::GR; ++gq) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(ai + abase[t0] + 16 * gq);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(ai + abase[two ? t0 + 1 : t0] + 16 * gq);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bf[f][gq][j], acc[t0], 0, 0, 0);
-          if (two) acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], bf[f][gq][j], acc[two ? t0 + 1 : t0], 0, 0, 0);
-        }
-      }
+    for (int j = 0; j < 4; ++j) {
+      acc[t0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[f][gq][j], fa[u % 3][0][j], acc[t0], 0, 0, 0);
+      if (two) acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[f][gq][j], fa[u % 3][1][j], acc[two ? t0 + 1 : t0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j == 0 && u + 2 < NSTEP) fin_load_a(u + 2, 1);
     }
-    __syncthreads();                                                     // B: the staging waves have read the previous pair
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      outl[(4 * kq + e) * WPITCH + 16 * wave + m] = fmaxf(acc[t0][e], 0.0f);
-      if (two) outl[C::OUTT + (4 * kq + e) * WPITCH + 16 * wave + m] = fmaxf(acc[two ? t0 + 1 : t0][e], 0.0f);
-    }
-    __syncthreads();                                                     // A
   }
+  asm volatile("s_barrier" ::: "memory");                                // the last pair: B, collection, A
+  collect(NP - 1);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   SS_STAMP_T(0, 5);
 }
 

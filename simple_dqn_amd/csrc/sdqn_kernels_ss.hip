@@ -11,10 +11,11 @@
 namespace sdqn {
 
 // two samples per workgroup when one per workgroup would not fit the chip in one round (nz B > 256 workgroups), else one
-typedef ss::Cfg<P1, Q1, K1, 4, 4, ST2, P2, Q2, 2> C2S2;
-typedef ss::Cfg<P1, Q1, K1, 4, 4, ST2, P2, Q2, 1> C2S1;
-typedef ss::Cfg<P2, Q2, K2, 3, 3, 1, P3, Q3, 2> C3S2;
-typedef ss::Cfg<P2, Q2, K2, 3, 3, 1, P3, Q3, 1> C3S1;
+// (the last three numbers: pixel / row / sample padding of the LDS image in floats — conflict-free fragment reads, tools/exp/ss_bank_search.py)
+typedef ss::Cfg<P1, Q1, K1, 4, 4, ST2, P2, Q2, 2, 4, 20, 56> C2S2;
+typedef ss::Cfg<P1, Q1, K1, 4, 4, ST2, P2, Q2, 1, 4, 20, 0> C2S1;
+typedef ss::Cfg<P2, Q2, K2, 3, 3, 1, P3, Q3, 2, 8, 48, 16> C3S2;
+typedef ss::Cfg<P2, Q2, K2, 3, 3, 1, P3, Q3, 1, 8, 48, 0> C3S1;
 
 hipError_t launch_kernel_ss(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = false;

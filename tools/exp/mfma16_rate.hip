@@ -107,11 +107,14 @@ int run(const char* name, F launch, int grid, int groups, int nt, int cyc_per) {
 }
 
 int main() {
-  const int G = 8000;
+  const int G = 2000;
 #define RUN(V, NT, NTHR, grid, label) run(label, [](int g, float* o, unsigned long long* c, int gr) { hipLaunchKernelGGL((k<V, NT, NTHR>), dim3(g), dim3(NTHR), 0, 0, o, c, gr); }, grid, G, NT, 32)
-  for (int grid : {1, 256}) {
+  for (int grid : {256}) {
     RUN(0, 11, 256, grid, "V0 regs only, NT 11");
     RUN(0, 4, 256, grid, "V0 regs only, NT 4");
+    RUN(0, 3, 256, grid, "V0 regs only, NT 3");
+    RUN(0, 2, 256, grid, "V0 regs only, NT 2");
+    RUN(0, 1, 256, grid, "V0 regs only, NT 1");
     RUN(1, 11, 256, grid, "V1 + ds_read_b128 / 3 MFMA, no conflicts");
     RUN(2, 11, 256, grid, "V2 + ds_read_b128 / 3 MFMA, 2-way+ conflicts");
     RUN(1, 11, 512, grid, "V3 = V1 + 4 parked waves");

@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -DSDQN_TIMING [-DSS_ABL=n] -I simple_dqn_amd/csrc -o ss_bench tools/exp/ss_bench.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include <algorithm>
 #include "conv_ss.h"
@@ -21,7 +22,7 @@ int bench(const char* name, int B) {
   CHK(hipMemcpy(w, hw.data(), 2 * nw * 4, hipMemcpyHostToDevice));
   CHK(hipMemset(dbg, 0, (size_t)nz * G * 64));
   CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_sdqn_dbg), &dbg, sizeof dbg));
-  ss::Args c; c.in = in; c.out = out; c.w[0] = w; c.w[1] = w + nw; c.B = B; c.G = G; c.wt = 1; c.dbg = 0;
+  ss::Args c; c.in = in; c.out = out; c.w[0] = w; c.w[1] = w + nw; c.B = B; c.G = G; c.wt = getenv("SS_WT") ? atoi(getenv("SS_WT")) : 1; c.dbg = getenv("SS_DBG") ? atoi(getenv("SS_DBG")) : 0;
   hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
   for (int r = 0; r < 3; ++r) CHK(ss::launch<C>(c, nz, 0));
   CHK(hipDeviceSynchronize());
@@ -41,13 +42,16 @@ int bench(const char* name, int B) {
 #endif
          ms * 1e3 / 20, med(0, 1), med(1, 2), med(2, 3) / 4, med(2, 3) / 4.0 / mf, C::KO - 1, C::KO > 5 ? med(3, 4) / (C::KO - 5) : 0, C::KO > 5 ? med(3, 4) / (double)(C::KO - 5) / mf : 0.0,
          med(4, 5), 32 * 4 * ss::FC * C::GR * C::NT, med(5, 7));
+#if defined(SS_ABL) && SS_ABL == 9
+  printf("   final phase: K-outer end -> step 0 %lld, pair 0 %lld, pair 1 %lld, pair 2 %lld, rest %lld\n", med(4, 2), med(2, 3), med(3, 6), med(6, 7), med(7, 5));
+#endif
   hipFree(in); hipFree(out); hipFree(w); hipFree(dbg);
   return 0;
 }
 
 int main() {
-  typedef ss::Cfg<P1, Q1, K1, 4, 4, ST2, P2, Q2, 2> C2S2;
-  typedef ss::Cfg<P2, Q2, K2, 3, 3, 1, P3, Q3, 2> C3S2;
+  typedef ss::Cfg<P1, Q1, K1, 4, 4, ST2, P2, Q2, 2, 4, 20, 56> C2S2;
+  typedef ss::Cfg<P2, Q2, K2, 3, 3, 1, P3, Q3, 2, 8, 48, 16> C3S2;
   if (bench<C2S2>("conv2_fwd", 256)) return 1;
   if (bench<C3S2>("conv3_fwd", 256)) return 1;
   return 0;
