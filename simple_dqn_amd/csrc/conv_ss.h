@@ -37,6 +37,7 @@ namespace ss {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NO = 64;            // output maps (conv2 and conv3 alike): four matrix waves x 16
 constexpr int WPITCH = NO + 4;    // floats per k-row of a staged weight chunk: rows k and k + 4 are 16 banks apart (conflict-free B reads)
@@ -57,8 +58,12 @@ struct Cfg {
   static_assert(PPAD_ % 4 == 0 && RPAD_ % 4 == 0 && SPAD_ % 4 == 0, "16-byte aligned pieces");
   static constexpr int NPOS = PO * QO;
   // tiles of 16 output positions per workgroup.  81 = 5 x 16 + 1 and 49 = 3 x 16 + 1: a padded tile for the 1-2 positions left over
-  // would be a tenth (conv2) / a seventh (conv3) of the matrix work.  They are computed by the STAGING waves instead, on the vector
-  // ALU, under the matrix waves' MFMAs: LV positions x 64 maps, every staging wave a quarter of each chunk's channels
+  // would be a tenth (conv2) / a seventh (conv3) of the matrix work.  They run on v_mfma_f32_4x4x1_16b_f32 instead — 16 blocks of 4 x 4,
+  // K = 1, 8 cycles: block b = output maps 4 b .. 4 b + 3 (lane l: W[k][map l]), the 4 rows = up to 4 positions (the same in every
+  // block), so one instruction is one k for LV positions x all 64 maps; every matrix wave takes a quarter of each chunk's channels
+  // (8 such MFMAs per conv2 chunk = 64 cycles against 256 for the padded tile) and the four partial sums meet in LDS at the end.
+  // (First form: the staging waves' vector ALU — fp32 MFMA runs on the same multipliers, and every vector instruction of a staging wave
+  // cost the matrix wave on its SIMD ~10 cycles: 160-390 cycles per chunk, whatever the instruction mix.)
   static constexpr int LV = (NS * NPOS) % 16 <= 4 ? (NS * NPOS) % 16 : 0;
   static constexpr int NT = LV ? (NS * NPOS) / 16 : (NS * NPOS + 15) / 16;
   static constexpr int NCH = R * S, KO = NCH - FC;      // weight chunks = kernel taps (r, s); the first KO with K as the outer loop
@@ -67,8 +72,9 @@ struct Cfg {
   static constexpr int OUTT = 16 * WPITCH;              // floats per collected output tile
   static constexpr int LDS = NS * IMG + NR * WCH + 2 * OUTT;
   static_assert(LDS * 4 <= 160 * 1024, "LDS budget");
-  static_assert(4 * LV * NO <= WCH && 2 * OUTT <= WCH, "the left-over positions' partial sums (and nothing else) live in the ring slot the final phase leaves free");
-  static_assert(FC * (CI / 16) >= 4, "a pair's collection rides in the next pair's first four steps");
+  static_assert(4 * LV * NO <= 2 * OUTT && CI % 16 == 0, "the left-over positions' four partial sums fit a collection buffer");
+  static_assert(2 * OUTT <= WCH, "the second collection buffer is the ring slot the final phase leaves free");
+  static_assert(FC * (CI / 16) >= 4 && FC * (CI / 16) > FC, "a pair's collection rides in the next pair's first four steps, the left-over positions' final chunks in the last pair's first FC + 1");
   static_assert(CI % 16 == 0 && (CI / 16) % 2 == 0 && KO >= S && S >= 3 && NCH > NR && (KO % S == 0 || KO % S + FC == S), "chunk schedule (the final phase stays inside ONE kernel row or starts one)");
   // staging geometry: 16-byte pieces
   static constexpr int PPX = CI / 4;                    // pieces per pixel
@@ -133,57 +139,46 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
     // fence also drains vmcnt, i.e. every interval would wait a memory round trip for the weight chunk it has just requested
     // (measured: 3 640-4 470 cycles per conv2 chunk for 2 816 of matrix time, tools/exp/ss_stamps.py)
     auto stg_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    const float* const wsrc = c.w[z];
+    // Every vector instruction of a staging wave costs the matrix wave on its SIMD ~8-10 cycles of its MFMA stream (fp32 MFMA runs on
+    // the vector ALU's multipliers; measured with the left-over positions' FMAs switched on and off) — so the staging code is written to
+    // issue as few as possible: buffer loads / stores whose per-piece part of the address is a SCALAR offset (one per-lane offset
+    // register for all pieces), LDS addresses = per-lane constant + immediate, the Rectlin and the left-over FMAs on packed-fp32
+    // instructions over NATURAL register pairs (no packing moves)
     const float* const isrc = c.in + ((int64_t)z * c.B + n0) * (C::HI * C::WI * C::CI);
+    // (global loads in their scalar-base form — global_load_dwordx4 v, v_lane_offset, s[base] — the base moved per piece on the scalar
+    //  unit; buffer loads with a scalar offset would do as well, but hipcc waits for them with vmcnt(0) whatever their order)
+    const char* const wsrc = reinterpret_cast<const char*>(c.w[z]);
+    auto ldb = [&](const char* base, unsigned voff, int soff) { return *reinterpret_cast<const f32x4*>(base + soff + voff); };
     f32x4 wv[NR][C::WP];                                                 // weight chunks in flight (prologue: four; later one)
     f32x4 r0[C::P0];                                                     // first rows
     f32x4 rr[C::LAG][C::PR > 0 ? C::PR : 1];                             // the rest rows in flight: LAG intervals' worth
+    const unsigned wvo = 16 * lid;                                            // weight piece lid + 256 j: byte offset 16 lid (+ 4096 j, + the chunk: scalar)
+    float* const wdst = wr + (lid >> 4) * WPITCH + 4 * (lid & 15);       // ... -> LDS k-row (lid >> 4) + 16 j, floats 4 (lid & 15) ..
     auto w_issue = [&](int ch, f32x4* q) {
       const int pc = C::rord(ch / C::S) * C::S + ch % C::S;              // logical chunk ch = physical tap (rord(ch / S), ch % S)
 #pragma unroll
-      for (int j = 0; j < C::WP; ++j) q[j] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)pc * (C::CI * NO) + 4 * (lid + NSTG * j));
+      for (int j = 0; j < C::WP; ++j) q[j] = ldb(wsrc, wvo, pc * (C::CI * NO * 4) + 4096 * j);
     };
     auto w_commit = [&](int ch, const f32x4* q) {
-      float* dst = wr + (ch % NR) * C::WCH;
 #pragma unroll
-      for (int j = 0; j < C::WP; ++j) { const int p = lid + NSTG * j, k = p >> 4, col = p & 15; *reinterpret_cast<f32x4*>(dst + k * WPITCH + 4 * col) = q[j]; }
+      for (int j = 0; j < C::WP; ++j) *reinterpret_cast<f32x4*>(wdst + (ch % NR) * C::WCH + 16 * j * WPITCH) = q[j];
     };
     // image rows, one per pass: lane lid < ROWP moves 16-byte piece lid of the row
     const bool rlane = lid < C::ROWP;
     const int rcp = rlane ? lid : 0;
-    const float* const rsrc = isrc + 4 * rcp;
-    float* const rdst = img + (rcp / C::PPX) * C::PITCH + 4 * (rcp % C::PPX);
+    const unsigned rvo = 16 * rcp;
+    int rdst[C::NS];                                                     // float index in img (one base per sample: the second sample's rows lie beyond the 16-bit offset field;
+#pragma unroll                                                           //  an INDEX, opaque to hipcc: an asm on the pointer itself turns every access through it into a flat one)
+    for (int q = 0; q < C::NS; ++q) { rdst[q] = q * C::IMG + (rcp / C::PPX) * C::PITCH + 4 * (rcp % C::PPX); asm volatile("" : "+v"(rdst[q])); }
     auto row_issue = [&](int s_, int row) {
-      const int se = s_ < nvalid ? s_ : nvalid - 1;                      // (an odd batch's missing sample: a duplicate nobody stores)
-      return *reinterpret_cast<const f32x4*>(rsrc + (se * C::HI + row) * (C::WI * C::CI));
+      const int se = s_ < nvalid ? s_ : nvalid - 1;                      // (an odd batch's missing sample: a duplicate nobody stores; wave-uniform)
+      return ldb(reinterpret_cast<const char*>(isrc), rvo, (se * C::HI + row) * (C::WI * C::CI * 4));
     };
-    auto row_commit = [&](int s_, int row, const f32x4& v) { if (rlane) *reinterpret_cast<f32x4*>(rdst + s_ * C::IMG + row * C::RPITCH) = v; };
-    // the left-over positions (Cfg::LV): lane = output map lid & 63, wave lid >> 6 = channel quarter; chunk ch = tap (r, s): CI / 4
-    // products per position, operands from LDS (the patch value is the same address in every lane: a broadcast read), fmaf chain =
-    // what the MFMA does per k-slot; the four waves' partial sums are added in wave order at the end
-    // (not free: fp32 MFMA runs on the vector ALU's multipliers, and every vector instruction of this wave costs the matrix wave it shares
-    //  the SIMD with ~10 cycles — 160 per conv2 chunk against 256+ for the padded tile; v_pk_fma_f32 pairs of positions: 250, worse)
-    float lacc[C::LV > 0 ? C::LV : 1];
-#pragma unroll
-    for (int l = 0; l < C::LV; ++l) lacc[l] = 0.0f;
-    auto left_chunk = [&](int ch) {
-      if constexpr (C::LV > 0) {
-        constexpr int CQ = C::CI / 4;
-        const int r = C::rord(ch / C::S), s_ = ch % C::S, wq = lid >> 6;
-        const float* const wsl = wr + (ch % NR) * C::WCH + (wq * CQ) * WPITCH + (lid & 63);
-#pragma unroll
-        for (int l = 0; l < C::LV; ++l) {
-          const int P = 16 * C::NT + l, sp = P / C::NPOS, pos = P - sp * C::NPOS, pp = pos / C::QO, qq = pos - pp * C::QO;
-          const float* const asl = img + sp * C::IMG + (C::ST * pp + r) * C::RPITCH + (C::ST * qq + s_) * C::PITCH + wq * CQ;
-#pragma unroll
-          for (int c4 = 0; c4 < CQ; c4 += 4) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(asl + c4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) lacc[l] = __builtin_fmaf(a4[e], wsl[(c4 + e) * WPITCH], lacc[l]);
-          }
-        }
-      }
-    };
+#if defined(SS_ABL) && SS_ABL == 7
+    auto row_commit = [&](int s_, int row, const f32x4& v) { *reinterpret_cast<f32x4*>(img + rdst[s_] + row * C::RPITCH) = v; };      // (timing experiment: no lane mask)
+#else
+    auto row_commit = [&](int s_, int row, const f32x4& v) { if (rlane) *reinterpret_cast<f32x4*>(img + rdst[s_] + row * C::RPITCH) = v; };
+#endif
     // ---- prologue: chunk 0 and the first rows are what the first MFMA waits for; chunks 1..3 fly behind them ----
     w_issue(0, wv[0]);
 #pragma unroll
@@ -224,10 +219,6 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
           for (int j = 0; j < C::PR; ++j) { const int q = i * C::PR + j; if (q < C::NQ) rr[i % C::LAG][j] = row_issue(q % C::NS, C::rest_row(q / C::NS)); }
         }
       }
-#ifdef SDQN_TIMING
-      if (!(c.dbg & 8))
-#endif
-      left_chunk(i);                                                   // (chunk i sits in its ring slot until interval i + 1 refills it)
       stg_barrier();                                                   // barrier #(i + 1)
     }
     // ---- final phase: finished tiles, two per round, leave as whole 256-byte rows ----
@@ -235,35 +226,39 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
     const int nrows = nvalid * C::NPOS;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)obase, 0, nrows * NO * 4, 0x00020000);
     const int orow = lid >> 4, ocol = 4 * (lid & 15);
-    float* const lpart = wr + ((C::KO + FC) % NR) * C::WCH;              // the ring slot of chunk KO - 1: free from barrier #KO on
-    if constexpr (C::LV > 0) {
-#pragma unroll
-      for (int f = 0; f < FC; ++f) left_chunk(C::KO + f);
-#pragma unroll
-      for (int l = 0; l < C::LV; ++l) lpart[((lid >> 6) * C::LV + l) * NO + (lid & 63)] = lacc[l];      // (visible behind the first round's barriers)
-    }
+    // the collection buffers alternate: round p (tiles 2 p, 2 p + 1) in outl (even p) / in the ring slot of chunk KO - 1, free from
+    // barrier #KO on (odd p).  ONE barrier per round: A (p) publishes round p, and — this wave reaches it only after it has read round
+    // p - 1 — tells the matrix waves that round p - 1's buffer may be overwritten (by round p + 1).  Between A (p) and A (p + 1) lie the
+    // MFMAs of a whole pair (1 500+ cycles): room for the ~30 vector instructions of a round, of which the staging wave gets about one
+    // into every gap of its SIMD's MFMA stream
+    const int ovo = (orow * NO + ocol) * 4;                              // byte offset of this lane's piece inside a tile's 16 rows (+ the tile: scalar)
+    const int olane = orow * WPITCH + ocol;                              // (integer indexes: a run-time choice between two POINTERS makes hipcc read through a flat one)
+    const int obuf1 = (int)(((C::KO + FC) % NR) * C::WCH) - NR * C::WCH;   // the second buffer relative to outl (it lies in front of it)
+    constexpr int NP = (C::NT + 1) / 2;
 #pragma unroll 1
-    for (int t0 = 0; t0 < C::NT; t0 += 2) {
-      stg_barrier();                                                   // B: the matrix waves may overwrite the collection buffers
-      stg_barrier();                                                   // A: both tiles are collected
+    for (int pi = 0; pi < NP; ++pi) {
+      stg_barrier();                                                   // A of round pi: both tiles are collected
+      const float* const ob = outl + olane + ((pi & 1) ? obuf1 : 0);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int P = 16 * (t0 + u) + orow;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(outl + u * C::OUTT + orow * WPITCH + ocol);
-        u32x4 w;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(fmaxf(v[e], 0.0f));      // Rectlin (deepqnetwork.py:85-87)
-        const int off = (P < nrows && t0 + u < C::NT ? P * NO + ocol : nrows * NO) * 4;     // (past the end: dropped by the buffer's range check)
+        const int t = 2 * pi + u;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ob + u * C::OUTT);
+        const f32x2 z2 = {0.0f, 0.0f};
+        const f32x2 lo = __builtin_elementwise_max(__builtin_shufflevector(v, v, 0, 1), z2), hi = __builtin_elementwise_max(__builtin_shufflevector(v, v, 2, 3), z2);   // Rectlin (deepqnetwork.py:85-87)
+        const u32x4 w = {__float_as_uint(lo[0]), __float_as_uint(lo[1]), __float_as_uint(hi[0]), __float_as_uint(hi[1])};
+        const int soff = t < C::NT ? t * (16 * NO * 4) : nrows * NO * 4;   // (a tile past the last one, rows past the batch: dropped by the buffer's range check)
 #ifdef SDQN_TIMING
         if (c.dbg & 4) continue;
 #endif
-        if (c.wt) __builtin_amdgcn_raw_buffer_store_b128(w, rs, off, 0, 16); else __builtin_amdgcn_raw_buffer_store_b128(w, rs, off, 0, 0);
+        if (c.wt) __builtin_amdgcn_raw_buffer_store_b128(w, rs, ovo, soff, 16); else __builtin_amdgcn_raw_buffer_store_b128(w, rs, ovo, soff, 0);
       }
     }
-    if constexpr (C::LV > 0) {                                           // the left-over positions: four partial sums in wave order, Rectlin, one 256-byte row each
+    if constexpr (C::LV > 0) {
+      // the left-over positions: the matrix waves' four partial sums (published with the last round, in chunk KO's ring slot — the other
+      // collection buffer is still being read when they are written: [wave][LV][64]) added in wave order, Rectlin, one 256-byte row each
       if (lid < C::LV * NO) {
         const int l = lid >> 6, n = lid & 63, P = 16 * C::NT + l;
-        const float* const q = lpart + l * NO + n;
+        const float* const q = wr + (C::KO % NR) * C::WCH + l * NO + n;
         const float v = ((q[0] + q[C::LV * NO]) + q[2 * C::LV * NO]) + q[3 * C::LV * NO];
         if (P < nrows) {
           float* const dst = obase + (size_t)P * NO + n;
@@ -293,11 +288,40 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
     asm volatile("" : "+v"(ap[t]));
   }
   const float* const wl = wr + (4 * kq) * WPITCH + 16 * wave + m;        // B fragment: k-row 4 kq (+ 16 g + j), map 16 w + m
+  // the left-over positions (Cfg::LV) on the 4 x 4 x 1 shape: this wave's channel quarter CQ w .. of every chunk; A operand = lane's
+  // position (lane & 3, clamped), B operand = W[k][map lane]; D register i of lane l = position i, map l
+  constexpr int CQ = C::CI / 4;
+  int lap = 0;                                                           // float index in img of the lane's left-over position (+ this wave's channels), at the current kernel row
+  if constexpr (C::LV > 0) {
+    const int l = (lane & 3) < C::LV ? (lane & 3) : C::LV - 1;
+    const int P = 16 * C::NT + l, sp = P / C::NPOS, pos = P - sp * C::NPOS, pp = pos / C::QO, qq = pos - pp * C::QO;
+    lap = sp * C::IMG + (C::ST * pp) * C::RPITCH + (C::ST * qq) * C::PITCH + wave * CQ;
+    asm volatile("" : "+v"(lap));
+  }
+  const float* const wll = wr + (wave * CQ) * WPITCH + lane;
+  f32x4 lacc[4];                                                         // four chains (channel c of the quarter -> chain c & 3): back to back on ONE accumulator the 4 x 4 x 1 MFMAs
+#pragma unroll                                                           // wait out their result latency (measured: 170 cycles per conv2 chunk for 8 of them)
+  for (int q = 0; q < 4; ++q) lacc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 lav[CQ / 4];
+  float lbv[CQ];
+  auto left_load = [&](int s_, int slot) {
+    if constexpr (C::LV > 0) {
+#pragma unroll
+      for (int c4 = 0; c4 < CQ / 4; ++c4) lav[c4] = *reinterpret_cast<const f32x4*>(img + lap + s_ * C::PITCH + 4 * c4);
+#pragma unroll
+      for (int c1 = 0; c1 < CQ; ++c1) lbv[c1] = wll[slot * C::WCH + c1 * WPITCH];
+    }
+  };
+  auto left_mfma = [&]() {
+    if constexpr (C::LV > 0) {
+#pragma unroll
+      for (int c1 = 0; c1 < CQ; ++c1) lacc[c1 & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(lav[c1 / 4][c1 % 4], lbv[c1], lacc[c1 & 3], 0, 0, 0);
+    }
+  };
   f32x4 acc[C::NT];
 #pragma unroll
   for (int t = 0; t < C::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   SS_STAMP_T(0, 0);
-  __builtin_amdgcn_s_setprio(3);                                         // (the staging wave on this SIMD issues its vector work in the MFMAs' shadow, never in front of one)
   __syncthreads();                                                       // barrier #0
   SS_STAMP_T(0, 1);
   // K-outer phase, software-pipelined by hand: the fragments of the NEXT group — (i, gq + 1), or (i + 1, 0) — are read from LDS while the
@@ -320,16 +344,18 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
 #pragma unroll
     for (int t = 0; t < C::NT; ++t) a_[t] = *reinterpret_cast<const f32x4*>(img + ap[t] + dr * C::RPITCH + s_ * C::PITCH + 16 * gq);
   };
-  auto mfma_group = [&](int buf) {
+  auto mfma_group = [&](int buf, bool with_left) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int t = 0; t < C::NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[buf][j], av[buf][t][j], acc[t], 0, 0, 0);
+    if (with_left) left_mfma();
     // the next group's reads, ONE between every three MFMAs: issued as a burst at the top of the group (all four matrix waves at once,
     // right behind the barrier) they fill the LDS queue and the in-order wave cannot issue its next MFMA for 300-400 cycles per group
+    // (best effort: the pattern lists more read slots than a group has reads; the left-over chunk's reads and MFMAs ride along)
 #pragma unroll
-    for (int q = 0; q < C::NT + 2; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * C::NT - 3 * (C::NT + 2), 0);
+    for (int q = 0; q < (4 * C::NT + CQ) / 3; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); }
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     __builtin_amdgcn_sched_barrier(0);
   };
   // one chunk = tap s_ of the current kernel row; `i` = its logical chunk index (ring slot i % NR); `bump` != 0: the row's last tap — the
@@ -343,10 +369,12 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
         if (row_end) {
 #pragma unroll
           for (int t = 0; t < C::NT; ++t) ap[t] += bump;                 // (this group's fragments are in registers already)
+          lap += bump;
           load_group(av[nb], bv[nb], 0, 0, 0, (i + 1) % NR);
         } else load_group(av[nb], bv[nb], 0, s_ + 1, 0, (i + 1) % NR);
       }
-      mfma_group(gq & 1);
+      if (gq == 0) left_load(s_, i % NR);                              // (this chunk's left-over operands: used by its LAST group)
+      mfma_group(gq & 1, gq + 1 == C::GR);
     }
     // barrier #(i + 1), WITHOUT __syncthreads()'s fence: that would drain lgkmcnt and expose the reads just issued for chunk i + 1.  This
     // wave wrote nothing; the operand makes the wait for chunk i's last B fragments (and, LDS reads returning in order, for every read of
@@ -358,6 +386,7 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
   };
 #pragma unroll
   for (int t = 0; t < C::NT; ++t) ap[t] += C::rord(0) * C::RPITCH;
+  lap += C::rord(0) * C::RPITCH;
   load_group(av[0], bv[0], 0, 0, 0, 0);
 #pragma unroll 1
   for (int ri = 0; ri < RK; ++ri) {
@@ -398,13 +427,14 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
   };
   auto fin_load = [&](int u) { fin_load_a(u, 0); fin_load_a(u, 1); };
   fin_load(0); fin_load(1);
-  // the collection of a finished pair (barrier B: the staging waves have read the previous one; Rectlin + LDS stores; barrier A) rides in
-  // the NEXT pair's steps 1..3 — its accumulators are final and stay where they are, so nothing waits: done at the pair's end it idled the
-  // matrix pipe ~500 cycles per pair (result latency + stores + lgkmcnt(0) + two barriers)
+  // the collection of a finished pair (two 16-byte LDS stores per lane into the round's buffer, barrier A) rides in the NEXT pair's steps
+  // 1..3 — its accumulators are final and stay where they are, so nothing waits: done at the pair's end it idled the matrix pipe ~500
+  // cycles per pair (result latency + stores + lgkmcnt(0) + barrier).  The buffers alternate (staging waves' comment above)
   auto collect = [&](int pi) {                                           // (raw sums: the staging waves apply the Rectlin on their way out)
     const int t0 = 2 * pi; const bool two = t0 + 1 < C::NT;
-    *reinterpret_cast<f32x4*>(outl + m * WPITCH + 16 * wave + 4 * kq) = acc[t0];
-    if (two) *reinterpret_cast<f32x4*>(outl + C::OUTT + m * WPITCH + 16 * wave + 4 * kq) = acc[two ? t0 + 1 : t0];
+    float* const ob = outl + ((pi & 1) ? (int)(((C::KO + FC) % NR) * C::WCH) - NR * C::WCH : 0) + m * WPITCH + 16 * wave + 4 * kq;
+    *reinterpret_cast<f32x4*>(ob) = acc[t0];
+    if (two) *reinterpret_cast<f32x4*>(ob + C::OUTT) = acc[two ? t0 + 1 : t0];
   };
 #pragma unroll
   for (int u = 0; u < NSTEP; ++u) {
@@ -417,8 +447,13 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
     if (u == 2 * SPP) SS_STAMP_T(0, 6);
     if (u == 3 * SPP) SS_STAMP_T(0, 7);
 #endif
-    if (pi > 0 && k == 1) { asm volatile("s_barrier" ::: "memory"); collect(pi - 1); }                          // B (bare: reads in flight)
-    if (pi > 0 && k == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                        // A (the stores and every read issued so far are two steps old)
+    // (the left-over positions' final chunks ride in the LAST pair's steps: operands read in step f, used in step f + 1)
+    if constexpr (C::LV > 0) {
+      if (pi == NP - 1 && k >= 1 && k <= FC) left_mfma();
+      if (pi == NP - 1 && k < FC) left_load((C::KO + k) % C::S, (C::KO + k) % NR);
+    }
+    if (pi > 0 && k == 1) collect(pi - 1);
+    if (pi > 0 && k == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                        // A (pi - 1) (the stores and every read issued so far are two steps old)
     // the order below IS the issue order (a sched_barrier behind every pair of MFMAs): left to itself the scheduler puts the two MFMAs
     // of ONE accumulator back to back — 40 cycles each instead of 32 (the 16 x 16 x 4 shape's dependent latency)
     if (u + 2 < NSTEP) fin_load_a(u + 2, 0);
@@ -430,8 +465,12 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
       if (j == 0 && u + 2 < NSTEP) fin_load_a(u + 2, 1);
     }
   }
-  asm volatile("s_barrier" ::: "memory");                                // the last pair: B, collection, A
-  collect(NP - 1);
+  collect(NP - 1);                                                       // the last pair — and this wave's partial sums of the left-over positions
+  if constexpr (C::LV > 0) {
+    float* const lb = wr + (C::KO % NR) * C::WCH + wave * (C::LV * NO) + lane;      // (chunk KO's ring slot: every read of it — bf, the left-over operands — is done)
+#pragma unroll
+    for (int l = 0; l < C::LV; ++l) lb[l * NO] = (lacc[0][l] + lacc[1][l]) + (lacc[2][l] + lacc[3][l]);
+  }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   SS_STAMP_T(0, 5);
 }

@@ -2,8 +2,9 @@
 // unit, like every other family of launch variants.
 //   conv2_fwd  a1 [2][B][20][20][32] -> a2 [2][B][81][64]     4 x 4 stride 2     (deepqnetwork.py:85)
 //   conv3_fwd  a2 [2][B][9][9][64]   -> a3 [2][B][49][64]     3 x 3 stride 1     (deepqnetwork.py:87)
-// float32, no batch-norm (the raw-output problems stay on the latency engine), B >= 128.  LaunchTune::bt[id] == 0 selects this routine;
-// menu entries > 0 are the block-tile engine's block shapes (sdqn_kernels_bt.hip; entry 6 = its former built-in 64 x 64 shape).
+// float32, no batch-norm (the raw-output problems stay on the latency engine), B >= 128.  LaunchTune::bt[id] == 0: this routine where its
+// workgroups fill the chip (below), else the block-tile engine's built-in shape; 7: this routine always; other menu entries > 0: the
+// block-tile engine's block shapes (sdqn_kernels_bt.hip; entry 6 = its built-in 64 x 64 shape).
 #include <stdlib.h>
 #include "conv_ss.h"
 #include "kernels.h"
@@ -21,8 +22,13 @@ hipError_t launch_kernel_ss(int id, const StepArgs& a, const LaunchTune& t, hipS
   *handled = false;
   if (a.B < 128 || a.bn || a.h16) return hipSuccess;
   if (id != K_CONV2_FWD && id != K_CONV3_FWD) return hipSuccess;
-  if (t.bt[id] != 0 || t.nw_override[id] > 0) return hipSuccess;
+  if ((t.bt[id] != 0 && t.bt[id] != 7) || t.nw_override[id] > 0) return hipSuccess;      // (menu entry 7: this routine whatever the batch size)
+  // one workgroup per CU, NS whole samples each: the routine pays when its workgroups fill (nearly) whole rounds of the chip's 256 CUs —
+  // B = 128 and 256 with both nets, B = 256 alone (predict) — and loses to the block-tile engine's finer blocks in between (measured,
+  // conv2 / conv3 forward, us: B = 160: 23.8 / 17.4 against 20.7 / 14.0; B = 256: 26.1 / 18.9 against 28.7 / 22.3): below 80 % it declines
   const int ns = a.nz * a.B > 256 ? 2 : 1;
+  const int wgs = a.nz * ((a.B + ns - 1) / ns), rounds = (wgs + 255) / 256;
+  if (t.bt[id] == 0 && wgs * 5 < rounds * 256 * 4) return hipSuccess;
   ss::Args c;
   c.B = a.B; c.G = (a.B + ns - 1) / ns; c.dbg = 0;
 #ifdef SDQN_TIMING

@@ -27,8 +27,8 @@ def main():
     for B in Bs:
         A = 3
         mb = random_minibatch(B, A, 40 + B, reward_range=(-2, 3))
-        new = net_of(A, B, [("keep_gradients", 1)])
-        new2 = net_of(A, B, [("keep_gradients", 1)])
+        new = net_of(A, B, [("keep_gradients", 1), ("bt:1", 7), ("bt:2", 7)])
+        new2 = net_of(A, B, [("keep_gradients", 1), ("bt:1", 7), ("bt:2", 7)])
         old = net_of(A, B, [("keep_gradients", 1), ("bt:1", 6), ("bt:2", 6)])
         for n in (new, new2, old):
             n.train(mb)
