@@ -565,9 +565,11 @@ def north_star_target(out, sd, B, A):
                                   "frac_hbm": round(frac_fused, 4) if frac_fused else None},
            "standalone_gather": {"algorithmic_bytes": g.get("algorithmic_bytes"), "us_per_launch": g.get("us_per_launch"),
                                  "frac_hbm": g.get("frac")}}
-    best = max([x for x in (frac_fused, g.get("frac")) if x is not None] or [0.0])
-    res["frac_hbm"] = round(best, 4)
-    res["met"] = bool(best >= 0.40)
+    # `met` is decided by the kernel the STEP runs — the fused gather + conv1 — alone; the standalone gather (getMinibatch()'s launch,
+    # not on train_from_memory's path) is reported beside it ("met" must not come from a kernel the step does not run)
+    res["frac_hbm"] = round(frac_fused, 4) if frac_fused else None
+    res["met"] = bool(frac_fused is not None and frac_fused >= 0.40)
+    res["decided_by"] = "fused_gather_conv1"
     res["ceiling_note"] = ("both launches move ~3-4.5 MB at B=32: 0.9-1.4 us at 40 % of 8 TB/s, below the ~1.55 us dependent-launch floor plus "
                            "one cold round trip (fused conv1 runs 3 exact bf16 planes on packed-bf16 MFMA: 0.5 us of matrix time). "
                            "The same gather kernel at B=256 / B=4096 is reported in config_b256 / replay_gather_large.")
@@ -683,7 +685,7 @@ def b256_leg(sd, make_args, seed, steps=300, warmup=100, ring=200000):
              "fp32_equivalent_tflops": round(w[0]["flops"] / (conv1_us * 1e-6) / 1e12, 1) if conv1_us else None,
              "bound": "hbm (three exact bf16 planes on packed-bf16 MFMA: 3 x %.2f GFLOP is %.1f us at the 2.5 PFLOP/s dense peak; storing 2 x a1 alone is %.1f us at 8 TB/s)"
                       % (w[0]["flops"] / 1e9, conv1_matrix_work(B, A) / BF16_PEAK * 1e6, w[0]["bytes"] / HBM_PEAK * 1e6)}
-    best = max(gather["frac"], fused["frac_hbm"] or 0.0)
+    best = fused["frac_hbm"] or 0.0          # decided by the fused kernel the step runs; the standalone gather is context
     return {"workload": "BASELINE.json configs[2]: Pong shapes, batch_size=256, num_actions=3, replay_size=%d (NOT the headline; same process, "
                         "after the headline's timed region)" % ring,
             "value": round(steps / el, 2), "unit": "train_steps/sec", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "warmup": warmup + 40,
@@ -692,7 +694,7 @@ def b256_leg(sd, make_args, seed, steps=300, warmup=100, ring=200000):
             "roofline": dict(_roofline_entry(dom["id"], dom["name"], dom["total_ms"] / dom["launches"], B, A), measured_in="warm-up pass, every launch bracketed"),
             "kernels_us": k_us, "q_vs_cpu_ref": yard,
             "north_star_target": {"path": "replay gather + conv1 (B=256)", "target_frac_hbm": 0.40, "standalone_gather": gather,
-                                  "fused_gather_conv1": fused, "frac_hbm": round(best, 4), "met": bool(best >= 0.40)}}
+                                  "fused_gather_conv1": fused, "frac_hbm": round(best, 4), "met": bool(best >= 0.40), "decided_by": "fused_gather_conv1"}}
 
 
 def dp_b256_leg(sd, make_args, dist, torch, rank, world, dev, seed, dry_run, steps=150, warmup=60, ring=100000):
@@ -1103,6 +1105,13 @@ def main():
                         out["config_fp16_b256"] = fp16_b256_leg(sd, make_args, a.seed)
                     except Exception as e:
                         out["config_fp16_b256"] = {"error": repr(e)[:300]}
+            if B == 32 and not a.profile_run and not a.zero_copy and not a.no_b256:
+                # the reference's own call pattern and the agent loop: host-side rates, after the timed region
+                for key, fn in (("tuple_api", tuple_api_leg), ("agent_loop", agent_loop_leg)):
+                    try:
+                        out[key] = fn(sd, make_args, a.seed)
+                    except Exception as e:
+                        out[key] = {"error": repr(e)[:300]}
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(B, A, a.seed, a.cpu_baseline_seconds)
                 try:
@@ -1131,6 +1140,73 @@ def main():
         # connections), no interpreter teardown (buffered C stdio of any rank would be flushed then)
         sys.stdout.flush()
         os._exit(0)
+
+
+def tuple_api_leg(sd, make_args, seed, iters=3000, warmup=200, ring=100000):
+    """The reference's OWN call pattern (src/agent.py:112-114): `net.train(mem.getMinibatch(), epoch)` — the gather launch, host arrays
+    handed back lazily, the step reading the device minibatch in place while the tuple is untouched.  Host-bound (one
+    Python iteration = two C calls + eleven launches): the rate depends on the box's CPU.  `served` = DeepQNetwork.tuple_counters():
+    (train calls, states used in place on the device, calls that uploaded nothing at all)."""
+    import random
+    B, A = 32, 4
+    args = make_args(batch_size=B, random_seed=seed + 3)
+    mem = sd.ReplayMemory(ring, args)
+    fill_ring(mem, seed + 79, A)
+    net = sd.DeepQNetwork(A, args)
+    net.update_target_network()
+    random.seed(seed + 11)
+    for _ in range(warmup):
+        net.train(mem.getMinibatch(), 0)
+    c0 = net.tuple_counters()
+    net.profile(True, -1); net.profile_reset()
+    for _ in range(64):
+        net.train(mem.getMinibatch(), 0)
+    launches = sum(p["launches"] for p in net.profile_read()) / 64.0
+    net.profile(False)
+    net.sync()
+    c0 = net.tuple_counters()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        net.train(mem.getMinibatch(), 0)
+    net.sync()
+    el = time.perf_counter() - t0
+    c1 = net.tuple_counters()
+    served = tuple(int(b - a) for a, b in zip(c0, c1))
+    return {"workload": "reference call pattern net.train(mem.getMinibatch(), epoch), batch_size=32, num_actions=4, replay_size=%d "
+                        "(NOT the headline: host-bound Python loop, PCIe-free while the tuple is untouched)" % ring,
+            "value": round(iters / el, 1), "unit": "train_steps/sec", "us_per_iteration": round(el / iters * 1e6, 2), "iterations": iters,
+            "tuple_counters": {"calls": served[0], "states_in_place_on_device": served[1], "nothing_uploaded": served[2]},
+            "launches_per_iteration": round(launches + 1.0, 2),        # the step's launches (profiled) + getMinibatch()'s gather launch
+            "h2d_d2h_copies_per_iteration": 0.0 if served[2] == served[0] else None,
+            "note": "an untouched tuple uploads and downloads nothing (tests/test_gpu_parity_r2.py asserts the counters case by case)"}
+
+
+def agent_loop_leg(sd, make_args, seed, train_steps=20000, test_steps=10000, random_steps=3000):
+    """The whole agent loop of the reference (src/main.py:127-153, src/agent.py:96-135) on the SyntheticEnvironment: play_random, one
+    train phase (an environment step + every 4th step one train step from the ring) and one test phase (epsilon = 0.05: the acting
+    forward), in environment steps per second.  Host-bound Python."""
+    import random
+    args = make_args(batch_size=32, replay_size=100000, random_steps=random_steps, random_seed=seed + 4)
+    random.seed(seed + 12)
+    env = sd.SyntheticEnvironment(args, num_actions=4, seed=seed + 5)
+    mem = sd.ReplayMemory(args.replay_size, args)
+    net = sd.DeepQNetwork(4, args)
+    agent = sd.Agent(env, mem, net, args)
+    agent.play_random(random_steps)
+    agent.train(2000, 0)                                   # warm-up
+    net.sync()
+    t0 = time.perf_counter()
+    agent.train(train_steps, 0)
+    net.sync()
+    t_train = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    agent.test(test_steps, 0)
+    net.sync()
+    t_test = time.perf_counter() - t0
+    return {"workload": "Agent.train / Agent.test on SyntheticEnvironment (84x84 frames from a pool), batch_size=32, train_frequency=%d, "
+                        "num_actions=4 (NOT the headline: host-bound Python loop)" % args.train_frequency,
+            "train_env_steps_per_s": round(train_steps / t_train, 1), "test_env_steps_per_s": round(test_steps / t_test, 1),
+            "unit": "environment steps/sec", "train_steps": train_steps, "test_steps": test_steps}
 
 
 def spawn_ranks(n):

@@ -984,3 +984,36 @@ def test_tuple_api_reuses_the_device_minibatch_only_while_it_is_the_same_data(sd
     ref = tuple(np.array(x) for x in mb)
     n1.train(mb); n2.train(ref)
     assert same()
+
+
+@pytest.mark.gpu
+def test_untouched_tuple_moves_nothing_across_pcie_and_the_bench_legs_report_it(sd):
+    """the reference's own loop body net.train(mem.getMinibatch(), epoch) (src/agent.py:112-114) performs ZERO host-to-
+    device / device-to-host copies per iteration while the tuple is untouched — sdqn_net_tuple_counters: every call served with the
+    states in place on the device AND nothing uploaded — and bench.py's `tuple_api` / `agent_loop` legs (the driver line's keys) report
+    exactly that."""
+    import random
+    import bench
+    A, B = 4, 32
+    args = make_args(batch_size=B)
+    mem = sd.ReplayMemory(3000, args)
+    synthetic_fill(mem, 77, num_actions=A)
+    mem.sync_mirror()
+    net = sd.DeepQNetwork(A, args)
+    random.seed(5)
+    for _ in range(25):
+        net.train(mem.getMinibatch(), 0)
+    assert net.tuple_counters() == (25, 25, 25)
+    mb = mem.getMinibatch()
+    _ = np.asarray(mb[0])[0, 0, 0, 0]                      # LOOKING at the states fetches them (one D2H) — they are still clean: in place, nothing up
+    net.train(mb, 0)
+    assert net.tuple_counters() == (26, 26, 26)
+    mb = mem.getMinibatch()
+    mb[2][0] += 1                                          # an edited reward: the small arrays are uploaded, the states stay in place
+    net.train(mb, 0)
+    assert net.tuple_counters() == (27, 27, 26)
+    leg = bench.tuple_api_leg(sd, make_args, 1, iters=200, warmup=20, ring=3000)
+    assert leg["tuple_counters"] == {"calls": 200, "states_in_place_on_device": 200, "nothing_uploaded": 200}
+    assert leg["h2d_d2h_copies_per_iteration"] == 0.0 and 10.5 <= leg["launches_per_iteration"] <= 11.5 and leg["value"] > 1000
+    ag = bench.agent_loop_leg(sd, make_args, 1, train_steps=800, test_steps=400, random_steps=300)
+    assert ag["train_env_steps_per_s"] > 1000 and ag["test_env_steps_per_s"] > 1000
