@@ -726,14 +726,18 @@ def dp_b256_leg(sd, make_args, dist, torch, rank, world, dev, seed, dry_run, ste
         _lib.check(sd.load().sdqn_mt_seed(mt, seed + 9 + 1000 * rank))
     except Exception as e:
         err = "setup: " + repr(e)[:200]
+    # the ranks agree on the SET-UP outcome before any of them enters sdqn_dp_init: ncclCommInitRank needs every rank to join, so a rank
+    # whose set-up failed must keep the healthy ones out of it — a vote(False) cast from outside would never reach ranks already blocked
+    # inside the communicator's rendezvous, and the headline record would be lost to a hang instead of a reported error
+    setup = [None] * world
+    dist.all_gather_object(setup, err)
+    if any(setup):
+        return {"error": "setup failed on ranks %s" % [i for i, e in enumerate(setup) if e], "per_rank_errors": setup}
     if not dry_run:
         try:
-            if err is None:
-                net.dp_init(ids[0], rank, world, vote=vote)
-            else:
-                vote(False)                                            # (the collective the healthy ranks are sitting in)
+            net.dp_init(ids[0], rank, world, vote=vote)
         except Exception as e:
-            err = err or ("dp_init: " + repr(e)[:200])
+            err = "dp_init: " + repr(e)[:200]
         flush_c_stdio()
     oks = [None] * world
     dist.all_gather_object(oks, err)

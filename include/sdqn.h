@@ -104,7 +104,8 @@ int sdqn_replay_declare_minibatch_clean(sdqn_replay_t h);
  * one-shot declaration for that case: "the two state arguments of the next sdqn_net_train_host stand for device minibatch `gen` — the
  * host buffers may not hold it yet, and I have not written into them".  Honoured only while `gen` still IS the device minibatch's
  * generation (gen = 0: whatever it holds now — the reference's aliased buffers always show the latest gather); otherwise the call uploads
- * the host buffers as always.  rewards / actions / terminals always come from the arguments — compared by value with what that gather
+ * the host buffers as always.  gen = UINT64_MAX names the minibatch of the LAST sdqn_replay_gather and is for a caller that has not
+ * fetched it: SDQN_ERR_STATE if another launch has overwritten the device minibatch since (round 6: those states exist nowhere).  rewards / actions / terminals always come from the arguments — compared by value with what that gather
  * left on the device (ring[idx] of the three arrays, snapshotted by sdqn_replay_gather): when they are equal the step reads the device
  * copy and the call uploads nothing; any edit (a clipped reward, another action) is uploaded and used, as before. */
 int sdqn_replay_minibatch_gen(sdqn_replay_t h, uint64_t* device_gen, uint64_t* host_gen);

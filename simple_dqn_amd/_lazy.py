@@ -9,6 +9,12 @@ first fetches the device minibatch into the pinned host buffers (`ReplayMemory._
 then behaves like the ndarray `mem.prestates` itself — same memory, same aliasing as the reference (the buffers are re-used by the
 next getMinibatch(), replay_memory.py:21-22,76-77), same write tracking.
 
+CAVEAT (differs from the reference): only the lazy OBJECT is live.  An ndarray taken from it earlier — `p = np.asarray(
+mem.prestates)` — is the pinned buffer itself, but the next getMinibatch() no longer fills that buffer at once: `p` keeps showing the
+previous batch until somebody looks at the lazy object again (any access fetches), whereas the reference's `mem.prestates` would already
+show the new one.  Code that holds such an alias across getMinibatch() calls (statistics.py:85-86 keeps `mem.prestates` itself, which IS
+the live object) must touch the lazy object — or call `mem._materialize()` — before reading the alias.
+
 There is ONE such object per ReplayMemory and role; it is what the `prestates` / `poststates` attributes are, so `pre is mem.prestates`
 holds for the tuple's elements exactly as in the reference (:79 returns the attributes themselves).
 

@@ -62,6 +62,7 @@ struct sdqn_replay_s {
   // master at enqueue time (== the device metadata in stream order), and the device generation it belongs to: a tuple whose small
   // arrays equal it trains on the device copy (sdqn_net_train_host)
   uint8_t* mb_snap = nullptr; uint64_t mb_snap_gen = 0;
+  uint64_t mb_gather_gen = 0;   // device-minibatch generation the last sdqn_replay_gather left (sdqn_replay_declare_minibatch_on_device(h, UINT64_MAX) names it)
 };
 extern std::vector<sdqn_replay_s*> g_replays;      // live handles: sdqn_net_train_host recognises their pinned minibatch buffers
 

@@ -198,17 +198,17 @@ extern "C" int sdqn_replay_gather(sdqn_replay_t r, const int64_t* idx_host) {
   if (!r->tuned_geom) {
     int slot; const int64_t* didx; int rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
     rc = replay_gather_generic(r, didx); if (rc) return rc;
-    snapshot_small(r, idx_host);
+    snapshot_small(r, idx_host); r->mb_gather_gen = r->mb_dev_gen;
     return replay_release_idx(r, slot);
   }
   if (r->B <= 256) {               // the indexes ride in the kernel arguments: no pinned slot, no release event (sdqn_kernels.hip)
     HIPCHK(launch_gather(gather_args(r, nullptr), g_stream, idx_host));
-    snapshot_small(r, idx_host);
+    snapshot_small(r, idx_host); r->mb_gather_gen = r->mb_dev_gen;
     return SDQN_OK;
   }
   int slot; const int64_t* didx; int rc = replay_push_idx(r, idx_host, &slot, &didx); if (rc) return rc;
   HIPCHK(launch_gather(gather_args(r, didx), g_stream));
-  snapshot_small(r, idx_host);
+  snapshot_small(r, idx_host); r->mb_gather_gen = r->mb_dev_gen;
   return replay_release_idx(r, slot);
 }
 extern "C" int sdqn_replay_minibatch_to_host(sdqn_replay_t r) {
@@ -231,6 +231,17 @@ extern "C" int sdqn_replay_minibatch_gen(sdqn_replay_t r, uint64_t* device_gen, 
 }
 extern "C" int sdqn_replay_declare_minibatch_on_device(sdqn_replay_t r, uint64_t gen) {
   ARGCHK(r, "NULL handle");
+  if (gen == UINT64_MAX) {
+    // "the minibatch of the last sdqn_replay_gather, whose host copy I have NOT fetched": if anything has overwritten the device
+    // minibatch since (the generic path's fused gather, a bench gather), those states exist nowhere any more — an error, never a
+    // silent step on another gather's states or on host buffers that were never filled
+    if (r->mb_gather_gen != r->mb_dev_gen && r->mb_host_gen != r->mb_gather_gen) {
+      set_error("the device minibatch of the last sdqn_replay_gather (generation %llu) was overwritten (now %llu) before its states were fetched",
+                (unsigned long long)r->mb_gather_gen, (unsigned long long)r->mb_dev_gen);
+      return SDQN_ERR_STATE;
+    }
+    gen = r->mb_gather_gen;
+  }
   r->mb_clean_declared = true; r->mb_clean_on_device = gen == 0 || gen == r->mb_dev_gen;    // (a stale generation: the host buffers are uploaded as always)
   return SDQN_OK;
 }

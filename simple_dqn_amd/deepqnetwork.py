@@ -82,8 +82,7 @@ class DeepQNetwork:
         _lib.check(self._lib.sdqn_net_create(C.byref(h), C.byref(cfg)))
         self._h = h
         import os
-        for env, opt in (("SDQN_TWO_STREAMS", b"two_streams"), ("SDQN_FUSED_LAUNCHES", b"fused_launches"),
-                         ("SDQN_XCD_MAP", b"xcd_map"), ("SDQN_H16_WGRAD_MFMA", b"h16_wgrad_mfma")):
+        for env, opt in (("SDQN_FUSED_LAUNCHES", b"fused_launches"), ("SDQN_XCD_MAP", b"xcd_map"), ("SDQN_H16_WGRAD_MFMA", b"h16_wgrad_mfma")):
             if os.environ.get(env) is not None:                       # A/B switches for benchmarking
                 _lib.check(self._lib.sdqn_net_set_option(h, opt, int(os.environ[env])))
         if os.environ.get("SDQN_F4_SHARE"):                           # tuning: "s3,s2" percent of fc4-wgrad tiles in bwd3 / bwd2
@@ -180,9 +179,10 @@ class DeepQNetwork:
                 and prestates._which == "pre" and poststates._which == "post"):
             mem = prestates._mem
             if mem._mb_pending:
-                # (generation 0 = "whatever the device minibatch holds now": the aliased buffers of the reference always show the LATEST
-                #  gather, replay_memory.py:21-22,76-77 — and while the host copy has not been fetched the device copy is that content)
-                _lib.check(self._lib.sdqn_replay_declare_minibatch_on_device(mem._h, 0))
+                # (generation 2^64 - 1 = "the minibatch of the last gather() call, not fetched yet": the library refuses — RuntimeError —
+                #  if anything has overwritten the device minibatch since; everything in this package that re-gathers into it
+                #  materialises a pending minibatch first, so this is the backstop for foreign callers of the C ABI)
+                _lib.check(self._lib.sdqn_replay_declare_minibatch_on_device(mem._h, 0xFFFFFFFFFFFFFFFF))
                 pre_p, post_p = mem._mb_ptrs                                   # (addresses only: they name the handle's buffers)
             else:
                 prestates, poststates = mem._states("pre"), mem._states("post")   # fetch; then the ordinary path below
@@ -308,6 +308,7 @@ class DeepQNetwork:
         (ctypes uint32 array) is given."""
         import random
         mem._check_mirror()
+        self._keep_pending_minibatch(mem)
         if mt_state is None:
             # Python's generator state goes in as a copy (array('I') of the 625 words: 6 us; a ctypes slice assignment took 25); afterwards
             # Python's own generator is advanced by exactly the 32-bit words the library drew — one getrandbits call instead of
@@ -366,16 +367,27 @@ class DeepQNetwork:
             self.callback.on_train(cost.value)
         return cost.value if want else None
 
+    def _keep_pending_minibatch(self, mem):
+        """A getMinibatch() whose states nobody has looked at yet lives ONLY in the device minibatch.  The generic path (float64, other
+        screen geometries) gathers a fused step's states into that very buffer: fetch the pending one to the host first, so that a
+        later net.train(mb) / np.asarray(mb[0]) still sees its own states (the tuned 84x84x4 path gathers inside conv1 and never
+        touches the buffer)."""
+        if getattr(mem, "_mb_pending", False) and self.step_structure()[0] == "generic":
+            mem._materialize()
+
     def train_indexes(self, mem, indexes, want_cost=False):
         idx = np.ascontiguousarray(indexes, dtype=np.int64)
         mem._check_mirror()
+        self._keep_pending_minibatch(mem)
         cost = C.c_float()
         _lib.check(self._lib.sdqn_net_train_replay(self._h, mem._h, _lib.ptr(idx, C.c_int64), C.byref(cost) if want_cost else None))
         self.train_iterations += 1
         return cost.value if want_cost else None
 
     def set_option(self, name, value):
-        """'keep_gradients' (materialise the fc4 gradient; disables the fused fc4 RMSProp), 'two_streams'."""
+        """Tuning / test hooks of the library (sdqn_net_set_option), e.g. 'keep_gradients' (materialise the fc4 gradient; disables the
+        fused fc4 RMSProp), 'fused_launches', 'bt:<kernel id>' (throughput-regime menu), 'nw:<id>', 'tps:<layer>', 's4'.  Retired
+        experiments ('two_streams', ...) are refused by name."""
         _lib.check(self._lib.sdqn_net_set_option(self._h, name.encode(), int(value)))
         if name == "dp_overlap":
             self._dp_overlap_opt = int(value)

@@ -226,6 +226,11 @@ class ReplayMemory:
         _lib.check(self._lib.sdqn_replay_gather(self._h, _lib.ptr(idx, C.c_int64)))
         self._mb_pending = True
         self._mb_dirty = False
+        if self._flags == ZERO_COPY:
+            # the enqueued gather reads the pinned ring ITSELF (no mirror): a host store by the next add() or a tracked write could race
+            # with the still-queued kernel (the sampler lets slot `current` fall inside a sampled window) — this flag keeps the
+            # synchronous fetch of rounds 1-4
+            self._materialize()
         self.last_indexes = idx.copy()
         raw = self._raw
         return self._lazy_pre, raw["actions"][idx], raw["rewards"][idx], self._lazy_post, raw["terminals"][idx]
@@ -265,6 +270,7 @@ class ReplayMemory:
         launch) or several [nsets, B] (cycled, one set per launch — what consecutive getMinibatch() calls look like to the memory system)."""
         idx = np.ascontiguousarray(indexes, dtype=np.int64)
         ms = C.c_float()
+        self._materialize()                     # (the timed launches overwrite the device minibatch: a pending getMinibatch() is fetched first)
         if idx.ndim == 2:
             assert idx.shape[1] == self.batch_size
             _lib.check(self._lib.sdqn_replay_bench_gather_sets(self._h, _lib.ptr(idx, C.c_int64), idx.shape[0], iters, C.byref(ms)))

@@ -1017,3 +1017,44 @@ def test_untouched_tuple_moves_nothing_across_pcie_and_the_bench_legs_report_it(
     assert leg["h2d_d2h_copies_per_iteration"] == 0.0 and 10.5 <= leg["launches_per_iteration"] <= 11.5 and leg["value"] > 1000
     ag = bench.agent_loop_leg(sd, make_args, 1, train_steps=800, test_steps=400, random_steps=300)
     assert ag["train_env_steps_per_s"] > 1000 and ag["test_env_steps_per_s"] > 1000
+
+
+@pytest.mark.gpu
+def test_a_pending_minibatch_survives_the_generic_paths_own_gathers(sd):
+    """getMinibatch() leaves its states ONLY in the device minibatch until somebody looks.  The generic path (other
+    screen geometries, float64) gathers a fused step's states into that very buffer — so train_from_memory / train_indexes / bench_gather
+    fetch a pending minibatch to the host first: the tuple still shows, and trains on, its OWN states.  And the C-ABI backstop: declaring
+    'the last gather, not fetched' after something overwrote the device minibatch is SDQN_ERR_STATE, never a silent step."""
+    import simple_dqn_amd._lib as L
+    A, B, size = 4, 8, 500
+    args = make_args(batch_size=B, history_length=3, screen_height=60, screen_width=52, datatype="float32")
+    mem = sd.ReplayMemory(size, args)
+    synthetic_fill(mem, 31, num_actions=A)
+    mem.sync_mirror()
+    net, ref = sd.DeepQNetwork(A, args), sd.DeepQNetwork(A, args)
+    assert net.step_structure()[0] == "generic"
+    ref.set_weights(net.get_weights(0), 0); ref.set_weights(net.get_weights(1), 1)
+    random.seed(9)
+    mb = mem.getMinibatch()
+    idx = mem.last_indexes.copy()
+    screens = np.asarray(mem.screens)
+    want_pre = np.stack([screens[i - 3:i] for i in idx])
+    step_idx = np.random.RandomState(3).randint(10, 400, size=B).astype(np.int64)
+    net.train_indexes(mem, step_idx)                       # the generic path's gather goes through the device minibatch
+    ref.train_indexes(mem, step_idx)
+    assert np.array_equal(np.asarray(mb[0]), want_pre)     # ... and the pending tuple still shows its own states
+    net.train(mb, 0)
+    ref.train((want_pre, mb[1].copy(), mb[2].copy(), np.stack([screens[i - 2:i + 1] for i in idx]), mb[4].copy()), 0)
+    for i in range(5):
+        assert np.array_equal(net.get_layer(i, 0), ref.get_layer(i, 0)), i
+    # the backstop at the C ABI: gather, overwrite (another gather launch through the same buffers), then claim the first one unfetched
+    lib = sd.load()
+    tmem = sd.ReplayMemory(600, make_args(batch_size=B))
+    synthetic_fill(tmem, 32, num_actions=A)
+    tmem.sync_mirror()
+    i1 = np.random.RandomState(4).randint(10, 500, size=B).astype(np.int64)
+    L.check(lib.sdqn_replay_gather(tmem._h, L.ptr(i1, C.c_int64)))
+    ms = C.c_float()
+    L.check(lib.sdqn_replay_bench_gather(tmem._h, L.ptr(i1, C.c_int64), 2, C.byref(ms)))
+    assert lib.sdqn_replay_declare_minibatch_on_device(tmem._h, C.c_uint64(0xFFFFFFFFFFFFFFFF)) != 0
+    assert b"overwritten" in lib.sdqn_last_error()

@@ -19,7 +19,7 @@ def rate(N=int(os.environ.get("N", 6000))):
         r.append(N / (time.perf_counter() - t))
     return max(r)
 print("base", round(rate()))
-OPTS = eval(os.environ.get("OPTS", "[]")) or ([("two_streams", 1)], [("f4_share3", 70), ("f4_share2", 15)], [("xcd_map", 1)])
+OPTS = eval(os.environ.get("OPTS", "[]")) or ([("f4_share3", 70), ("f4_share2", 15)], [("xcd_map", 1)])
 for opts in OPTS:
     for k, v in opts: net.set_option(k, v)
     print(opts, round(rate()))
