@@ -428,9 +428,6 @@ __device__ __forceinline__ void gemm_tile_h(const StepArgs& a, int bx, int by, i
   }
 }
 
-}  // namespace sdqn
-#include "gemm_engine_rb.h"      // register-blocked routine of the float16 mode (B >= 128)
-namespace sdqn {
 
 
 // ---- fp16-mode weight gradients on packed-fp16 MFMA ---------------------------------------------------------------
@@ -566,21 +563,18 @@ __device__ __forceinline__ void gemm_tile_hw(const StepArgs& a, int bx, int by, 
 
 template <class P, int NW, int NT>
 __device__ __forceinline__ void run_tile(const StepArgs& a, int bx, int by, int bz, float* smem) {
-  if constexpr (is_rb<P>::value && uses_f16_mfma<P>::value) gemm_tile_hb<P, NW, NT>(a, bx, by, bz, smem);
-  else if constexpr (is_rb<P>::value) static_assert(!is_rb<P>::value, "register blocking exists for the packed-fp16 problems only (gemm_engine_rb.h)");
-  else if constexpr (uses_f16_wgrad<P>::value) gemm_tile_hw<P, NW, NT>(a, bx, by, bz, smem);
+  if constexpr (uses_f16_wgrad<P>::value) gemm_tile_hw<P, NW, NT>(a, bx, by, bz, smem);
   else if constexpr (uses_f16_mfma<P>::value) gemm_tile_h<P, NW, NT>(a, bx, by, bz, smem);
   else gemm_tile<P, NW, NT>(a, bx, by, bz, smem);
 }
 template <class P, int NW>
 constexpr int tile_lds_any() {
-  if constexpr (is_rb<P>::value) return NW > 1 ? NW * PANEL : 1;       // sub-tiles are combined one at a time
-  else if constexpr (uses_f16_wgrad<P>::value) return NW * HW_WAVE_LDS;   // staging tiles, reused as combine panels
+  if constexpr (uses_f16_wgrad<P>::value) return NW * HW_WAVE_LDS;   // staging tiles, reused as combine panels
   else return uses_f16_mfma<P>::value ? NW * PANEL : tile_lds<P, NW>();
 }
 // rows / columns of C one wave-tile covers
-template <class P> constexpr int tile_m() { return 32 * rb_m<P>::value; }
-template <class P> constexpr int tile_n() { return 32 * rb_n<P>::value; }
+template <class P> constexpr int tile_m() { return 32; }
+template <class P> constexpr int tile_n() { return 32; }
 
 // (xcd_tile_id / xcd_tile_id_range, the XCD-aware workgroup -> tile maps: problems.h — host + device, tests/emul executes them)
 

@@ -387,7 +387,7 @@ __device__ __forceinline__ void bt_tile(const StepArgs& a, int bx, int by, int b
 // Same structure with half panels: chunks of 64 k (a 128-byte row chunk = 8 lanes x 16 bytes, like the fp32 chunk), LDS rows of 72 halves
 // (= 36 dwords: the fp32 panel's bank picture), a lane's fragment of a 16-deep step = ONE ds_read_b128, four v_mfma_f32_32x32x16_f16 per
 // sub-tile and chunk.  At B >= 128 these launches were operand-traffic bound on the wave-tile routines (every 64 x 64 wave block fetched
-// its own rows from L2: gemm_engine_rb.h); here a row leaves L2 once per workgroup.
+// its own rows from L2: round 3's register-blocked routine, tools/exp/gemm_engine_rb.h); here a row leaves L2 once per workgroup.
 template <class P_, int BM_, int BN_, int WM_, int WN_, int D_ = 2, int BK_ = 64>
 struct BtCfgH {
   typedef P_ P;

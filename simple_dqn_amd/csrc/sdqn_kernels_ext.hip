@@ -1,7 +1,7 @@
 // sdqn_kernels_ext.hip — every launch variant that is not the default fp32 step:
 //   * --datatype float16 (problems_h16.h: packed-fp16 MFMA forward / dgrad, LDS-transposed packed-fp16 weight gradients),
-//   * its register-blocked forward at B >= 128 (gemm_engine_rb.h): what a launch runs when `bt:<id>` = -1 takes it off the half block-tile
-//     routine (round 3's kernels, kept as the same-box reference of tools/sweep_bt.py).
+//   * what a float16 launch runs at B >= 128 when `bt:<id>` = -1 takes it off the half block-tile routine (the same-box reference of
+//     tools/sweep_bt.py): the latency regime's kernels.
 // Kept apart from sdqn_kernels.hip on purpose: see the note there.
 #include "gemm_engine.h"
 #include "problems_h16.h"
@@ -60,19 +60,8 @@ static hipError_t launch_kernel_h16(int id, const StepArgs& a, const LaunchTune&
       default: break;
     }
   }
-  if (a.B >= 128) {
-    // throughput regime: the forward launches are operand-traffic bound (their time is flat in the number of K-split waves,
-    // tools/sweep_nw.py), so they run on the register-blocked routine (gemm_tile_hb: each half8 fragment feeds 2 MFMAs) —
-    // DATATYPE=float16 tools/exp/sweep_rb.py at B = 256 (round 3): conv1_fwd 24.8 -> 20.8 us, conv2_fwd 27.5 -> 20.4, conv3_fwd 19.8 -> 16.5,
-    // fc4_fwd 17.3 -> 14.9.  The dgrads (M = B or few tiles per N) lose parallelism when blocked and stay unblocked.
-    switch (id) {
-      case K_CONV1_FWD: return launch_gemm<RB<Conv1FwdH, 2, 1>, 1>(a, s);
-      case K_CONV2_FWD: return launch_gemm<RB<Conv2FwdH, 2, 2>, 4>(a, s);
-      case K_CONV3_FWD: return launch_gemm<RB<Conv3FwdH, 2, 2>, 4>(a, s);
-      case K_FC4_FWD: return launch_gemm<RB<Fc4FwdH, 2, 2>, 1>(a, s);
-      default: break;
-    }
-  }
+  // (B >= 128 comes here only when a launch is taken off the half block-tile routine — `bt:<id>` = -1, the same-box reference of
+  //  tools/sweep_bt.py; round 3's register-blocked forward routine for that case left the tree in round 6: tools/exp/gemm_engine_rb.h)
   switch (id) {
     case K_CONV1_FWD: return launch_gemm<Conv1FwdH, 8>(a, s);
     case K_CONV2_FWD: return launch_gemm<Conv2FwdH, 16>(a, s);

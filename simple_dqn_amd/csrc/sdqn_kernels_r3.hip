@@ -293,85 +293,8 @@ __global__ void __launch_bounds__(256) conv1_bf16_kernel(const Conv1Args c, cons
   conv1_bf16_body<IDX_IN, false>(c, my_idx, (int)blockIdx.x, sw, fw);
 }
 
-// ---- the same conv1 forward for B >= 128: one workgroup per (net, sample), the sample's four frames staged ONCE in LDS -------------------
-// conv1_bf16_body fetches every patch row (8 bytes) of every output position straight from memory — 16 divergent loads per lane and
-// tile, which the texture path serialises: 18.6 us at B = 256 for 0.84 GFLOP and 41 MB.  Here the 28 KB of a sample (contiguous in the
-// ring) arrive with coalesced 16-byte loads beside the 50 KB of weight planes (2 workgroups per CU), and a lane's 16 patch rows are 32
-// LDS dword reads.  Same fragments, same three MFMA chains in the same k order, same epilogue: bit-identical to conv1_bf16_body.
-__global__ void __launch_bounds__(256) conv1_bf16_staged_kernel(const Conv1Args c) {
-  __shared__ __attribute__((aligned(16))) unsigned short sw[3 * K1 * W1P_PITCH];          // 50 688 B
-  __shared__ __attribute__((aligned(16))) unsigned char img[STATE];                       // 28 224 B
-  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int z = blockIdx.x / c.B, n = blockIdx.x - z * c.B;
-  const int64_t org = c.from_ring ? (c.idx[n] - C0 + z) * (int64_t)FRAME : ((int64_t)z * c.B + n) * (int64_t)STATE;       // problems.h: sbase
-  {
-    const uint4* fp = reinterpret_cast<const uint4*>(c.src + org);
-    const uint4* wp = reinterpret_cast<const uint4*>(c.w1p[z]);
-    uint4 fv[7], v[12];
-#pragma unroll
-    for (int u = 0; u < 7; ++u) { const int it = threadIdx.x + 256 * u; fv[u] = fp[it < STATE / 16 ? it : STATE / 16 - 1]; }
-#pragma unroll
-    for (int u = 0; u < 12; ++u) v[u] = wp[threadIdx.x + 256 * u];
-#pragma unroll
-    for (int u = 0; u < 7; ++u) { const int it = threadIdx.x + 256 * u; if (it < STATE / 16) *reinterpret_cast<uint4*>(img + 16 * it) = fv[u]; }
-#pragma unroll
-    for (int u = 0; u < 12; ++u) {
-      const int cc = threadIdx.x + 256 * u, row = cc >> 5, col = cc & 31;
-      *reinterpret_cast<uint4*>(sw + row * W1P_PITCH + col * 8) = v[u];
-    }
-  }
-  __syncthreads();
-  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-  const unsigned short* bw = sw + i * W1P_PITCH + 8 * h;
-  auto cvt = [](const u32x2& r, bf16x8_t& out) {                                              // 8 bytes -> 8 exact bf16 (as conv1_bf16_body)
-    union { uint32_t u[4]; bf16x8_t v; } A;
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      const uint32_t w = d ? r.y : r.x;
-      const uint32_t f0 = __float_as_uint((float)(w & 255u)), f1 = __float_as_uint((float)((w >> 8) & 255u));
-      const uint32_t f2 = __float_as_uint((float)((w >> 16) & 255u)), f3 = __float_as_uint((float)(w >> 24));
-      A.u[2 * d] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);
-      A.u[2 * d + 1] = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
-    }
-    out = A.v;
-  };
-  const int M = c.B * PIX1;
-  for (int tile = wave; tile < (PIX1 + 31) / 32; tile += 4) {
-    const int pos = 32 * tile + i, pc = pos < PIX1 ? pos : PIX1 - 1, p = pc / Q1, q = pc - p * Q1;
-    const unsigned char* src = img + (p * ST1 + h) * W0 + q * ST1;
-    u32x2 raw[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const uint32_t* q32 = reinterpret_cast<const uint32_t*>(src + (t >> 2) * FRAME + 2 * (t & 3) * W0);
-      raw[t].x = q32[0]; raw[t].y = q32[1];
-    }
-    f32x16 acc0, acc1, acc2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; acc2[r] = 0.0f; }
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      bf16x8_t Ac; cvt(raw[t], Ac);
-      const bf16x8_t B0 = *reinterpret_cast<const bf16x8_t*>(bw + 16 * t), B1 = *reinterpret_cast<const bf16x8_t*>(bw + K1 * W1P_PITCH + 16 * t),
-                     B2 = *reinterpret_cast<const bf16x8_t*>(bw + 2 * K1 * W1P_PITCH + 16 * t);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac, B0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac, B1, acc1, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ac, B2, acc2, 0, 0, 0);
-    }
-    float* out = c.a1 + ((int64_t)z * M + (int64_t)n * PIX1 + 32 * tile + 4 * h) * K1 + i;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = (r & 3) + 8 * (r >> 2);
-      if (32 * tile + 4 * h + ml < PIX1) {
-        const float v = fmaxf(div255((acc0[r] + acc1[r]) + acc2[r]), 0.0f);
-        if (c.pad_) wt_store(out + ml * K1, v); else out[ml * K1] = v;
-      }
-    }
-  }
-}
-
 // ---- conv1 forward for B >= 128, round 5: persistent workgroups, W1's planes in REGISTERS, the frames streamed through LDS in row chunks ----
-// conv1_bf16_staged_kernel runs one serial phase per workgroup — load 28 KB of frames plus 50 KB of weight planes, barrier, 13 tiles over 4
+// Round 4's staged kernel (one workgroup per (net, sample); tools/exp/conv1_forms_r5.hip.txt) ran one serial phase per workgroup — load 28 KB of frames plus 50 KB of weight planes, barrier, 13 tiles over 4
 // waves, stores — and both co-resident workgroups of a CU sit in the same phase at the same time (15.9 us at B = 256: 0.28 of the HBM
 // roofline of its 35 MB; 52 % of the wave-cycles in s_waitcnt, matrix pipe 9 % busy); every tile re-reads all 48 KB of planes from LDS and
 // re-converts its bytes (each byte 4 x per net).  Here:
@@ -401,133 +324,6 @@ typedef float c1p_f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t c1p_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t c1p_u32x2 __attribute__((ext_vector_type(2)));
 static_assert(P1 % 4 == 0 && (4 * Q1) % 16 == 0 && C1R_SEG % 16 == 0 && (4 * ST1 * W0) % 16 == 0, "an item is whole tiles and whole 16-byte pieces");
-
-__global__ void __launch_bounds__(640) conv1_bf16_rows_kernel(const Conv1Args c) {
-  __shared__ __attribute__((aligned(16))) unsigned short img[2 * C1R_ITEM];                   // 26 880 B
-  __shared__ __attribute__((aligned(16))) unsigned short sw[3 * K1 * W1P_PITCH];              // 50 688 B (used once, before the loop)
-  __shared__ __attribute__((aligned(16))) float outl[2 * C1R_OUT];                           // 23 040 B: an item's output, double-buffered
-  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kg = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int Gz = c.wgs_per_net;                                                               // workgroups per net
-  const int z = (int)blockIdx.x / Gz, g = (int)blockIdx.x - z * Gz;
-  const int tj = wave >> 1, nh = wave & 1;                                                     // this wave's tile of the item and its 16-map half
-  const int nsamp = (c.B - g + Gz - 1) / Gz, nitems = C1R_NCH * nsamp;
-  // the ring indexes of ALL this workgroup's samples in one vector load at wave start (lane j: sample g + j Gz; at most 32 per workgroup at
-  // B = 4096), picked with v_readlane per item: an index load inside the loop would sit behind the stores in the in-order vmcnt queue
-  int64_t my_idx = 0;
-  if (c.from_ring) { const int nn = g + Gz * lane; my_idx = c.idx[nn < c.B ? nn : c.B - 1]; }
-  // this thread's 16-byte piece of an item: frame fc, piece w of its 105
-  const int fc = tid / (C1R_SEG / 16), pw = tid - fc * (C1R_SEG / 16);
-  const bool loader = tid < C1R_CHUNKS;
-  const int src_off = loader ? fc * FRAME + 16 * pw : 0;
-  auto gload = [&](int item, c1p_u32x4& fv) {                                                 // (clamped, unconditional: a guarded load costs a vmcnt(0))
-    const int ic = item < nitems ? item : nitems - 1;
-    const int si = ic / C1R_NCH, ch = ic - si * C1R_NCH;
-    int64_t org;
-    if (c.from_ring) {                                                                        // problems.h: sbase
-      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_idx, si), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_idx >> 32), si);
-      org = ((int64_t)(((uint64_t)hi << 32) | lo) - C0 + z) * (int64_t)FRAME;
-    } else org = ((int64_t)z * c.B + g + (int64_t)si * Gz) * (int64_t)STATE;
-    fv = *reinterpret_cast<const c1p_u32x4*>(c.src + org + ch * (4 * ST1 * W0) + src_off);
-  };
-  auto lstore = [&](const c1p_u32x4& fv, unsigned short* dst) {                               // 16 bytes -> 16 bf16 (the upper half of the float of an 8-bit integer)
-    if (!loader) return;
-    c1p_u32x4 o[2];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint32_t w = fv[e];
-      const uint32_t f0 = __float_as_uint((float)(w & 255u)), f1 = __float_as_uint((float)((w >> 8) & 255u));
-      const uint32_t f2 = __float_as_uint((float)((w >> 16) & 255u)), f3 = __float_as_uint((float)(w >> 24));
-      o[e >> 1][2 * (e & 1)] = __builtin_amdgcn_perm(f1, f0, 0x07060302u);
-      o[e >> 1][2 * (e & 1) + 1] = __builtin_amdgcn_perm(f3, f2, 0x07060302u);
-    }
-    c1p_u32x4* d = reinterpret_cast<c1p_u32x4*>(dst + fc * C1R_SEG + 16 * pw);
-    d[0] = o[0]; d[1] = o[1];
-  };
-  c1p_u32x4 fv[C1R_D];
-#pragma unroll
-  for (int u = 0; u < C1R_D; ++u) gload(u, fv[u]);
-  // W1's planes: ONE coalesced copy per workgroup into LDS ([plane][map][k], pitch 264: conflict-free 16-byte fragment reads), from there
-  // into registers as fragments — lane (m, kg) holds, per plane p / step t, the 8 bf16 k = 32 t + 8 kg .. + 7 of map 16 nh + m.  (Fetched
-  // as fragments straight from memory, every wave of the chip pulls its 24 KB through 64-byte pieces of the same 768 cache lines: 61 MB
-  // of requests queued on a few L2 channels, ~12 us before the first MFMA.)
-  bf16x8_t Bf[3][8];
-  {
-    const c1p_u32x4* wp = reinterpret_cast<const c1p_u32x4*>(c.w1p[z]);
-    c1p_u32x4 wv[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) { const int cc = tid + 640 * j; wv[j] = wp[cc < 3 * K1 * CRS1 / 8 ? cc : 3 * K1 * CRS1 / 8 - 1]; }
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int cc = tid + 640 * j, row = cc >> 5, col = cc & 31;
-      if (cc < 3 * K1 * CRS1 / 8) *reinterpret_cast<c1p_u32x4*>(sw + row * W1P_PITCH + col * 8) = wv[j];
-    }
-    __syncthreads();
-    const unsigned short* bw = sw + (nh * 16 + m) * W1P_PITCH + 8 * kg;
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int t = 0; t < 8; ++t) Bf[p][t] = *reinterpret_cast<const bf16x8_t*>(bw + p * K1 * W1P_PITCH + 32 * t);
-  }
-  // this lane's patch inside an item's image — the same for every item: position 16 tj + m of the 80 = (row pl, column q)
-  const int pos = 16 * tj + m, pl = pos / Q1, q = pos - pl * Q1;
-  const int a_off = (ST1 * pl + kg) * W0 + ST1 * q;
-  lstore(fv[0], img);                                                                         // item 0 (waits for its load only)
-  gload(C1R_D, fv[0]);
-  __syncthreads();
-  // An item's output is 80 positions x 32 maps = 10 240 CONTIGUOUS bytes of a1: one 16-byte store per thread, whole 128-byte lines in
-  // order (stored from the lanes' own fragments — 64-byte halves of a line from two different waves — the launch's 26 MB of stores ran at
-  // 2.9 TB/s and were 9 of its 15.5 us).  Issued one step later, from the LDS image the waves filled before the barrier.
-  auto flush = [&](int item) {
-    const int si = item / C1R_NCH, ch = item - si * C1R_NCH;
-    float* outs = c.a1 + (((int64_t)z * c.B + g + (int64_t)si * Gz) * PIX1 + ch * (4 * Q1)) * K1;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)outs, 0, 4 * Q1 * K1 * 4, 0x00020000);
-    const c1p_f32x4 v = *reinterpret_cast<const c1p_f32x4*>(outl + (item & 1) * C1R_OUT + (tid >> 3) * C1R_OPITCH + 4 * (tid & 7));
-    c1p_u32x4 w;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(v[e]);
-    if (c.pad_) __builtin_amdgcn_raw_buffer_store_b128(w, rs, 16 * tid, 0, 16);               // write-through (LaunchTune::wt bit 7)
-    else __builtin_amdgcn_raw_buffer_store_b128(w, rs, 16 * tid, 0, 0);
-  };
-  auto step = [&](int item, c1p_u32x4& fnext) {    // fnext: the register slot holding item + 1 (refilled with item + 1 + C1R_D)
-    const unsigned short* cur = img + (item & 1) * C1R_ITEM + a_off;
-    auto aread = [&](int t) -> bf16x8_t {
-      const unsigned short* ap = cur + (t >> 1) * C1R_SEG + 4 * (t & 1) * W0;
-      union { c1p_u32x2 u[2]; bf16x8_t v; } X;
-      X.u[0] = *reinterpret_cast<const c1p_u32x2*>(ap); X.u[1] = *reinterpret_cast<const c1p_u32x2*>(ap + 4);
-      return X.v;
-    };
-    // staging first (last item's output out, next item's image in, the load C1R_D items ahead), then the fragment reads, the 24 MFMAs
-    // and the epilogue into the LDS output image.  (Running the two halves in the opposite order on half of the waves, so that a SIMD's
-    // staging sits under its neighbours' MFMAs, measured the same or slower: 15.5-16.0 vs 15.1-15.3 us.)
-    if (item > 0) flush(item - 1);
-    lstore(fnext, img + ((item + 1) & 1) * C1R_ITEM);                                         // the next item's image (its reads ended at the last barrier)
-    gload(item + 1 + C1R_D, fnext);
-    __builtin_amdgcn_sched_barrier(0);
-    bf16x8_t A[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) A[t] = aread(t);
-    c1p_f32x4 acc[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) acc[p] = c1p_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Bf[p][t], A[t], acc[p], 0, 0, 0);
-    // D[map 4 kg + e][position m]: 4 consecutive maps of one position per lane -> the item's output image in LDS
-    c1p_f32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = fmaxf(div255((acc[0][e] + acc[1][e]) + acc[2][e]), 0.0f);
-    *reinterpret_cast<c1p_f32x4*>(outl + (item & 1) * C1R_OUT + pos * C1R_OPITCH + nh * 16 + 4 * kg) = v;
-    __syncthreads();
-  };
-  for (int i0 = 0; i0 < nitems; i0 += C1R_D) {     // one sample per trip, no branch inside: the compiler's counted waits stay exact
-#pragma unroll
-    for (int u = 0; u < C1R_D; ++u) step(i0 + u, fv[(u + 1) % C1R_D]);
-  }
-  if (nitems > 0) flush(nitems - 1);
-}
-
 
 // ---- conv1 weight gradient on packed-bf16 MFMA ---------------------------------------------------------------------------
 // gW1[(c,r,s)][map] = sum over (sample, y, x) of byte(c, 4y + r, 4x + s) / 255 * delta1(sample, y, x, map): the bytes are exact in
@@ -734,8 +530,8 @@ struct Conv1WgradHWWT : Conv1WgradHW {
 
   __device__ static void store(const StepArgs& a, int, int ks, int m, int n, float v) { wt_store(&a.slab1[(int64_t)ks * NW1 + m * K1 + n], v * a.inv_loss_scale); }
 };
-// ---- the same pipeline with SPECIALISED waves: 10 matrix waves + NLW = 4 staging waves (one per SIMD) ------------------------------------
-// In conv1_bf16_rows_kernel every wave does both halves of a trip — staging (last item's output out, next item's bytes converted into
+// ---- the pipeline with SPECIALISED waves: 10 matrix waves + NLW = 4 staging waves (one per SIMD) ------------------------------------
+// In the first form of this kernel (conv1_bf16_rows_kernel, round 5; tools/exp/conv1_forms_r5.hip.txt) every wave did both halves of a trip — staging (last item's output out, next item's bytes converted into
 // LDS, the load five items ahead) and matrix work — so its MFMAs start behind a vmcnt wait and the ten waves reach their MFMAs together
 // (1.1 us per item where the matrix pipe needs 0.5).  Here the staging waves (10 and up) do ALL the global traffic (2 loads + 3 stores per
 // thread and item with four of them) and the conversion; waves 0..9 only read fragments from LDS, run their 24 MFMAs and write the output image: no matrix wave ever
@@ -885,17 +681,14 @@ hipError_t launch_kernel_r3(int id, const StepArgs& a, const LaunchTune& t, hipS
     Conv1Args c; c.src = a.src; c.a1 = a.a1; c.w1p[0] = a.w1p[0]; c.w1p[1] = a.w1p[1]; c.idx = a.idx;
     c.B = a.B; c.nz = a.nz; c.from_ring = a.from_ring; c.tiles_per_net = tiles; c.wgs_per_net = wgs; c.tpw = tpw; c.xcd = t.r3_xcd & 1; c.pad_ = (t.wt >> 7) & 1;
     static_assert(sizeof(Conv1Args) == 72, "the index block follows 8-byte aligned at byte 72");
-    if (a.B >= 128 && t.bt[K_CONV1_FWD] >= 0) {           // throughput regime  (option bt:0 = -1: the per-tile kernel)
-      if (t.bt[K_CONV1_FWD] == 1) {                       // round 4: one workgroup per (net, sample), frames + planes staged in LDS
-        SDQN_LAUNCH(conv1_bf16_staged_kernel, dim3(a.nz * a.B), dim3(256), 0, s, c);
-        return hipGetLastError();
-      }
+    if (a.B >= 128 && t.bt[K_CONV1_FWD] >= 0) {           // throughput regime  (option bt:0 = -1: the per-tile kernel, the test reference)
       // round 5: persistent workgroups (one per CU), planes in registers, frames streamed in 4-row items; every workgroup of a net the same
       // number of samples where that is possible: Gz = ceil(B / ceil(B / (256 / nz)))
+      // (rounds 4-5's other forms — one workgroup per sample with the frames staged, and the 10-wave pipeline without specialised
+      //  waves, 15.9 / 14.5 us against 12.4-13.5 at B = 256 — left the tree in round 6: tools/exp/conv1_forms_r5.hip.txt)
       const int cap = 256 / (a.nz > 1 ? 2 : 1), per = (a.B + cap - 1) / cap;
       c.wgs_per_net = (a.B + per - 1) / per;
-      if (t.bt[K_CONV1_FWD] == 2) SDQN_LAUNCH(conv1_bf16_rows_kernel, dim3(a.nz * c.wgs_per_net), dim3(640), 0, s, c);      // (one role per wave set: the 10-wave form)
-      else SDQN_LAUNCH(conv1_bf16_rows2_kernel<4>, dim3(a.nz * c.wgs_per_net), dim3(896), 0, s, c);      // (staging waves 2 / 4 / 6: 14.8 / 13.5 / 13.4 us)
+      SDQN_LAUNCH(conv1_bf16_rows2_kernel<4>, dim3(a.nz * c.wgs_per_net), dim3(896), 0, s, c);      // (staging waves 2 / 4 / 6: 14.8 / 13.5 / 13.4 us)
       return hipGetLastError();
     }
     IdxIn ix;
