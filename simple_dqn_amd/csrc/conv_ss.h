@@ -119,9 +119,18 @@ struct Args {
   int dbg;                  // timing build only: ablation bits (tools/exp/ss_stamps.py); 0 in the product
 };
 
-template <class C>
-__global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
-  __shared__ __attribute__((aligned(16))) float smem[C::LDS];
+// what a staging thread carries from layer 1 to layer 2 of a chained launch (conv_ss_chain_kernel), in registers: the Rectlin'ed output
+// pieces it stored (its 16 bytes of two tiles per collection round), its left-over value, and layer 2's first NR weight chunks, whose
+// loads it issued when layer 1's final phase began
+template <int NPIECE, int NWREG>
+struct Keep { f32x4 v[NPIECE > 0 ? NPIECE : 1]; float left; f32x4 w[NWREG > 0 ? NWREG : 1]; };
+struct NoNext { static constexpr int WP = 0, CI = 0, S = 1; static constexpr int rord(int) { return 0; } };
+
+// one layer for this workgroup's samples (every wave of the workgroup calls it; waves 0-3 = matrix, 4-7 = staging).
+// MODE bit 0: layer 1 of a chain (keep the output in `keep`, prefetch CN's first weight chunks from cn_w); bit 1: layer 2 (the image and
+// the first weight chunks come out of `keep`: no image row is loaded)
+template <class C, int MODE = 0, class CN = NoNext, class KeepT = Keep<0, 0> >
+__device__ __forceinline__ void conv_ss_body(const Args& c, float* const smem, KeepT& keep, const float* const* cn_w = nullptr) {
   float* const img = smem;
   float* const wr = smem + C::NS * C::IMG;
   float* const outl = wr + NR * C::WCH;
@@ -180,6 +189,32 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
     auto row_commit = [&](int s_, int row, const f32x4& v) { if (rlane) *reinterpret_cast<f32x4*>(img + rdst[s_] + row * C::RPITCH) = v; };
 #endif
     // ---- prologue: chunk 0 and the first rows are what the first MFMA waits for; chunks 1..3 fly behind them ----
+    if constexpr (MODE & 2) {
+      // layer 2 of a chain: the whole image out of the previous layer's registers (piece j of this thread = its 16 bytes of output row
+      // P = 16 j + (lid >> 4) = pixel P % (HI WI) of sample P / (HI WI)); the first NR weight chunks were requested long ago
+      constexpr int NPX = C::HI * C::WI;
+#pragma unroll
+      for (int j = 0; j < (int)(sizeof(keep.v) / sizeof(keep.v[0])); ++j) {
+        const int P = 16 * j + (lid >> 4);
+        if (P < C::NS * NPX) {
+          const int sp = P / NPX, px = P - sp * NPX, y = px / C::WI, x = px - y * C::WI;
+          *reinterpret_cast<f32x4*>(img + sp * C::IMG + y * C::RPITCH + x * C::PITCH + 4 * (lid & 15)) = keep.v[j];
+        }
+      }
+      {                                                                  // the previous layer's left-over positions: one value per lane (position, map)
+        constexpr int NL = (C::NS * NPX) % 16;
+        if (lid < NL * NO) {
+          const int P = C::NS * NPX - NL + (lid >> 6), sp = P / NPX, px = P - sp * NPX, y = px / C::WI, x = px - y * C::WI;
+          img[sp * C::IMG + y * C::RPITCH + x * C::PITCH + (lid & 63)] = keep.left;
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < NR; ++d)
+#pragma unroll
+        for (int j = 0; j < C::WP; ++j) wv[d][j] = keep.w[d * C::WP + j];
+      w_commit(0, wv[0]);
+      w_commit(1, wv[1]);
+    } else {
     w_issue(0, wv[0]);
 #pragma unroll
     for (int j = 0; j < C::P0; ++j) r0[j] = row_issue(j / C::PO, C::first_row(j % C::PO));
@@ -189,6 +224,7 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
 #pragma unroll
     for (int j = 0; j < C::P0; ++j) row_commit(j / C::PO, C::first_row(j % C::PO), r0[j]);
     w_commit(1, wv[1]);                                                  // (the matrix waves prefetch chunk 1's first fragments before barrier #1)
+    }
 #if !defined(SS_ABL) || SS_ABL != 9
     SS_STAMP_T(256, 6);
 #endif
@@ -203,7 +239,7 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
 #pragma unroll
         for (int d = 2; d < NR; ++d) w_commit(d, wv[d]);
       } else w_commit(i + 3, wv[0]);
-      if constexpr (C::PR > 0) {
+      if constexpr (C::PR > 0 && !(MODE & 2)) {
         if (i >= C::LAG && i - C::LAG < C::NI) {
 #pragma unroll
           for (int j = 0; j < C::PR; ++j) { const int q = (i - C::LAG) * C::PR + j; if (q < C::NQ) row_commit(q % C::NS, C::rest_row(q / C::NS), rr[i % C::LAG][j]); }
@@ -213,7 +249,7 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
       if (c.dbg & 2) continue;
 #endif
       if (i + 4 < C::NCH) w_issue(i + 4, wv[0]);
-      if constexpr (C::PR > 0) {
+      if constexpr (C::PR > 0 && !(MODE & 2)) {
         if (i < C::NI) {
 #pragma unroll
           for (int j = 0; j < C::PR; ++j) { const int q = i * C::PR + j; if (q < C::NQ) rr[i % C::LAG][j] = row_issue(q % C::NS, C::rest_row(q / C::NS)); }
@@ -235,8 +271,15 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
     const int olane = orow * WPITCH + ocol;                              // (integer indexes: a run-time choice between two POINTERS makes hipcc read through a flat one)
     const int obuf1 = (int)(((C::KO + FC) % NR) * C::WCH) - NR * C::WCH;   // the second buffer relative to outl (it lies in front of it)
     constexpr int NP = (C::NT + 1) / 2;
-#pragma unroll 1
-    for (int pi = 0; pi < NP; ++pi) {
+    if constexpr (MODE & 1) {                                            // layer 1 of a chain: the next layer's first weight chunks, requested now
+#pragma unroll
+      for (int d = 0; d < NR; ++d) {
+        const int pc = CN::rord(d / CN::S) * CN::S + d % CN::S;
+#pragma unroll
+        for (int j = 0; j < CN::WP; ++j) keep.w[d * CN::WP + j] = ldb(reinterpret_cast<const char*>(cn_w[z]), wvo, pc * (CN::CI * NO * 4) + 4096 * j);
+      }
+    }
+    auto round = [&](int pi) {
       stg_barrier();                                                   // A of round pi: both tiles are collected
       const float* const ob = outl + olane + ((pi & 1) ? obuf1 : 0);
 #pragma unroll
@@ -245,6 +288,7 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(ob + u * C::OUTT);
         const f32x2 z2 = {0.0f, 0.0f};
         const f32x2 lo = __builtin_elementwise_max(__builtin_shufflevector(v, v, 0, 1), z2), hi = __builtin_elementwise_max(__builtin_shufflevector(v, v, 2, 3), z2);   // Rectlin (deepqnetwork.py:85-87)
+        if constexpr (MODE & 1) keep.v[2 * pi + u] = f32x4{lo[0], lo[1], hi[0], hi[1]};
         const u32x4 w = {__float_as_uint(lo[0]), __float_as_uint(lo[1]), __float_as_uint(hi[0]), __float_as_uint(hi[1])};
         const int soff = t < C::NT ? t * (16 * NO * 4) : nrows * NO * 4;   // (a tile past the last one, rows past the batch: dropped by the buffer's range check)
 #ifdef SDQN_TIMING
@@ -252,6 +296,13 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
 #endif
         if (c.wt) __builtin_amdgcn_raw_buffer_store_b128(w, rs, ovo, soff, 16); else __builtin_amdgcn_raw_buffer_store_b128(w, rs, ovo, soff, 0);
       }
+    };
+    if constexpr (MODE & 1) {                                            // (unrolled: the kept pieces need compile-time register indexes)
+#pragma unroll
+      for (int pi = 0; pi < NP; ++pi) round(pi);
+    } else {
+#pragma unroll 1
+      for (int pi = 0; pi < NP; ++pi) round(pi);
     }
     if constexpr (C::LV > 0) {
       // the left-over positions: the matrix waves' four partial sums (published with the last round, in chunk KO's ring slot — the other
@@ -260,6 +311,7 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
         const int l = lid >> 6, n = lid & 63, P = 16 * C::NT + l;
         const float* const q = wr + (C::KO % NR) * C::WCH + l * NO + n;
         const float v = ((q[0] + q[C::LV * NO]) + q[2 * C::LV * NO]) + q[3 * C::LV * NO];
+        if constexpr (MODE & 1) keep.left = fmaxf(v, 0.0f);
         if (P < nrows) {
           float* const dst = obase + (size_t)P * NO + n;
           if (c.wt) __hip_atomic_store(dst, fmaxf(v, 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *dst = fmaxf(v, 0.0f);
@@ -473,6 +525,36 @@ __global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   SS_STAMP_T(0, 5);
+}
+
+template <class C>
+__global__ void __launch_bounds__(512) conv_ss_kernel(const Args c) {
+  __shared__ __attribute__((aligned(16))) float smem[C::LDS];
+  Keep<0, 0> none;
+  conv_ss_body<C>(c, smem, none);
+}
+
+// conv2 -> conv3 for the SAME samples in one launch (round 6): both layers are sample-stationary with the same samples per workgroup, so
+// a workgroup's conv3 needs nothing another workgroup computes — it follows its conv2 behind a workgroup barrier instead of a kernel
+// boundary (~1.5 us + the second launch's ramp).  Layer 1's output still goes to memory (the backward pass reads it); layer 2's copy
+// never leaves the CU: every staging thread keeps the pieces it stored in registers and writes them into layer 2's LDS image behind
+// the barrier — no re-read, no wait for the stores — and layer 2's first weight chunks were requested when layer 1's final phase began.
+struct ChainArgs { Args l1, l2; };
+template <class CA, class CB>
+__global__ void __launch_bounds__(512) conv_ss_chain_kernel(const ChainArgs c) {
+  static_assert(CA::NS == CB::NS && CA::NPOS == CB::HI * CB::WI && CB::CI == NO, "layer 2 consumes layer 1's samples");
+  __shared__ __attribute__((aligned(16))) float smem[CA::LDS > CB::LDS ? CA::LDS : CB::LDS];
+  typedef Keep<2 * ((CA::NT + 1) / 2), NR * CB::WP> K;
+  K keep;
+  conv_ss_body<CA, 1, CB, K>(c.l1, smem, keep, c.l2.w);
+  __syncthreads();                                                       // every LDS access of layer 1 is done before layer 2 overwrites the images
+  conv_ss_body<CB, 2, NoNext, K>(c.l2, smem, keep);
+}
+
+template <class CA, class CB>
+inline hipError_t launch_chain(const ChainArgs& c, int nz, hipStream_t s) {
+  SDQN_LAUNCH((conv_ss_chain_kernel<CA, CB>), dim3(nz * c.l1.G), dim3(512), 0, s, c);
+  return hipGetLastError();
 }
 
 template <class C>

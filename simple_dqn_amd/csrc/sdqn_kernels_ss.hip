@@ -3,8 +3,9 @@
 //   conv2_fwd  a1 [2][B][20][20][32] -> a2 [2][B][81][64]     4 x 4 stride 2     (deepqnetwork.py:85)
 //   conv3_fwd  a2 [2][B][9][9][64]   -> a3 [2][B][49][64]     3 x 3 stride 1     (deepqnetwork.py:87)
 // float32, no batch-norm (the raw-output problems stay on the latency engine), B >= 128.  LaunchTune::bt[id] == 0: this routine where its
-// workgroups fill the chip (below), else the block-tile engine's built-in shape; 7: this routine always; other menu entries > 0: the
-// block-tile engine's block shapes (sdqn_kernels_bt.hip; entry 6 = its built-in 64 x 64 shape).
+// workgroups fill the chip (below), else the block-tile engine's built-in shape; 7: this routine always; 8: always, and never chained
+// with the other layer; other menu entries > 0: the block-tile engine's block shapes (sdqn_kernels_bt.hip; entry 6 = its built-in 64 x 64).
+// When both layers run here they are ONE launch (conv_ss_chain_kernel: a workgroup's conv3 follows its own conv2 behind a barrier).
 #include <stdlib.h>
 #include "conv_ss.h"
 #include "kernels.h"
@@ -18,29 +19,44 @@ typedef ss::Cfg<P1, Q1, K1, 4, 4, ST2, P2, Q2, 1, 4, 20, 0> C2S1;
 typedef ss::Cfg<P2, Q2, K2, 3, 3, 1, P3, Q3, 2, 8, 48, 16> C3S2;
 typedef ss::Cfg<P2, Q2, K2, 3, 3, 1, P3, Q3, 1, 8, 48, 0> C3S1;
 
-hipError_t launch_kernel_ss(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
-  *handled = false;
-  if (a.B < 128 || a.bn || a.h16) return hipSuccess;
-  if (id != K_CONV2_FWD && id != K_CONV3_FWD) return hipSuccess;
-  if ((t.bt[id] != 0 && t.bt[id] != 7) || t.nw_override[id] > 0) return hipSuccess;      // (menu entry 7: this routine whatever the batch size)
+// does launch `id` (conv2 / conv3 forward) run on this routine?  LaunchTune::bt[id]: 0 = where its workgroups fill the chip, 7 / 8 = always
+static bool ss_takes(int id, const StepArgs& a, const LaunchTune& t) {
+  if (a.B < 128 || a.bn || a.h16) return false;
+  if ((t.bt[id] != 0 && t.bt[id] != 7 && t.bt[id] != 8) || t.nw_override[id] > 0) return false;
   // one workgroup per CU, NS whole samples each: the routine pays when its workgroups fill (nearly) whole rounds of the chip's 256 CUs —
   // B = 128 and 256 with both nets, B = 256 alone (predict) — and loses to the block-tile engine's finer blocks in between (measured,
   // conv2 / conv3 forward, us: B = 160: 23.8 / 17.4 against 20.7 / 14.0; B = 256: 26.1 / 18.9 against 28.7 / 22.3): below 80 % it declines
   const int ns = a.nz * a.B > 256 ? 2 : 1;
   const int wgs = a.nz * ((a.B + ns - 1) / ns), rounds = (wgs + 255) / 256;
-  if (t.bt[id] == 0 && wgs * 5 < rounds * 256 * 4) return hipSuccess;
-  ss::Args c;
-  c.B = a.B; c.G = (a.B + ns - 1) / ns; c.dbg = 0;
-#ifdef SDQN_TIMING
-  if (const char* e = getenv("SDQN_SS_DBG")) c.dbg = atoi(e);
-#endif
+  return t.bt[id] != 0 || wgs * 5 >= rounds * 256 * 4;
+}
+// conv2 and conv3 forward both on this routine: ONE launch (conv_ss_chain_kernel) at K_CONV2_FWD, nothing at K_CONV3_FWD — unless menu
+// entry 8 asks for the two launches (tests, same-box A/B)
+static bool ss_chains(const StepArgs& a, const LaunchTune& t) {
+  return ss_takes(K_CONV2_FWD, a, t) && ss_takes(K_CONV3_FWD, a, t) && t.bt[K_CONV2_FWD] != 8 && t.bt[K_CONV3_FWD] != 8;
+}
+
+hipError_t launch_kernel_ss(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
+  *handled = false;
+  if (id != K_CONV2_FWD && id != K_CONV3_FWD) return hipSuccess;
+  if (!ss_takes(id, a, t)) return hipSuccess;
   *handled = true;
-  if (id == K_CONV2_FWD) {
-    c.in = a.a1; c.out = a.a2; c.w[0] = a.theta[0] + OFF2; c.w[1] = a.theta[a.nz > 1 ? 1 : 0] + OFF2; c.wt = t.wt & 1;
-    return ns == 2 ? ss::launch<C2S2>(c, a.nz, s) : ss::launch<C2S1>(c, a.nz, s);
+  const bool chain = ss_chains(a, t);
+  if (chain && id == K_CONV3_FWD) return hipSuccess;            // (rode in the conv2 launch)
+  const int ns = a.nz * a.B > 256 ? 2 : 1;
+  ss::Args c2, c3;
+  c2.B = c3.B = a.B; c2.G = c3.G = (a.B + ns - 1) / ns; c2.dbg = c3.dbg = 0;
+#ifdef SDQN_TIMING
+  if (const char* e = getenv("SDQN_SS_DBG")) c2.dbg = c3.dbg = atoi(e);
+#endif
+  c2.in = a.a1; c2.out = a.a2; c2.w[0] = a.theta[0] + OFF2; c2.w[1] = a.theta[a.nz > 1 ? 1 : 0] + OFF2; c2.wt = t.wt & 1;
+  c3.in = a.a2; c3.out = a.a3; c3.w[0] = a.theta[0] + OFF3; c3.w[1] = a.theta[a.nz > 1 ? 1 : 0] + OFF3; c3.wt = (t.wt >> 1) & 1;
+  if (chain) {
+    ss::ChainArgs cc; cc.l1 = c2; cc.l2 = c3;
+    return ns == 2 ? ss::launch_chain<C2S2, C3S2>(cc, a.nz, s) : ss::launch_chain<C2S1, C3S1>(cc, a.nz, s);
   }
-  c.in = a.a2; c.out = a.a3; c.w[0] = a.theta[0] + OFF3; c.w[1] = a.theta[a.nz > 1 ? 1 : 0] + OFF3; c.wt = (t.wt >> 1) & 1;
-  return ns == 2 ? ss::launch<C3S2>(c, a.nz, s) : ss::launch<C3S1>(c, a.nz, s);
+  if (id == K_CONV2_FWD) return ns == 2 ? ss::launch<C2S2>(c2, a.nz, s) : ss::launch<C2S1>(c2, a.nz, s);
+  return ns == 2 ? ss::launch<C3S2>(c3, a.nz, s) : ss::launch<C3S1>(c3, a.nz, s);
 }
 
 #ifdef SDQN_TIMING

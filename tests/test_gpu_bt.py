@@ -182,17 +182,20 @@ def test_sample_stationary_forward_convolutions(sd, A, B):
     im2col at ds_read time, weights streamed through an LDS ring, exact-fp32 16 x 16 x 4 MFMA, specialised staging waves).  Same
     products, one accumulator per output, another k order than the block-tile routine (menu entry 6, the former default): every
     activation agrees to fp32 round-off — two samples per workgroup (2 B > 256), one (B = 128), an odd batch whose last workgroup
-    holds one sample (B = 129) — and the result is bit-stable from run to run and from net to net.  (By default the routine runs where
+    holds one sample (B = 129) — and the result is bit-stable from run to run, from net to net and between the chained (one launch for
+    both layers) and the unchained (menu entry 8) form.  (By default the routine runs where
     its workgroups fill at least 80 % of whole rounds of the chip — B = 128, B >= 208 — and leaves the sizes in between to the
     block-tile engine; menu entry 7 selects it whatever the batch size.)"""
     mb = random_minibatch(B, A, 300 + B, reward_range=(-2, 3))
     force = [] if B in (128, 256) else [("bt:1", 7), ("bt:2", 7)]
     new = _net(sd, A, B, 31, [("keep_gradients", 1)] + force)
-    again = _net(sd, A, B, 31, [("keep_gradients", 1)] + force)
+    # when both layers run on the routine they are ONE launch (conv_ss_chain_kernel: a workgroup's conv3 follows its own conv2 behind a
+    # barrier, its input image written from the staging threads' registers): menu entry 8 = the same routine as two launches — same bits
+    again = _net(sd, A, B, 31, [("keep_gradients", 1), ("bt:1", 8), ("bt:2", 8)])
     old = _net(sd, A, B, 31, [("keep_gradients", 1), ("bt:1", 6), ("bt:2", 6)])
     # predict() (one net: the routine runs with one sample per workgroup at B = 256) on the same weights
     q1, q2 = new.predict(mb[0]), old.predict(mb[0])
-    assert np.abs(q1 - q2).max() < 2e-6 and np.array_equal(q1, again.predict(mb[0]))
+    assert np.abs(q1 - q2).max() < 2e-6 and np.abs(q1 - again.predict(mb[0])).max() < 2e-6      # (one net at B = 128 fills half the chip: the default declines)
     for n in (new, again, old):
         n.train(mb)
     for name, cnt in dict(a2=2 * B * 81 * 64, a3=2 * B * 49 * 64, a4=2 * B * 512).items():

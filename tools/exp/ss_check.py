@@ -27,17 +27,17 @@ def main():
     for B in Bs:
         A = 3
         mb = random_minibatch(B, A, 40 + B, reward_range=(-2, 3))
-        new = net_of(A, B, [("keep_gradients", 1), ("bt:1", 7), ("bt:2", 7)])
-        new2 = net_of(A, B, [("keep_gradients", 1), ("bt:1", 7), ("bt:2", 7)])
+        new = net_of(A, B, [("keep_gradients", 1), ("bt:1", 7), ("bt:2", 7)])          # both layers: ONE chained launch
+        new2 = net_of(A, B, [("keep_gradients", 1), ("bt:1", 8), ("bt:2", 8)])         # the same routine, two launches
         old = net_of(A, B, [("keep_gradients", 1), ("bt:1", 6), ("bt:2", 6)])
         for n in (new, new2, old):
             n.train(mb)
         for name, cnt in dict(a1=2 * B * 400 * 32, a2=2 * B * 81 * 64, a3=2 * B * 49 * 64, a4=2 * B * 512).items():
             x, x2, y = new.debug_read(name, cnt), new2.debug_read(name, cnt), old.debug_read(name, cnt)
             bad = np.flatnonzero(np.abs(x - y) > 1e-4 * max(1e-6, np.abs(y).max()))
-            print("B=%d %s rel err vs block-tile %.3e  bit-stable %s  nbad %d first %s" % (B, name, rel(x, y), np.array_equal(x, x2), bad.size, bad[:6]))
+            print("B=%d %s rel err vs block-tile %.3e  chained == two launches %s  nbad %d first %s" % (B, name, rel(x, y), np.array_equal(x, x2), bad.size, bad[:6]))
         print("B=%d q max abs diff %.3e" % (B, np.abs(new.last_q()[0] - old.last_q()[0]).max()))
-        for tag, n in (("ss", new), ("bt", old)):
+        for tag, n in (("ss-chain", new), ("ss-2launch", new2), ("bt", old), ("ss-chain", new), ("ss-2launch", new2), ("bt", old)):
             for _ in range(20):
                 n.train(mb)
             n.profile(True, -1); n.profile_reset()
