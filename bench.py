@@ -604,11 +604,12 @@ def gather_large(sd, args_factory, mem_small_fill, A, Bbig=4096):
     return e
 
 
-def box_check(gather_large_entry, capture="profiles/r05_final_bench.json"):
+def box_check(gather_large_entry, capture=None):
     """How THIS box compares with the one the committed captures were taken on, by the one HBM-bound probe the line already carries
     (the standalone gather at B = 4096: 376 MB per launch).  Boxes of the pool differ: with the same build one that reads 0.90 here
     ran the B = 256 legs 15 % and the float16 B = 256 leg 22 % slower, the B = 32 headline 4 % — but the probe is short and runs first, on
     a cold device: 0.91-0.95 has been read on boxes that then ran every leg at the captures' rates, so it is context, not a verdict."""
+    capture = capture or _latest("r[0-9][0-9]_final_bench.json", "profiles/r05_final_bench.json")
     try:
         ref = json.load(open(os.path.join(ROOT, capture)))["replay_gather_large"]["achieved"]
         x = gather_large_entry["achieved"]

@@ -182,7 +182,7 @@ def test_oracle_yardstick_block_and_fp64_fields_of_the_metric():
 def test_box_check_compares_the_live_probe_with_the_committed_capture():
     """The pool's boxes differ (one reads 10 % less HBM bandwidth and runs the B = 256 legs 15 % slower with the same build): the line
     says how this box's HBM-bound probe compares with the capture box's, and never fails on a missing capture or a failed probe."""
-    ref = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_final_bench.json")))
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", os.path.basename(bench._latest("r[0-9][0-9]_final_bench.json", "profiles/r05_final_bench.json")))))
     ref = ref["replay_gather_large"]["achieved"]
     b = bench.box_check({"achieved": 0.9 * ref})
     assert b["capture_box_GBps"] == ref and abs(b["ratio"] - 0.9) < 1e-3 and b["capture"].startswith("profiles/")
