@@ -78,7 +78,7 @@ class OracleDQN:
                  discount_rate=0.99, clip_error=1.0, min_reward=-1.0, max_reward=1.0,
                  learning_rate=0.00025, decay_rate=0.95, epsilon=None, target_steps=10000,
                  dtype=np.float32, weights=None, seed=0, optimizer="rmsprop", beta_1=0.9, beta_2=0.999,
-                 half_activations=False):
+                 half_activations=False, exact_conv1_input=None):
         self.num_actions = num_actions
         self.batch_size = batch_size
         self.history_length = history_length
@@ -96,6 +96,10 @@ class OracleDQN:
         # GPU-only and unpinned): activations, deltas and the MFMA weight operands are rounded to IEEE half, every
         # accumulation, the master weights, the gradients and the optimizer state stay fp32.
         self.half = bool(half_activations)
+        # conv1 FORWARD's input operand in half mode: half(x / 255) (the B < 128 routines: problems_h16.h ldh8_u8), or the exact byte with the
+        # 1 / 255 applied to the fp32 sum (B >= 128: conv1_hb_kernel, sdqn_kernels_bt.hip).  None = by batch size, as the library chooses.
+        # (conv1's weight gradient stages half(x / 255) either way: c1w_h_kernel.)
+        self.exact_conv1_input = (batch_size >= 128) if exact_conv1_input is None else bool(exact_conv1_input)
         self.loss_scale = 1024.0                                  # deltas are stored as half(delta * 1024) (power of two: exact)
         ws = weights if weights is not None else xavier_weights(num_actions, seed, dtype, history_length,
                                                                 screen_height, screen_width)
@@ -126,12 +130,16 @@ class OracleDQN:
 
     def fprop(self, W, x, keep=False):
         """x (N, C, H, W) normalised. Returns q (N, A) [+ saved tensors]."""
+        x_exact = x
         x = self._h(x)
         acts, cols_all = [x], []
         a = x
         for li, (R, S, K, st) in enumerate(CONV):
             cols, P, Q = _im2col(a, R, S, st)
-            z = cols @ self._h(W[li])                             # (N, PQ, K)
+            if li == 0 and self.half and self.exact_conv1_input:
+                z = _im2col(x_exact, R, S, st)[0] @ self._h(W[li])   # exact bytes / 255 x half weights, fp32 sum
+            else:
+                z = cols @ self._h(W[li])                         # (N, PQ, K)
             z = self._h(np.maximum(z, 0))                         # Rectlin (A5)
             a = np.ascontiguousarray(z.transpose(0, 2, 1)).reshape(x.shape[0], K, P, Q)
             acts.append(a)

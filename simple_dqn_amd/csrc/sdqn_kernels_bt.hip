@@ -419,9 +419,96 @@ __global__ void __launch_bounds__(256) conv1_h_kernel(const Conv1HArgs c) {
   }
 }
 
-static hipError_t launch_conv1_h(const StepArgs& a, hipStream_t s) {
+// Second form (round 6, the default): the frame bytes stay EXACT.  half(1024 + b) is the bit pattern 0x6400 | b, so a dword of four bytes
+// becomes four halves with two v_perm_b32 and two v_pk_add_f16 (- 1024: exact) instead of four (cvt, IEEE divide by 255, cvt) chains —
+// the conversion was ~1 000 vector instructions per thread in front of the first MFMA; the 1 / 255 of deepqnetwork.py:100 multiplies the
+// fp32 sum once per output (the sum of exact byte x half products is CLOSER to the fp32 reference than the first form's half(b / 255)
+// operands; the oracle's half mode models the latter, the difference is below the half rounding of the output: test).  The LDS image is
+// the state's own byte order widened (row pitch 84 halves: a 16-byte piece of the ring is 32 contiguous LDS bytes, no index arithmetic),
+// the weights are the ROW operand (D[map][position]: a lane holds 4 consecutive maps of one position) and a tile's 16 x 32 outputs are
+// collected in a wave-private 1 KB LDS tile and leave as whole 128-byte lines, one 16-byte store per lane (the first form: eight 2-byte
+// stores per lane into 32-byte pieces of lines).
+constexpr int C1G_FR = H0 * W0;                       // halves per frame of the linear image
+constexpr int C1G_OPITCH = 40;                        // halves per position of a wave's output tile (80 bytes: 16-byte aligned, conflict-free)
+constexpr int C1G_LDS = C0 * C1G_FR + K1 * C1F_WPITCH + 4 * 16 * C1G_OPITCH;      // 28 224 + 8 448 + 2 560 halves = 78 464 bytes: two workgroups per CU
+typedef _Float16 c1g_h2 __attribute__((ext_vector_type(2)));
+
+template <bool WT>
+__global__ void __launch_bounds__(256) conv1_hb_kernel(const Conv1HArgs c) {
+  __shared__ __attribute__((aligned(16))) half_t smem[C1G_LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int z = blockIdx.x / c.B, n = blockIdx.x - z * c.B;
+  const int64_t fb = c.from_ring ? (c.idx[n] - C0 + z) * (int64_t)FRAME : ((int64_t)z * c.B + n) * (int64_t)STATE;      // problems.h: sbase
+  const c1h_u32x4* fp = reinterpret_cast<const c1h_u32x4*>(c.src + fb);
+  const c1h_u32x4* wp = reinterpret_cast<const c1h_u32x4*>(c.wht[z] + OFF1);
+  c1h_u32x4 fv[7], wv[4];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) { const int it = tid + 256 * j; fv[j] = fp[it < STATE / 16 ? it : STATE / 16 - 1]; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wv[j] = wp[tid + 256 * j];
+  half_t* wl = smem + C0 * C1G_FR;
+  half_t* ot = wl + K1 * C1F_WPITCH + wave * (16 * C1G_OPITCH);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int it = tid + 256 * j, nn = it >> 5, k8 = it & 31; *reinterpret_cast<c1h_u32x4*>(wl + nn * C1F_WPITCH + 8 * k8) = wv[j]; }
+  const c1g_h2 m1024 = {(half_t)-1024.0f, (half_t)-1024.0f};
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int it = tid + 256 * j;
+    if (it < STATE / 16) {
+      c1h_u32x4 o[2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t w = fv[j][e];
+        union { uint32_t u; c1g_h2 h; } lo, hi;
+        lo.u = __builtin_amdgcn_perm(0x64646464u, w, 0x04010400u);          // halves 0x6400 | b0, 0x6400 | b1 = 1024 + b
+        hi.u = __builtin_amdgcn_perm(0x64646464u, w, 0x04030402u);
+        lo.h = lo.h + m1024; hi.h = hi.h + m1024;                             // exact: b < 2048
+        o[e >> 1][2 * (e & 1)] = lo.u; o[e >> 1][2 * (e & 1) + 1] = hi.u;
+      }
+      c1h_u32x4* d = reinterpret_cast<c1h_u32x4*>(smem + 16 * it);
+      d[0] = o[0]; d[1] = o[1];
+    }
+  }
+  __syncthreads();
+  const int r = lane & 15, kg = lane >> 4;
+  const half_t* wb0 = wl + r * C1F_WPITCH + 8 * kg;                     // weights: map r (and 16 + r), k = 32 st + 8 kg ..
+  half8 fw[2][8];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) { fw[0][st] = *reinterpret_cast<const half8*>(wb0 + 32 * st); fw[1][st] = *reinterpret_cast<const half8*>(wb0 + 16 * C1F_WPITCH + 32 * st); }
+  half_t* const outs = c.h_a1 + ((int64_t)z * c.B + n) * (PIX1 * K1);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)outs, 0, PIX1 * K1 * 2, 0x00020000);
+  for (int rt = wave; rt < PIX1 / 16; rt += 4) {
+    const int pos = 16 * rt + r, p = pos / Q1, q = pos - p * Q1;
+    const half_t* pa = smem + (ST1 * p + kg) * W0 + ST1 * q;
+    c1f_f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const half_t* ap = pa + (st >> 1) * C1G_FR + 4 * (st & 1) * W0;
+      const c1f_h4 a_lo = *reinterpret_cast<const c1f_h4*>(ap), a_hi = *reinterpret_cast<const c1f_h4*>(ap + 4);
+      half8 fa; fa[0] = a_lo[0]; fa[1] = a_lo[1]; fa[2] = a_lo[2]; fa[3] = a_lo[3]; fa[4] = a_hi[0]; fa[5] = a_hi[1]; fa[6] = a_hi[2]; fa[7] = a_hi[3];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][st], fa, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[1][st], fa, acc1, 0, 0, 0);
+    }
+    // D[map 4 kg + e][position r]: Rectlin(sum / 255) as half, 4 consecutive maps = 8 bytes of the position's 64-byte row
+    c1f_h4 h0, h1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h0[e] = (half_t)fmaxf(acc0[e] * (1.0f / 255.0f), 0.0f); h1[e] = (half_t)fmaxf(acc1[e] * (1.0f / 255.0f), 0.0f); }
+    *reinterpret_cast<c1f_h4*>(ot + r * C1G_OPITCH + 4 * kg) = h0;
+    *reinterpret_cast<c1f_h4*>(ot + r * C1G_OPITCH + 16 + 4 * kg) = h1;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                  // lgkmcnt(0): the tile is wave-private
+    __builtin_amdgcn_wave_barrier();
+    const c1h_u32x4 v = *reinterpret_cast<const c1h_u32x4*>(ot + (lane >> 2) * C1G_OPITCH + 8 * (lane & 3));
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, 1024 * rt + 16 * lane, 0, WT ? 16 : 0);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+static hipError_t launch_conv1_h(const StepArgs& a, const LaunchTune& t, hipStream_t s) {
   Conv1HArgs c; c.src = a.src; c.idx = a.idx; c.wht[0] = a.wht[0]; c.wht[1] = a.wht[1]; c.h_a1 = a.h_a1; c.B = a.B; c.from_ring = a.from_ring;
-  SDQN_LAUNCH(conv1_h_kernel, dim3(a.nz * a.B), dim3(256), 0, s, c);
+  if (t.bt[K_CONV1_FWD] == 1) SDQN_LAUNCH(conv1_h_kernel, dim3(a.nz * a.B), dim3(256), 0, s, c);           // first form (half(b / 255) operands)
+  else if (t.bt[K_CONV1_FWD] == 2) SDQN_LAUNCH(conv1_hb_kernel<false>, dim3(a.nz * a.B), dim3(256), 0, s, c);
+  else SDQN_LAUNCH(conv1_hb_kernel<true>, dim3(a.nz * a.B), dim3(256), 0, s, c);
   return hipGetLastError();
 }
 
@@ -578,9 +665,9 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
       if (t.bt[id] == 2) return launch_bt_multi<BtCfgHW<Fc4WgradH, 64, 64, 2, 2, 3>, BtCfgHW<Conv3WgradH, 64, 64, 2, 2, 3>, BtCfgHW<Conv2WgradH, 64, 64, 2, 2, 3>>(a, true, true, true, s);
       return launch_bt_multi<HF4W, HC3W, HC2W>(a, true, true, true, s);
     }
-    if (id == K_CONV1_FWD && t.bt[id] == 0 && t.nw_override[id] == 0 && a.idx_t == nullptr) {   // one workgroup per (net, sample)
+    if (id == K_CONV1_FWD && t.bt[id] >= 0 && t.bt[id] <= 2 && t.nw_override[id] == 0 && a.idx_t == nullptr) {   // one workgroup per (net, sample)
       *handled = true;
-      return launch_conv1_h(a, s);
+      return launch_conv1_h(a, t, s);
     }
     if (id == K_BWD1 && a.h16 == 2 && a.f4w_count == 0) {    // conv1's weight gradient: all 256 x 32 outputs of a K slab per workgroup, A from the bytes
       // (the generic half routine with A from the bytes — BtCfgHW<Conv1WgradH, 256, 32, 4, 1> — fetches 8-byte patch-row pieces straight

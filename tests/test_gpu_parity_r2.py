@@ -162,6 +162,30 @@ def test_fp16_blocked_forward_ragged_batches(sd, B):
     assert np.abs(qs[0] - qs[1]).max() < H_TOL
 
 
+@pytest.mark.parametrize("B", [128, 131, 256])
+def test_fp16_conv1_forward_on_exact_bytes(sd, B):
+    """float16, B >= 128: conv1 forward keeps the frame bytes exact (half(1024 + b) is the bit pattern 0x6400 | b; - 1024 is exact; the
+    1 / 255 of deepqnetwork.py:100 multiplies the fp32 sum) — conv1_hb_kernel, with write-through (default) and plain output stores —
+    against the first form's half(b / 255) operands (bt:0 = 1).  Each form is held to the oracle of ITS input semantics more tightly than
+    the two semantics differ, the two store kinds are bit-identical, and the result is run-to-run stable."""
+    A = 3
+    mb = random_minibatch(B, A, 750 + B, reward_range=(-2, 3))
+    qs = {}
+    for name, menu in (("exact", 0), ("exact_plain", 2), ("first", 1)):
+        net, ws, wt = _net(sd, A, B, 749, datatype="float16")
+        net.set_option("bt:0", menu)
+        qs[name] = net.predict(mb[0]).copy()
+        assert np.array_equal(qs[name], net.predict(mb[0]))
+    o_exact = OracleDQN(A, batch_size=B, weights=ws, half_activations=True, exact_conv1_input=True)
+    o_half = OracleDQN(A, batch_size=B, weights=ws, half_activations=True, exact_conv1_input=False)
+    qe, qh = o_exact.predict(mb[0]), o_half.predict(mb[0])
+    print("fp16 B=%d conv1: exact form vs its oracle %.2e, first form vs its oracle %.2e, the two semantics apart %.2e (library) / %.2e (oracles)" % (
+        B, np.abs(qs["exact"] - qe).max(), np.abs(qs["first"] - qh).max(), np.abs(qs["exact"] - qs["first"]).max(), np.abs(qe - qh).max()))
+    assert np.array_equal(qs["exact"], qs["exact_plain"])
+    assert np.abs(qs["exact"] - qe).max() < 1.5e-4 and np.abs(qs["first"] - qh).max() < 1.5e-4
+    assert np.abs(qs["exact"] - qs["first"]).max() < H_TOL
+
+
 # ---- configs[2]: B = 256 --------------------------------------------------------------------------------------------
 def test_batch256_a6_one_step(sd):
     A, B = 6, 256
