@@ -96,9 +96,9 @@ class OracleDQN:
         # GPU-only and unpinned): activations, deltas and the MFMA weight operands are rounded to IEEE half, every
         # accumulation, the master weights, the gradients and the optimizer state stay fp32.
         self.half = bool(half_activations)
-        # conv1 FORWARD's input operand in half mode: half(x / 255) (the B < 128 routines: problems_h16.h ldh8_u8), or the exact byte with the
-        # 1 / 255 applied to the fp32 sum (B >= 128: conv1_hb_kernel, sdqn_kernels_bt.hip).  None = by batch size, as the library chooses.
-        # (conv1's weight gradient stages half(x / 255) either way: c1w_h_kernel.)
+        # conv1's input operand in half mode (forward and weight gradient alike): half(x / 255) (the B < 128 routines: problems_h16.h ldh8_u8),
+        # or the exact byte with the 1 / 255 applied to the fp32 sum (B >= 128: conv1_hb_kernel / c1w_h_kernel<true>, sdqn_kernels_bt.hip).
+        # None = by batch size, as the library chooses.
         self.exact_conv1_input = (batch_size >= 128) if exact_conv1_input is None else bool(exact_conv1_input)
         self.loss_scale = 1024.0                                  # deltas are stored as half(delta * 1024) (power of two: exact)
         ws = weights if weights is not None else xavier_weights(num_actions, seed, dtype, history_length,
@@ -130,16 +130,13 @@ class OracleDQN:
 
     def fprop(self, W, x, keep=False):
         """x (N, C, H, W) normalised. Returns q (N, A) [+ saved tensors]."""
-        x_exact = x
-        x = self._h(x)
+        if not (self.half and self.exact_conv1_input):
+            x = self._h(x)
         acts, cols_all = [x], []
         a = x
         for li, (R, S, K, st) in enumerate(CONV):
             cols, P, Q = _im2col(a, R, S, st)
-            if li == 0 and self.half and self.exact_conv1_input:
-                z = _im2col(x_exact, R, S, st)[0] @ self._h(W[li])   # exact bytes / 255 x half weights, fp32 sum
-            else:
-                z = cols @ self._h(W[li])                         # (N, PQ, K)
+            z = cols @ self._h(W[li])                             # (N, PQ, K)
             z = self._h(np.maximum(z, 0))                         # Rectlin (A5)
             a = np.ascontiguousarray(z.transpose(0, 2, 1)).reshape(x.shape[0], K, P, Q)
             acts.append(a)

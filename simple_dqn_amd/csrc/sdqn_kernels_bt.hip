@@ -257,6 +257,10 @@ constexpr int C1H_DPITCH = K1 + 16;                 // halves per k row of delta
 constexpr int C1H_STAGE = C0 * C1H_FR + C1W_CH * C1H_DPITCH;      // halves per LDS stage: 7040 + 3840
 typedef unsigned int c1h_u32x4 __attribute__((ext_vector_type(4)));
 
+// EXACT (round 6, the default): the frame bytes enter as exact halves (half(1024 + b) = 0x6400 | b, - 1024: two perms + two packed adds per
+// dword instead of four cvt / IEEE-divide / cvt chains — the conversion was ~3x the chunk's matrix time) from 16-byte loads, and the 1 / 255 of
+// deepqnetwork.py:100 multiplies the split-K partial once, with the loss scale.  !EXACT: the first form (half(b / 255) operands, 4-byte loads).
+template <bool EXACT>
 __global__ void __launch_bounds__(256) c1w_h_kernel(const C1wHArgs c) {
   __shared__ __attribute__((aligned(16))) half_t smem[2 * C1H_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
@@ -264,30 +268,65 @@ __global__ void __launch_bounds__(256) c1w_h_kernel(const C1wHArgs c) {
   const int ks = blockIdx.x, Kt = c.Kt, kb = ks * c.tps1 * 32;
   int ke = kb + c.tps1 * 32; if (ke > Kt) ke = Kt;
   const int nch = (ke - kb) / C1W_CH;               // (the host launches this kernel only with slabs of whole chunks)
-  // loader items: frame rows = 4 frames x 20 rows x 21 dwords = 1680 dwords (7 per thread, the last partly), delta = 320 x 16 bytes (2, partly)
-  struct Stg { uint32_t b[7]; c1h_u32x4 d0, d1; };
+  // loader items: frame rows = 4 frames x 20 rows x 84 bytes, contiguous and 16-byte aligned per frame: 420 pieces of 16 bytes (EXACT; 2 per
+  // thread, the second partly) or 1680 dwords (7 per thread); delta = 320 x 16 bytes (2, partly)
+  struct Stg { uint32_t b[EXACT ? 1 : 7]; c1h_u32x4 f[2]; c1h_u32x4 d0, d1; };
+  int fsrc[2], fdst[2][4];                          // EXACT: byte offset of piece j in the chunk's frame window / LDS half offsets of its 4 dwords
+  if constexpr (EXACT) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int it = tid + 256 * j; if (it > 419) it = 419;
+      const int fc = it / 105, q4 = it - fc * 105;
+      fsrc[j] = fc * FRAME + 16 * q4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const int q = 4 * q4 + e, row = q / 21, col = 4 * (q - row * 21); fdst[j][e] = fc * C1H_FR + row * C1H_PITCH + col; }
+    }
+  }
   auto gload = [&](int ch, Stg& g) {
     const int k0 = kb + ch * C1W_CH, n = k0 / PIX1, y0 = (k0 - n * PIX1) / Q1;
     const int64_t fb = (c.from_ring ? (c.idx[n] - C0) * (int64_t)FRAME : (int64_t)n * STATE) + (int64_t)y0 * (ST1 * W0);     // problems.h: sbase, z = 0
+    if constexpr (EXACT) {
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      int it = tid + 256 * j; if (it > 1679) it = 1679;
-      const int fc = it / 420, q = it - fc * 420;                             // 420 dwords = 20 rows x 84 bytes, contiguous in the frame
-      g.b[j] = *reinterpret_cast<const uint32_t*>(c.src + fb + (int64_t)fc * FRAME + 4 * q);
+      for (int j = 0; j < 2; ++j) g.f[j] = *reinterpret_cast<const c1h_u32x4*>(c.src + fb + fsrc[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        int it = tid + 256 * j; if (it > 1679) it = 1679;
+        const int fc = it / 420, q = it - fc * 420;                             // 420 dwords = 20 rows x 84 bytes, contiguous in the frame
+        g.b[j] = *reinterpret_cast<const uint32_t*>(c.src + fb + (int64_t)fc * FRAME + 4 * q);
+      }
     }
     const c1h_u32x4* dp = reinterpret_cast<const c1h_u32x4*>(c.d1 + (size_t)k0 * K1);
     g.d0 = dp[tid]; g.d1 = dp[tid + 256 < 320 ? tid + 256 : 319];
   };
   auto lds_store = [&](const Stg& g, half_t* st) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    if constexpr (EXACT) {
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      const h2 m1024 = {(half_t)-1024.0f, (half_t)-1024.0f};
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const int it = tid + 256 * j;
-      if (it < 1680) {
-        const int fc = it / 420, q = it - fc * 420, row = q / 21, col = 4 * (q - row * 21);
-        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        h4 v; const uint32_t w = g.b[j];
-        v[0] = (half_t)norm_u8(w & 255u); v[1] = (half_t)norm_u8((w >> 8) & 255u); v[2] = (half_t)norm_u8((w >> 16) & 255u); v[3] = (half_t)norm_u8(w >> 24);
-        *reinterpret_cast<h4*>(st + fc * C1H_FR + row * C1H_PITCH + col) = v;
+      for (int j = 0; j < 2; ++j) {
+        if (tid + 256 * j >= 420) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t w = g.f[j][e];
+          union { uint32_t u; h2 v; } lo, hi;
+          lo.u = __builtin_amdgcn_perm(0x64646464u, w, 0x04010400u); hi.u = __builtin_amdgcn_perm(0x64646464u, w, 0x04030402u);
+          lo.v = lo.v + m1024; hi.v = hi.v + m1024;
+          union { uint32_t u[2]; h4 v; } o; o.u[0] = lo.u; o.u[1] = hi.u;
+          *reinterpret_cast<h4*>(st + fdst[j][e]) = o.v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int it = tid + 256 * j;
+        if (it < 1680) {
+          const int fc = it / 420, q = it - fc * 420, row = q / 21, col = 4 * (q - row * 21);
+          h4 v; const uint32_t w = g.b[j];
+          v[0] = (half_t)norm_u8(w & 255u); v[1] = (half_t)norm_u8((w >> 8) & 255u); v[2] = (half_t)norm_u8((w >> 16) & 255u); v[3] = (half_t)norm_u8(w >> 24);
+          *reinterpret_cast<h4*>(st + fc * C1H_FR + row * C1H_PITCH + col) = v;
+        }
       }
     }
     half_t* dl = st + C0 * C1H_FR;
@@ -336,15 +375,16 @@ __global__ void __launch_bounds__(256) c1w_h_kernel(const C1wHArgs c) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int m = 64 * wave + 32 * sm + bt::acc_row(q, h);
-      c.slab1[(int64_t)ks * NW1 + m * K1 + i] = acc[sm][q] * c.inv_loss_scale;
+      c.slab1[(int64_t)ks * NW1 + m * K1 + i] = acc[sm][q] * (EXACT ? c.inv_loss_scale * (1.0f / 255.0f) : c.inv_loss_scale);
     }
 }
 
-static hipError_t launch_c1w_h(const StepArgs& a, hipStream_t s) {
+static hipError_t launch_c1w_h(const StepArgs& a, const LaunchTune& t, hipStream_t s) {
   if ((a.tps1 * 32) % C1W_CH != 0) return hipErrorInvalidValue;       // slabs of whole 80-position chunks only
   C1wHArgs c; c.src = a.src; c.d1 = a.h_d1; c.slab1 = a.slab1; c.idx = a.idx; c.B = a.B; c.from_ring = a.from_ring; c.tps1 = a.tps1; c.Kt = a.B * PIX1;
   c.inv_loss_scale = a.inv_loss_scale;
-  SDQN_LAUNCH(c1w_h_kernel, dim3(Conv1Wgrad::nbz(a)), dim3(256), 0, s, c);
+  if (t.bt[K_BWD1] == 1) SDQN_LAUNCH(c1w_h_kernel<false>, dim3(Conv1Wgrad::nbz(a)), dim3(256), 0, s, c);        // first form (half(b / 255) operands)
+  else SDQN_LAUNCH(c1w_h_kernel<true>, dim3(Conv1Wgrad::nbz(a)), dim3(256), 0, s, c);
   return hipGetLastError();
 }
 
@@ -672,7 +712,7 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
     if (id == K_BWD1 && a.h16 == 2 && a.f4w_count == 0) {    // conv1's weight gradient: all 256 x 32 outputs of a K slab per workgroup, A from the bytes
       // (the generic half routine with A from the bytes — BtCfgHW<Conv1WgradH, 256, 32, 4, 1> — fetches 8-byte patch-row pieces straight
       //  from memory: 16 divergent loads per thread and chunk, 18.9 us at B = 256, no better than the wave-tile routine's 18.7)
-      const hipError_t e1 = launch_c1w_h(a, s);
+      const hipError_t e1 = launch_c1w_h(a, t, s);
       if (e1 == hipErrorInvalidValue) return hipSuccess;
       *handled = true;
       return e1;

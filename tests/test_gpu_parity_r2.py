@@ -184,6 +184,19 @@ def test_fp16_conv1_forward_on_exact_bytes(sd, B):
     assert np.array_equal(qs["exact"], qs["exact_plain"])
     assert np.abs(qs["exact"] - qe).max() < 1.5e-4 and np.abs(qs["first"] - qh).max() < 1.5e-4
     assert np.abs(qs["exact"] - qs["first"]).max() < H_TOL
+    # conv1's weight gradient with the same two input semantics (c1w_h_kernel<true> / <false>: bt:18 = 0 / 1) behind the SAME forward pass
+    # (another forward semantics flips Rectlin gates through the net: 2-4e-2 of the gradient, tools/exp/c1w_h_iso.py): the two differ by
+    # the half rounding of the inputs only, and the default pair is held to the oracle of its semantics
+    g0 = {}
+    for name, menu in (("exact", 0), ("first", 1)):
+        net, ws, wt = _net(sd, A, B, 749, datatype="float16")
+        net.set_option("keep_gradients", 1); net.set_option("bt:18", menu)
+        net.train(mb)
+        g0[name] = net.get_layer(0, which=3)
+    o_exact.Wt = [w.copy() for w in wt]
+    ge = o_exact.gradients(mb)[0][0]
+    print("fp16 B=%d conv1 wgrad: exact vs first (same forward) %.2e, exact vs the oracle %.2e (rel Frobenius)" % (B, _rel_fro(g0["exact"], g0["first"]), _rel_fro(g0["exact"], ge)))
+    assert _rel_fro(g0["exact"], g0["first"]) < 2e-3 and _rel_fro(g0["exact"], ge) < 5e-2
 
 
 # ---- configs[2]: B = 256 --------------------------------------------------------------------------------------------

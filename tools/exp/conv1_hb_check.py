@@ -24,7 +24,7 @@ def main():
     for B in Bs:
         A = 3
         mb = random_minibatch(B, A, 40 + B, reward_range=(-2, 3))
-        nets = [("exact-wt", net_of(A, B)), ("exact-plain", net_of(A, B, [("bt:0", 2)])), ("first", net_of(A, B, [("bt:0", 1)]))]
+        nets = [("exact-wt", net_of(A, B)), ("exact-plain", net_of(A, B, [("bt:0", 2)])), ("first", net_of(A, B, [("bt:0", 1), ("bt:18", 1)]))]
         o = OracleDQN(A, batch_size=B, weights=xavier_weights(A, 7), half_activations=True)
         o32 = OracleDQN(A, batch_size=B, weights=xavier_weights(A, 7))
         qo, q32 = o.predict(mb[0]), o32.predict(mb[0])
