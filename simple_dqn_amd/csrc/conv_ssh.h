@@ -1,0 +1,220 @@
+// conv_ssh.h — float16 mode, throughput regime (B >= 128): conv2 -> conv3 forward as ONE sample-stationary launch
+// (deepqnetwork.py:85-87; the online and the target net of :119-130 together).
+//
+// The packed-fp16 block-tile routines run these two layers in 9.1 + 7.4 us at B = 256 for 1.1 + 0.8 us of matrix time: they are data
+// movement (every 64 x 64 block re-fetches its patches, expanded 4x / 9x by im2col, and the whole weight panel) plus two launch boundaries.
+// Here one workgroup per CU owns NS whole samples of one net:
+//   * its input maps ([20][20][32] halves per sample, contiguous), W2^T ([64 maps][512 k] halves) and — into REGISTERS, for later — W3^T
+//     ([64][576]) are requested once, up front, with 16-byte loads; image and W2 go to LDS (pixel pitch 40 halves, weight row pitch 592:
+//     a tile's 16 positions / maps are 160 bytes apart modulo 256, conflict-free ds_read_b128);
+//   * conv2 = v_mfma_f32_16x16x32_f16 with im2col at ds_read time: one MFMA step is one kernel tap (r, s) x 32 channels; lane (m, kq) reads
+//     the 8 channels 8 kq .. + 7 of pixel (2 p + r, 2 q + s) with one ds_read_b128; the weights are the ROW operand (D[map][position]: a lane
+//     holds 4 consecutive maps of a position).  Eight waves: wave = (map pair, position group): 2 map tiles x 3 position tiles = 6
+//     accumulators, 5 fragment reads per 6 MFMAs (the launch is LDS-bandwidth bound, not matrix bound);
+//   * behind a barrier the Rectlin'ed half outputs are written into the conv3 image (pixel pitch 80 halves) over the dead conv2 image, W3
+//     comes out of the registers over W2, and a2 leaves for the backward pass as whole lines copied from the LDS image;
+//   * conv3 the same way (two MFMA steps per tap: 64 channels), a3 collected in LDS and stored as whole lines.
+// a2 is never read back from memory by the forward pass.  Arithmetic: half operands, fp32 accumulation, k ascending in the order (r, s, c)
+// in ONE accumulator per output — the same sums as the block-tile routine's, in another order of the same fp32 additions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "launch.h"
+
+namespace sdqn {
+namespace ssh {
+
+typedef _Float16 h_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NT_ = 512;                       // threads: eight waves, all of them load, compute and store
+constexpr int NO = 64;                         // output maps of both layers
+constexpr int P1 = 40;                         // halves per pixel of the conv2 image (32 + 8)
+constexpr int P2 = 80;                         // halves per pixel of the conv3 image / the a3 collection (64 + 16)
+constexpr int KP = 592;                        // halves per map row of a staged weight matrix (512 / 576 + padding: 1184 bytes = 160 mod 256)
+constexpr int PX1 = 400, PX2 = 81, PX3 = 49;   // pixels per sample: a1, a2, a3
+constexpr int KK2 = 512, KK3 = 576;            // k per output: conv2, conv3
+
+struct Args {
+  const h_t* a1;            // [nz][B][400][32]
+  const h_t* w2[2];         // per net: W2^T [64][512]   (k = (r, s, c))
+  const h_t* w3[2];         // per net: W3^T [64][576]
+  h_t* a2;                  // [nz][B][81][64]
+  h_t* a3;                  // [nz][B][49][64]
+  int B, G;                 // G = workgroups per net = ceil(B / NS)
+};
+
+template <int NS> struct Lds {
+  static constexpr int R1 = NS * PX1 * P1;                   // conv2 image; later: conv3 image (NS * 81 * 80) + a3 collection (NS * 49 * 80)
+  static_assert(NS * PX2 * P2 + NS * PX3 * P2 <= R1, "conv3 image and a3 collection fit the dead conv2 image");
+  static constexpr int RW = NO * KP;
+  static constexpr int TOTAL = R1 + RW;                      // NS = 2: 32 000 + 37 888 halves = 139 776 bytes
+  static_assert(TOTAL * 2 <= 160 * 1024, "LDS budget");
+};
+
+// one layer's matrix work for this wave: NPT position tiles x 2 map tiles; A fragments from `img` (lane base apos[t], + the tap's immediate),
+// weight fragments from `wl`.  STEPS k-steps of 32; step -> (tap, channel half) -> immediate offsets.
+template <int NPT, int STEPS, int CI, int S, int WI, int PITCH>
+__device__ __forceinline__ void mm(const h_t* img, const int (&apos)[3], const h_t* wb, f32x4 (&acc)[2][3]) {
+  constexpr int SPT = CI / 32;                               // MFMA steps per tap
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const int tap = st / SPT, hf = st - tap * SPT, r = tap / S, s = tap - r * S;
+    const int aoff = (r * WI + s) * PITCH + 32 * hf;
+    const h8 w0 = *reinterpret_cast<const h8*>(wb + 32 * st), w1 = *reinterpret_cast<const h8*>(wb + 16 * KP + 32 * st);
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+      const h8 x = *reinterpret_cast<const h8*>(img + apos[t] + aoff);
+      acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, x, acc[0][t], 0, 0, 0);
+      acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x, acc[1][t], 0, 0, 0);
+    }
+  }
+}
+
+template <int NS, bool WT>
+__global__ void __launch_bounds__(NT_) conv_ssh_chain_kernel(const Args c) {
+  typedef Lds<NS> L;
+  __shared__ __attribute__((aligned(16))) h_t smem[L::TOTAL];
+  h_t* const r1 = smem;
+  h_t* const rw = smem + L::R1;
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int z = (int)blockIdx.x / c.G, g = (int)blockIdx.x - z * c.G;
+  const int n0 = g * NS;
+  const int nvalid = c.B - n0 < NS ? c.B - n0 : NS;          // (the last workgroup of an odd batch has one sample)
+
+  // ---- every global read of the launch, up front: image, W2 (-> LDS now), W3 (-> registers, into LDS behind conv2) ----
+  constexpr int IPC = NS * PX1 * 4, IPT = (IPC + NT_ - 1) / NT_;            // 16-byte pieces of the image / per thread
+  constexpr int W2P = NO * KK2 / 8 / NT_, W3P = NO * KK3 / 8 / NT_;         // 8, 9 pieces per thread
+  static_assert(W2P * NT_ * 8 == NO * KK2 && W3P * NT_ * 8 == NO * KK3, "whole weight pieces per thread");
+  const u32x4* const ip = reinterpret_cast<const u32x4*>(c.a1 + ((int64_t)z * c.B + n0) * (PX1 * 32));
+  const u32x4* const w2p = reinterpret_cast<const u32x4*>(c.w2[z]);
+  const u32x4* const w3p = reinterpret_cast<const u32x4*>(c.w3[z]);
+  u32x4 iv[IPT], w2v[W2P], w3v[W3P];
+  const int ipmax = nvalid * PX1 * 4 - 1;
+#pragma unroll
+  for (int j = 0; j < W2P; ++j) w2v[j] = w2p[tid + NT_ * j];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) { const int pc = tid + NT_ * j; iv[j] = ip[pc < ipmax ? pc : ipmax]; }
+#pragma unroll
+  for (int j = 0; j < W3P; ++j) w3v[j] = w3p[tid + NT_ * j];
+#pragma unroll
+  for (int j = 0; j < W2P; ++j) { const int pc = tid + NT_ * j; *reinterpret_cast<u32x4*>(rw + (pc >> 6) * KP + 8 * (pc & 63)) = w2v[j]; }
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) { const int pc = tid + NT_ * j; if (pc < IPC) *reinterpret_cast<u32x4*>(r1 + (pc >> 2) * P1 + 8 * (pc & 3)) = iv[j]; }
+  __syncthreads();
+
+  // ---- conv2: 16 taps x 32 channels.  wave = (map pair mp, position group pg): maps 32 mp .. + 31, position tiles TPG pg .. + TPG - 1 ----
+  const int mp = wave & 1, pg = wave >> 1;
+  const h_t* const wb = rw + (32 * mp + m) * KP + 8 * kq;
+  f32x4 acc[2][3];
+  int apos[3];
+  {
+    constexpr int NPOS = NS * PX2, NTL = (NPOS + 15) / 16, TPG = (NTL + 3) / 4;    // 162 positions: 11 tiles, 3 per group (NS = 1: 81, 6 tiles, 2)
+    static_assert(TPG <= 3, "accumulators");
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+      int P = 16 * (TPG * pg + t) + m; if (P > NPOS - 1) P = NPOS - 1;      // (padding rows of the last tile: a valid pixel nobody stores)
+      const int sp = P / PX2, rem = P - sp * PX2, p = rem / 9, q = rem - p * 9;
+      apos[t] = (sp * PX1 + (2 * p) * 20 + 2 * q) * P1 + 8 * kq;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    {
+      const int nt = NTL - TPG * pg;                                         // this wave's tiles (wave-uniform)
+      if (nt >= 3 && TPG >= 3) mm<3, 16, 32, 4, 20, P1>(r1, apos, wb, acc);
+      else if (nt >= 2 && TPG >= 2) mm<2, 16, 32, 4, 20, P1>(r1, apos, wb, acc);
+      else if (nt >= 1) mm<1, 16, 32, 4, 20, P1>(r1, apos, wb, acc);
+    }
+    __syncthreads();                                                         // every read of the conv2 image and of W2 is done
+    // a2 = Rectlin(.) as half into the conv3 image (over the conv2 image): D[map 4 kq + e][position m]
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+      const int P = 16 * (TPG * pg + t) + m;
+      if (P < NPOS) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          h4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (h_t)fmaxf(acc[u][t][e], 0.0f);
+          *reinterpret_cast<h4*>(r1 + P * P2 + 32 * mp + 16 * u + 4 * kq) = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < W3P; ++j) { const int pc = tid + NT_ * j, n = pc / 72, k8 = pc - n * 72; *reinterpret_cast<u32x4*>(rw + n * KP + 8 * k8) = w3v[j]; }
+    __syncthreads();
+    // a2 leaves for the backward pass: nvalid x 81 rows of 128 bytes, whole lines from the LDS image
+    {
+      h_t* const o2 = c.a2 + ((int64_t)z * c.B + n0) * (PX2 * NO);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)o2, 0, nvalid * PX2 * NO * 2, 0x00020000);
+      constexpr int OPC = NPOS * 8;                                          // 16-byte pieces
+#pragma unroll
+      for (int j = 0; j < (OPC + NT_ - 1) / NT_; ++j) {
+        const int pc = tid + NT_ * j;
+        if (pc < OPC) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(r1 + (pc >> 3) * P2 + 8 * (pc & 7));
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, 16 * pc, 0, WT ? 16 : 0);      // (rows past the batch: dropped by the range check)
+        }
+      }
+    }
+  }
+  // ---- conv3: 9 taps x 64 channels (two steps per tap).  Position tiles 2 pg, 2 pg + 1 of 7 (NS = 1: 4) ----
+  {
+    constexpr int NPOS = NS * PX3, NTL = (NPOS + 15) / 16, TPG = (NTL + 3) / 4;    // 98 positions: 7 tiles, 2 per group (NS = 1: 49, 4 tiles, 1)
+    static_assert(TPG <= 3, "accumulators");
+    h_t* const o3l = r1 + NS * PX2 * P2;                                     // a3 collection, behind the conv3 image
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+      int P = 16 * (TPG * pg + t) + m; if (P > NPOS - 1) P = NPOS - 1;
+      const int sp = P / PX3, rem = P - sp * PX3, p = rem / 7, q = rem - p * 7;
+      apos[t] = (sp * PX2 + p * 9 + q) * P2 + 8 * kq;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    {
+      const int nt = NTL - TPG * pg;
+      if (nt >= 3 && TPG >= 3) mm<3, 18, 64, 3, 9, P2>(r1, apos, wb, acc);
+      else if (nt >= 2 && TPG >= 2) mm<2, 18, 64, 3, 9, P2>(r1, apos, wb, acc);
+      else if (nt >= 1) mm<1, 18, 64, 3, 9, P2>(r1, apos, wb, acc);
+    }
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+      const int P = 16 * (TPG * pg + t) + m;
+      if (P < NPOS) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          h4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (h_t)fmaxf(acc[u][t][e], 0.0f);
+          *reinterpret_cast<h4*>(o3l + P * P2 + 32 * mp + 16 * u + 4 * kq) = v;
+        }
+      }
+    }
+    __syncthreads();
+    h_t* const o3 = c.a3 + ((int64_t)z * c.B + n0) * (PX3 * NO);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)o3, 0, nvalid * PX3 * NO * 2, 0x00020000);
+    constexpr int OPC = NPOS * 8;
+#pragma unroll
+    for (int j = 0; j < (OPC + NT_ - 1) / NT_; ++j) {
+      const int pc = tid + NT_ * j;
+      if (pc < OPC) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(o3l + (pc >> 3) * P2 + 8 * (pc & 7));
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, 16 * pc, 0, WT ? 16 : 0);
+      }
+    }
+  }
+}
+
+template <int NS, bool WT>
+inline hipError_t launch_chain(const Args& c, int nz, hipStream_t s) {
+  if (c.B <= 0) return hipSuccess;
+  SDQN_LAUNCH((conv_ssh_chain_kernel<NS, WT>), dim3(nz * c.G), dim3(NT_), 0, s, c);
+  return hipGetLastError();
+}
+
+}  // namespace ssh
+}  // namespace sdqn

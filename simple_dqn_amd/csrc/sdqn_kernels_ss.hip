@@ -8,6 +8,7 @@
 // When both layers run here they are ONE launch (conv_ss_chain_kernel: a workgroup's conv3 follows its own conv2 behind a barrier).
 #include <stdlib.h>
 #include "conv_ss.h"
+#include "conv_ssh.h"
 #include "kernels.h"
 
 namespace sdqn {
@@ -36,9 +37,32 @@ static bool ss_chains(const StepArgs& a, const LaunchTune& t) {
   return ss_takes(K_CONV2_FWD, a, t) && ss_takes(K_CONV3_FWD, a, t) && t.bt[K_CONV2_FWD] != 8 && t.bt[K_CONV3_FWD] != 8;
 }
 
+// float16 mode, B >= 128: conv2 -> conv3 forward as one launch (conv_ssh.h) under the same rule (workgroups fill >= 80 % of whole 256-CU
+// rounds); menu entries bt:1 / bt:2: 0 = this launch where it pays, 7 = always, 8 = always with plain (write-back) stores, anything else
+// the packed-fp16 block-tile routines (sdqn_kernels_bt.hip: launch_single_h)
+static bool ssh_takes(const StepArgs& a, const LaunchTune& t) {
+  if (!a.h16 || a.B < 128 || a.bn) return false;
+  for (int id : {K_CONV2_FWD, K_CONV3_FWD}) if ((t.bt[id] != 0 && t.bt[id] != 7 && t.bt[id] != 8) || t.nw_override[id] > 0) return false;
+  if (t.bt[K_CONV2_FWD] != t.bt[K_CONV3_FWD]) return false;
+  const int ns = a.nz * a.B > 256 ? 2 : 1;
+  const int wgs = a.nz * ((a.B + ns - 1) / ns), rounds = (wgs + 255) / 256;
+  return t.bt[K_CONV2_FWD] != 0 || wgs * 5 >= rounds * 256 * 4;
+}
+
 hipError_t launch_kernel_ss(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = false;
   if (id != K_CONV2_FWD && id != K_CONV3_FWD) return hipSuccess;
+  if (a.h16) {
+    if (!ssh_takes(a, t)) return hipSuccess;
+    *handled = true;
+    if (id == K_CONV3_FWD) return hipSuccess;                    // (rode in the conv2 launch)
+    const int ns = a.nz * a.B > 256 ? 2 : 1, z1 = a.nz > 1 ? 1 : 0;
+    ssh::Args c; c.a1 = a.h_a1; c.a2 = a.h_a2; c.a3 = a.h_a3; c.B = a.B; c.G = (a.B + ns - 1) / ns;
+    c.w2[0] = a.wht[0] + OFF2; c.w2[1] = a.wht[z1] + OFF2; c.w3[0] = a.wht[0] + OFF3; c.w3[1] = a.wht[z1] + OFF3;
+    const bool wt = t.bt[K_CONV2_FWD] != 8;
+    if (ns == 2) return wt ? ssh::launch_chain<2, true>(c, a.nz, s) : ssh::launch_chain<2, false>(c, a.nz, s);
+    return wt ? ssh::launch_chain<1, true>(c, a.nz, s) : ssh::launch_chain<1, false>(c, a.nz, s);
+  }
   if (!ss_takes(id, a, t)) return hipSuccess;
   *handled = true;
   const bool chain = ss_chains(a, t);

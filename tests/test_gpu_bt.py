@@ -18,8 +18,8 @@ def sd():
     return simple_dqn_amd
 
 
-def _net(sd, A, B, seed, opts=()):
-    net = sd.DeepQNetwork(A, make_args(batch_size=B))
+def _net(sd, A, B, seed, opts=(), **kw):
+    net = sd.DeepQNetwork(A, make_args(batch_size=B, **kw))
     net.set_weights(xavier_weights(A, seed + 1), 1)
     net.set_weights(xavier_weights(A, seed), 0)
     for k, v in opts:
@@ -207,3 +207,36 @@ def test_sample_stationary_forward_convolutions(sd, A, B):
         assert np.array_equal(new.get_layer(i, 3), again.get_layer(i, 3)), i
     new.train(mb); again.train(mb); old.train(mb)      # a second step from the updated weights: still the same bits
     assert np.array_equal(new.debug_read("a3", 2 * B * 49 * 64), again.debug_read("a3", 2 * B * 49 * 64))
+
+
+@pytest.mark.parametrize("A,B", [(3, 256), (6, 160), (4, 128), (3, 129)])
+def test_float16_conv2_conv3_forward_as_one_sample_stationary_launch(sd, A, B):
+    """Round 6, float16 mode at B >= 128: conv2 -> conv3 forward as ONE launch (csrc/conv_ssh.h: a workgroup's samples, W2 and — through
+    registers — W3 fetched once, im2col at ds_read time on v_mfma_f32_16x16x32_f16, the conv3 image written from the accumulators, a2 /
+    a3 stored as whole lines).  Same half operands, fp32 accumulation in the same k order in one accumulator per output as the packed-fp16
+    block-tile routines (menu entry 6): Q-values, cost and every gradient are BIT-IDENTICAL — two samples per workgroup (B = 256, 160),
+    one (B = 128; predict at any size), an odd batch (B = 129) — with write-through (7) and plain (8) output stores, over two steps."""
+    mb = random_minibatch(B, A, 400 + B, reward_range=(-2, 3))
+    mk = lambda menu: _net(sd, A, B, 41, [("keep_gradients", 1)] + ([("bt:1", menu), ("bt:2", menu)] if menu is not None else []), datatype="float16")
+    nets = {"default": mk(None), "forced": mk(7), "plain": mk(8), "bt": mk(6)}
+    qs = {k: n.predict(mb[0]).copy() for k, n in nets.items()}
+    for k in ("default", "forced", "plain"):
+        assert np.array_equal(qs[k], qs["bt"]) and np.abs(qs[k]).max() > 0, k
+    for step in range(2):
+        for n in nets.values():
+            n.train(mb)
+        for k in ("default", "forced", "plain"):
+            assert np.array_equal(nets[k].last_q()[0], nets["bt"].last_q()[0]), (k, step)
+            for i in range(5):
+                assert np.array_equal(nets[k].get_layer(i, 3), nets["bt"].get_layer(i, 3)), (k, step, i)
+    # the launch structure says so: one launch fewer per net pass where the chained launch runs by default (B = 128, 256)
+    counts = {}
+    for k in ("default", "bt"):
+        n = nets[k]
+        n.profile(True, -1); n.profile_reset()
+        for _ in range(3):
+            n.train(mb)
+        counts[k] = {p["name"].split("(")[0]: p["launches"] for p in n.profile_read() if p["launches"] > 0}
+        n.profile(False)
+    assert counts["bt"].get("conv3_fwd", 0) == 3
+    assert counts["default"].get("conv3_fwd", 0) == (0 if B in (128, 256) else 3), counts["default"]
