@@ -209,6 +209,198 @@ __global__ void __launch_bounds__(NT_) conv_ssh_chain_kernel(const Args c) {
   }
 }
 
+// ---- the backward data path of the same two layers, float16, B >= 128: conv3_dgrad -> conv2_dgrad as ONE launch ------------------------------
+// (deepqnetwork.py:162, model.bprop through the third and second Convolution layers; online net only.)  One workgroup per sample:
+//   * delta3's padded plane ([11][11][64] halves, borders zero), W3 in its master layout ([(r, s, c)][64 f]: the row of output map c at tap
+//     (r, s) is k-contiguous), a2 (the Rectlin gate) are fetched once into LDS; W2 (master layout) and a1 (the second gate) into registers;
+//   * delta2 = full correlation: position (y, x), tap (r, s) reads pixel (y + 2 - r, x + 2 - s) of the padded plane — im2col at ds_read
+//     time again, k = (r, s, f) ascending, v_mfma_f32_16x16x32_f16 with the weights as the row operand; 6 position tiles x 4 map tiles over
+//     six waves (2 x 2 each: 4 fragment reads per 4 MFMAs);
+//   * gated by a2 > 0 it is written as half into a second padded plane in LDS (borders zeroed at entry) — conv2_dgrad's input, never
+//     re-read from memory — and leaves as the dense delta2 of conv2's weight gradient; W2 replaces W3 in LDS;
+//   * delta1: the stride-2 transposed convolution as four parity classes (py, px), each a 2 x 2 correlation over the padded delta2 plane
+//     (class position (i, j), tap (aa, bb) reads pixel (i + 1 - aa, j + 1 - bb); weights row ((py + 2 aa) 4 + px + 2 bb) 32 + c): wave =
+//     (class, half of its 7 position tiles), both 16-map tiles; the outputs are collected as the dense [20][20][32] plane in LDS and leave
+//     as whole lines, gated by a1 > 0 from the registers on the way out.
+// Same half operands and the same k order in one fp32 accumulator per output as Conv3DgradH / Conv2DgradH on the block-tile routine.
+struct DArgs {
+  const h_t* d3p;           // [B][11][11][64], loss-scaled, borders zero
+  const h_t* w3;            // master layout [(r, s, c)][64 f]  (9 x 64 rows)
+  const h_t* w2;            // master layout [(r, s, c)][64 f]  (16 x 32 rows)
+  const h_t* a2;            // [B][81][64]  (online net)
+  const h_t* a1;            // [B][400][32]
+  h_t* d2;                  // [B][81][64]
+  h_t* d1;                  // [B][400][32]
+  int B;
+};
+constexpr int DP = 80;                                   // halves per pixel of a padded delta plane / per weight row in LDS (64 + 16)
+constexpr int D_A = 0;                                   // delta3 plane: 121 x 80
+constexpr int D_C = D_A + 121 * DP;                      // a2 gate: 81 x 64
+constexpr int D_D = D_C + PX2 * NO;                      // delta2 plane: 121 x 80
+constexpr int D_B = D_D + 121 * DP;                      // weights: 576 rows x 80 (W3), then 512 rows (W2)
+constexpr int D_E = 0;                                   // delta1 collection [400][32] over the dead delta3 plane + gate
+constexpr int D_TOTAL = D_B + KK3 * DP;                  // 70 624 halves = 141 248 bytes
+static_assert(PX1 * 32 <= D_D && D_TOTAL * 2 <= 160 * 1024, "LDS budget");
+
+// NPT position tiles x 2 map tiles, STEPS k-steps of 32; AOFF(st) / WOFF(st): the step's offsets (compile-time after unrolling)
+template <int NPT, int STEPS, class AOFF, class WOFF>
+__device__ __forceinline__ void mmg(const h_t* img, const int* apos, const h_t* wb, f32x4 (*acc)[4], AOFF aoff, WOFF woff) {
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    const h8 w0 = *reinterpret_cast<const h8*>(wb + woff(st)), w1 = *reinterpret_cast<const h8*>(wb + 16 * DP + woff(st));
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+      const h8 x = *reinterpret_cast<const h8*>(img + apos[t] + aoff(st));
+      acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, x, acc[0][t], 0, 0, 0);
+      acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x, acc[1][t], 0, 0, 0);
+    }
+  }
+}
+
+template <bool WT>
+__global__ void __launch_bounds__(NT_) conv_ssh_dgrad_chain_kernel(const DArgs c) {
+  __shared__ __attribute__((aligned(16))) h_t smem[D_TOTAL];
+  const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.x;
+  const u32x4* const p3 = reinterpret_cast<const u32x4*>(c.d3p + (int64_t)n * (121 * NO));
+  const u32x4* const pw3 = reinterpret_cast<const u32x4*>(c.w3);
+  const u32x4* const pa2 = reinterpret_cast<const u32x4*>(c.a2 + (int64_t)n * (PX2 * NO));
+  const u32x4* const pw2 = reinterpret_cast<const u32x4*>(c.w2);
+  const u32x4* const pa1 = reinterpret_cast<const u32x4*>(c.a1 + (int64_t)n * (PX1 * 32));
+  constexpr int N3 = 121 * 8, NA2 = PX2 * 8, NA1 = PX1 * 4;                 // 16-byte pieces: 968, 648, 1600
+  u32x4 v3[2], vw3[9], va2[2], vw2[8], va1[4];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) vw3[j] = pw3[tid + NT_ * j];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int pc = tid + NT_ * j; v3[j] = p3[pc < N3 ? pc : N3 - 1]; va2[j] = pa2[pc < NA2 ? pc : NA2 - 1]; }
+  {                                                                          // the delta2 plane's borders (all of it: the interior is overwritten)
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const int pc = tid + NT_ * j; if (pc < 121 * DP / 8) *reinterpret_cast<u32x4*>(smem + D_D + 8 * pc) = z4; }
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) { const int pc = tid + NT_ * j; *reinterpret_cast<u32x4*>(smem + D_B + (pc >> 3) * DP + 8 * (pc & 7)) = vw3[j]; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pc = tid + NT_ * j;
+    if (pc < N3) *reinterpret_cast<u32x4*>(smem + D_A + (pc >> 3) * DP + 8 * (pc & 7)) = v3[j];
+    if (pc < NA2) *reinterpret_cast<u32x4*>(smem + D_C + 8 * pc) = va2[j];
+  }
+  // (needed behind conv3_dgrad only: in flight under it)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) vw2[j] = pw2[tid + NT_ * j];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int pc = tid + NT_ * j; va1[j] = pa1[pc < NA1 ? pc : NA1 - 1]; }
+  __syncthreads();
+
+  f32x4 acc[2][4];
+  int apos[4];
+  // ---- conv3_dgrad: wave = (map pair mp, position group pg of two 16-position tiles; 6 tiles: pg = 3 idles) ----
+  {
+    const int mp = wave & 1, pg = wave >> 1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      int P = 16 * (2 * pg + t) + m; if (P > PX2 - 1) P = PX2 - 1;
+      const int y = P / 9, x = P - y * 9;
+      apos[t] = D_A + (y * 11 + x) * DP + 8 * kq;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const h_t* const wb = smem + D_B + (32 * mp + m) * DP + 8 * kq;
+    auto aoff = [](int st) { const int rs = st >> 1, r = rs / 3, s = rs - r * 3; return ((2 - r) * 11 + (2 - s)) * DP + 32 * (st & 1); };
+    auto woff = [](int st) { return (st >> 1) * (NO * DP) + 32 * (st & 1); };
+    if (pg < 3) mmg<2, 18>(smem, apos, wb, acc, aoff, woff);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int P = 16 * (2 * pg + t) + m;
+      if (pg < 3 && P < PX2) {
+        const int y = P / 9, x = P - y * 9;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int c0 = 32 * mp + 16 * u + 4 * kq;
+          const h4 g = *reinterpret_cast<const h4*>(smem + D_C + P * NO + c0);
+          h4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (float)g[e] > 0.0f ? (h_t)acc[u][t][e] : (h_t)0.0f;
+          *reinterpret_cast<h4*>(smem + D_D + ((y + 1) * 11 + x + 1) * DP + c0) = v;
+        }
+      }
+    }
+  }
+  __syncthreads();                                                           // delta2 plane complete; every read of W3 is done
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const int pc = tid + NT_ * j; *reinterpret_cast<u32x4*>(smem + D_B + (pc >> 3) * DP + 8 * (pc & 7)) = vw2[j]; }
+  {                                                                          // the dense delta2 (conv2's weight gradient reads it): 81 rows of 128 bytes
+    h_t* const o2 = c.d2 + (int64_t)n * (PX2 * NO);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)o2, 0, PX2 * NO * 2, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pc = tid + NT_ * j;
+      if (pc < NA2) {
+        const int P = pc >> 3, y = P / 9, x = P - y * 9;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + D_D + ((y + 1) * 11 + x + 1) * DP + 8 * (pc & 7));
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, 16 * pc, 0, WT ? 16 : 0);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- conv2_dgrad: wave = (parity class z = (py, px), half h of the class's 7 position tiles: 4 + 3), both 16-map tiles ----
+  {
+    const int z = wave >> 1, h = wave & 1, py = z >> 1, px = z & 1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      int P = 16 * (4 * h + t) + m; if (P > 99) P = 99;
+      const int i = P / 10, j = P - i * 10;
+      apos[t] = D_D + (i * 11 + j) * DP + 8 * kq;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const h_t* const wb = smem + D_B + ((py * 4 + px) * 32 + m) * DP + 8 * kq;
+    auto aoff = [](int st) { const int ab = st >> 1, aa = ab >> 1, bb = ab & 1; return ((1 - aa) * 11 + (1 - bb)) * DP + 32 * (st & 1); };
+    auto woff = [](int st) { const int ab = st >> 1, aa = ab >> 1, bb = ab & 1; return (8 * aa + 2 * bb) * (32 * DP) + 32 * (st & 1); };
+    if (h == 0) mmg<4, 8>(smem, apos, wb, acc, aoff, woff); else mmg<3, 8>(smem, apos, wb, acc, aoff, woff);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int P = 16 * (4 * h + t) + m;
+      if (4 * h + t < 7 && P < 100) {
+        const int i = P / 10, j = P - i * 10, pix = (2 * i + py) * 20 + 2 * j + px;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          h4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (h_t)acc[u][t][e];
+          *reinterpret_cast<h4*>(smem + D_E + pix * 32 + 16 * u + 4 * kq) = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {                                                                          // delta1 = collected plane gated by a1 > 0: 400 rows of 64 bytes, whole lines
+    h_t* const o1 = c.d1 + (int64_t)n * (PX1 * 32);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)o1, 0, PX1 * 32 * 2, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pc = tid + NT_ * j;
+      if (pc < NA1) {
+        union { u32x4 u; h8 h; } g, v, o;
+        g.u = va1[j];
+        v.u = *reinterpret_cast<const u32x4*>(smem + D_E + 8 * pc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.h[e] = (float)g.h[e] > 0.0f ? v.h[e] : (h_t)0.0f;
+        __builtin_amdgcn_raw_buffer_store_b128(o.u, rs, 16 * pc, 0, WT ? 16 : 0);
+      }
+    }
+  }
+}
+
+template <bool WT>
+inline hipError_t launch_dgrad_chain(const DArgs& c, hipStream_t s) {
+  if (c.B <= 0) return hipSuccess;
+  SDQN_LAUNCH((conv_ssh_dgrad_chain_kernel<WT>), dim3(c.B), dim3(NT_), 0, s, c);
+  return hipGetLastError();
+}
+
 template <int NS, bool WT>
 inline hipError_t launch_chain(const Args& c, int nz, hipStream_t s) {
   if (c.B <= 0) return hipSuccess;

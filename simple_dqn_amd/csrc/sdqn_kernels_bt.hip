@@ -681,8 +681,8 @@ static hipError_t launch_single_h(int id, int menu, const StepArgs& a, hipStream
     case K_CONV3_FWD: switch (menu) { BTH_CASE(0, Conv3FwdH, 64, 64, 2, 2, 2); BTH_CASE(6, Conv3FwdH, 64, 64, 2, 2, 2); BTH128_CASE(3, Conv3FwdH, 64, 64, 2, 2); BTH_CASE(1, Conv3FwdH, 128, 64, 2, 2, 2); BTH_CASE(2, Conv3FwdH, 64, 64, 2, 2, 3); default: break; } break;
     case K_FC4_FWD: switch (menu) { BTH_CASE(0, Fc4FwdH, 64, 64, 2, 2, 2); BTH128_CASE(3, Fc4FwdH, 64, 64, 2, 2); BTH_CASE(1, Fc4FwdH, 128, 128, 2, 2, 2); BTH_CASE(2, Fc4FwdH, 64, 128, 2, 2, 2); default: break; } break;
     case K_FC4_DGRAD: switch (menu) { BTH_CASE(0, Fc4DgradH, 64, 64, 2, 2, 2); BTH128_CASE(3, Fc4DgradH, 64, 64, 2, 2); BTH_CASE(1, Fc4DgradH, 128, 128, 2, 2, 2); BTH_CASE(2, Fc4DgradH, 64, 128, 2, 2, 2); default: break; } break;
-    case K_CONV3_DGRAD: switch (menu) { BTH_CASE(0, Conv3DgradH, 64, 64, 2, 2, 2); BTH128_CASE(3, Conv3DgradH, 64, 64, 2, 2); BTH_CASE(1, Conv3DgradH, 128, 64, 2, 2, 2); BTH_CASE(2, Conv3DgradH, 64, 64, 2, 2, 3); default: break; } break;
-    case K_CONV2_DGRAD: switch (menu) { BTH_CASE(0, Conv2DgradH, 128, 32, 4, 1, 2); BTH128_CASE(3, Conv2DgradH, 128, 32, 4, 1); BTH_CASE(1, Conv2DgradH, 256, 32, 4, 1, 2); BTH_CASE(2, Conv2DgradH, 128, 32, 4, 1, 3); default: break; } break;
+    case K_CONV3_DGRAD: switch (menu) { BTH_CASE(0, Conv3DgradH, 64, 64, 2, 2, 2); BTH_CASE(6, Conv3DgradH, 64, 64, 2, 2, 2); BTH128_CASE(3, Conv3DgradH, 64, 64, 2, 2); BTH_CASE(1, Conv3DgradH, 128, 64, 2, 2, 2); BTH_CASE(2, Conv3DgradH, 64, 64, 2, 2, 3); default: break; } break;
+    case K_CONV2_DGRAD: switch (menu) { BTH_CASE(0, Conv2DgradH, 128, 32, 4, 1, 2); BTH_CASE(6, Conv2DgradH, 128, 32, 4, 1, 2); BTH128_CASE(3, Conv2DgradH, 128, 32, 4, 1); BTH_CASE(1, Conv2DgradH, 256, 32, 4, 1, 2); BTH_CASE(2, Conv2DgradH, 128, 32, 4, 1, 3); default: break; } break;
     default: break;
   }
   return hipErrorInvalidValue;

@@ -49,8 +49,25 @@ static bool ssh_takes(const StepArgs& a, const LaunchTune& t) {
   return t.bt[K_CONV2_FWD] != 0 || wgs * 5 >= rounds * 256 * 4;
 }
 
+// float16 mode, B >= 128: conv3_dgrad -> conv2_dgrad as one launch (conv_ssh.h: one workgroup per sample of the online net), same menu
+// (bt:7 / bt:9) and the same fill rule
+static bool ssh_dgrad_takes(const StepArgs& a, const LaunchTune& t) {
+  if (!a.h16 || a.B < 128 || a.bn) return false;
+  for (int id : {K_CONV3_DGRAD, K_CONV2_DGRAD}) if ((t.bt[id] != 0 && t.bt[id] != 7 && t.bt[id] != 8) || t.nw_override[id] > 0) return false;
+  if (t.bt[K_CONV3_DGRAD] != t.bt[K_CONV2_DGRAD]) return false;
+  const int rounds = (a.B + 255) / 256;
+  return t.bt[K_CONV3_DGRAD] != 0 || a.B * 5 >= rounds * 256 * 4;
+}
+
 hipError_t launch_kernel_ss(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = false;
+  if (id == K_CONV3_DGRAD || id == K_CONV2_DGRAD) {
+    if (!ssh_dgrad_takes(a, t)) return hipSuccess;
+    *handled = true;
+    if (id == K_CONV2_DGRAD) return hipSuccess;                  // (rode in the conv3_dgrad launch)
+    ssh::DArgs c; c.d3p = a.h_d3p; c.w3 = a.wh[0] + OFF3; c.w2 = a.wh[0] + OFF2; c.a2 = a.h_a2; c.a1 = a.h_a1; c.d2 = a.h_d2; c.d1 = a.h_d1; c.B = a.B;
+    return t.bt[K_CONV3_DGRAD] != 8 ? ssh::launch_dgrad_chain<true>(c, s) : ssh::launch_dgrad_chain<false>(c, s);
+  }
   if (id != K_CONV2_FWD && id != K_CONV3_FWD) return hipSuccess;
   if (a.h16) {
     if (!ssh_takes(a, t)) return hipSuccess;

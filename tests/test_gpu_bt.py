@@ -209,15 +209,19 @@ def test_sample_stationary_forward_convolutions(sd, A, B):
     assert np.array_equal(new.debug_read("a3", 2 * B * 49 * 64), again.debug_read("a3", 2 * B * 49 * 64))
 
 
-@pytest.mark.parametrize("A,B", [(3, 256), (6, 160), (4, 128), (3, 129)])
-def test_float16_conv2_conv3_forward_as_one_sample_stationary_launch(sd, A, B):
-    """Round 6, float16 mode at B >= 128: conv2 -> conv3 forward as ONE launch (csrc/conv_ssh.h: a workgroup's samples, W2 and — through
-    registers — W3 fetched once, im2col at ds_read time on v_mfma_f32_16x16x32_f16, the conv3 image written from the accumulators, a2 /
-    a3 stored as whole lines).  Same half operands, fp32 accumulation in the same k order in one accumulator per output as the packed-fp16
-    block-tile routines (menu entry 6): Q-values, cost and every gradient are BIT-IDENTICAL — two samples per workgroup (B = 256, 160),
-    one (B = 128; predict at any size), an odd batch (B = 129) — with write-through (7) and plain (8) output stores, over two steps."""
+@pytest.mark.parametrize("A,B", [(3, 256), (6, 160), (4, 128), (3, 129), (4, 255)])
+def test_float16_conv2_conv3_chains_forward_and_backward(sd, A, B):
+    """Round 6, float16 mode at B >= 128 (csrc/conv_ssh.h).  FORWARD: conv2 -> conv3 as ONE launch (a workgroup's samples, W2 and —
+    through registers — W3 fetched once, im2col at ds_read time on v_mfma_f32_16x16x32_f16, the conv3 image written from the
+    accumulators, a2 / a3 stored as whole lines).  BACKWARD: conv3_dgrad -> conv2_dgrad as ONE launch (one workgroup per sample: the padded
+    delta3 plane, W3 and the gate a2 in LDS, delta2 written gated into a second padded LDS plane that the four parity classes of the
+    stride-2 transposed convolution read; delta1 collected as a dense plane and gated by a1 on the way out).  Same half operands, fp32
+    accumulation in the same k order in one accumulator per output as the packed-fp16 block-tile routines (menu entry 6): Q-values and
+    every gradient are BIT-IDENTICAL — two samples per forward workgroup (B = 256, 255, 160), one (B = 128; predict at any size), odd
+    batches (129, 255) — with write-through (7) and plain (8) output stores, over two steps."""
     mb = random_minibatch(B, A, 400 + B, reward_range=(-2, 3))
-    mk = lambda menu: _net(sd, A, B, 41, [("keep_gradients", 1)] + ([("bt:1", menu), ("bt:2", menu)] if menu is not None else []), datatype="float16")
+    ids = (1, 2, 7, 9)                                             # conv2_fwd, conv3_fwd, conv3_dgrad, conv2_dgrad
+    mk = lambda menu: _net(sd, A, B, 41, [("keep_gradients", 1)] + ([("bt:%d" % i, menu) for i in ids] if menu is not None else []), datatype="float16")
     nets = {"default": mk(None), "forced": mk(7), "plain": mk(8), "bt": mk(6)}
     qs = {k: n.predict(mb[0]).copy() for k, n in nets.items()}
     for k in ("default", "forced", "plain"):
@@ -229,14 +233,18 @@ def test_float16_conv2_conv3_forward_as_one_sample_stationary_launch(sd, A, B):
             assert np.array_equal(nets[k].last_q()[0], nets["bt"].last_q()[0]), (k, step)
             for i in range(5):
                 assert np.array_equal(nets[k].get_layer(i, 3), nets["bt"].get_layer(i, 3)), (k, step, i)
-    # the launch structure says so: one launch fewer per net pass where the chained launch runs by default (B = 128, 256)
+                assert np.abs(nets[k].get_layer(i, 3)).max() > 0
+    # the launch structure says so: the chained launches run by default where their workgroups fill >= 80 % of whole rounds of the chip
+    # (forward: 2 B / samples-per-workgroup workgroups — B = 128, 255, 256; backward: B workgroups — B = 255, 256)
     counts = {}
-    for k in ("default", "bt"):
+    for k in ("default", "forced", "bt"):
         n = nets[k]
         n.profile(True, -1); n.profile_reset()
         for _ in range(3):
             n.train(mb)
         counts[k] = {p["name"].split("(")[0]: p["launches"] for p in n.profile_read() if p["launches"] > 0}
         n.profile(False)
-    assert counts["bt"].get("conv3_fwd", 0) == 3
-    assert counts["default"].get("conv3_fwd", 0) == (0 if B in (128, 256) else 3), counts["default"]
+    assert counts["bt"].get("conv3_fwd", 0) == 3 and counts["bt"].get("conv2_dgrad", 0) == 3
+    assert counts["forced"].get("conv3_fwd", 0) == 0 and counts["forced"].get("conv2_dgrad", 0) == 0 and counts["forced"]["conv2_fwd"] == 3 and counts["forced"]["conv3_dgrad"] == 3
+    assert counts["default"].get("conv3_fwd", 0) == (0 if B in (128, 255, 256) else 3), counts["default"]
+    assert counts["default"].get("conv2_dgrad", 0) == (0 if B in (255, 256) else 3), counts["default"]

@@ -28,8 +28,9 @@ def main():
     for B in Bs:
         A = 3
         mb = random_minibatch(B, A, 40 + B, reward_range=(-2, 3))
-        nets = [("chain", net_of(A, B, [("bt:1", 7), ("bt:2", 7)])), ("chain-plain", net_of(A, B, [("bt:1", 8), ("bt:2", 8)])),
-                ("bt", net_of(A, B, [("bt:1", 6), ("bt:2", 6)])), ("default", net_of(A, B))]
+        ids = (1, 2, 7, 9)               # conv2_fwd, conv3_fwd, conv3_dgrad, conv2_dgrad
+        nets = [("chain", net_of(A, B, [("bt:%d" % i, 7) for i in ids])), ("chain-plain", net_of(A, B, [("bt:%d" % i, 8) for i in ids])),
+                ("bt", net_of(A, B, [("bt:%d" % i, 6) for i in ids])), ("fwd-only", net_of(A, B, [("bt:7", 6), ("bt:9", 6)])), ("default", net_of(A, B))]
         o = OracleDQN(A, batch_size=B, weights=xavier_weights(A, 7), half_activations=True)
         o.Wt = [w.copy() for w in xavier_weights(A, 8)]
         qo = o.predict(mb[0])
