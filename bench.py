@@ -232,11 +232,15 @@ def step_roofline(B, A, ms_per_step, conv1_bf16=True):
 
 def chained_convs(k_us):
     """The throughput regime's conv2 + conv3 forward run as one launch under kernel id 1 (no sample for id 2): rename the entry."""
-    if "conv2_fwd" in k_us and "conv3_fwd" not in k_us:
+    chained = "conv2_fwd" in k_us and "conv3_fwd" not in k_us
+    if chained:
         k_us = dict(k_us)
         k_us["conv2_fwd+conv3_fwd (one chained sample-stationary launch)"] = k_us.pop("conv2_fwd")
-        return k_us, True
-    return k_us, False
+    # float16 mode: conv3_dgrad -> conv2_dgrad likewise, under kernel id 7 (the fp32 step fuses its dgrads with the weight gradients: bwd3 / bwd2)
+    if "conv3_dgrad" in k_us and "conv2_dgrad" not in k_us and not any(k.startswith("bwd2") for k in k_us):
+        k_us = dict(k_us)
+        k_us["conv3_dgrad+conv2_dgrad (one chained sample-stationary launch)"] = k_us.pop("conv3_dgrad")
+    return k_us, chained
 
 
 def _roofline_entry(kid, name, ms_per_launch, B, A):
