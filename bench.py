@@ -830,7 +830,7 @@ def fp16_b256_leg(sd, make_args, seed, steps=300, warmup=140, ring=200000):
                         "timed region)" % ring,
             "value": round(steps / el, 2), "unit": "train_steps/sec", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "warmup": warmup,
             "frac_fp16_peak_whole_step": round(flops / (el / steps) / BF16_PEAK, 4), "flops_per_step": flops,
-            "kernels_us": {p["name"]: round(p["total_ms"] / p["launches"] * 1e3, 2) for p in prof},
+            "kernels_us": chained_convs({p["name"]: round(p["total_ms"] / p["launches"] * 1e3, 2) for p in prof})[0],
             "dtype": "f16 activations/deltas/MFMA operands, f32 accumulate + master weights + RMSProp"}
 
 

@@ -43,12 +43,14 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
 hipError_t launch_kernel_ss(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled);
 
 hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s) {
-  if (a.B >= 128) {            // throughput regime: the sample-stationary forward convolutions (round 6; sdqn_kernels_ss.hip), then the
-    bool handled = false;      // block-tile engine (round 4; sdqn_kernels_bt.hip) take what they implement
+  if (a.B >= 128 || a.h16) {   // throughput regime (and float16 at any batch size): the sample-stationary convolution chains (round 6;
+    bool handled = false;      // sdqn_kernels_ss.hip), then — B >= 128 — the block-tile engine (round 4; sdqn_kernels_bt.hip) take what they implement
     hipError_t e = launch_kernel_ss(id, a, t, s, &handled);
     if (handled) return e;
-    e = launch_kernel_bt(id, a, t, s, &handled);
-    if (handled) return e;
+    if (a.B >= 128) {
+      e = launch_kernel_bt(id, a, t, s, &handled);
+      if (handled) return e;
+    }
   }
   if (t.r3 || t.wt) {          // round-3 launch variants live in their own translation unit (same reason as sdqn_kernels_ext.hip)
     bool handled = false;

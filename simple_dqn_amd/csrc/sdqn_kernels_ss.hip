@@ -41,7 +41,8 @@ static bool ss_chains(const StepArgs& a, const LaunchTune& t) {
 // rounds); menu entries bt:1 / bt:2: 0 = this launch where it pays, 7 = always, 8 = always with plain (write-back) stores, anything else
 // the packed-fp16 block-tile routines (sdqn_kernels_bt.hip: launch_single_h)
 static bool ssh_takes(const StepArgs& a, const LaunchTune& t) {
-  if (!a.h16 || a.B < 128 || a.bn) return false;
+  if (!a.h16 || a.bn) return false;
+  if (a.B < 128 && t.bt[K_CONV2_FWD] != 7 && t.bt[K_CONV2_FWD] != 8) return false;       // (below the throughput regime: on request only)
   for (int id : {K_CONV2_FWD, K_CONV3_FWD}) if ((t.bt[id] != 0 && t.bt[id] != 7 && t.bt[id] != 8) || t.nw_override[id] > 0) return false;
   if (t.bt[K_CONV2_FWD] != t.bt[K_CONV3_FWD]) return false;
   const int ns = a.nz * a.B > 256 ? 2 : 1;
