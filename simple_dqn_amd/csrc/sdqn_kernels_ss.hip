@@ -37,27 +37,23 @@ static bool ss_chains(const StepArgs& a, const LaunchTune& t) {
   return ss_takes(K_CONV2_FWD, a, t) && ss_takes(K_CONV3_FWD, a, t) && t.bt[K_CONV2_FWD] != 8 && t.bt[K_CONV3_FWD] != 8;
 }
 
-// float16 mode, B >= 128: conv2 -> conv3 forward as one launch (conv_ssh.h) under the same rule (workgroups fill >= 80 % of whole 256-CU
-// rounds); menu entries bt:1 / bt:2: 0 = this launch where it pays, 7 = always, 8 = always with plain (write-back) stores, anything else
-// the packed-fp16 block-tile routines (sdqn_kernels_bt.hip: launch_single_h)
+// float16 mode, ANY batch size: conv2 -> conv3 forward as one launch (conv_ssh.h).  No fill rule here — the launch is data movement and
+// latency, not matrix time, and wins wherever it was measured (fused-loop steps/s, chain against the launches it replaces: B = 32 18 894 vs
+// 17 594, 64 13 399 vs 12 006, 100 10 487 vs 9 115, 160 12 181 vs 11 711, 192 11 786 vs 11 138).  Menu entries bt:1 / bt:2: 0 / 7 = this
+// launch, 8 = with plain (write-back) stores, anything else the packed-fp16 routines (latency engine / block tiles: launch_single_h)
 static bool ssh_takes(const StepArgs& a, const LaunchTune& t) {
   if (!a.h16 || a.bn) return false;
-  if (a.B < 128 && t.bt[K_CONV2_FWD] != 7 && t.bt[K_CONV2_FWD] != 8) return false;       // (below the throughput regime: on request only)
   for (int id : {K_CONV2_FWD, K_CONV3_FWD}) if ((t.bt[id] != 0 && t.bt[id] != 7 && t.bt[id] != 8) || t.nw_override[id] > 0) return false;
-  if (t.bt[K_CONV2_FWD] != t.bt[K_CONV3_FWD]) return false;
-  const int ns = a.nz * a.B > 256 ? 2 : 1;
-  const int wgs = a.nz * ((a.B + ns - 1) / ns), rounds = (wgs + 255) / 256;
-  return t.bt[K_CONV2_FWD] != 0 || wgs * 5 >= rounds * 256 * 4;
+  return t.bt[K_CONV2_FWD] == t.bt[K_CONV3_FWD];
 }
 
-// float16 mode, B >= 128: conv3_dgrad -> conv2_dgrad as one launch (conv_ssh.h: one workgroup per sample of the online net), same menu
-// (bt:7 / bt:9) and the same fill rule
+// float16 mode, B >= 128 (where the two dgrads are launches of their own: step structure h16_block_tile): conv3_dgrad -> conv2_dgrad as one
+// launch (conv_ssh.h: one workgroup per sample of the online net), same menu on bt:7 / bt:9.  Measured with the forward chain on, steps/s:
+// B = 128 14 761 vs 13 641, 160 13 451 vs 12 181, 192 13 059 vs 11 786, 256 11 900 vs 10 575
 static bool ssh_dgrad_takes(const StepArgs& a, const LaunchTune& t) {
   if (!a.h16 || a.B < 128 || a.bn) return false;
   for (int id : {K_CONV3_DGRAD, K_CONV2_DGRAD}) if ((t.bt[id] != 0 && t.bt[id] != 7 && t.bt[id] != 8) || t.nw_override[id] > 0) return false;
-  if (t.bt[K_CONV3_DGRAD] != t.bt[K_CONV2_DGRAD]) return false;
-  const int rounds = (a.B + 255) / 256;
-  return t.bt[K_CONV3_DGRAD] != 0 || a.B * 5 >= rounds * 256 * 4;
+  return t.bt[K_CONV3_DGRAD] == t.bt[K_CONV2_DGRAD];
 }
 
 hipError_t launch_kernel_ss(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
