@@ -248,7 +248,7 @@ def test_float16_conv2_conv3_chains_forward_and_backward(sd, A, B):
     assert counts["default"]["conv2_fwd"] == 3 and counts["default"]["conv3_dgrad"] == 3
 
 
-@pytest.mark.parametrize("A,B", [(4, 32), (6, 32), (3, 64), (4, 100)])
+@pytest.mark.parametrize("A,B", [(4, 32), (6, 32), (3, 64), (4, 100), (3, 5), (4, 1)])
 def test_float16_forward_chain_below_the_throughput_regime(sd, A, B):
     """float16, B < 128: conv2 -> conv3 forward is the same one launch (2 B workgroups of one sample; +7 % steps/s at B = 32, +15 % at
     B = 100) in place of the latency engine's two K-split launches (menu entry 6 -> declined -> those): same half operands, another order
