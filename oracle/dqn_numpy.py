@@ -97,9 +97,11 @@ class OracleDQN:
         # accumulation, the master weights, the gradients and the optimizer state stay fp32.
         self.half = bool(half_activations)
         # conv1's input operand in half mode (forward and weight gradient alike): half(x / 255) (the B < 128 routines: problems_h16.h ldh8_u8),
-        # or the exact byte with the 1 / 255 applied to the fp32 sum (B >= 128: conv1_hb_kernel / c1w_h_kernel<true>, sdqn_kernels_bt.hip).
+        # or the exact byte with the 1 / 255 applied to the fp32 sum (B >= 48: conv1_hb_kernel; B >= 128: c1w_h_kernel<true>; sdqn_kernels_bt.hip).
         # None = by batch size, as the library chooses.
-        self.exact_conv1_input = (batch_size >= 128) if exact_conv1_input is None else bool(exact_conv1_input)
+        # (48 <= B < 128: the forward runs on exact bytes, the weight gradient still stages half(x / 255) — 2e-4 of that gradient, tools/exp/c1w_h_iso.py —
+        #  and is modelled exact here)
+        self.exact_conv1_input = (batch_size >= 48) if exact_conv1_input is None else bool(exact_conv1_input)
         self.loss_scale = 1024.0                                  # deltas are stored as half(delta * 1024) (power of two: exact)
         ws = weights if weights is not None else xavier_weights(num_actions, seed, dtype, history_length,
                                                                 screen_height, screen_width)

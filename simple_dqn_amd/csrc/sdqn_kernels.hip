@@ -47,10 +47,8 @@ hipError_t launch_kernel(int id, const StepArgs& a, const LaunchTune& t, hipStre
     bool handled = false;      // sdqn_kernels_ss.hip), then — B >= 128 — the block-tile engine (round 4; sdqn_kernels_bt.hip) take what they implement
     hipError_t e = launch_kernel_ss(id, a, t, s, &handled);
     if (handled) return e;
-    if (a.B >= 128) {
-      e = launch_kernel_bt(id, a, t, s, &handled);
-      if (handled) return e;
-    }
+    e = launch_kernel_bt(id, a, t, s, &handled);        // (B < 128: float16's conv1 kernels on request only)
+    if (handled) return e;
   }
   if (t.r3 || t.wt) {          // round-3 launch variants live in their own translation unit (same reason as sdqn_kernels_ext.hip)
     bool handled = false;

@@ -692,8 +692,20 @@ static hipError_t launch_single_h(int id, int menu, const StepArgs& a, hipStream
 // (the loaders mask any k >= kend), so the routine takes every B >= 128; what it does not take: fp16 mode, batch-norm (raw outputs)
 hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = false;
-  if (a.B < 128 || a.bn) return hipSuccess;
+  if (a.bn) return hipSuccess;
   if (id < 0 || id >= K_COUNT || t.bt[id] < 0) return hipSuccess;
+  if (a.B < 128) {                         // below the throughput regime: float16's exact-byte conv1 kernels
+    // forward: one workgroup per (net, sample) pays from 2 x 48 workgroups up (fused-loop steps/s against the latency engine's tiles:
+    // B = 32 18 490 vs 18 755, 48 14 833 vs 14 527, 64 13 943 vs 13 370, 100 11 198 vs 10 453); menu entry 7 = always, 6 = never
+    if (a.h16 && id == K_CONV1_FWD && (t.bt[id] == 7 || (t.bt[id] == 0 && a.B >= 48)) && t.nw_override[id] == 0 && a.idx_t == nullptr) { *handled = true; return launch_conv1_h(a, t, s); }
+    if (a.h16 == 2 && id == K_BWD1 && t.bt[id] == 7 && a.f4w_count == 0) {
+      const hipError_t e1 = launch_c1w_h(a, t, s);
+      if (e1 == hipErrorInvalidValue) return hipSuccess;
+      *handled = true;
+      return e1;
+    }
+    return hipSuccess;
+  }
   if (a.h16) {                             // float16 mode: forward launches, dgrads, and the weight gradients behind them
     if (id == K_WGRADS && a.h16 == 2) {    // fc4_wgrad (+ fused RMSProp) || conv3_wgrad || conv2_wgrad: k-major half panels, transpose reads
       // (2 chunks of loads in flight per thread: 20.5 us at B = 256 against 22.4 / 22.0 with 3 / 4 — the launch is not load-latency bound)
