@@ -1,11 +1,13 @@
-// sdqn_kernels_ss.hip — the throughput regime's forward convolutions on the SAMPLE-STATIONARY routine (conv_ss.h): own translation
-// unit, like every other family of launch variants.
-//   conv2_fwd  a1 [2][B][20][20][32] -> a2 [2][B][81][64]     4 x 4 stride 2     (deepqnetwork.py:85)
-//   conv3_fwd  a2 [2][B][9][9][64]   -> a3 [2][B][49][64]     3 x 3 stride 1     (deepqnetwork.py:87)
-// float32, no batch-norm (the raw-output problems stay on the latency engine), B >= 128.  LaunchTune::bt[id] == 0: this routine where its
-// workgroups fill the chip (below), else the block-tile engine's built-in shape; 7: this routine always; 8: always, and never chained
-// with the other layer; other menu entries > 0: the block-tile engine's block shapes (sdqn_kernels_bt.hip; entry 6 = its built-in 64 x 64).
-// When both layers run here they are ONE launch (conv_ss_chain_kernel: a workgroup's conv3 follows its own conv2 behind a barrier).
+// sdqn_kernels_ss.hip — the SAMPLE-STATIONARY convolution launches (round 6): own translation unit, like every other family of launch variants.
+//   float32, B >= 128 (conv_ss.h):   conv2_fwd  a1 [2][B][20][20][32] -> a2 [2][B][81][64]   4 x 4 stride 2   (deepqnetwork.py:85)
+//                                    conv3_fwd  a2 [2][B][9][9][64]   -> a3 [2][B][49][64]   3 x 3 stride 1   (deepqnetwork.py:87)
+//     no batch-norm (the raw-output problems stay on the latency engine).  LaunchTune::bt[id] == 0: this routine where its workgroups fill the
+//     chip (below), else the block-tile engine's built-in shape; 7: this routine always; 8: always, and never chained with the other layer;
+//     other menu entries > 0: the block-tile engine's block shapes (sdqn_kernels_bt.hip; entry 6 = its built-in 64 x 64).  When both layers
+//     run here they are ONE launch (conv_ss_chain_kernel: a workgroup's conv3 follows its own conv2 behind a barrier).
+//   float16, any B (conv_ssh.h):     the same two layers as one launch (conv_ssh_chain_kernel), and — B >= 128, where the two dgrads are
+//     launches of their own — conv3_dgrad -> conv2_dgrad as one launch (conv_ssh_dgrad_chain_kernel; deepqnetwork.py:162).  Menu entries
+//     0 / 7: these launches; 8: with plain (write-back) stores; 6 (any other): the packed-fp16 routines they replace.
 #include <stdlib.h>
 #include "conv_ss.h"
 #include "conv_ssh.h"
