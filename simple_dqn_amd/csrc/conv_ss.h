@@ -42,7 +42,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int NO = 64;            // output maps (conv2 and conv3 alike): four matrix waves x 16
 constexpr int WPITCH = NO + 4;    // floats per k-row of a staged weight chunk: rows k and k + 4 are 16 banks apart (conflict-free B reads)
 constexpr int NR = 4;             // weight-chunk ring
-constexpr int FC = 3;             // chunks of the tile-by-tile final phase
+#ifndef SS_FC
+#define SS_FC 3
+#endif
+constexpr int FC = SS_FC;         // chunks of the tile-by-tile final phase (-DSS_FC=2: correct, the chained launch 40.3 -> 42.1 us, 5 351-5 366 -> 5 304-5 321 steps/s)
 constexpr int NSTG = 256;         // staging threads (waves 4..7)
 
 template <int HI_, int WI_, int CI_, int R_, int S_, int ST_, int PO_, int QO_, int NS_, int PPAD_, int RPAD_, int SPAD_>
