@@ -10,7 +10,8 @@
 //   * conv2 = v_mfma_f32_16x16x32_f16 with im2col at ds_read time: one MFMA step is one kernel tap (r, s) x 32 channels; lane (m, kq) reads
 //     the 8 channels 8 kq .. + 7 of pixel (2 p + r, 2 q + s) with one ds_read_b128; the weights are the ROW operand (D[map][position]: a lane
 //     holds 4 consecutive maps of a position).  Eight waves: wave = (map pair, position group): 2 map tiles x 3 position tiles = 6
-//     accumulators, 5 fragment reads per 6 MFMAs (the launch is LDS-bandwidth bound, not matrix bound);
+//     accumulators, 5 fragment reads per 6 MFMAs on all eight waves (all 64 maps x 3 tiles on four waves — 27 fragment reads per step
+//     instead of 38 — is no faster at B = 256 and 10 % slower with one sample per workgroup: two waves per SIMD hide each other's LDS latency);
 //   * behind a barrier the Rectlin'ed half outputs are written into the conv3 image (pixel pitch 80 halves) over the dead conv2 image, W3
 //     comes out of the registers over W2, and a2 leaves for the backward pass as whole lines copied from the LDS image;
 //   * conv3 the same way (two MFMA steps per tap: 64 channels), a3 collected in LDS and stored as whole lines.
@@ -59,6 +60,9 @@ template <int NS> struct Lds {
 // weight fragments from `wl`.  STEPS k-steps of 32; step -> (tap, channel half) -> immediate offsets.
 template <int NPT, int STEPS, int CI, int S, int WI, int PITCH>
 __device__ __forceinline__ void mm(const h_t* img, const int (&apos)[3], const h_t* wb, f32x4 (&acc)[2][3]) {
+#if defined(SSH_ABL) && SSH_ABL == 1                         // (tools/exp/ssh_bench.hip: the launch without its matrix work: 9.4 -> 5.1 us at B = 256)
+  return;
+#endif
   constexpr int SPT = CI / 32;                               // MFMA steps per tap
 #pragma unroll
   for (int st = 0; st < STEPS; ++st) {
