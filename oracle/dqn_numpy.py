@@ -96,12 +96,11 @@ class OracleDQN:
         # GPU-only and unpinned): activations, deltas and the MFMA weight operands are rounded to IEEE half, every
         # accumulation, the master weights, the gradients and the optimizer state stay fp32.
         self.half = bool(half_activations)
-        # conv1's input operand in half mode (forward and weight gradient alike): half(x / 255) (the B < 128 routines: problems_h16.h ldh8_u8),
-        # or the exact byte with the 1 / 255 applied to the fp32 sum (B >= 48: conv1_hb_kernel; B >= 128: c1w_h_kernel<true>; sdqn_kernels_bt.hip).
-        # None = by batch size, as the library chooses.
-        # (48 <= B < 128: the forward runs on exact bytes, the weight gradient still stages half(x / 255) — 2e-4 of that gradient, tools/exp/c1w_h_iso.py —
-        #  and is modelled exact here)
-        self.exact_conv1_input = (batch_size >= 48) if exact_conv1_input is None else bool(exact_conv1_input)
+        # conv1's input operand in half mode: the exact byte with the 1 / 255 applied to the fp32 sum (the library's default at every batch size
+        # since conv1 rides in the float16 forward chain: conv_ssh.h; the weight gradient likewise at B >= 128: c1w_h_kernel<true>), or
+        # half(x / 255) (the first forms: problems_h16.h ldh8_u8; still the weight gradient's staging at B < 128 — 2e-4 of that gradient,
+        # tools/exp/c1w_h_iso.py — modelled exact here).  None = as the library does by default.
+        self.exact_conv1_input = True if exact_conv1_input is None else bool(exact_conv1_input)
         self.loss_scale = 1024.0                                  # deltas are stored as half(delta * 1024) (power of two: exact)
         ws = weights if weights is not None else xavier_weights(num_actions, seed, dtype, history_length,
                                                                 screen_height, screen_width)
@@ -138,7 +137,13 @@ class OracleDQN:
         a = x
         for li, (R, S, K, st) in enumerate(CONV):
             cols, P, Q = _im2col(a, R, S, st)
-            z = cols @ self._h(W[li])                             # (N, PQ, K)
+            if li == 0 and self.half and self.exact_conv1_input:
+                # the library's operation order (conv1 in conv_ssh.h / conv1_hb_kernel): exact byte x half weight products summed in fp32, THEN
+                # 1 / 255 — (x / 255) . W differs by ~1e-7, which moves ~2e-4 of the half-rounded activations by an ulp and, through
+                # flipped Rectlin gates, the gradients by 1e-2 (tools/exp/h16_grad_b32.py)
+                z = (_im2col(np.rint(a * self.dtype(255)), R, S, st)[0] @ self._h(W[li])) * self.dtype(1.0 / 255.0)
+            else:
+                z = cols @ self._h(W[li])                         # (N, PQ, K)
             z = self._h(np.maximum(z, 0))                         # Rectlin (A5)
             a = np.ascontiguousarray(z.transpose(0, 2, 1)).reshape(x.shape[0], K, P, Q)
             acts.append(a)

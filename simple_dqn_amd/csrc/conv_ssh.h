@@ -46,6 +46,9 @@ struct Args {
   h_t* a2;                  // [nz][B][81][64]
   h_t* a3;                  // [nz][B][49][64]
   int B, G;                 // G = workgroups per net = ceil(B / NS)
+  // C1 (conv1 rides in front: the workgroup computes its own a1 from the frames): the replay ring / the staged states, the sampled
+  // indexes, W1^T [32 maps][256 k] per net, and where a1 goes for the backward pass
+  const uint8_t* src; const int64_t* idx; const h_t* w1[2]; h_t* a1w; int from_ring;
 };
 
 template <int NS> struct Lds {
@@ -54,6 +57,7 @@ template <int NS> struct Lds {
   static constexpr int RW = NO * KP;
   static constexpr int TOTAL = R1 + RW;                      // NS = 2: 32 000 + 37 888 halves = 139 776 bytes
   static_assert(TOTAL * 2 <= 160 * 1024, "LDS budget");
+  static_assert(4 * 84 * 84 + 32 * 264 <= RW, "conv1's frames (as halves) + W1 stage in the weight region before W2 arrives");
 };
 
 // one layer's matrix work for this wave: NPT position tiles x 2 map tiles; A fragments from `img` (lane base apos[t], + the tap's immediate),
@@ -78,7 +82,7 @@ __device__ __forceinline__ void mm(const h_t* img, const int (&apos)[3], const h
   }
 }
 
-template <int NS, bool WT>
+template <int NS, bool WT, bool C1>
 __global__ void __launch_bounds__(NT_) conv_ssh_chain_kernel(const Args c) {
   typedef Lds<NS> L;
   __shared__ __attribute__((aligned(16))) h_t smem[L::TOTAL];
@@ -94,10 +98,101 @@ __global__ void __launch_bounds__(NT_) conv_ssh_chain_kernel(const Args c) {
   constexpr int IPC = NS * PX1 * 4, IPT = (IPC + NT_ - 1) / NT_;            // 16-byte pieces of the image / per thread
   constexpr int W2P = NO * KK2 / 8 / NT_, W3P = NO * KK3 / 8 / NT_;         // 8, 9 pieces per thread
   static_assert(W2P * NT_ * 8 == NO * KK2 && W3P * NT_ * 8 == NO * KK3, "whole weight pieces per thread");
-  const u32x4* const ip = reinterpret_cast<const u32x4*>(c.a1 + ((int64_t)z * c.B + n0) * (PX1 * 32));
   const u32x4* const w2p = reinterpret_cast<const u32x4*>(c.w2[z]);
   const u32x4* const w3p = reinterpret_cast<const u32x4*>(c.w3[z]);
-  u32x4 iv[IPT], w2v[W2P], w3v[W3P];
+  u32x4 w2v[W2P], w3v[W3P];
+  if constexpr (C1) {
+    // ---- conv1 in front (deepqnetwork.py:83 + the gather and the / 255 of :94-100): per sample, the state's four frames (28 224 contiguous
+    // bytes of the ring) -> exact halves (0x6400 | b = half(1024 + b), - 1024) in the weight region, W1^T beside them; 25 tiles of 16
+    // positions over the eight waves, both 16-map tiles per fragment, v_mfma_f32_16x16x32_f16 (one step = 4 kernel rows x 8 columns of one
+    // frame); Rectlin(sum / 255) as half straight into the conv2 image.  W2 / W3 wait in registers meanwhile.
+    constexpr int FPC = 4 * 84 * 84 / 16, FPT = (FPC + NT_ - 1) / NT_;      // 1 764 pieces of 16 bytes: 4 per thread, the last partly
+    h_t* const ci = rw;                                                      // [frame][84][84] halves (the state's own byte order widened)
+    h_t* const cw = rw + 4 * 84 * 84;                                        // W1^T [32][256 + 8]
+    auto frames = [&](int sI, u32x4 (&fv)[FPT]) {
+      const int nn = n0 + (sI < nvalid ? sI : nvalid - 1);
+      const int64_t fb = c.from_ring ? (c.idx[nn] - 4 + z) * (int64_t)(84 * 84) : ((int64_t)z * c.B + nn) * (int64_t)(4 * 84 * 84);      // problems.h: sbase
+      const u32x4* const fp = reinterpret_cast<const u32x4*>(c.src + fb);
+#pragma unroll
+      for (int j = 0; j < FPT; ++j) { const int it = tid + NT_ * j; fv[j] = fp[it < FPC ? it : FPC - 1]; }
+    };
+    u32x4 fv[2][FPT], w1v[2];
+    frames(0, fv[0]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w1v[j] = reinterpret_cast<const u32x4*>(c.w1[z])[tid + NT_ * j];
+    if constexpr (NS > 1) frames(1, fv[1]);
+#pragma unroll
+    for (int j = 0; j < W2P; ++j) w2v[j] = w2p[tid + NT_ * j];
+#pragma unroll
+    for (int j = 0; j < W3P; ++j) w3v[j] = w3p[tid + NT_ * j];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int it = tid + NT_ * j; *reinterpret_cast<u32x4*>(cw + (it >> 5) * 264 + 8 * (it & 31)) = w1v[j]; }
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 m1024 = {(h_t)-1024.0f, (h_t)-1024.0f};
+    const h_t* const wb1 = cw + m * 264 + 8 * kq;                            // weights: map m (and 16 + m), k = 32 st + 8 kq ..
+#pragma unroll
+    for (int sI = 0; sI < NS; ++sI) {
+      if (sI > 0) __syncthreads();                                           // the previous sample's fragments are read
+#pragma unroll
+      for (int j = 0; j < FPT; ++j) {
+        const int it = tid + NT_ * j;
+        if (it < FPC) {
+          u32x4 o[2];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned w = fv[sI][j][e];
+            union { unsigned u; h2 h; } lo, hi;
+            lo.u = __builtin_amdgcn_perm(0x64646464u, w, 0x04010400u); hi.u = __builtin_amdgcn_perm(0x64646464u, w, 0x04030402u);
+            lo.h = lo.h + m1024; hi.h = hi.h + m1024;
+            o[e >> 1][2 * (e & 1)] = lo.u; o[e >> 1][2 * (e & 1) + 1] = hi.u;
+          }
+          u32x4* const d = reinterpret_cast<u32x4*>(ci + 16 * it);
+          d[0] = o[0]; d[1] = o[1];
+        }
+      }
+      __syncthreads();
+      h8 fw[2][8];
+#pragma unroll
+      for (int st = 0; st < 8; ++st) { fw[0][st] = *reinterpret_cast<const h8*>(wb1 + 32 * st); fw[1][st] = *reinterpret_cast<const h8*>(wb1 + 16 * 264 + 32 * st); }
+      for (int rt = wave; rt < PX1 / 16; rt += 8) {
+        const int pos = 16 * rt + m, p = pos / 20, q = pos - p * 20;
+        const h_t* const pa = ci + (4 * p + kq) * 84 + 4 * q;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          const h_t* const ap = pa + (st >> 1) * (84 * 84) + 4 * (st & 1) * 84;
+          const h4 xl = *reinterpret_cast<const h4*>(ap), xh = *reinterpret_cast<const h4*>(ap + 4);
+          h8 x; x[0] = xl[0]; x[1] = xl[1]; x[2] = xl[2]; x[3] = xl[3]; x[4] = xh[0]; x[5] = xh[1]; x[6] = xh[2]; x[7] = xh[3];
+          a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][st], x, a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[1][st], x, a1, 0, 0, 0);
+        }
+        h4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v0[e] = (h_t)fmaxf(a0[e] * (1.0f / 255.0f), 0.0f); v1[e] = (h_t)fmaxf(a1[e] * (1.0f / 255.0f), 0.0f); }
+        h_t* const o = r1 + (sI * PX1 + pos) * P1 + 4 * kq;
+        *reinterpret_cast<h4*>(o) = v0;
+        *reinterpret_cast<h4*>(o + 16) = v1;
+      }
+    }
+    __syncthreads();                                                         // a1 complete in the conv2 image; conv1's staging is dead
+#pragma unroll
+    for (int j = 0; j < W2P; ++j) { const int pc = tid + NT_ * j; *reinterpret_cast<u32x4*>(rw + (pc >> 6) * KP + 8 * (pc & 63)) = w2v[j]; }
+    {                                                                        // a1 leaves for the backward pass: nvalid x 400 rows of 64 bytes, whole lines
+      h_t* const o1 = c.a1w + ((int64_t)z * c.B + n0) * (PX1 * 32);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)o1, 0, nvalid * PX1 * 32 * 2, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const int pc = tid + NT_ * j;
+        if (pc < IPC) {
+          const u32x4 v = *reinterpret_cast<const u32x4*>(r1 + (pc >> 2) * P1 + 8 * (pc & 3));
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, 16 * pc, 0, WT ? 16 : 0);
+        }
+      }
+    }
+    __syncthreads();
+  } else {
+  const u32x4* const ip = reinterpret_cast<const u32x4*>(c.a1 + ((int64_t)z * c.B + n0) * (PX1 * 32));
+  u32x4 iv[IPT];
   const int ipmax = nvalid * PX1 * 4 - 1;
 #pragma unroll
   for (int j = 0; j < W2P; ++j) w2v[j] = w2p[tid + NT_ * j];
@@ -110,6 +205,7 @@ __global__ void __launch_bounds__(NT_) conv_ssh_chain_kernel(const Args c) {
 #pragma unroll
   for (int j = 0; j < IPT; ++j) { const int pc = tid + NT_ * j; if (pc < IPC) *reinterpret_cast<u32x4*>(r1 + (pc >> 2) * P1 + 8 * (pc & 3)) = iv[j]; }
   __syncthreads();
+  }
 
   // ---- conv2: 16 taps x 32 channels.  wave = (map pair mp, position group pg): maps 32 mp .. + 31, position tiles TPG pg .. + TPG - 1 ----
   const int mp = wave & 1, pg = wave >> 1;
@@ -405,10 +501,10 @@ inline hipError_t launch_dgrad_chain(const DArgs& c, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int NS, bool WT>
+template <int NS, bool WT, bool C1>
 inline hipError_t launch_chain(const Args& c, int nz, hipStream_t s) {
   if (c.B <= 0) return hipSuccess;
-  SDQN_LAUNCH((conv_ssh_chain_kernel<NS, WT>), dim3(nz * c.G), dim3(NT_), 0, s, c);
+  SDQN_LAUNCH((conv_ssh_chain_kernel<NS, WT, C1>), dim3(nz * c.G), dim3(NT_), 0, s, c);
   return hipGetLastError();
 }
 

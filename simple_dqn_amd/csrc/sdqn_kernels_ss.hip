@@ -58,8 +58,18 @@ static bool ssh_dgrad_takes(const StepArgs& a, const LaunchTune& t) {
   return t.bt[K_CONV3_DGRAD] == t.bt[K_CONV2_DGRAD];
 }
 
+// float16: conv1 rides in FRONT of the forward chain (the workgroup computes its own samples' a1 from the frames: conv_ssh.h, C1) wherever the
+// chain runs and nothing asks for a conv1 launch of its own (bt:0 = 0, no nw override): then K_CONV1_FWD launches nothing
+static bool ssh_c1(const StepArgs& a, const LaunchTune& t) {
+  return ssh_takes(a, t) && t.bt[K_CONV1_FWD] == 0 && t.nw_override[K_CONV1_FWD] == 0 && a.idx_t == nullptr && a.src != nullptr;
+}
+
 hipError_t launch_kernel_ss(int id, const StepArgs& a, const LaunchTune& t, hipStream_t s, bool* handled) {
   *handled = false;
+  if (id == K_CONV1_FWD) {
+    if (a.h16 && ssh_c1(a, t)) *handled = true;                  // (rides in the conv2 launch)
+    return hipSuccess;
+  }
   if (id == K_CONV3_DGRAD || id == K_CONV2_DGRAD) {
     if (!ssh_dgrad_takes(a, t)) return hipSuccess;
     *handled = true;
@@ -75,9 +85,14 @@ hipError_t launch_kernel_ss(int id, const StepArgs& a, const LaunchTune& t, hipS
     const int ns = a.nz * a.B > 256 ? 2 : 1, z1 = a.nz > 1 ? 1 : 0;
     ssh::Args c; c.a1 = a.h_a1; c.a2 = a.h_a2; c.a3 = a.h_a3; c.B = a.B; c.G = (a.B + ns - 1) / ns;
     c.w2[0] = a.wht[0] + OFF2; c.w2[1] = a.wht[z1] + OFF2; c.w3[0] = a.wht[0] + OFF3; c.w3[1] = a.wht[z1] + OFF3;
-    const bool wt = t.bt[K_CONV2_FWD] != 8;
-    if (ns == 2) return wt ? ssh::launch_chain<2, true>(c, a.nz, s) : ssh::launch_chain<2, false>(c, a.nz, s);
-    return wt ? ssh::launch_chain<1, true>(c, a.nz, s) : ssh::launch_chain<1, false>(c, a.nz, s);
+    const bool wt = t.bt[K_CONV2_FWD] != 8, c1 = ssh_c1(a, t);
+    c.src = a.src; c.idx = a.idx; c.from_ring = a.from_ring; c.a1w = a.h_a1; c.w1[0] = a.wht[0] + OFF1; c.w1[1] = a.wht[z1] + OFF1;
+    if (c1) {
+      if (ns == 2) return wt ? ssh::launch_chain<2, true, true>(c, a.nz, s) : ssh::launch_chain<2, false, true>(c, a.nz, s);
+      return wt ? ssh::launch_chain<1, true, true>(c, a.nz, s) : ssh::launch_chain<1, false, true>(c, a.nz, s);
+    }
+    if (ns == 2) return wt ? ssh::launch_chain<2, true, false>(c, a.nz, s) : ssh::launch_chain<2, false, false>(c, a.nz, s);
+    return wt ? ssh::launch_chain<1, true, false>(c, a.nz, s) : ssh::launch_chain<1, false, false>(c, a.nz, s);
   }
   if (!ss_takes(id, a, t)) return hipSuccess;
   *handled = true;

@@ -21,10 +21,10 @@ template <int NS> int bench(int B) {
   ssh::Args c; c.a1 = a1; c.a2 = a2; c.a3 = a3; c.B = B; c.G = (B + NS - 1) / NS;
   c.w2[0] = w; c.w3[0] = w + 64 * 512; c.w2[1] = w + nw; c.w3[1] = w + nw + 64 * 512;
   hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-  for (int r = 0; r < 3; ++r) CHK((ssh::launch_chain<NS, true>(c, nz, 0)));
+  for (int r = 0; r < 3; ++r) CHK((ssh::launch_chain<NS, true, false>(c, nz, 0)));
   CHK(hipDeviceSynchronize());
   CHK(hipEventRecord(e0));
-  for (int r = 0; r < 50; ++r) CHK((ssh::launch_chain<NS, true>(c, nz, 0)));
+  for (int r = 0; r < 50; ++r) CHK((ssh::launch_chain<NS, true, false>(c, nz, 0)));
   CHK(hipEventRecord(e1)); CHK(hipDeviceSynchronize());
   float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
   printf("forward chain B %d NS %d abl %d: %6.2f us/launch (back to back)\n", B, NS,
