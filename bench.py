@@ -235,7 +235,10 @@ def chained_convs(k_us):
     chained = "conv2_fwd" in k_us and "conv3_fwd" not in k_us
     if chained:
         k_us = dict(k_us)
-        k_us["conv2_fwd+conv3_fwd (one chained sample-stationary launch)"] = k_us.pop("conv2_fwd")
+        if any(k.startswith("conv1_fwd") for k in k_us):
+            k_us["conv2_fwd+conv3_fwd (one chained sample-stationary launch)"] = k_us.pop("conv2_fwd")
+        else:                                    # float16 mode: conv1 (with the replay gather) rides in front of the same launch
+            k_us["conv1_fwd(gather+norm+conv+relu)+conv2_fwd+conv3_fwd (one chained sample-stationary launch)"] = k_us.pop("conv2_fwd")
     # float16 mode: conv3_dgrad -> conv2_dgrad likewise, under kernel id 7 (the fp32 step fuses its dgrads with the weight gradients: bwd3 / bwd2)
     if "conv3_dgrad" in k_us and "conv2_dgrad" not in k_us and not any(k.startswith("bwd2") for k in k_us):
         k_us = dict(k_us)
