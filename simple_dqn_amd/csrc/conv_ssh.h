@@ -1,9 +1,11 @@
-// conv_ssh.h — float16 mode, throughput regime (B >= 128): conv2 -> conv3 forward as ONE sample-stationary launch
-// (deepqnetwork.py:85-87; the online and the target net of :119-130 together).
+// conv_ssh.h — float16 mode: the convolution layers as sample-stationary CHAINS, one launch each:
+//   forward   conv1 -> conv2 -> conv3 (deepqnetwork.py:83-87 with the replay gather and the / 255 of :94-100; the online and the target net of
+//             :119-130 together), at every batch size                                                      conv_ssh_chain_kernel
+//   backward  conv3_dgrad -> conv2_dgrad (deepqnetwork.py:162), B >= 128                                    conv_ssh_dgrad_chain_kernel
 //
 // The packed-fp16 block-tile routines run these two layers in 9.1 + 7.4 us at B = 256 for 1.1 + 0.8 us of matrix time: they are data
 // movement (every 64 x 64 block re-fetches its patches, expanded 4x / 9x by im2col, and the whole weight panel) plus two launch boundaries.
-// Here one workgroup per CU owns NS whole samples of one net:
+// Here one workgroup per CU owns NS whole samples of one net (conv1 in front: template flag C1, described at its code):
 //   * its input maps ([20][20][32] halves per sample, contiguous), W2^T ([64 maps][512 k] halves) and — into REGISTERS, for later — W3^T
 //     ([64][576]) are requested once, up front, with 16-byte loads; image and W2 go to LDS (pixel pitch 40 halves, weight row pitch 592:
 //     a tile's 16 positions / maps are 160 bytes apart modulo 256, conflict-free ds_read_b128);

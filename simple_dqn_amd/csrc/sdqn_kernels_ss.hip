@@ -5,8 +5,8 @@
 //     chip (below), else the block-tile engine's built-in shape; 7: this routine always; 8: always, and never chained with the other layer;
 //     other menu entries > 0: the block-tile engine's block shapes (sdqn_kernels_bt.hip; entry 6 = its built-in 64 x 64).  When both layers
 //     run here they are ONE launch (conv_ss_chain_kernel: a workgroup's conv3 follows its own conv2 behind a barrier).
-//   float16, any B (conv_ssh.h):     the same two layers as one launch (conv_ssh_chain_kernel), and — B >= 128, where the two dgrads are
-//     launches of their own — conv3_dgrad -> conv2_dgrad as one launch (conv_ssh_dgrad_chain_kernel; deepqnetwork.py:162).  Menu entries
+//   float16, any B (conv_ssh.h):     conv1 -> conv2 -> conv3 as one launch (conv_ssh_chain_kernel; K_CONV1_FWD and K_CONV3_FWD then launch nothing),
+//     and — B >= 128, where the two dgrads are launches of their own — conv3_dgrad -> conv2_dgrad as one launch (conv_ssh_dgrad_chain_kernel; deepqnetwork.py:162).  Menu entries
 //     0 / 7: these launches; 8: with plain (write-back) stores; 6 (any other): the packed-fp16 routines they replace.
 #include <stdlib.h>
 #include "conv_ss.h"
