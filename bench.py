@@ -243,6 +243,11 @@ def chained_convs(k_us):
     if "conv3_dgrad" in k_us and "conv2_dgrad" not in k_us and not any(k.startswith("bwd2") for k in k_us):
         k_us = dict(k_us)
         k_us["conv3_dgrad+conv2_dgrad (one chained sample-stationary launch)"] = k_us.pop("conv3_dgrad")
+    # float16 mode, B >= 128: conv1's weight gradient rides in the weight-gradient launch (no bwd1 sample)
+    wk = [k for k in k_us if k.startswith("wgrads")]
+    if wk and not any(k.startswith("bwd1") for k in k_us):
+        k_us = dict(k_us)
+        k_us["wgrads(fc4+conv3+conv2+conv1)"] = k_us.pop(wk[0])
     return k_us, chained
 
 

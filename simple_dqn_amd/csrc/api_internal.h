@@ -129,6 +129,7 @@ struct sdqn_net_s {
   half_t* gh = nullptr; int* ovf_flag = nullptr; int64_t* ovf_count = nullptr;    // fp16 data parallel: half gradient payload, overflow flag / skipped steps
   int dp_half = 1, dp_half_scale_log2 = -1;  // fp16 mode: all-reduce the gradient as half; -1 = dynamic payload scale (starts at 2^10, device-side), >= 0 = fixed 2^n
   bool h16_wgrad_mfma = true;              // fp16 mode: weight gradients on packed-fp16 MFMA (LDS transposes); false = fp32 MFMA with half operands
+  int c1w_in_wgrads = 1;                   // fp16 mode, B >= 128: conv1's weight gradient as a block range of the weight-gradient launch (0 off, 1 last, 2 first)
   bool half_payload_pending = false;       // sdqn_net_grad_from_half ran: the next sdqn_net_apply_update honours the overflow flag / moves the scale
   bool grad_only = false;                  // true: a train step stops after the local gradient sums (update mode 1): what a
                                            // data-parallel rank has before the all-reduce; sdqn_net_apply_update finishes it

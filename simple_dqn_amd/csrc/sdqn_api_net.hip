@@ -459,6 +459,7 @@ extern "C" int sdqn_net_set_option(sdqn_net_t h, const char* name, int value) {
   if (!strcmp(name, "keep_gradients")) h->keep_grads = value != 0;
   else if (!strcmp(name, "grad_only")) h->grad_only = value != 0;
   else if (!strcmp(name, "h16_wgrad_mfma")) h->h16_wgrad_mfma = value != 0;
+  else if (!strcmp(name, "c1w_in_wgrads")) { if (value < 0 || value > 2) { set_error("bad c1w_in_wgrads (0..2)"); return SDQN_ERR_ARG; } h->c1w_in_wgrads = value; }
   else if (!strcmp(name, "dp_half")) h->dp_half = value != 0;              // fp16 mode: half (1, default) or fp32 (0) all-reduce payload
   else if (!strcmp(name, "dp_half_scale_log2")) {          // -1: dynamic (default); n >= 0: fixed payload scale 2^n
     ARGCHK(value >= -1 && value <= 40 && h->ovf_flag, "bad scale (or not a float16 network)");

@@ -194,8 +194,13 @@ int run_train(sdqn_net_s* h, const StepArgs& a, const HeadArgs& hd, const PrepAr
     StepArgs b1 = a; b1.f4w_count = 0; b1.xcd_map |= 2;
     LAUNCH(K_CONV3_DGRAD, launch_tuned(h, K_CONV3_DGRAD, a, g_stream));
     LAUNCH(K_CONV2_DGRAD, launch_tuned(h, K_CONV2_DGRAD, a, g_stream));
-    LAUNCH(K_WGRADS, launch_tuned(h, K_WGRADS, w, g_stream));
-    LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream));
+    // round 6: conv1's weight gradient (c1w_h_kernel's K-slab workgroups) as a fourth block range of the weight-gradient launch — delta1 is
+    // complete by then — where that kernel applies (packed-fp16 weight gradients, slabs of whole 80-position chunks) and nothing asks for
+    // another form (bt:18 / bt:22 = 0; option c1w_in_wgrads: 0 = off, 1 = its workgroups last (built-in), 2 = first)
+    const int merge = (h->c1w_in_wgrads && h->h16_wgrad_mfma && (h->tps1 * 32) % 80 == 0 && h->bt[K_BWD1] == 0 && h->bt[K_WGRADS] == 0 &&
+                       h->nw_override[K_CONV1_WGRAD] == 0) ? (h->c1w_in_wgrads == 2 ? 48 : 16) : 0;
+    LAUNCH(K_WGRADS, launch_tuned(h, K_WGRADS, w, g_stream, merge));
+    LAUNCH(K_BWD1, launch_tuned(h, K_BWD1, b1, g_stream, merge));
   } else if (st == STEP_FUSED) {
     // fc4 wgrad (1568 tiles at B <= 32) may be spread over the three backward launches as background traffic (options f4_share3 / f4_share2;
     // built-in: all of it in bwd3); for B > 32 (K-split workgroups) it all rides in the first one

@@ -261,11 +261,10 @@ typedef unsigned int c1h_u32x4 __attribute__((ext_vector_type(4)));
 // dword instead of four cvt / IEEE-divide / cvt chains — the conversion was ~3x the chunk's matrix time) from 16-byte loads, and the 1 / 255 of
 // deepqnetwork.py:100 multiplies the split-K partial once, with the loss scale.  !EXACT: the first form (half(b / 255) operands, 4-byte loads).
 template <bool EXACT>
-__global__ void __launch_bounds__(256) c1w_h_kernel(const C1wHArgs c) {
-  __shared__ __attribute__((aligned(16))) half_t smem[2 * C1H_STAGE];
+__device__ __forceinline__ void c1w_h_body(const C1wHArgs& c, const int ks, half_t* const smem) {      // smem: 2 * C1H_STAGE halves
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ks = blockIdx.x, Kt = c.Kt, kb = ks * c.tps1 * 32;
+  const int Kt = c.Kt, kb = ks * c.tps1 * 32;
   int ke = kb + c.tps1 * 32; if (ke > Kt) ke = Kt;
   const int nch = (ke - kb) / C1W_CH;               // (the host launches this kernel only with slabs of whole chunks)
   // loader items: frame rows = 4 frames x 20 rows x 84 bytes, contiguous and 16-byte aligned per frame: 420 pieces of 16 bytes (EXACT; 2 per
@@ -377,6 +376,42 @@ __global__ void __launch_bounds__(256) c1w_h_kernel(const C1wHArgs c) {
       const int m = 64 * wave + 32 * sm + bt::acc_row(q, h);
       c.slab1[(int64_t)ks * NW1 + m * K1 + i] = acc[sm][q] * (EXACT ? c.inv_loss_scale * (1.0f / 255.0f) : c.inv_loss_scale);
     }
+}
+template <bool EXACT>
+__global__ void __launch_bounds__(256) c1w_h_kernel(const C1wHArgs c) {
+  __shared__ __attribute__((aligned(16))) half_t smem[2 * C1H_STAGE];
+  c1w_h_body<EXACT>(c, (int)blockIdx.x, smem);
+}
+// conv1's weight gradient INSIDE the float16 weight-gradient launch (round 6): delta1 is complete before that launch starts (both dgrads run
+// in front of it), so its K-slab workgroups are a fourth block-id range of the same launch — one launch and one boundary fewer, and the
+// 7.8 us of bwd1 packs under fc4_wgrad's RMSProp stream instead of following it.  Same body, same slabs: bit-identical.
+template <class C0, class C1, class C2>
+__global__ void __launch_bounds__(bt::NT) bt_multi_c1w_kernel(const StepArgs a, const MultiDims d, const C1wHArgs c1, const int nc1, const int c1_first) {
+  constexpr int L01 = C0::LDS > C1::LDS ? C0::LDS : C1::LDS, L012 = L01 > C2::LDS ? L01 : C2::LDS, LC = C1H_STAGE, L = L012 > LC ? L012 : LC;     // floats
+  __shared__ __attribute__((aligned(16))) float smem[L];
+  static_assert(bt::NT == 256, "c1w_h_body is written for 256 threads");
+  if constexpr (has_preload_multi<typename C1::P>::value) C1::P::preload_multi(a, d);
+  const int nb = d.n[0] + d.n[1] + d.n[2];
+  int b = blockIdx.x;
+  if (c1_first) { if (b < nc1) { c1w_h_body<true>(c1, b, reinterpret_cast<half_t*>(smem)); return; } b -= nc1; }
+  else if (b >= nb) { c1w_h_body<true>(c1, b - nb, reinterpret_cast<half_t*>(smem)); return; }
+  const int xm = a.xcd_map;
+  if (b < d.n[0]) { const int l = (xm & 1) ? xcd_tile_id_range(b, 0, d.n[0]) : b, pz = d.gx[0] * d.gy[0], bz = l / pz, r = l - bz * pz; bt_run_tile<C0>(a, r % d.gx[0], r / d.gx[0], bz, smem); }
+  else if (b < d.n[0] + d.n[1]) { const int l = (xm & 2) ? xcd_tile_id_range(b, d.n[0], d.n[1]) : b - d.n[0], pz = d.gx[1] * d.gy[1], bz = l / pz, r = l - bz * pz; bt_run_tile<C1>(a, r % d.gx[1], r / d.gx[1], bz, smem); }
+  else { const int l = (xm & 4) ? xcd_tile_id_range(b, d.n[0] + d.n[1], d.n[2]) : b - d.n[0] - d.n[1], pz = d.gx[2] * d.gy[2], bz = l / pz, r = l - bz * pz; bt_run_tile<C2>(a, r % d.gx[2], r / d.gx[2], bz, smem); }
+}
+template <class C0, class C1, class C2>
+static hipError_t launch_bt_multi_c1w(const StepArgs& a, int c1_first, hipStream_t stream) {
+  MultiDims d; memset(&d, 0, sizeof d);
+  int gz;
+  bt_grid<C0>(a, d.gx[0], d.gy[0], gz); d.n[0] = d.gx[0] * d.gy[0] * gz;
+  bt_grid<C1>(a, d.gx[1], d.gy[1], gz); d.n[1] = d.gx[1] * d.gy[1] * gz;
+  bt_grid<C2>(a, d.gx[2], d.gy[2], gz); d.n[2] = d.gx[2] * d.gy[2] * gz;
+  C1wHArgs c; c.src = a.src; c.d1 = a.h_d1; c.slab1 = a.slab1; c.idx = a.idx; c.B = a.B; c.from_ring = a.from_ring; c.tps1 = a.tps1; c.Kt = a.B * PIX1;
+  c.inv_loss_scale = a.inv_loss_scale;
+  const int nc1 = Conv1Wgrad::nbz(a);
+  SDQN_LAUNCH((bt_multi_c1w_kernel<C0, C1, C2>), dim3(d.n[0] + d.n[1] + d.n[2] + nc1), dim3(bt::NT), 0, stream, a, d, c, nc1, c1_first);
+  return hipGetLastError();
 }
 
 static hipError_t launch_c1w_h(const StepArgs& a, const LaunchTune& t, hipStream_t s) {
@@ -720,6 +755,9 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
       typedef BtCfgHW<Conv3WgradH, 64, 64, 2, 2, 2> HC3W;
       typedef BtCfgHW<Conv2WgradH, 64, 64, 2, 2, 2> HC2W;
       *handled = true;
+      // r3 bit 4 (the step orchestration's decision, sdqn_api_step.hip): conv1's weight gradient rides in this launch and K_BWD1 launches nothing;
+      // bit 5: its workgroups first in the block-id order
+      if (t.r3 & 16) return launch_bt_multi_c1w<HF4W, HC3W, HC2W>(a, (t.r3 & 32) ? 1 : 0, s);
       if (t.bt[id] == 1) return launch_bt_multi<BtCfgHW<Fc4WgradH, 64, 64, 2, 2, 4>, BtCfgHW<Conv3WgradH, 64, 64, 2, 2, 4>, BtCfgHW<Conv2WgradH, 64, 64, 2, 2, 4>>(a, true, true, true, s);
       if (t.bt[id] == 2) return launch_bt_multi<BtCfgHW<Fc4WgradH, 64, 64, 2, 2, 3>, BtCfgHW<Conv3WgradH, 64, 64, 2, 2, 3>, BtCfgHW<Conv2WgradH, 64, 64, 2, 2, 3>>(a, true, true, true, s);
       return launch_bt_multi<HF4W, HC3W, HC2W>(a, true, true, true, s);
@@ -728,6 +766,7 @@ hipError_t launch_kernel_bt(int id, const StepArgs& a, const LaunchTune& t, hipS
       *handled = true;
       return launch_conv1_h(a, t, s);
     }
+    if (id == K_BWD1 && (t.r3 & 16)) { *handled = true; return hipSuccess; }      // (rode in the weight-gradient launch)
     if (id == K_BWD1 && a.h16 == 2 && a.f4w_count == 0) {    // conv1's weight gradient: all 256 x 32 outputs of a K slab per workgroup, A from the bytes
       // (the generic half routine with A from the bytes — BtCfgHW<Conv1WgradH, 256, 32, 4, 1> — fetches 8-byte patch-row pieces straight
       //  from memory: 16 divergent loads per thread and chunk, 18.9 us at B = 256, no better than the wave-tile routine's 18.7)

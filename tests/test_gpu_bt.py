@@ -271,3 +271,30 @@ def test_float16_forward_chain_below_the_throughput_regime(sd, A, B):
     co = {p["name"].split("(")[0]: p["launches"] for p in old.profile_read() if p["launches"] > 0}
     assert cn.get("conv3_fwd", 0) == 0 and cn.get("conv1_fwd", 0) == 0 and cn["conv2_fwd"] == 3 and co["conv3_fwd"] == 3 and co["conv1_fwd"] == 3, (cn, co)
     # (no free-running comparison: three half-precision steps from two summation orders drift 1e-3 .. 3e-2 apart with |Q| ~ 1)
+
+
+@pytest.mark.parametrize("A,B", [(3, 256), (4, 129), (6, 160)])
+def test_float16_conv1_weight_gradient_inside_the_weight_gradient_launch(sd, A, B):
+    """Round 6, float16 at B >= 128: conv1's weight gradient (c1w_h_kernel's K-slab workgroups) is a fourth block-id range of the launch that
+    carries fc4_wgrad (+ RMSProp) || conv3_wgrad || conv2_wgrad — delta1 is complete before it starts — instead of a launch of its own
+    (option c1w_in_wgrads: 0 = own launch, 1 = last in the block order (built-in), 2 = first).  Same body, same slabs: every gradient and the
+    updated network are bit-identical over two steps; the launch structure shows one launch fewer."""
+    mb = random_minibatch(B, A, 600 + B, reward_range=(-2, 3))
+    nets = {}
+    for m in (0, 1, 2):
+        n = _net(sd, A, B, 61, [("keep_gradients", 1), ("c1w_in_wgrads", m)], datatype="float16")
+        n.train(mb); n.train(mb)
+        nets[m] = n
+    for m in (1, 2):
+        for i in range(5):
+            assert np.array_equal(nets[m].get_layer(i, 3), nets[0].get_layer(i, 3)) and np.abs(nets[m].get_layer(i, 3)).max() > 0, (m, i)
+        assert np.array_equal(nets[m].predict(mb[0]), nets[0].predict(mb[0]))
+    counts = {}
+    for m in (0, 1):
+        n = nets[m]
+        n.profile(True, -1); n.profile_reset()
+        for _ in range(3):
+            n.train(mb)
+        counts[m] = {p["name"].split("(")[0]: p["launches"] for p in n.profile_read() if p["launches"] > 0}
+        n.profile(False)
+    assert counts[0].get("bwd1", 0) == 3 and counts[1].get("bwd1", 0) == 0 and counts[1]["wgrads"] == 3, counts
