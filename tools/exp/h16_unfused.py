@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, simple_dqn_amd as sd
 from util import make_args, random_minibatch
-B, A = 256, 3
+B, A = int(os.environ.get("B", 256)), 3
 mb = random_minibatch(B, A, 3)
 for spec in sys.argv[1:] or ["fused_launches=0"]:
     net = sd.DeepQNetwork(A, make_args(batch_size=B, datatype=os.environ.get("DATATYPE", "float16"))); net.update_target_network()
